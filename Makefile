@@ -1,0 +1,34 @@
+# Top-level build: the product library (HIP, gfx950 only) and the CPU checker.
+#   make            -> plaac_amd/libplaac_native.so + oracle/libplaac_oracle.so (+ bin/plaac when its source exists)
+# -ffp-contract=off is part of the numerical contract: never remove it.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result
+CSRC      = plaac_amd/csrc
+LIB       = plaac_amd/libplaac_native.so
+
+all: $(LIB) oracle $(if $(wildcard $(CSRC)/plaac_cli.cpp),cli)
+
+LIBSRC    = $(CSRC)/plaac_kernels.hip $(CSRC)/plaac_host.cpp $(wildcard $(CSRC)/plaac_io.cpp)
+$(LIB): $(LIBSRC) $(wildcard include/*.h)
+	$(HIPCC) $(HIPFLAGS) -Iinclude -shared -o $@ $(LIBSRC) -Wl,-rpath,/opt/rocm/lib
+
+cli: bin/plaac
+bin/plaac: $(CSRC)/plaac_cli.cpp $(LIB)
+	mkdir -p bin
+	$(HIPCC) -O2 -std=c++17 -Iinclude -o $@ $(CSRC)/plaac_cli.cpp -Lplaac_amd -lplaac_native \
+		-Wl,-rpath,'$$ORIGIN/../plaac_amd' -Wl,-rpath,/opt/rocm/lib
+
+oracle:
+	$(MAKE) -C oracle
+
+asm: $(CSRC)/plaac_kernels.hip
+	mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -Iinclude --cuda-device-only -S -o build/plaac_kernels.s $(CSRC)/plaac_kernels.hip \
+		-Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || true
+
+clean:
+	rm -f $(LIB) bin/plaac
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle cli asm clean

@@ -1,0 +1,175 @@
+/*
+ * plaac_native.h — C ABI of the MI355X-native PLAAC scoring engine (libplaac_native.so).
+ *
+ * This is the drop-in boundary for the reference's per-protein scoring loops
+ * (reference = cli/src/plaac.java of whitehead/plaac). The reference has no FFI of its own:
+ * the seam is the body of `scoreallfastas` (plaac.java:759-880) and `plotsomefastas`
+ * (plaac.java:625-633). A JNI / ctypes / C++ host encodes FASTA records to residue codes,
+ * calls plaac_score once per batch and formats rows (see INTEGRATION.md for the JNI stub).
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary; every call returns a plaac_status and
+ *     leaves a message retrievable with plaac_last_error().
+ *   - caller owns every buffer; the ctx owns device memory and streams. A ctx is
+ *     single-caller; distinct ctxs are independent; there are no process globals.
+ *   - residue codes 0..21 = X A C D E F G H I K L M N P Q R S T V W Y *  (plaac.java:26).
+ *   - a batch is `codes` (all records concatenated, UNTRIMMED) + `offsets[nprot+1]`.
+ *     Scoring drops exactly one trailing stop code (21) per record (plaac.java:758);
+ *     the background histogram does not (plaac.java:1698-1706).
+ *   - results do not depend on batch split, protein order or device count.
+ *   - there is NO CPU fallback: every compute entry point runs the HIP kernels or fails.
+ */
+#ifndef PLAAC_NATIVE_H
+#define PLAAC_NATIVE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLAAC_ABI_VERSION 1
+#define PLAAC_NAA 22
+#define PLAAC_LUTLEN 4001
+
+typedef enum plaac_status {
+    PLAAC_OK = 0,
+    PLAAC_ERR_ARG = 1,    /* bad argument (null pointer, non-monotone offsets, code > 21 ...) */
+    PLAAC_ERR_DEVICE = 2, /* HIP runtime / kernel failure, or no gfx950 device                */
+    PLAAC_ERR_NOMEM = 3,  /* host or device allocation failed                                 */
+    PLAAC_ERR_IO = 4      /* file could not be read (host helpers only)                       */
+} plaac_status;
+
+/* Log-space 2-state HMM as hmm.initialize leaves it (plaac.java:2893-2935). */
+typedef struct plaac_hmm {
+    double lt[2][2];         /* ltprob[from][to] */
+    double li[2];            /* liprob           */
+    double le[2][PLAAC_NAA]; /* leprob[state][code] */
+    double lf[2];            /* lfprob (0.0: free end) */
+} plaac_hmm;
+
+/* Everything the kernels need, so the device never calls log():
+ * replaces the locals of main (plaac.java:444-500), the statics loglut/lodpapa1/aahydro2/aacharge
+ * (:33, :201, :90, :37) and the two hmm objects (:517-518). */
+typedef struct plaac_params {
+    int32_t corelength;      /* -c, default 60 (:319) */
+    int32_t ww1, ww2, ww3;   /* -w, -W, ww3=ww2 (:320-322, :355) */
+    int32_t adjustprolines;  /* always true in the reference (:329) */
+    int32_t reserved_;
+    double alpha;            /* -a after the [0,1] clamp (:444-447) */
+    double cc[3];            /* FoldIndex coefficients {2.785,-1,-1.151} (:800) */
+    double big_neg;          /* -1000000.0 (:819) */
+    double fg[PLAAC_NAA];      /* "## fg_used"   */
+    double bgscer[PLAAC_NAA];  /* "## bg_scer"   */
+    double bgthis[PLAAC_NAA];  /* "## bg_input"  */
+    double bg[PLAAC_NAA];      /* "## bg_used"   */
+    double llr[PLAAC_NAA];     /* "## plaac_llr" */
+    double lodpapa[PLAAC_NAA]; /* "## papa_lods" */
+    double hydro2[PLAAC_NAA];  /* aahydro2 */
+    double charge[PLAAC_NAA];  /* aacharge */
+    plaac_hmm hmm1;            /* prionhmm1 (:968-981) */
+    plaac_hmm hmm0;            /* prionhmm0 (:988-1001) */
+    double loglut[PLAAC_LUTLEN]; /* loglut (:283) */
+} plaac_params;
+
+/* One summary row per record: the raw values behind the 38 printed columns of
+ * scoreallfastas (plaac.java:899-945). Indices are ZERO-based with the reference's
+ * sentinels (start -1 / end -2 when there is none); the host adds 1 when printing.
+ * prot_len == 0 marks a record that is skipped (empty after the stop trim, :762). */
+typedef struct plaac_row {
+    double llr_score;     /* LLR      (-inf when n < corelength)            */
+    double core_score;    /* COREscore (NaN when no core)                   */
+    double prd_score;     /* PRDscore (0.0 when no core)                    */
+    double hmm_all;       /* HMMall                                         */
+    double hmm_vit;       /* HMMvit                                         */
+    double fi_meanhydro;  /* FImeanhydro                                    */
+    double fi_meancharge; /* FImeancharge                                   */
+    double fi_meancombo;  /* FImeancombo                                    */
+    double papa_combo;    /* PAPAcombo (-inf when no centre; printed NaN)   */
+    double papa_prop;     /* PAPAprop                                       */
+    double papa_fi;       /* PAPAfi                                         */
+    double papa_llr;      /* PAPAllr                                        */
+    double papa_llr2;     /* PAPAllr2                                       */
+    int32_t mw_score, mw_start, mw_end;
+    int32_t llr_start, llr_end;
+    int32_t vit_maxrun;
+    int32_t core_start, core_end;
+    int32_t prd_start, prd_end;
+    int32_t prot_len;
+    int32_t fi_numaa, fi_maxrun;
+    int32_t papa_cen;
+} plaac_row; /* 13 x f64 + 14 x i32 = 160 bytes */
+
+/* Per-residue tracks (plotsomefastas, plaac.java:635-643): SoA arrays indexed by the
+ * position of the residue in `codes` (entries of a trimmed stop are left untouched).
+ * All twelve pointers must be non-null when a tracks struct is passed. */
+typedef struct plaac_tracks {
+    uint8_t *vit, *map;
+    double *charge, *hydro, *fi, *plaacllr, *papa, *fix2, *plaacllrx2, *papax2;
+    double *post0, *post1; /* HMM.background, HMM.PrD-like */
+} plaac_tracks;
+
+typedef struct plaac_ctx plaac_ctx;
+
+int plaac_abi_version(void);
+size_t plaac_sizeof_params(void);
+size_t plaac_sizeof_row(void);
+
+/* ---- host-side parameter setup (no device needed) ------------------------------------ */
+
+/* Built-in tables of the reference: bg_freq_scer (:261), prd_freq_scer_28 (:269), prd_freq_scer_04 (:265). */
+void plaac_builtin_tables(double bg_scer[PLAAC_NAA], double fg28[PLAAC_NAA], double fg04[PLAAC_NAA]);
+
+/* Table setup of main (plaac.java:444-500) + plaac() (:279-291) + prionhmm1/0 (:968-1001).
+ * fgfreq: foreground frequencies or counts (NULL = prd_freq_scer_28); bgcounts: background counts or
+ * frequencies of the scored organism, i.e. what -B / -b / -i produce (NULL = all zero).
+ * alpha outside [0,1] is replaced by 1.0 (the caller prints the reference's warning line). */
+plaac_status plaac_params_init(plaac_params *out, const double fgfreq[PLAAC_NAA], const double bgcounts[PLAAC_NAA],
+                               double alpha, int corelength, int ww1, int ww2, int ww3, int adjustprolines);
+
+/* aatoint / string2aa (plaac.java:1508-1534, :1764-1769): text -> codes, one byte per residue. */
+void plaac_encode(const char *text, size_t n, uint8_t *codes);
+
+/* ---- device context -------------------------------------------------------------------- */
+
+/* Binds a gfx950 device, uploads the tables, creates streams. Fails (PLAAC_ERR_DEVICE) when no GPU is usable. */
+plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_ctx **out);
+/* Re-upload tables (parameter sweeps reuse one ctx and one resident batch). */
+plaac_status plaac_ctx_set_params(plaac_ctx *ctx, const plaac_params *params);
+void plaac_ctx_destroy(plaac_ctx *ctx);
+/* Message of the last failing call on this ctx (ctx == NULL: last failing ctx_create on this thread). */
+const char *plaac_last_error(const plaac_ctx *ctx);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* computeaafreq / countaas / isvalidprotein (plaac.java:1655-1666, :1698-1706, :1732-1739):
+ * 22-bin residue histogram over the valid records of the batch (raw counts, bins 0 and 21 included). */
+plaac_status plaac_histogram(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                             int64_t counts[PLAAC_NAA]);
+
+/* Body of the per-protein loops (plaac.java:759-880 and :625-633) for a whole batch.
+ * Host buffers in, host buffers out; rows in input order. tracks may be NULL (summary mode). */
+plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                         plaac_row *rows, const plaac_tracks *tracks);
+
+/* Same, on buffers already resident in device memory (all pointers are device pointers, including
+ * the ones inside *tracks; the tracks struct itself lives on the host). `stream` is a hipStream_t
+ * (NULL = the ctx's own stream). Asynchronous: returns after enqueueing; synchronise the stream
+ * (or call plaac_ctx_sync) before reading rows. Work buffers are grown on demand and reused. */
+plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,
+                                uint64_t total_residues, plaac_row *d_rows, const plaac_tracks *d_tracks,
+                                void *stream);
+plaac_status plaac_histogram_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
+                                    uint32_t nprot, int64_t *d_counts, void *stream);
+plaac_status plaac_ctx_sync(plaac_ctx *ctx);
+
+/* Device time (ms, HIP events on the launch stream) of the kernels of the most recent completed
+ * plaac_score_device / plaac_score call: [0] total, [1] sort/plan, [2] recurrence kernel (HMM + windows
+ * over prefix sums), [3] window-track kernel (FoldIndex/PAPA). Requires a prior sync. */
+plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLAAC_NATIVE_H */

@@ -1,0 +1,1092 @@
+// plaac_kernels.hip — gfx950 (CDNA4) kernels + the device half of the C ABI (include/plaac_native.h).
+//
+// MUST be compiled with -ffp-contract=off: the reference (Java) never fuses a*b+c and the
+// tie-breaks of the window searches depend on the exact rounding of every add.
+//
+// Kernel map (reference = cli/src/plaac.java):
+//   k_plan_*      length histogram / scan / scatter: descending-length order, so that the 64 lanes
+//                 of a wave run recurrences of similar length and the longest chains start first.
+//   k_recur       "K-A", ONE LANE PER PROTEIN. All order-sensitive serial fp64 chains:
+//                   Viterbi + traceback            hmm.viterbidecodel   :3077-3121
+//                   forward with the LUT log-sum-exp  hmm.posteriorl    :3354-3375, logeapeb :1024-1047
+//                   hmm0 (degenerates to a running sum)                  :795, SURVEY H4
+//                   MW and LLR fixed-width windows over prefix sums  hss2 :1206-1257 via :767-783
+//                   masked core window, PRD expansion, PRD score          :816-880
+//                   mean hydropathy / charge / FoldIndex                  :4877-4885
+//                   (track mode) backward, posteriors, MAP path           :3377-3405, :4032-4045
+//                 A serial chain cannot be re-associated (bit-exactness), so the parallelism is
+//                 ACROSS proteins: 64 independent chains per wave, tables + 32 KB loglut in LDS.
+//   k_tracks      "K-B", ONE WAVE PER PROTEIN, position-parallel. The window tracks of disorderreport
+//                 (:4866-5068): hydro/charge/FoldIndex, PLAAC-LLR and PAPA sliding means (fixed-order
+//                 41-term sums per position), their weighted second smoothing, the PAPA arg-max and the
+//                 FoldIndex run statistics. Tiles stream through LDS rings; wave ballots/shuffles for
+//                 the run-length and arg-max reductions.
+//   k_hist        22-bin histogram over valid records (countaas/isvalidprotein :1698-1739).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "plaac_native.h"
+
+// ------------------------------------------------------------------------------------------------
+// device tables
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int NAA = PLAAC_NAA;
+constexpr int LUTLEN = PLAAC_LUTLEN;
+constexpr int LEN_BINS = 1 << 16; // lengths >= LEN_BINS-1 share the last bin
+
+// per-code row used by k_recur: one LDS row per residue code
+enum { R_LE0 = 0, R_LE1 = 1, R_LLR = 2, R_HYD = 3, R_LE0H = 4, R_PAD = 5, R_W = 6 };
+
+struct DevTables {
+    double row[NAA][R_W]; // {hmm1.le[0], hmm1.le[1], llr, hydro2, hmm0.le[0], -}
+    double lod[NAA];      // papa log-odds
+    double hyd[NAA];      // hydro2
+    double llr[NAA];
+    int32_t chg[NAA];     // aacharge as integers (-1, 0, 1)
+    int32_t pad0_[2];
+    double lt[2][2], li[2], lf[2]; // hmm1
+    double h0_lt00, h0_li0, h0_lf0; // hmm0 (identity transitions: only state 0 is reachable)
+    double cc[3];
+    double big_neg;
+    int32_t corelength, ww1, ww2, ww3, adjustprolines, pad1_;
+    double loglut[LUTLEN];
+};
+
+struct TrackPtrs {
+    uint8_t *vit, *map;
+    double *charge, *hydro, *fi, *plaacllr, *papa, *fix2, *plaacllrx2, *papax2, *post0, *post1;
+};
+
+// ------------------------------------------------------------------------------------------------
+// planning kernels: effective lengths, descending-length counting sort
+// ------------------------------------------------------------------------------------------------
+__global__ void k_plan_lengths(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets, uint32_t nprot,
+                               uint32_t *__restrict__ neff, uint32_t *__restrict__ hist) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprot) return;
+    uint64_t b = offsets[p], e = offsets[p + 1];
+    uint64_t len = e > b ? e - b : 0;
+    if (len > 0 && codes[e - 1] == 21) --len; // one trailing stop is dropped before scoring (:758)
+    if (len > 0x7fffffffu) len = 0x7fffffffu;
+    neff[p] = (uint32_t)len;
+    uint32_t bin = len < (uint64_t)(LEN_BINS - 1) ? (uint32_t)len : (uint32_t)(LEN_BINS - 1);
+    atomicAdd(&hist[bin], 1u);
+}
+
+// single block: cursor[b] = number of proteins in bins > b (descending order start positions)
+__global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *__restrict__ hist) {
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    constexpr int PER = LEN_BINS / 1024;
+    // thread tid owns bins [hi - PER + 1, hi] with hi = LEN_BINS-1 - tid*PER (descending)
+    const int hi = LEN_BINS - 1 - tid * PER;
+    uint32_t s = 0;
+    for (int j = 0; j < PER; ++j) s += hist[hi - j];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s; // exclusive prefix for this thread's first (largest) bin
+    for (int j = 0; j < PER; ++j) {
+        uint32_t c = hist[hi - j];
+        hist[hi - j] = run;
+        run += c;
+    }
+}
+
+__global__ void k_plan_scatter(const uint32_t *__restrict__ neff, uint32_t nprot, uint32_t *__restrict__ cursor,
+                               uint32_t *__restrict__ order) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprot) return;
+    uint32_t len = neff[p];
+    uint32_t bin = len < (uint32_t)(LEN_BINS - 1) ? len : (uint32_t)(LEN_BINS - 1);
+    uint32_t pos = atomicAdd(&cursor[bin], 1u);
+    order[pos] = p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-A: one lane per protein — serial recurrences
+// ------------------------------------------------------------------------------------------------
+// logeapeb (:1024-1047), branch-free. a==b (incl. -inf,-inf) falls out of the same formula:
+// dex=0 gives a + (0*lut[1] + 1*lut[0]) = a + ln 2, and -inf - -inf = NaN fails (c<40) -> hi.
+__device__ __forceinline__ double lse_lut(const double *__restrict__ lut, double a, double b) {
+    const bool agt = a > b;
+    const double hi = agt ? a : b;
+    const double lo = agt ? b : a;
+    const double c = hi - lo;
+    const bool inrange = c < 40.0;
+    const double x = 100.0 * (inrange ? c : 0.0);
+    const double dexf = floor(x);
+    const int dex = (int)dexf;
+    const double r = hi + ((x - dexf) * lut[dex + 1] + ((dexf + 1.0) - x) * lut[dex]);
+    return inrange ? r : hi;
+}
+
+__device__ __forceinline__ uint32_t ld_code(const uint8_t *__restrict__ x, uint32_t t) {
+    uint32_t c = x[t];
+    return c > 21u ? 0u : c;
+}
+
+constexpr int KA_THREADS = 256;
+
+template <bool TRACKS>
+__global__ __launch_bounds__(KA_THREADS) void k_recur(const uint8_t *__restrict__ codes,
+                                                      const uint64_t *__restrict__ offsets,
+                                                      const uint32_t *__restrict__ neff,
+                                                      const uint32_t *__restrict__ order, uint32_t nprot,
+                                                      const DevTables *__restrict__ T, uint32_t *__restrict__ bits,
+                                                      plaac_row *__restrict__ rows, TrackPtrs tr,
+                                                      double *__restrict__ fwd) {
+    __shared__ double s_lut[LUTLEN + 1];
+    __shared__ double s_row[NAA * R_W];
+    for (int i = threadIdx.x; i < LUTLEN; i += KA_THREADS) s_lut[i] = T->loglut[i];
+    if (threadIdx.x == 0) s_lut[LUTLEN] = 0.0;
+    for (int i = threadIdx.x; i < NAA * R_W; i += KA_THREADS) s_row[i] = (&T->row[0][0])[i];
+    __syncthreads();
+
+    const uint32_t gid = blockIdx.x * KA_THREADS + threadIdx.x;
+    if (gid >= nprot) return;
+    const uint32_t p = order[gid];
+    const uint32_t n = neff[p];
+    const uint64_t off = offsets[p];
+    plaac_row *row = rows + p;
+    if (n == 0) { // skipped record (:762): zero the fields this kernel owns
+        row->llr_score = row->core_score = row->prd_score = row->hmm_all = row->hmm_vit = 0.0;
+        row->fi_meanhydro = row->fi_meancharge = row->fi_meancombo = 0.0;
+        row->mw_score = row->mw_start = row->mw_end = row->llr_start = row->llr_end = 0;
+        row->vit_maxrun = row->core_start = row->core_end = row->prd_start = row->prd_end = 0;
+        row->prot_len = 0;
+        return;
+    }
+    const uint8_t *__restrict__ x = codes + off;
+    // private bit scratch: 2 bits/residue of traceback, later 1 bit/residue of Viterbi path
+    uint32_t *__restrict__ wbits = bits + (off >> 4) + p;
+
+    const double lt00 = T->lt[0][0], lt01 = T->lt[0][1], lt10 = T->lt[1][0], lt11 = T->lt[1][1];
+    const double lf0 = T->lf[0], lf1 = T->lf[1];
+    const uint32_t c = (uint32_t)T->corelength;
+    const uint32_t mw = n < 80u ? n : 80u; // :769-770
+
+    // ---------------- pass 1: t = 0 .. n-1 --------------------------------------------------
+    double s0 = 0, s1 = 0, a0 = 0, a1 = 0, h0 = 0;
+    double hydsum = 0.0;
+    int chg = 0;
+    int cntL = 0, cntT = 0, mwbest = 0, mwstart = 0;          // MW window (exact integers)
+    double psL = 0.0, psT = 0.0, llrbest = -INFINITY;          // LLR window over prefix sums
+    int llrstart = -1;
+    uint32_t tbw = 0;
+    for (uint32_t t = 0; t < n; ++t) {
+        const uint32_t xc = ld_code(x, t);
+        const double *__restrict__ r = s_row + xc * R_W;
+        const double e0 = r[R_LE0], e1 = r[R_LE1];
+        if (t == 0) {
+            s0 = T->li[0] + e0;
+            s1 = T->li[1] + e1;
+            a0 = s0;
+            a1 = s1;
+            h0 = T->h0_li0 + r[R_LE0H];
+        } else {
+            // Viterbi (:3087-3100): state 0 stays the arg-max on ties (strict >)
+            const double v00 = lt00 + s0, v10 = lt10 + s1, v01 = lt01 + s0, v11 = lt11 + s1;
+            const bool g0 = v10 > v00, g1 = v11 > v01;
+            s0 = (g0 ? v10 : v00) + e0;
+            s1 = (g1 ? v11 : v01) + e1;
+            tbw |= ((uint32_t)g0 | ((uint32_t)g1 << 1)) << (2u * (t & 15u));
+            // forward (:3360-3368): LSE(-inf, u) returns u unchanged, so one LUT-LSE per state
+            const double f0 = lse_lut(s_lut, lt00 + a0, lt10 + a1);
+            const double f1 = lse_lut(s_lut, lt01 + a0, lt11 + a1);
+            if (TRACKS) {
+                fwd[2 * (off + t - 1)] = a0;
+                fwd[2 * (off + t - 1) + 1] = a1;
+            }
+            a0 = f0 + e0;
+            a1 = f1 + e1;
+            h0 = (T->h0_lt00 + h0) + r[R_LE0H];
+        }
+        if ((t & 15u) == 15u || t == n - 1) {
+            wbits[t >> 4] = tbw;
+            tbw = 0;
+        }
+        hydsum = hydsum + r[R_HYD];                                  // mean (:1584-1588)
+        chg += (xc == 3u || xc == 4u) ? 1 : ((xc == 9u || xc == 15u) ? -1 : 0);
+        // MW (:767-771): counts of N (12) and Q (14)
+        cntL += (xc == 12u || xc == 14u) ? 1 : 0;
+        if (t >= mw) {
+            const uint32_t xo = ld_code(x, t - mw);
+            cntT += (xo == 12u || xo == 14u) ? 1 : 0;
+        }
+        if (t + 1 >= mw) {
+            const int d = cntL - cntT;
+            if (t + 1 == mw || d > mwbest) {
+                mwbest = d;
+                mwstart = (int)(t + 1 - mw);
+            }
+        }
+        // LLR (:782-783): psum[i+1] = psum[i] + llr[x_i]; the trailing prefix sum is the same chain c steps later
+        psL = psL + r[R_LLR];
+        if (t >= c) psT = psT + s_row[ld_code(x, t - c) * R_W + R_LLR];
+        if (t + 1 >= c) {
+            const double d = (t + 1 == c) ? psL : psL - psT;
+            if (t + 1 == c || d > llrbest) {
+                llrbest = d;
+                llrstart = (int)(t + 1 - c);
+            }
+        }
+    }
+    if (TRACKS) {
+        fwd[2 * (off + n - 1)] = a0;
+        fwd[2 * (off + n - 1) + 1] = a1;
+    }
+    // end of Viterbi (:3102-3109) and of forward (:3369-3375)
+    const double vend0 = s0 + lf0, vend1 = s1 + lf1;
+    uint32_t state = vend1 > vend0 ? 1u : 0u;
+    const double lvit1 = state ? vend1 : vend0;
+    const double lmarg1 = lse_lut(s_lut, a0 + lf0, a1 + lf1);
+    const double l0 = h0 + T->h0_lf0;
+    row->hmm_all = lmarg1 - l0;
+    row->hmm_vit = lvit1 - l0;
+    row->prot_len = (int32_t)n;
+    row->mw_score = mwbest;
+    row->mw_start = mwstart;
+    row->mw_end = mwstart + (int)mw - 1;
+    row->llr_score = llrbest;
+    row->llr_start = llrstart;
+    row->llr_end = llrstart < 0 ? -2 : llrstart + (int)c - 1;
+    {
+        const double meanhydro = (1.0 * hydsum) / (double)(int)n;
+        const double meancharge = (1.0 * (double)chg) / (double)(int)n;
+        row->fi_meanhydro = meanhydro;
+        row->fi_meancharge = meancharge;
+        row->fi_meancombo = (T->cc[2] + T->cc[1] * fabs(meancharge)) + T->cc[0] * meanhydro; // :4885
+    }
+
+    // ---------------- pass 2: traceback t = n-1 .. 0 (:3111-3113), longest run (:1787-1804) ----
+    {
+        // (track mode) backward recurrence and posteriors run in the same reverse sweep (:3377-3405)
+        double b0 = lf0, b1 = lf1, lpseq = 0.0;
+        if (TRACKS) {
+            // lpseq needs b[.][0], i.e. a full backward sweep first
+            double q0 = lf0, q1 = lf1;
+            for (uint32_t t = n - 1; t >= 1; --t) {
+                const double *__restrict__ r = s_row + ld_code(x, t) * R_W;
+                const double u0 = (lt00 + q0) + r[R_LE0], u1 = (lt01 + q1) + r[R_LE1];
+                const double w0 = (lt10 + q0) + r[R_LE0], w1 = (lt11 + q1) + r[R_LE1];
+                q0 = lse_lut(s_lut, u0, u1);
+                q1 = lse_lut(s_lut, w0, w1);
+            }
+            lpseq = lse_lut(s_lut, fwd[2 * off] + q0, fwd[2 * off + 1] + q1);
+        }
+        int cur = 0, maxrun = 0;
+        uint32_t vw = 0; // Viterbi-path bits of the current 16-residue word
+        uint32_t word = wbits[(n - 1) >> 4];
+        for (uint32_t t = n - 1;; --t) {
+            // here `state` = vit[t]
+            vw |= state << (t & 15u);
+            cur = state ? cur + 1 : 0;
+            maxrun = cur > maxrun ? cur : maxrun;
+            if (TRACKS) {
+                const double fa0 = fwd[2 * (off + t)], fa1 = fwd[2 * (off + t) + 1];
+                const double pp0 = exp((fa0 + b0) - lpseq), pp1 = exp((fa1 + b1) - lpseq);
+                tr.post0[off + t] = pp0;
+                tr.post1[off + t] = pp1;
+                tr.map[off + t] = pp1 > pp0 ? 1 : 0; // MAP ties -> 0 (:4039)
+                tr.vit[off + t] = (uint8_t)state;
+                if (t > 0) {
+                    const double *__restrict__ r = s_row + ld_code(x, t) * R_W;
+                    const double u0 = (lt00 + b0) + r[R_LE0], u1 = (lt01 + b1) + r[R_LE1];
+                    const double w0 = (lt10 + b0) + r[R_LE0], w1 = (lt11 + b1) + r[R_LE1];
+                    b0 = lse_lut(s_lut, u0, u1);
+                    b1 = lse_lut(s_lut, w0, w1);
+                }
+            }
+            const uint32_t tbits = (word >> (2u * (t & 15u))) & 3u;
+            const uint32_t prev = (tbits >> state) & 1u; // tb[vit[t]][t]
+            if ((t & 15u) == 0u) {
+                wbits[t >> 4] = vw; // this word now holds vit[16j..16j+15]
+                vw = 0;
+                if (t == 0) break;
+                word = wbits[(t - 1) >> 4];
+            }
+            state = prev;
+        }
+        row->vit_maxrun = maxrun;
+    }
+
+    // ---------------- pass 3: masked core window + PRD (:818-880) ---------------------------
+    {
+        const double big_neg = T->big_neg;
+        double mL = 0.0, mT = 0.0, best = -INFINITY;
+        int bstart = -1;
+        bool inrun = false, flag = false;
+        int runstart = 0, prds = -1, prde = -2;
+        double runsum = 0.0, prdsum = 0.0;
+        uint32_t wl = 0, wt_ = 0;
+        for (uint32_t t = 0; t < n; ++t) {
+            if ((t & 15u) == 0u) wl = wbits[t >> 4];
+            const uint32_t v = (wl >> (t & 15u)) & 1u;
+            const double lv = s_row[ld_code(x, t) * R_W + R_LLR];
+            mL = mL + (v ? lv : big_neg);
+            if (t >= c) {
+                const uint32_t to = t - c;
+                if ((to & 15u) == 0u || t == c) wt_ = wbits[to >> 4];
+                const uint32_t vo = (wt_ >> (to & 15u)) & 1u;
+                mT = mT + (vo ? s_row[ld_code(x, to) * R_W + R_LLR] : big_neg);
+            }
+            // run bookkeeping: PRD = maximal Viterbi run around the core, PRDscore = its left-to-right sum
+            if (v) {
+                if (!inrun) {
+                    inrun = true;
+                    runstart = (int)t;
+                    runsum = 0.0;
+                    flag = false;
+                }
+                runsum = runsum + lv;
+            } else if (inrun) {
+                if (flag) {
+                    prds = runstart;
+                    prde = (int)t - 1;
+                    prdsum = runsum;
+                }
+                inrun = false;
+            }
+            if (t + 1 >= c) {
+                const double d = (t + 1 == c) ? mL : mL - mT;
+                if (t + 1 == c || d > best) {
+                    best = d;
+                    bstart = (int)(t + 1 - c);
+                    flag = v != 0u;
+                }
+            }
+        }
+        if (inrun && flag) {
+            prds = runstart;
+            prde = (int)n - 1;
+            prdsum = runsum;
+        }
+        if (best > big_neg / 2) { // :861
+            row->core_score = best;
+            row->core_start = bstart;
+            row->core_end = bstart + (int)c - 1;
+            row->prd_score = prdsum;
+            row->prd_start = prds;
+            row->prd_end = prde;
+        } else { // :873-880
+            row->core_score = __builtin_nan("");
+            row->core_start = -1;
+            row->core_end = -2;
+            row->prd_score = 0.0;
+            row->prd_start = -1;
+            row->prd_end = -2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-B: one wave per protein — window tracks (disorderreport :4866-5068)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// sum over p in [i-w, i+w] of min(p, w) for i >= w  (weights of the second smoothing, exact integers)
+__device__ __forceinline__ int sum_min_left(int i, int w) {
+    // p < w contributes p, otherwise w
+    if (i - w >= w) return (2 * w + 1) * w;
+    const int lo = i - w;            // first p
+    const int cnt = w - lo;          // p = lo .. w-1
+    const int s = (lo + (w - 1)) * cnt / 2;
+    return s + (2 * w + 1 - cnt) * w;
+}
+
+template <int RING, bool TRACKS>
+__global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets,
+                                               const uint32_t *__restrict__ neff,
+                                               const uint32_t *__restrict__ order, uint32_t nprot,
+                                               const DevTables *__restrict__ T, plaac_row *__restrict__ rows,
+                                               TrackPtrs tr) {
+    constexpr int M = RING - 1;
+    __shared__ double t_hyd[NAA], t_llr[NAA], t_lod[NAA];
+    __shared__ int t_chg[NAA];
+    __shared__ double in_h[RING], in_l[RING], in_p[RING];   // mapped inputs, 0.0 outside [0,n)
+    __shared__ int in_c[RING];                               // charge as integer
+    __shared__ double w_fi[RING], w_ll[RING], w_pa[RING];    // weight * first-level track
+    __shared__ double r_ll[RING];                            // first-level PLAAC-LLR (for PAPAllr)
+
+    const int lane = threadIdx.x;
+    const uint32_t p = order[blockIdx.x];
+    const int n = (int)neff[p];
+    plaac_row *row = rows + p;
+    if (n == 0) {
+        if (lane == 0) {
+            row->papa_combo = row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = 0.0;
+            row->fi_numaa = row->fi_maxrun = row->papa_cen = 0;
+        }
+        return;
+    }
+    if (lane < NAA) {
+        t_hyd[lane] = T->hyd[lane];
+        t_llr[lane] = T->llr[lane];
+        t_lod[lane] = T->lod[lane];
+        t_chg[lane] = T->chg[lane];
+    }
+    for (int i = lane; i < RING; i += 64) {
+        in_h[i] = 0.0;
+        in_l[i] = 0.0;
+        in_p[i] = 0.0;
+        in_c[i] = 0;
+        w_fi[i] = 0.0;
+        w_ll[i] = 0.0;
+        w_pa[i] = 0.0;
+        r_ll[i] = 0.0;
+    }
+    const uint64_t off = offsets[p];
+    const uint8_t *__restrict__ x = codes + off;
+    const int ww1 = T->ww1, ww2 = T->ww2, ww3 = T->ww3;
+    // w = ww/2 clamped to n-1 (:2588-2589)
+    const int w1 = imin(ww1 / 2, n - 1), w2 = imin(ww2 / 2, n - 1), w3 = imin(ww3 / 2, n - 1);
+    const int wm = imax(w1, imax(w2, w3));
+    const bool adjust = T->adjustprolines != 0;
+    const double cc0 = T->cc[0], cc1 = T->cc[1], cc2 = T->cc[2];
+    // FoldIndex run scan domain (:5010-5013) and PAPA centre range (:4942)
+    int halfw = (ww1 - 1) / 2;
+    if (halfw > n / 2) halfw = n / 2;
+    const int dlo = halfw, dhi = n - halfw - 1;
+    const int plo = (ww2 - 1) / 2, phi = n - (ww2 - 1) / 2; // k in [plo, phi)
+
+    // per-lane PAPA arg-max state (positions visited in increasing order -> strict > keeps the first max)
+    double pbest = -INFINITY, pfi = 0.0, pll = 0.0, pll2 = 0.0;
+    int pcen = -1;
+    // wave-uniform FoldIndex run state
+    bool run_open = false;
+    int run_start = 0, numaa = 0, maxlen = 0;
+    auto close_run = [&](int s, int e) {
+        if (s == dlo) s = 0;
+        if (e == dhi) e = n - 1;
+        const int len = e - s + 1;
+        if (len >= 5) {
+            numaa += len;
+            maxlen = len > maxlen ? len : maxlen;
+        }
+    };
+    __syncthreads();
+
+    const int nchunks = (n + 2 * wm + 63) / 64;
+    for (int k = 0; k < nchunks; ++k) {
+        // ---- stage 0: residues -> mapped inputs at q = 64k + lane
+        {
+            const int q = 64 * k + lane;
+            double vh = 0.0, vl = 0.0, vp = 0.0;
+            int vc = 0;
+            if (q < n) {
+                const uint32_t cq = ld_code(x, (uint32_t)q);
+                vh = t_hyd[cq];
+                vl = t_llr[cq];
+                vc = t_chg[cq];
+                bool skip = false;
+                if (adjust && cq == 13u) { // only the first P of PP / PxP scores (:2653-2654)
+                    skip = (q >= 1 && ld_code(x, (uint32_t)(q - 1)) == 13u) ||
+                           (q >= 2 && ld_code(x, (uint32_t)(q - 2)) == 13u);
+                }
+                vp = skip ? 0.0 : t_lod[cq];
+            }
+            in_h[q & M] = vh;
+            in_l[q & M] = vl;
+            in_p[q & M] = vp;
+            in_c[q & M] = vc;
+        }
+        __syncthreads();
+        // ---- stage 1: first-level tracks at i = 64k + lane - wm
+        {
+            const int i = 64 * k + lane - wm;
+            const bool live = i >= 0 && i < n;
+            bool neg = false;
+            if (live) {
+                double sh = 0.0, sl = 0.0, sp = 0.0;
+                int sc = 0;
+                for (int j = -w1; j <= w1; ++j) {
+                    sh = sh + in_h[(i + j) & M];
+                    sc += in_c[(i + j) & M];
+                }
+                for (int j = -w3; j <= w3; ++j) sl = sl + in_l[(i + j) & M];
+                for (int j = -w2; j <= w2; ++j) sp = sp + in_p[(i + j) & M];
+                const double d1 = (double)(imin(i + w1, n - 1) - imax(i - w1, 0) + 1);
+                const double d2 = (double)(imin(i + w2, n - 1) - imax(i - w2, 0) + 1);
+                const double d3 = (double)(imin(i + w3, n - 1) - imax(i - w3, 0) + 1);
+                const double hydro = sh / d1;
+                const double charge = (double)sc / d1;
+                const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
+                const double llr1 = sl / d3;
+                const double papa = sp / d2;
+                const double wt1 = (double)(1 + imin(i, w1) + imin(n - i - 1, w1));
+                const double wt2 = (double)(1 + imin(i, w2) + imin(n - i - 1, w2));
+                const double wt3 = (double)(1 + imin(i, w3) + imin(n - i - 1, w3));
+                w_fi[i & M] = wt1 * fi;
+                w_pa[i & M] = wt2 * papa;
+                w_ll[i & M] = wt3 * llr1;
+                r_ll[i & M] = llr1;
+                neg = (fi < 0.0) && i >= dlo && i <= dhi;
+                if (TRACKS) {
+                    tr.charge[off + i] = charge;
+                    tr.hydro[off + i] = hydro;
+                    tr.fi[off + i] = fi;
+                    tr.plaacllr[off + i] = llr1;
+                    tr.papa[off + i] = papa;
+                }
+            }
+            // FoldIndex<0 runs (:5020-5058): ballot -> wave-uniform run-length machine
+            unsigned long long m = __ballot(neg);
+            const int base = 64 * k - wm;
+            if (run_open) {
+                const int t1 = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
+                if (t1 < 64) {
+                    close_run(run_start, base + t1 - 1);
+                    run_open = false;
+                    m &= ~((1ull << t1) - 1ull);
+                } else {
+                    m = 0ull;
+                }
+            }
+            while (m) {
+                const int s = __builtin_ctzll(m);
+                const unsigned long long rest = ~(m >> s);
+                const int len = rest == 0ull ? 64 - s : __builtin_ctzll(rest);
+                if (s + len >= 64) {
+                    run_open = true;
+                    run_start = base + s;
+                    break;
+                }
+                close_run(base + s, base + s + len - 1);
+                m &= ~(((1ull << len) - 1ull) << s);
+            }
+        }
+        __syncthreads();
+        // ---- stage 2: weighted second smoothing at i = 64k + lane - 2*wm, PAPA arg-max
+        {
+            const int i = 64 * k + lane - 2 * wm;
+            if (i >= 0 && i < n) {
+                double fix2 = __builtin_nan(""), llx2 = __builtin_nan(""), pax2 = __builtin_nan("");
+                if (i >= w1 && i <= n - w1 - 1) {
+                    double s = 0.0;
+                    for (int j = -w1; j <= w1; ++j) s = s + w_fi[(i + j) & M];
+                    const int den = (2 * w1 + 1) + sum_min_left(i, w1) + sum_min_left(n - 1 - i, w1);
+                    fix2 = s / (double)den;
+                }
+                if (i >= w3 && i <= n - w3 - 1) {
+                    double s = 0.0;
+                    for (int j = -w3; j <= w3; ++j) s = s + w_ll[(i + j) & M];
+                    const int den = (2 * w3 + 1) + sum_min_left(i, w3) + sum_min_left(n - 1 - i, w3);
+                    llx2 = s / (double)den;
+                }
+                if (i >= w2 && i <= n - w2 - 1) {
+                    double s = 0.0;
+                    for (int j = -w2; j <= w2; ++j) s = s + w_pa[(i + j) & M];
+                    const int den = (2 * w2 + 1) + sum_min_left(i, w2) + sum_min_left(n - 1 - i, w2);
+                    pax2 = s / (double)den;
+                }
+                if (TRACKS) {
+                    tr.fix2[off + i] = fix2;
+                    tr.plaacllrx2[off + i] = llx2;
+                    tr.papax2[off + i] = pax2;
+                }
+                if (i >= plo && i < phi && (pax2 > pbest) && (fix2 < 0.0)) { // papamode 1 (:4942-4948)
+                    pbest = pax2;
+                    pcen = i;
+                    pfi = fix2;
+                    pll2 = llx2;
+                    pll = r_ll[i & M];
+                }
+            }
+        }
+        // the next iteration's stage 0 only overwrites ring slots that no later read needs
+    }
+    if (run_open) close_run(run_start, dhi);
+
+    // wave arg-max: largest papax2, smallest centre among equals (first max of the serial loop)
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double ob = __shfl_xor(pbest, d);
+        const int oc = __shfl_xor(pcen, d);
+        const double ofi = __shfl_xor(pfi, d), oll = __shfl_xor(pll, d), oll2 = __shfl_xor(pll2, d);
+        const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
+        if (take) {
+            pbest = ob;
+            pcen = oc;
+            pfi = ofi;
+            pll = oll;
+            pll2 = oll2;
+        }
+    }
+    if (lane == 0) {
+        row->fi_numaa = numaa;
+        row->fi_maxrun = maxlen;
+        row->papa_cen = pcen;
+        if (pcen >= 0) {
+            row->papa_combo = pbest;
+            row->papa_prop = pbest;
+            row->papa_fi = pfi;
+            row->papa_llr = pll;
+            row->papa_llr2 = pll2;
+        } else {
+            row->papa_combo = -INFINITY;
+            row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// histogram over valid records (:1698-1706, :1732-1739); one wave per record, grid-stride
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hist(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets,
+                                              uint32_t nprot, unsigned long long *__restrict__ counts) {
+    __shared__ unsigned int s_cnt[4][NAA + 2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = lane; i < NAA + 2; i += 64) s_cnt[wave][i] = 0;
+    unsigned long long acc = 0; // lane k (< 22) accumulates bin k for this wave
+    const uint32_t nw = gridDim.x * 4u;
+    for (uint32_t p = blockIdx.x * 4u + wave; p < nprot; p += nw) {
+        const uint64_t b = offsets[p], e = offsets[p + 1];
+        if (e <= b) continue;
+        const uint64_t m = e - b;
+        const uint8_t *__restrict__ x = codes + b;
+        // validity: no X/* strictly inside, last residue not X (position 0 is not checked)
+        bool bad = false;
+        for (uint64_t i = lane; i < m; i += 64) {
+            const uint32_t cq = ld_code(x, (uint32_t)i);
+            if (i >= 1 && i + 1 < m && (cq == 0u || cq == 21u)) bad = true;
+            if (i + 1 == m && cq == 0u) bad = true;
+        }
+        if (__ballot(bad) != 0ull) continue;
+        for (uint64_t i = lane; i < m; i += 64) atomicAdd(&s_cnt[wave][ld_code(x, (uint32_t)i)], 1u);
+        // flush per record so the 32-bit LDS bins cannot overflow
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < NAA) {
+            acc += s_cnt[wave][lane];
+            s_cnt[wave][lane] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane < NAA && acc) atomicAdd(&counts[lane], acc);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI — device half
+// ------------------------------------------------------------------------------------------------
+struct plaac_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevTables *d_tab = nullptr;
+    plaac_params params;
+    // plan / scratch buffers (grown on demand)
+    uint32_t *d_neff = nullptr, *d_order = nullptr, *d_hist = nullptr, *d_bits = nullptr;
+    double *d_fwd = nullptr;
+    size_t cap_prot = 0, cap_bits = 0, cap_fwd = 0;
+    // staging for the host-buffer entry points
+    uint8_t *d_codes = nullptr;
+    uint64_t *d_offsets = nullptr;
+    plaac_row *d_rows = nullptr;
+    uint8_t *d_trk8 = nullptr;
+    double *d_trk64 = nullptr;
+    unsigned long long *d_counts = nullptr;
+    size_t cap_codes = 0, cap_offs = 0, cap_rows = 0, cap_trk = 0;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+#define PL_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return e_ == hipErrorOutOfMemory ? PLAAC_ERR_NOMEM : PLAAC_ERR_DEVICE;                     \
+        }                                                                                              \
+    } while (0)
+
+plaac_status fail(plaac_ctx *ctx, plaac_status st, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return st;
+}
+
+void fill_tables(const plaac_params &P, DevTables &D) {
+    std::memset(&D, 0, sizeof D);
+    for (int k = 0; k < NAA; ++k) {
+        D.row[k][R_LE0] = P.hmm1.le[0][k];
+        D.row[k][R_LE1] = P.hmm1.le[1][k];
+        D.row[k][R_LLR] = P.llr[k];
+        D.row[k][R_HYD] = P.hydro2[k];
+        D.row[k][R_LE0H] = P.hmm0.le[0][k];
+        D.lod[k] = P.lodpapa[k];
+        D.hyd[k] = P.hydro2[k];
+        D.llr[k] = P.llr[k];
+        D.chg[k] = (int32_t)P.charge[k];
+    }
+    for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j) D.lt[i][j] = P.hmm1.lt[i][j];
+        D.li[i] = P.hmm1.li[i];
+        D.lf[i] = P.hmm1.lf[i];
+    }
+    D.h0_lt00 = P.hmm0.lt[0][0];
+    D.h0_li0 = P.hmm0.li[0];
+    D.h0_lf0 = P.hmm0.lf[0];
+    for (int i = 0; i < 3; ++i) D.cc[i] = P.cc[i];
+    D.big_neg = P.big_neg;
+    D.corelength = P.corelength;
+    D.ww1 = P.ww1;
+    D.ww2 = P.ww2;
+    D.ww3 = P.ww3;
+    D.adjustprolines = P.adjustprolines;
+    std::memcpy(D.loglut, P.loglut, sizeof D.loglut);
+}
+
+// The kernels exploit the structure of the reference's two models; refuse anything else loudly.
+const char *check_params(const plaac_params &P) {
+    if (P.corelength < 1) return "corelength must be >= 1";
+    if (P.ww1 < 1 || P.ww2 < 1 || P.ww3 < 1) return "window sizes must be >= 1";
+    if (P.ww1 / 2 > 256 || P.ww2 / 2 > 256 || P.ww3 / 2 > 256) return "window sizes above 513 are not supported";
+    for (int k = 0; k < NAA; ++k) {
+        if (!(std::isfinite(P.hmm1.le[0][k]) && std::isfinite(P.hmm1.le[1][k]) && std::isfinite(P.hmm0.le[0][k])))
+            return "hmm emission log-probabilities must be finite";
+        if (P.charge[k] != -1.0 && P.charge[k] != 0.0 && P.charge[k] != 1.0) return "charge table must be -1/0/1";
+    }
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (!std::isfinite(P.hmm1.lt[i][j])) return "hmm1 transitions must be finite in log space";
+    // hmm0 must be the identity-transition null model started in state 0 (prionhmm0, :988-1001)
+    if (!(P.hmm0.lt[0][1] == -INFINITY && P.hmm0.lt[1][0] == -INFINITY && P.hmm0.li[1] == -INFINITY &&
+          std::isfinite(P.hmm0.lt[0][0]) && std::isfinite(P.hmm0.li[0]) && std::isfinite(P.hmm0.lf[0])))
+        return "hmm0 must be the single-state null model";
+    return nullptr;
+}
+
+template <class Tp>
+plaac_status grow(plaac_ctx *ctx, Tp *&ptr, size_t &cap, size_t need) {
+    if (need <= cap && ptr) return PLAAC_OK;
+    if (ptr) PL_HIP(ctx, hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    size_t want = need + need / 8 + 64;
+    PL_HIP(ctx, hipMalloc((void **)&ptr, want * sizeof(Tp)));
+    cap = want;
+    return PLAAC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *plaac_last_error(const plaac_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_ctx **out) {
+    if (!params || !out) {
+        g_create_err = "plaac_ctx_create: null argument";
+        return PLAAC_ERR_ARG;
+    }
+    *out = nullptr;
+    if (const char *why = check_params(*params)) {
+        g_create_err = why;
+        return PLAAC_ERR_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count=0");
+        return PLAAC_ERR_DEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_create_err = "device_id out of range";
+        return PLAAC_ERR_ARG;
+    }
+    plaac_ctx *ctx = new (std::nothrow) plaac_ctx();
+    if (!ctx) {
+        g_create_err = "out of host memory";
+        return PLAAC_ERR_NOMEM;
+    }
+    ctx->device = device_id;
+    ctx->params = *params;
+    auto bail = [&](const char *what, hipError_t err) {
+        g_create_err = std::string(what) + ": " + hipGetErrorString(err);
+        plaac_ctx_destroy(ctx);
+        return PLAAC_ERR_DEVICE;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        plaac_ctx_destroy(ctx);
+        return PLAAC_ERR_DEVICE;
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    for (auto &ev : ctx->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc((void **)&ctx->d_tab, sizeof(DevTables))) != hipSuccess) return bail("hipMalloc(tables)", e);
+    if ((e = hipMalloc((void **)&ctx->d_hist, sizeof(uint32_t) * LEN_BINS)) != hipSuccess)
+        return bail("hipMalloc(hist)", e);
+    if ((e = hipMalloc((void **)&ctx->d_counts, sizeof(unsigned long long) * NAA)) != hipSuccess)
+        return bail("hipMalloc(counts)", e);
+    plaac_status st = plaac_ctx_set_params(ctx, params);
+    if (st != PLAAC_OK) {
+        g_create_err = ctx->err;
+        plaac_ctx_destroy(ctx);
+        return st;
+    }
+    *out = ctx;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_ctx_set_params(plaac_ctx *ctx, const plaac_params *params) {
+    if (!ctx || !params) return fail(ctx, PLAAC_ERR_ARG, "plaac_ctx_set_params: null argument");
+    if (const char *why = check_params(*params)) return fail(ctx, PLAAC_ERR_ARG, why);
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    DevTables *h = new (std::nothrow) DevTables();
+    if (!h) return fail(ctx, PLAAC_ERR_NOMEM, "out of host memory");
+    fill_tables(*params, *h);
+    // previous work on the ctx stream may still read the old tables
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tab, h, sizeof(DevTables), hipMemcpyHostToDevice);
+    delete h;
+    if (e != hipSuccess) {
+        ctx->err = std::string("table upload: ") + hipGetErrorString(e);
+        return PLAAC_ERR_DEVICE;
+    }
+    ctx->params = *params;
+    return PLAAC_OK;
+}
+
+void plaac_ctx_destroy(plaac_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    void *bufs[] = {ctx->d_tab,  ctx->d_neff,    ctx->d_order, ctx->d_hist, ctx->d_bits,  ctx->d_fwd,   ctx->d_codes,
+                    ctx->d_offsets, ctx->d_rows, ctx->d_trk8,  ctx->d_trk64, ctx->d_counts};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto &ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+plaac_status plaac_ctx_sync(plaac_ctx *ctx) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PLAAC_OK;
+}
+
+plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,
+                                uint64_t total_residues, plaac_row *d_rows, const plaac_tracks *d_tracks,
+                                void *stream_) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (nprot == 0) return PLAAC_OK;
+    if (!d_offsets || !d_rows || (!d_codes && total_residues)) return fail(ctx, PLAAC_ERR_ARG, "null device buffer");
+    TrackPtrs tp{};
+    if (d_tracks) {
+        tp = TrackPtrs{d_tracks->vit,   d_tracks->map,  d_tracks->charge,     d_tracks->hydro,
+                       d_tracks->fi,    d_tracks->plaacllr, d_tracks->papa,   d_tracks->fix2,
+                       d_tracks->plaacllrx2, d_tracks->papax2, d_tracks->post0, d_tracks->post1};
+        const void *all[] = {tp.vit, tp.map, tp.charge, tp.hydro, tp.fi, tp.plaacllr,
+                             tp.papa, tp.fix2, tp.plaacllrx2, tp.papax2, tp.post0, tp.post1};
+        for (const void *q : all)
+            if (!q) return fail(ctx, PLAAC_ERR_ARG, "tracks struct has a null array");
+    }
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+
+    plaac_status rc;
+    if ((rc = grow(ctx, ctx->d_neff, ctx->cap_prot, (size_t)nprot)) != PLAAC_OK) return rc;
+    {
+        size_t dummy = ctx->d_order ? ctx->cap_prot : 0;
+        if (!ctx->d_order || dummy < nprot) {
+            if (ctx->d_order) PL_HIP(ctx, hipFree(ctx->d_order));
+            ctx->d_order = nullptr;
+            PL_HIP(ctx, hipMalloc((void **)&ctx->d_order, ctx->cap_prot * sizeof(uint32_t)));
+        }
+    }
+    if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, (size_t)(total_residues / 16 + nprot + 2))) != PLAAC_OK) return rc;
+    if (d_tracks)
+        if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, (size_t)(2 * total_residues + 2))) != PLAAC_OK) return rc;
+
+    const int wmax = std::max(ctx->params.ww1 / 2, std::max(ctx->params.ww2 / 2, ctx->params.ww3 / 2));
+
+    PL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * LEN_BINS, st));
+    const unsigned pb = (nprot + 255u) / 256u;
+    hipLaunchKernelGGL(k_plan_lengths, dim3(pb), dim3(256), 0, st, d_codes, d_offsets, nprot, ctx->d_neff, ctx->d_hist);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ctx->d_hist);
+    hipLaunchKernelGGL(k_plan_scatter, dim3(pb), dim3(256), 0, st, ctx->d_neff, nprot, ctx->d_hist, ctx->d_order);
+    PL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+    const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
+    if (d_tracks)
+        hipLaunchKernelGGL(k_recur<true>, dim3(ab), dim3(KA_THREADS), 0, st, d_codes, d_offsets, ctx->d_neff,
+                           ctx->d_order, nprot, ctx->d_tab, ctx->d_bits, d_rows, tp, ctx->d_fwd);
+    else
+        hipLaunchKernelGGL(k_recur<false>, dim3(ab), dim3(KA_THREADS), 0, st, d_codes, d_offsets, ctx->d_neff,
+                           ctx->d_order, nprot, ctx->d_tab, ctx->d_bits, d_rows, tp, (double *)nullptr);
+    PL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+#define LAUNCH_KB(RING)                                                                                            \
+    do {                                                                                                           \
+        if (d_tracks)                                                                                              \
+            hipLaunchKernelGGL((k_tracks<RING, true>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,           \
+                               ctx->d_neff, ctx->d_order, nprot, ctx->d_tab, d_rows, tp);                          \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,          \
+                               ctx->d_neff, ctx->d_order, nprot, ctx->d_tab, d_rows, tp);                          \
+    } while (0)
+    if (wmax <= 32) LAUNCH_KB(128);
+    else if (wmax <= 96) LAUNCH_KB(256);
+    else LAUNCH_KB(1024);
+#undef LAUNCH_KB
+    PL_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+    PL_HIP(ctx, hipGetLastError());
+    ctx->timed = true;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[4]) {
+    if (!ctx || !ms) return PLAAC_ERR_ARG;
+    if (!ctx->timed) return fail(ctx, PLAAC_ERR_ARG, "no scored batch to time yet");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PL_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+    PL_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[3]));
+    PL_HIP(ctx, hipEventElapsedTime(&ms[1], ctx->ev[0], ctx->ev[1]));
+    PL_HIP(ctx, hipEventElapsedTime(&ms[2], ctx->ev[1], ctx->ev[2]));
+    PL_HIP(ctx, hipEventElapsedTime(&ms[3], ctx->ev[2], ctx->ev[3]));
+    return PLAAC_OK;
+}
+
+plaac_status plaac_histogram_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
+                                    uint32_t nprot, int64_t *d_counts, void *stream_) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (!d_counts || (nprot && (!d_codes || !d_offsets))) return fail(ctx, PLAAC_ERR_ARG, "null device buffer");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    PL_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int64_t) * NAA, st));
+    if (nprot) {
+        unsigned blocks = (nprot + 3u) / 4u;
+        if (blocks > 256u * 16u) blocks = 256u * 16u;
+        hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(256), 0, st, d_codes, d_offsets, nprot,
+                           (unsigned long long *)d_counts);
+        PL_HIP(ctx, hipGetLastError());
+    }
+    return PLAAC_OK;
+}
+
+static plaac_status stage_in(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                             uint64_t *total_out) {
+    if (!offsets) return fail(ctx, PLAAC_ERR_ARG, "null offsets");
+    if (offsets[0] != 0) return fail(ctx, PLAAC_ERR_ARG, "offsets[0] must be 0");
+    for (uint32_t p = 0; p < nprot; ++p)
+        if (offsets[p + 1] < offsets[p]) return fail(ctx, PLAAC_ERR_ARG, "offsets must be non-decreasing");
+    const uint64_t total = offsets[nprot];
+    if (total && !codes) return fail(ctx, PLAAC_ERR_ARG, "null codes");
+    for (uint64_t i = 0; i < total; ++i)
+        if (codes[i] > 21) return fail(ctx, PLAAC_ERR_ARG, "residue code > 21");
+    plaac_status rc;
+    if ((rc = grow(ctx, ctx->d_codes, ctx->cap_codes, (size_t)total + 16)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, ctx->d_offsets, ctx->cap_offs, (size_t)nprot + 1)) != PLAAC_OK) return rc;
+    if (total) PL_HIP(ctx, hipMemcpyAsync(ctx->d_codes, codes, total, hipMemcpyHostToDevice, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, sizeof(uint64_t) * ((size_t)nprot + 1), hipMemcpyHostToDevice,
+                               ctx->stream));
+    *total_out = total;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_histogram(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                             int64_t counts[PLAAC_NAA]) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (!counts) return fail(ctx, PLAAC_ERR_ARG, "null counts");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t total = 0;
+    plaac_status rc = stage_in(ctx, codes, offsets, nprot, &total);
+    if (rc != PLAAC_OK) return rc;
+    rc = plaac_histogram_device(ctx, ctx->d_codes, ctx->d_offsets, nprot, (int64_t *)ctx->d_counts, ctx->stream);
+    if (rc != PLAAC_OK) return rc;
+    PL_HIP(ctx, hipMemcpyAsync(counts, ctx->d_counts, sizeof(int64_t) * NAA, hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PLAAC_OK;
+}
+
+plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                         plaac_row *rows, const plaac_tracks *tracks) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (nprot == 0) return PLAAC_OK;
+    if (!rows) return fail(ctx, PLAAC_ERR_ARG, "null rows");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t total = 0;
+    plaac_status rc = stage_in(ctx, codes, offsets, nprot, &total);
+    if (rc != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, ctx->d_rows, ctx->cap_rows, (size_t)nprot)) != PLAAC_OK) return rc;
+    plaac_tracks dt{};
+    if (tracks) {
+        const size_t need = (size_t)total + 8;
+        if (need > ctx->cap_trk || !ctx->d_trk8) {
+            if (ctx->d_trk8) PL_HIP(ctx, hipFree(ctx->d_trk8));
+            if (ctx->d_trk64) PL_HIP(ctx, hipFree(ctx->d_trk64));
+            ctx->d_trk8 = nullptr;
+            ctx->d_trk64 = nullptr;
+            ctx->cap_trk = 0;
+            PL_HIP(ctx, hipMalloc((void **)&ctx->d_trk8, 2 * need));
+            PL_HIP(ctx, hipMalloc((void **)&ctx->d_trk64, 10 * need * sizeof(double)));
+            ctx->cap_trk = need;
+        }
+        const size_t s = ctx->cap_trk;
+        dt.vit = ctx->d_trk8;
+        dt.map = ctx->d_trk8 + s;
+        double *b = ctx->d_trk64;
+        dt.charge = b;
+        dt.hydro = b + s;
+        dt.fi = b + 2 * s;
+        dt.plaacllr = b + 3 * s;
+        dt.papa = b + 4 * s;
+        dt.fix2 = b + 5 * s;
+        dt.plaacllrx2 = b + 6 * s;
+        dt.papax2 = b + 7 * s;
+        dt.post0 = b + 8 * s;
+        dt.post1 = b + 9 * s;
+        // entries of trimmed stops are "left untouched": start from the caller's bytes
+        PL_HIP(ctx, hipMemsetAsync(ctx->d_trk8, 0, 2 * s, ctx->stream));
+        PL_HIP(ctx, hipMemsetAsync(ctx->d_trk64, 0xff, 10 * s * sizeof(double), ctx->stream));
+    }
+    rc = plaac_score_device(ctx, ctx->d_codes, ctx->d_offsets, nprot, total, ctx->d_rows, tracks ? &dt : nullptr,
+                            ctx->stream);
+    if (rc != PLAAC_OK) return rc;
+    PL_HIP(ctx, hipMemcpyAsync(rows, ctx->d_rows, sizeof(plaac_row) * (size_t)nprot, hipMemcpyDeviceToHost, ctx->stream));
+    if (tracks && total) {
+        const size_t nb = (size_t)total;
+        uint8_t *h8[2] = {tracks->vit, tracks->map};
+        uint8_t *d8[2] = {dt.vit, dt.map};
+        for (int i = 0; i < 2; ++i) PL_HIP(ctx, hipMemcpyAsync(h8[i], d8[i], nb, hipMemcpyDeviceToHost, ctx->stream));
+        double *hd[10] = {tracks->charge, tracks->hydro,      tracks->fi,     tracks->plaacllr, tracks->papa,
+                          tracks->fix2,   tracks->plaacllrx2, tracks->papax2, tracks->post0,    tracks->post1};
+        double *dd[10] = {dt.charge, dt.hydro, dt.fi, dt.plaacllr, dt.papa, dt.fix2, dt.plaacllrx2, dt.papax2, dt.post0,
+                          dt.post1};
+        for (int i = 0; i < 10; ++i) {
+            if (!hd[i]) return fail(ctx, PLAAC_ERR_ARG, "tracks struct has a null array");
+            PL_HIP(ctx, hipMemcpyAsync(hd[i], dd[i], nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PLAAC_OK;
+}
+
+} // extern "C"

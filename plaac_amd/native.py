@@ -1,0 +1,243 @@
+"""ctypes binding of the C ABI in include/plaac_native.h (libplaac_native.so).
+
+This is the host-side mirror used by tests, bench.py and the Python tooling. It contains no
+arithmetic of its own: every number comes out of the HIP kernels behind the C ABI. There is no
+CPU fallback; if the shared library is missing or no gfx950 device is usable the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplaac_native.so")
+
+NAA = 22
+LUTLEN = 4001
+ABI_VERSION = 1
+
+PLAAC_OK, PLAAC_ERR_ARG, PLAAC_ERR_DEVICE, PLAAC_ERR_NOMEM, PLAAC_ERR_IO = range(5)
+
+
+class PlaacError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("plaac_native status %d: %s" % (status, msg))
+        self.status = status
+
+
+class Hmm(C.Structure):
+    _fields_ = [("lt", (C.c_double * 2) * 2), ("li", C.c_double * 2), ("le", (C.c_double * NAA) * 2),
+                ("lf", C.c_double * 2)]
+
+
+class Params(C.Structure):
+    """plaac_params"""
+    _fields_ = [("corelength", C.c_int32), ("ww1", C.c_int32), ("ww2", C.c_int32), ("ww3", C.c_int32),
+                ("adjustprolines", C.c_int32), ("reserved_", C.c_int32), ("alpha", C.c_double),
+                ("cc", C.c_double * 3), ("big_neg", C.c_double),
+                ("fg", C.c_double * NAA), ("bgscer", C.c_double * NAA), ("bgthis", C.c_double * NAA),
+                ("bg", C.c_double * NAA), ("llr", C.c_double * NAA), ("lodpapa", C.c_double * NAA),
+                ("hydro2", C.c_double * NAA), ("charge", C.c_double * NAA), ("hmm1", Hmm), ("hmm0", Hmm),
+                ("loglut", C.c_double * LUTLEN)]
+
+
+ROW_DTYPE = np.dtype([
+    ("llr_score", "<f8"), ("core_score", "<f8"), ("prd_score", "<f8"), ("hmm_all", "<f8"), ("hmm_vit", "<f8"),
+    ("fi_meanhydro", "<f8"), ("fi_meancharge", "<f8"), ("fi_meancombo", "<f8"),
+    ("papa_combo", "<f8"), ("papa_prop", "<f8"), ("papa_fi", "<f8"), ("papa_llr", "<f8"), ("papa_llr2", "<f8"),
+    ("mw_score", "<i4"), ("mw_start", "<i4"), ("mw_end", "<i4"), ("llr_start", "<i4"), ("llr_end", "<i4"),
+    ("vit_maxrun", "<i4"), ("core_start", "<i4"), ("core_end", "<i4"), ("prd_start", "<i4"), ("prd_end", "<i4"),
+    ("prot_len", "<i4"), ("fi_numaa", "<i4"), ("fi_maxrun", "<i4"), ("papa_cen", "<i4"),
+])
+ROW_BYTES = 160
+assert ROW_DTYPE.itemsize == ROW_BYTES
+
+TRACK_U8 = ("vit", "map")
+TRACK_F64 = ("charge", "hydro", "fi", "plaacllr", "papa", "fix2", "plaacllrx2", "papax2", "post0", "post1")
+TRACK_BYTES_PER_RESIDUE = 2 + 8 * len(TRACK_F64)  # 82
+
+
+class Tracks(C.Structure):
+    """plaac_tracks"""
+    _fields_ = [(k, C.c_void_p) for k in TRACK_U8 + TRACK_F64]
+
+
+# every symbol include/plaac_native.h declares
+EXPORTS = (
+    "plaac_abi_version", "plaac_sizeof_params", "plaac_sizeof_row", "plaac_builtin_tables", "plaac_params_init",
+    "plaac_encode", "plaac_ctx_create", "plaac_ctx_set_params", "plaac_ctx_destroy", "plaac_last_error",
+    "plaac_histogram", "plaac_score", "plaac_score_device", "plaac_histogram_device", "plaac_ctx_sync",
+    "plaac_last_timings",
+)
+
+_lib = None
+
+
+def load():
+    """Load libplaac_native.so. Raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "plaac_amd: %s is missing - build the HIP extension first (`make` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+    if os.environ.get("PLAAC_AMD_NO_TORCH", "0") != "1":
+        # PyTorch bundles its own libamdhip64 (same soname). Loading torch FIRST makes this library bind
+        # to that one runtime, so device pointers and streams can be shared with torch tensors.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing, not a requirement
+            pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.plaac_abi_version.restype = C.c_int
+    L.plaac_sizeof_params.restype = C.c_size_t
+    L.plaac_sizeof_row.restype = C.c_size_t
+    if L.plaac_abi_version() != ABI_VERSION:
+        raise ImportError("plaac_amd: ABI version mismatch (%d != %d)" % (L.plaac_abi_version(), ABI_VERSION))
+    if L.plaac_sizeof_params() != C.sizeof(Params) or L.plaac_sizeof_row() != ROW_BYTES:
+        raise ImportError("plaac_amd: struct layout mismatch between native.py and plaac_native.h")
+    L.plaac_builtin_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.plaac_builtin_tables.restype = None
+    L.plaac_params_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int]
+    L.plaac_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+    L.plaac_encode.restype = None
+    L.plaac_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.plaac_ctx_set_params.argtypes = [C.c_void_p, C.c_void_p]
+    L.plaac_ctx_destroy.argtypes = [C.c_void_p]
+    L.plaac_ctx_destroy.restype = None
+    L.plaac_last_error.argtypes = [C.c_void_p]
+    L.plaac_last_error.restype = C.c_char_p
+    L.plaac_histogram.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.plaac_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.plaac_score_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+    L.plaac_histogram_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.plaac_ctx_sync.argtypes = [C.c_void_p]
+    L.plaac_last_timings.argtypes = [C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def builtin_tables():
+    bg, f28, f04 = (np.zeros(NAA) for _ in range(3))
+    load().plaac_builtin_tables(bg.ctypes.data, f28.ctypes.data, f04.ctypes.data)
+    return {"bg_scer": bg, "fg28": f28, "fg04": f04}
+
+
+def make_params(fg=None, bgcounts=None, alpha=1.0, corelength=60, ww1=41, ww2=41, ww3=None, adjustprolines=True):
+    """plaac_params_init: the table setup of main (plaac.java:444-500). ww3 defaults to ww2 (:355)."""
+    P = Params()
+    fgp = None if fg is None else np.ascontiguousarray(fg, dtype=np.float64)
+    bgp = None if bgcounts is None else np.ascontiguousarray(bgcounts, dtype=np.float64)
+    st = load().plaac_params_init(C.addressof(P), None if fgp is None else fgp.ctypes.data,
+                                  None if bgp is None else bgp.ctypes.data, float(alpha), int(corelength), int(ww1),
+                                  int(ww2), int(ww2 if ww3 is None else ww3), int(bool(adjustprolines)))
+    if st != PLAAC_OK:
+        raise PlaacError(st, "plaac_params_init rejected its arguments")
+    return P
+
+
+def encode(seq):
+    b = seq.encode("latin-1") if isinstance(seq, str) else bytes(seq)
+    out = np.zeros(len(b), dtype=np.uint8)
+    load().plaac_encode(b, len(b), out.ctypes.data)
+    return out
+
+
+def pack(seqs):
+    """records (str/bytes, untrimmed) -> (codes u8[total], offsets u64[n+1])"""
+    enc = [encode(s) for s in seqs]
+    offsets = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        offsets[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
+    codes = np.concatenate(enc) if enc else np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(codes, dtype=np.uint8), offsets
+
+
+def alloc_tracks(total):
+    tr = {k: np.zeros(total, dtype=np.uint8) for k in TRACK_U8}
+    for k in TRACK_F64:
+        tr[k] = np.full(total, np.nan, dtype=np.float64)
+    return tr
+
+
+class Context:
+    """plaac_ctx: one device, one caller."""
+
+    def __init__(self, params=None, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        self.params = params if params is not None else make_params()
+        st = self._L.plaac_ctx_create(C.addressof(self.params), int(device), C.byref(self._h))
+        if st != PLAAC_OK:
+            msg = self._L.plaac_last_error(None)
+            self._h = C.c_void_p()
+            raise PlaacError(st, msg.decode() if msg else "plaac_ctx_create failed")
+
+    def _check(self, st):
+        if st != PLAAC_OK:
+            msg = self._L.plaac_last_error(self._h)
+            raise PlaacError(st, msg.decode() if msg else "?")
+
+    def close(self):
+        if self._h:
+            self._L.plaac_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_params(self, params):
+        self._check(self._L.plaac_ctx_set_params(self._h, C.addressof(params)))
+        self.params = params
+
+    def histogram(self, codes, offsets):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        counts = np.zeros(NAA, dtype=np.int64)
+        self._check(self._L.plaac_histogram(self._h, codes.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                            counts.ctypes.data))
+        return counts
+
+    def score(self, codes, offsets, tracks=False):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nprot = len(offsets) - 1
+        rows = np.zeros(nprot, dtype=ROW_DTYPE)
+        tr, tptr, T = None, None, None
+        if tracks:
+            tr = alloc_tracks(int(offsets[-1]) if nprot >= 0 else 0)
+            T = Tracks(**{k: tr[k].ctypes.data for k in TRACK_U8 + TRACK_F64})
+            tptr = C.addressof(T)
+        self._check(self._L.plaac_score(self._h, codes.ctypes.data, offsets.ctypes.data, nprot, rows.ctypes.data,
+                                        tptr))
+        return (rows, tr) if tracks else rows
+
+    # ---- device-resident entry points: raw device pointers (e.g. torch tensors' data_ptr()) ----
+    def score_device(self, d_codes, d_offsets, nprot, total, d_rows, d_tracks=None, stream=None):
+        T = None
+        if d_tracks is not None:
+            T = Tracks(**{k: int(d_tracks[k]) for k in TRACK_U8 + TRACK_F64})
+        self._check(self._L.plaac_score_device(self._h, int(d_codes), int(d_offsets), int(nprot), int(total),
+                                               int(d_rows), None if T is None else C.addressof(T),
+                                               None if stream is None else int(stream)))
+
+    def histogram_device(self, d_codes, d_offsets, nprot, d_counts, stream=None):
+        self._check(self._L.plaac_histogram_device(self._h, int(d_codes), int(d_offsets), int(nprot), int(d_counts),
+                                                   None if stream is None else int(stream)))
+
+    def sync(self):
+        self._check(self._L.plaac_ctx_sync(self._h))
+
+    def last_timings(self):
+        """device ms of the last scored batch: total, plan, recurrence kernel, window-track kernel"""
+        ms = (C.c_float * 4)()
+        self._check(self._L.plaac_last_timings(self._h, C.addressof(ms)))
+        return {"total": ms[0], "plan": ms[1], "recur": ms[2], "tracks": ms[3]}

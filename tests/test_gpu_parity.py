@@ -1,0 +1,241 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar (BASELINE.json north_star): HMM parse boundaries and core start/end bit-exact; here EVERY integer
+field must be equal and every float field must have identical bits (NaN == NaN), because both sides
+evaluate the same fp64 operation order without FMA. The only tolerance is on the posteriors, which go
+through exp(): the device libm and glibc may differ in the last ulp (POST_RTOL below).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, runs_of_ones
+
+pytestmark = pytest.mark.gpu
+
+POST_RTOL = 1e-12  # exp() of device libm vs glibc; everything else is compared bit for bit
+
+INT_FIELDS = ("mw_score", "mw_start", "mw_end", "llr_start", "llr_end", "vit_maxrun", "core_start", "core_end",
+              "prd_start", "prd_end", "prot_len", "fi_numaa", "fi_maxrun", "papa_cen")
+F64_FIELDS = ("llr_score", "core_score", "prd_score", "hmm_all", "hmm_vit", "fi_meanhydro", "fi_meancharge",
+              "fi_meancombo", "papa_combo", "papa_prop", "papa_fi", "papa_llr", "papa_llr2")
+EXACT_TRACKS = ("charge", "hydro", "fi", "plaacllr", "papa", "fix2", "plaacllrx2", "papax2")
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+
+
+def assert_rows_equal(got, want, what=""):
+    assert len(got) == len(want)
+    for f in INT_FIELDS:
+        bad = np.nonzero(got[f] != want[f])[0]
+        assert bad.size == 0, "%s int field %s differs at %s: got %s want %s" % (
+            what, f, bad[:5], got[f][bad[:5]], want[f][bad[:5]])
+    for f in F64_FIELDS:
+        ok = same_bits(got[f], want[f])
+        bad = np.nonzero(~ok)[0]
+        assert bad.size == 0, "%s f64 field %s differs at %s: got %r want %r" % (
+            what, f, bad[:5], got[f][bad[:5]], want[f][bad[:5]])
+
+
+def valid_mask(codes, offsets):
+    """positions that belong to a scored residue (not a trimmed stop)"""
+    m = np.ones(len(codes), dtype=bool)
+    ends = offsets[1:].astype(np.int64)
+    starts = offsets[:-1].astype(np.int64)
+    nz = ends > starts
+    last = ends[nz] - 1
+    m[last[codes[last] == 21]] = False
+    return m
+
+
+def assert_tracks_equal(got, want, codes, offsets, what=""):
+    m = valid_mask(codes, offsets)
+    for k in ("vit", "map"):
+        bad = np.nonzero((got[k] != want[k]) & m)[0]
+        assert bad.size == 0, "%s track %s differs at %s" % (what, k, bad[:5])
+    for k in EXACT_TRACKS:
+        bad = np.nonzero(~same_bits(got[k], want[k]) & m)[0]
+        assert bad.size == 0, "%s track %s differs at %s: %r vs %r" % (what, k, bad[:5], got[k][bad[:5]],
+                                                                         want[k][bad[:5]])
+    for k in ("post0", "post1"):
+        np.testing.assert_allclose(got[k][m], want[k][m], rtol=POST_RTOL, atol=1e-300, err_msg=what + k)
+
+
+def both_params(native, oracle, **kw):
+    return native.make_params(**kw), oracle.build_params(**kw)
+
+
+@pytest.fixture(scope="module")
+def ctx(native):
+    c = native.Context(native.make_params())
+    yield c
+    c.close()
+
+
+def check_batch(native, oracle, ctx, codes, offsets, tracks=True, what="", **kw):
+    Pn, Po = both_params(native, oracle, **kw)
+    ctx.set_params(Pn)
+    want = oracle.score_batch(Po, codes, offsets, tracks=tracks, nthreads=8)
+    got = ctx.score(codes, offsets, tracks=tracks)
+    if tracks:
+        assert_rows_equal(got[0], want[0], what)
+        assert_tracks_equal(got[1], want[1], codes, offsets, what)
+        return got[0]
+    assert_rows_equal(got, want, what)
+    return got
+
+
+def test_kat28_viterbi_boundaries(native, oracle, ctx, kat28):
+    """The reference's own known answers: 28 PrD [start-end] annotations, fg = prd_freq_scer_04."""
+    recs, rows = kat28
+    fg04 = np.loadtxt(os.path.join(GOLDEN, "prd_freq_scer_04.txt"), usecols=0)
+    ctx.set_params(native.make_params(fg=fg04))
+    codes, offs = native.pack([s for _, s in recs])
+    got, tr = ctx.score(codes, offs, tracks=True)
+    for i, (gene, orf, s, e) in enumerate(rows):
+        v = tr["vit"][int(offs[i]):int(offs[i]) + int(got["prot_len"][i])]
+        assert (s, e) in runs_of_ones(v), (gene, orf, s, e, runs_of_ones(v))
+
+
+def test_classic_prions_config1(native, oracle, ctx, classic4):
+    """BASELINE config 1 (Sup35p, -c 60 -a 1.0) plus the three other classic prions."""
+    codes, offs = native.pack([s for _, s in classic4])
+    rows = check_batch(native, oracle, ctx, codes, offs, what="classic4")
+    # plausibility anchors: Sup35p core [5-64], PrD [1-133]
+    assert (rows["core_start"][0] + 1, rows["core_end"][0] + 1) == (5, 64)
+    assert (rows["prd_start"][0] + 1, rows["prd_end"][0] + 1) == (1, 133)
+    assert abs(rows["core_score"][0] - 51.215) < 1e-3
+
+
+def test_kat28_full_rows(native, oracle, ctx, kat28):
+    recs, _ = kat28
+    codes, offs = native.pack([s for _, s in recs])
+    check_batch(native, oracle, ctx, codes, offs, what="kat28-default")
+    fg04 = np.loadtxt(os.path.join(GOLDEN, "prd_freq_scer_04.txt"), usecols=0)
+    check_batch(native, oracle, ctx, codes, offs, what="kat28-fg04", fg=fg04)
+
+
+def test_yeast_shaped_batch(native, oracle, ctx):
+    from plaac_amd import synth
+    codes, offs = synth.make_batch(2, nprot=1500, stop_fraction=0.2)
+    rows = check_batch(native, oracle, ctx, codes, offs, what="cfg2")
+    assert (rows["core_start"] >= 0).sum() > 10  # the generator does produce cores
+
+
+@pytest.mark.parametrize("kw", [
+    dict(alpha=0.5), dict(alpha=0.0), dict(corelength=30), dict(corelength=90),
+    dict(ww1=21, ww2=31), dict(ww1=61, ww2=41), dict(ww1=40, ww2=40), dict(ww1=101, ww2=81),
+    dict(ww1=3, ww2=1), dict(ww1=301, ww2=201), dict(adjustprolines=False),
+])
+def test_parameter_variants(native, oracle, ctx, kw):
+    from plaac_amd import synth
+    codes, offs = synth.make_batch(2, nprot=300, seed=77, stop_fraction=0.1)
+    if "alpha" in kw:
+        kw = dict(kw, bgcounts=oracle.histogram(codes, offs).astype(np.float64))
+    check_batch(native, oracle, ctx, codes, offs, what=str(kw), **kw)
+
+
+def test_edge_lengths(native, oracle, ctx):
+    """n = 1, 2, ... around every window/threshold; trailing stops; X runs; empty and stop-only records."""
+    rng = np.random.default_rng(5)
+    aas = "ACDEFGHIKLMNPQRSTVWY"
+    seqs = []
+    for n in list(range(1, 90)) + [119, 120, 121, 127, 128, 129, 160, 161, 255, 256, 257, 1000]:
+        seqs.append("".join(rng.choice(list(aas), n)))
+    seqs += ["", "*", "A*", "Q" * 70, "N" * 200 + "*", "X" * 50, "QNQNQ" * 30 + "XXXX" + "QN" * 40, "m" * 61,
+             "PPPPPPPPPP" * 8, "P.P-P P" * 12, "QQQQ**", "KDEKR" * 20, "qnqnqnqnyy" * 9]
+    codes, offs = native.pack(seqs)
+    rows = check_batch(native, oracle, ctx, codes, offs, what="edges")
+    assert rows["prot_len"][seqs.index("")] == 0 and rows["prot_len"][seqs.index("*")] == 0
+    check_batch(native, oracle, ctx, codes, offs, what="edges-c1", corelength=1, ww1=5, ww2=7)
+
+
+def test_long_protein_and_mixed_lengths(native, oracle, ctx):
+    from plaac_amd import synth
+    P = native.make_params()
+    rng = np.random.default_rng(9)
+    lens = np.array([36000, 11, 8192, 64, 63, 65, 20000, 1, 300, 300, 300, 5000], dtype=np.int64)
+    codes, offs = synth.residues(lens, np.array(P.fg), np.array(P.bg), rng)
+    check_batch(native, oracle, ctx, codes, offs, what="long")
+
+
+def test_human_shaped_two_pass(native, oracle, ctx):
+    """config 3 shape: background from the input itself (histogram pass), alpha = 0.5"""
+    from plaac_amd import synth
+    codes, offs = synth.make_batch(3, nprot=400, stop_fraction=0.3)
+    counts = ctx.histogram(codes, offs)
+    assert np.array_equal(counts, oracle.histogram(codes, offs))
+    check_batch(native, oracle, ctx, codes, offs, tracks=False, what="cfg3", alpha=0.5,
+                bgcounts=counts.astype(np.float64))
+
+
+def test_histogram_validity_rules(native, oracle, ctx):
+    seqs = ["MKV*", "MKVX", "XMKV", "MK*V", "MKV**", "M", "X", "*", "", "MXKV", "mkvl", "AAAA*", "A" * 1000 + "*",
+            "A" * 999 + "X", "*AAAA"]
+    codes, offs = native.pack(seqs)
+    got = ctx.histogram(codes, offs)
+    assert np.array_equal(got, oracle.histogram(codes, offs))
+    assert got.sum() > 0
+
+
+def test_results_independent_of_batch_split(native, ctx):
+    from plaac_amd import synth
+    ctx.set_params(native.make_params())
+    codes, offs = synth.make_batch(2, nprot=257, seed=3)
+    full = ctx.score(codes, offs)
+    cut = 100
+    a = ctx.score(codes[:int(offs[cut])], offs[:cut + 1])
+    b = ctx.score(codes[int(offs[cut]):], offs[cut:] - offs[cut])
+    assert full.tobytes() == np.concatenate([a, b]).tobytes()
+
+
+def test_device_resident_entry_matches_host_entry(native, ctx):
+    torch = pytest.importorskip("torch")
+    from plaac_amd import synth
+    ctx.set_params(native.make_params())
+    codes, offs = synth.make_batch(2, nprot=500, seed=11)
+    want = ctx.score(codes, offs)
+    dev = torch.device("cuda:0")
+    d_codes = torch.from_numpy(codes).to(dev)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_rows = torch.zeros(len(want) * native.ROW_BYTES, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.score_device(d_codes.data_ptr(), d_offs.data_ptr(), len(want), int(offs[-1]), d_rows.data_ptr())
+    ctx.sync()
+    got = d_rows.cpu().numpy().view(native.ROW_DTYPE)
+    assert got.tobytes() == want.tobytes()
+    t = ctx.last_timings()
+    assert t["total"] > 0
+
+
+def test_full_size_config2_properties(native, ctx):
+    """BASELINE config 2 at full size (5,880 proteins): size-independent invariants of the outputs."""
+    from plaac_amd import synth
+    P = native.make_params()
+    ctx.set_params(P)
+    codes, offs = synth.make_batch(2)
+    rows, tr = ctx.score(codes, offs, tracks=True)
+    n = rows["prot_len"]
+    c = P.corelength
+    assert np.array_equal(n, np.diff(offs).astype(np.int64))
+    has = rows["core_start"] >= 0
+    # debug checks of the reference (plaac.java:841-848): longest PrD run >= c  <=>  a core exists
+    assert np.array_equal(has, rows["vit_maxrun"] >= c)
+    assert np.all(rows["core_end"][has] - rows["core_start"][has] + 1 == c)
+    assert np.all(rows["prd_start"][has] <= rows["core_start"][has])
+    assert np.all(rows["prd_end"][has] >= rows["core_end"][has])
+    assert np.all(np.isnan(rows["core_score"][~has])) and np.all(rows["prd_score"][~has] == 0.0)
+    # the unmasked LLR window can only be at least as good as the masked core window, up to the rounding
+    # noise the -1e6 mask puts into the prefix sums (ulp(3.6e10) = 7.6e-6 for a 36k-residue protein)
+    assert np.all(rows["llr_score"][has] >= rows["core_score"][has] - 1e-4)
+    # posteriors are a (LUT-noisy) probability pair
+    m = valid_mask(codes, offs)
+    s = tr["post0"][m] + tr["post1"][m]
+    assert np.all(np.abs(s - 1.0) < 1e-3)
+    assert np.all(rows["mw_score"] <= np.minimum(n, 80))
+    assert np.all((rows["fi_maxrun"] <= n) & (rows["fi_numaa"] <= n))
