@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — PLAAC scoring hot path on MI355X: residues/s with roofline and CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nprot P] [--config 2|3|4] [--tracks]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[3], the one `metric` is quoted on): UniRef50-shaped synthetic proteome,
+10 M sequences sharded over 8 GPUs = 1.25 M sequences (~0.36 G residues) PER GPU, default parameters.
+Scaling is weak: every rank scores its own 1.25 M-sequence shard, then the 160-byte summary rows are
+gathered to rank 0 over RCCL (the only exchange of the path). A step = one pass of the whole hot path
+(plan + recurrence kernel + window-track kernel + row gather) over the resident shard.
+Inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec 8 TB/s (6.3 TB/s achievable)
+FP64_VALU_PEAK_GOPS = 39300.0  # 78.6 TFLOP/s vector fp64 counts FMA as 2; this path may not fuse -> 39.3 T op/s
+ALGO_OPS_PER_RESIDUE = 470     # non-fusable fp64 ops per residue (summary mode)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4))
+    ap.add_argument("--nprot", type=int, default=0, help="sequences per GPU (default: config 4 -> 1,250,000)")
+    ap.add_argument("--tracks", action="store_true", help="per-residue track mode (82 B/residue written)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from plaac_amd import dist as pdist
+    from plaac_amd import native, synth
+
+    rank, local_rank, world = pdist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the scoring path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    nprot = args.nprot or {2: 5880, 3: 20600, 4: 1_250_000}[args.config]
+    P = native.make_params()  # defaults: c=60, ww=41, alpha=1, fg28
+    ctx = native.Context(P, device=local_rank)
+
+    # ---- synthetic shard, generated in HBM (seed differs per rank) -------------------------------
+    codes, offsets = synth.make_batch_torch(args.config, nprot, np.array(P.fg), np.array(P.bg), dev,
+                                            seed=synth.SEED0 + args.config + 1000 * rank)
+    total = int(offsets[-1].item())
+    rows = torch.zeros(nprot * native.ROW_BYTES, dtype=torch.uint8, device=dev)
+    d_tracks = None
+    if args.tracks:
+        trk = {k: torch.zeros(total, dtype=torch.uint8, device=dev) for k in native.TRACK_U8}
+        trk.update({k: torch.zeros(total, dtype=torch.float64, device=dev) for k in native.TRACK_F64})
+        d_tracks = {k: v.data_ptr() for k, v in trk.items()}
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty_like(rows) for _ in range(world)]
+    # a real (non-null) HIP stream: the kernels are launched on it, the HIP events that time them are
+    # recorded on it, and RCCL orders the row gather after it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+
+    def step():
+        with torch.cuda.stream(stream):
+            ctx.score_device(codes.data_ptr(), offsets.data_ptr(), nprot, total, rows.data_ptr(), d_tracks,
+                             stream=stream.cuda_stream)
+            if world > 1:  # final gather of per-protein summary rows, ordered after the kernels
+                dist.gather(rows, gather_list, dst=0)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([total, nprot], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        job_res, job_prot = int(tot[0].item()), int(tot[1].item())
+    else:
+        job_res, job_prot = total, nprot
+
+    if rank != 0:
+        ctx.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- rank 0: kernel times (HIP events on the launch stream, mean over the timed steps) ------
+    ktimes = ctx.last_timings(min(args.steps, 32))
+    dom = "k_tracks" if ktimes["tracks"] >= ktimes["recur"] else "k_recur"
+    dom_ms = max(ktimes["tracks"], ktimes["recur"])
+    tb = native.TRACK_BYTES_PER_RESIDUE if args.tracks else 0
+    # algorithmic bytes of ONE launch of each kernel (DESIGN.md "Algorithmic bytes"):
+    #   k_tracks: codes R + per protein (8 offset + 4 len + 4 order + 52 B of the row it owns) [+ 64 B/res tracks]
+    #   k_recur : codes R + per protein (8 + 4 + 4 + 108 B of the row it owns)               [+ 18 B/res tracks]
+    bytes_tracks = total * (1 + (64 if args.tracks else 0)) + nprot * (16 + 52)
+    bytes_recur = total * (1 + (18 if args.tracks else 0)) + nprot * (16 + 108)
+    dom_bytes = bytes_tracks if dom == "k_tracks" else bytes_recur
+    path_bytes = total * (1 + tb) + nprot * 168
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+        "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
+        "path_achieved_GBps": round(path_bytes / (ktimes["total"] * 1e-3) / 1e9, 3),
+        "note": "fp64-VALU-bound path (SURVEY §8d M3): secondary roof below",
+        "valu_fp64": {
+            "achieved_Gops": round(ALGO_OPS_PER_RESIDUE * total / (ktimes["total"] * 1e-3) / 1e9, 1),
+            "peak_Gops": FP64_VALU_PEAK_GOPS,
+            "frac": round(ALGO_OPS_PER_RESIDUE * total / (ktimes["total"] * 1e-3) / 1e9 / FP64_VALU_PEAK_GOPS, 4),
+        },
+    }
+
+    # ---- rank 0: CPU baseline = the oracle (a port, not the Java reference: no JVM on this box) ----
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle_ctypes as oc
+        Po = oc.build_params()
+        ncores = os.cpu_count() or 1
+        nthreads = min(ncores, 256)
+        n_s = min(nprot, 60000)
+        off_h = offsets[:n_s + 1].cpu().numpy().astype(np.uint64)
+        codes_h = codes[:int(off_h[-1])].cpu().numpy()
+        n_1 = min(n_s, 4000)
+        t1 = time.perf_counter()
+        oc.score_batch(Po, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)
+        dt1 = time.perf_counter() - t1
+        oc.score_batch(Po, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=nthreads)  # thread-pool warm-up
+        t1 = time.perf_counter()
+        want = oc.score_batch(Po, codes_h, off_h, nthreads=nthreads)
+        dtn = time.perf_counter() - t1
+        got = rows[:n_s * native.ROW_BYTES].cpu().numpy().view(native.ROW_DTYPE)
+        cpu = {
+            "value": round(int(off_h[-1]) / dtn, 1), "unit": "residues/s", "cores": nthreads, "kind": "port",
+            "sample": "first %d sequences (%d residues) of rank 0's shard, all host threads; oracle/plaac_oracle.c "
+                      "(dead work of the Java reference omitted)" % (n_s, int(off_h[-1])),
+            "value_1core": round(int(off_h[n_1]) / dt1, 1),
+            "gpu_rows_match_oracle": bool(got.tobytes() == want.tobytes()),
+        }
+
+    out = {
+        "metric": "residues/sec", "value": round(job_res * args.steps / dt, 1), "unit": "residues/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "proteins_per_sec": round(job_prot * args.steps / dt, 1),
+        "config": {
+            "workload": {2: "cfg2 yeast-shaped proteome", 3: "cfg3 human-shaped proteome",
+                         4: "cfg4 UniRef50-shaped, 10M sequences over 8 GPUs = 1.25M sequences per GPU"}[
+                args.config],
+            "mode": "tracks" if args.tracks else "summary", "sequences_per_gpu": nprot,
+            "residues_per_gpu": total, "sequences_total": job_prot, "residues_total": job_res,
+            "params": "c=60 ww=41 alpha=1.0 fg=prd_freq_scer_28", "sharding": "by sequence, %d rank(s)" % world,
+            "exchange": "RCCL gather of 160 B rows to rank 0" if world > 1 else "none (1 GPU)",
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,7 +102,7 @@ typedef struct plaac_row {
 } plaac_row; /* 13 x f64 + 14 x i32 = 160 bytes */
 
 /* Per-residue tracks (plotsomefastas, plaac.java:635-643): SoA arrays indexed by the
- * position of the residue in `codes` (entries of a trimmed stop are left untouched).
+ * position of the residue in `codes` (the entry of a trimmed stop is unspecified).
  * All twelve pointers must be non-null when a tracks struct is passed. */
 typedef struct plaac_tracks {
     uint8_t *vit, *map;
@@ -168,6 +168,9 @@ plaac_status plaac_ctx_sync(plaac_ctx *ctx);
  * plaac_score_device / plaac_score call: [0] total, [1] sort/plan, [2] recurrence kernel (HMM + windows
  * over prefix sums), [3] window-track kernel (FoldIndex/PAPA). Requires a prior sync. */
 plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[4]);
+/* Same four figures averaged over the most recent `ncalls` scored batches (the ctx keeps the events of
+ * the last 32). This is how bench.py times the kernels over its whole timed region without a sync per step. */
+plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[4]);
 
 #ifdef __cplusplus
 }

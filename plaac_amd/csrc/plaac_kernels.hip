@@ -702,8 +702,9 @@ struct plaac_ctx {
     double *d_trk64 = nullptr;
     unsigned long long *d_counts = nullptr;
     size_t cap_codes = 0, cap_offs = 0, cap_rows = 0, cap_trk = 0;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool timed = false;
+    static constexpr int EV_SETS = 32; // timings of the last 32 scored batches
+    hipEvent_t ev[EV_SETS][4] = {};
+    uint64_t ncalls = 0;
     std::string err;
 };
 
@@ -836,8 +837,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
-    for (auto &ev : ctx->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    for (auto &set : ctx->ev)
+        for (auto &ev : set)
+            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void **)&ctx->d_tab, sizeof(DevTables))) != hipSuccess) return bail("hipMalloc(tables)", e);
     if ((e = hipMalloc((void **)&ctx->d_hist, sizeof(uint32_t) * LEN_BINS)) != hipSuccess)
         return bail("hipMalloc(hist)", e);
@@ -880,8 +882,9 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
                     ctx->d_offsets, ctx->d_rows, ctx->d_trk8,  ctx->d_trk64, ctx->d_counts};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
-    for (auto &ev : ctx->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto &set : ctx->ev)
+        for (auto &ev : set)
+            if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -928,13 +931,14 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
 
     const int wmax = std::max(ctx->params.ww1 / 2, std::max(ctx->params.ww2 / 2, ctx->params.ww3 / 2));
 
-    PL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    hipEvent_t *evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
+    PL_HIP(ctx, hipEventRecord(evs[0], st));
     PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * LEN_BINS, st));
     const unsigned pb = (nprot + 255u) / 256u;
     hipLaunchKernelGGL(k_plan_lengths, dim3(pb), dim3(256), 0, st, d_codes, d_offsets, nprot, ctx->d_neff, ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scatter, dim3(pb), dim3(256), 0, st, ctx->d_neff, nprot, ctx->d_hist, ctx->d_order);
-    PL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+    PL_HIP(ctx, hipEventRecord(evs[1], st));
     const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
     if (d_tracks)
         hipLaunchKernelGGL(k_recur<true>, dim3(ab), dim3(KA_THREADS), 0, st, d_codes, d_offsets, ctx->d_neff,
@@ -942,7 +946,7 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     else
         hipLaunchKernelGGL(k_recur<false>, dim3(ab), dim3(KA_THREADS), 0, st, d_codes, d_offsets, ctx->d_neff,
                            ctx->d_order, nprot, ctx->d_tab, ctx->d_bits, d_rows, tp, (double *)nullptr);
-    PL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+    PL_HIP(ctx, hipEventRecord(evs[2], st));
 #define LAUNCH_KB(RING)                                                                                            \
     do {                                                                                                           \
         if (d_tracks)                                                                                              \
@@ -956,23 +960,35 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     else if (wmax <= 96) LAUNCH_KB(256);
     else LAUNCH_KB(1024);
 #undef LAUNCH_KB
-    PL_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+    PL_HIP(ctx, hipEventRecord(evs[3], st));
     PL_HIP(ctx, hipGetLastError());
-    ctx->timed = true;
+    ctx->ncalls++;
     return PLAAC_OK;
 }
 
-plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[4]) {
+plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[4]) {
     if (!ctx || !ms) return PLAAC_ERR_ARG;
-    if (!ctx->timed) return fail(ctx, PLAAC_ERR_ARG, "no scored batch to time yet");
+    if (ctx->ncalls == 0) return fail(ctx, PLAAC_ERR_ARG, "no scored batch to time yet");
+    if (ncalls == 0) ncalls = 1;
+    if (ncalls > plaac_ctx::EV_SETS) ncalls = plaac_ctx::EV_SETS;
+    if (ncalls > ctx->ncalls) ncalls = (uint32_t)ctx->ncalls;
     PL_HIP(ctx, hipSetDevice(ctx->device));
-    PL_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
-    PL_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[3]));
-    PL_HIP(ctx, hipEventElapsedTime(&ms[1], ctx->ev[0], ctx->ev[1]));
-    PL_HIP(ctx, hipEventElapsedTime(&ms[2], ctx->ev[1], ctx->ev[2]));
-    PL_HIP(ctx, hipEventElapsedTime(&ms[3], ctx->ev[2], ctx->ev[3]));
+    double acc[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < ncalls; ++k) {
+        hipEvent_t *evs = ctx->ev[(ctx->ncalls - 1 - k) % plaac_ctx::EV_SETS];
+        float t[4];
+        PL_HIP(ctx, hipEventSynchronize(evs[3]));
+        PL_HIP(ctx, hipEventElapsedTime(&t[0], evs[0], evs[3]));
+        PL_HIP(ctx, hipEventElapsedTime(&t[1], evs[0], evs[1]));
+        PL_HIP(ctx, hipEventElapsedTime(&t[2], evs[1], evs[2]));
+        PL_HIP(ctx, hipEventElapsedTime(&t[3], evs[2], evs[3]));
+        for (int i = 0; i < 4; ++i) acc[i] += t[i];
+    }
+    for (int i = 0; i < 4; ++i) ms[i] = (float)(acc[i] / ncalls);
     return PLAAC_OK;
 }
+
+plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[4]) { return plaac_timings_mean(ctx, 1, ms); }
 
 plaac_status plaac_histogram_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
                                     uint32_t nprot, int64_t *d_counts, void *stream_) {

@@ -1,0 +1,122 @@
+"""One process per GPU: sharding by sequence and the final gather of summary rows.
+
+Proteins are independent given the parameter tables, so the data path has NO
+collective. The only exchanges are
+  (i)  an all-reduce(sum) of the 22 x int64 background histogram, needed when the background comes
+       from the scored input (plaac.java:377-384 -> one full pass over the input), and
+  (ii) the final gather of 160-byte summary rows to rank 0 (plaac.java:755-945 prints in file order).
+Backend "nccl" is RCCL on ROCm (rows stay in HBM and travel over xGMI); "gloo" is used by the CPU tests.
+"""
+import os
+
+import numpy as np
+
+ROW_BYTES = 160
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(
+        os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_process_group(backend=None):
+    """Join the job described by RANK/WORLD_SIZE/MASTER_* (torchrun). Returns (rank, local_rank, world)."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def shard_plan(offsets, world):
+    """Deal proteins to ranks so that every rank gets about the same number of RESIDUES:
+    sort by length (descending) and deal in a boustrophedon (0..w-1, w-1..0, ...). Returns a list of
+    index arrays (ascending input order inside each shard, so per-shard output stays in file order)."""
+    lens = np.diff(np.asarray(offsets).astype(np.int64))
+    order = np.argsort(-lens, kind="stable")
+    pos = np.arange(len(order))
+    lap, col = pos // world, pos % world
+    owner_sorted = np.where(lap % 2 == 0, col, world - 1 - col)
+    owner = np.empty(len(order), dtype=np.int64)
+    owner[order] = owner_sorted
+    return [np.nonzero(owner == r)[0] for r in range(world)]
+
+
+def extract_shard(codes, offsets, idx):
+    """(codes, offsets) of the records idx (ascending), still untrimmed"""
+    offsets = np.asarray(offsets).astype(np.int64)
+    lens = offsets[idx + 1] - offsets[idx]
+    new_off = np.zeros(len(idx) + 1, dtype=np.uint64)
+    new_off[1:] = np.cumsum(lens)
+    out = np.empty(int(new_off[-1]), dtype=np.uint8)
+    # vectorised ragged gather
+    if len(idx):
+        starts = np.repeat(offsets[idx] - new_off[:-1].astype(np.int64), lens)
+        out[:] = codes[starts + np.arange(len(out), dtype=np.int64)]
+    return out, new_off
+
+
+def allreduce_counts(counts, device=None):
+    """sum the 22-bin histogram over ranks (exchange step (i))"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(counts, dtype=np.int64)
+    t = torch.as_tensor(np.asarray(counts, dtype=np.int64))
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def gather_rows(rows_local, idx_local, nprot_total, device=None):
+    """Exchange step (ii): gather per-rank row blocks to rank 0 and restore input order.
+    rows_local: torch uint8 tensor [n_local*160] (any device) or a numpy structured/uint8 array.
+    Returns a uint8 numpy array [nprot_total*160] on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if isinstance(rows_local, np.ndarray):
+        rows_t = torch.from_numpy(np.ascontiguousarray(rows_local).view(np.uint8).reshape(-1))
+    else:
+        rows_t = rows_local.reshape(-1)
+    if device is not None:
+        rows_t = rows_t.to(device)
+    idx_t = torch.as_tensor(np.asarray(idx_local, dtype=np.int64), device=rows_t.device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        out = np.empty(nprot_total * ROW_BYTES, dtype=np.uint8)
+        out.reshape(nprot_total, ROW_BYTES)[idx_t.cpu().numpy()] = rows_t.cpu().numpy().reshape(-1, ROW_BYTES)
+        return out
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_local = torch.tensor([idx_t.numel()], dtype=torch.int64, device=rows_t.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    sizes = [int(s.item()) for s in sizes]
+    nmax = max(sizes)
+    # equal-size blocks for dist.gather: pad the short shards
+    pad_rows = torch.zeros(nmax * ROW_BYTES, dtype=torch.uint8, device=rows_t.device)
+    pad_rows[:rows_t.numel()] = rows_t
+    pad_idx = torch.full((nmax,), -1, dtype=torch.int64, device=rows_t.device)
+    pad_idx[:idx_t.numel()] = idx_t
+    if rank == 0:
+        got_rows = [torch.empty_like(pad_rows) for _ in range(world)]
+        got_idx = [torch.empty_like(pad_idx) for _ in range(world)]
+    else:
+        got_rows = got_idx = None
+    dist.gather(pad_rows, got_rows, dst=0)
+    dist.gather(pad_idx, got_idx, dst=0)
+    if rank != 0:
+        return None
+    out = torch.empty(nprot_total, ROW_BYTES, dtype=torch.uint8, device=rows_t.device)
+    for r in range(world):
+        k = sizes[r]
+        out[got_idx[r][:k]] = got_rows[r].reshape(nmax, ROW_BYTES)[:k]
+    return out.reshape(-1).cpu().numpy()

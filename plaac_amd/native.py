@@ -67,7 +67,7 @@ EXPORTS = (
     "plaac_abi_version", "plaac_sizeof_params", "plaac_sizeof_row", "plaac_builtin_tables", "plaac_params_init",
     "plaac_encode", "plaac_ctx_create", "plaac_ctx_set_params", "plaac_ctx_destroy", "plaac_last_error",
     "plaac_histogram", "plaac_score", "plaac_score_device", "plaac_histogram_device", "plaac_ctx_sync",
-    "plaac_last_timings",
+    "plaac_last_timings", "plaac_timings_mean",
 )
 
 _lib = None
@@ -116,6 +116,7 @@ def load():
     L.plaac_histogram_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.plaac_ctx_sync.argtypes = [C.c_void_p]
     L.plaac_last_timings.argtypes = [C.c_void_p, C.c_void_p]
+    L.plaac_timings_mean.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     _lib = L
     return L
 
@@ -236,8 +237,9 @@ class Context:
     def sync(self):
         self._check(self._L.plaac_ctx_sync(self._h))
 
-    def last_timings(self):
-        """device ms of the last scored batch: total, plan, recurrence kernel, window-track kernel"""
+    def last_timings(self, ncalls=1):
+        """device ms (HIP events on the launch stream), mean over the last `ncalls` scored batches:
+        total, plan (sort), recurrence kernel, window-track kernel"""
         ms = (C.c_float * 4)()
-        self._check(self._L.plaac_last_timings(self._h, C.addressof(ms)))
+        self._check(self._L.plaac_timings_mean(self._h, int(ncalls), C.addressof(ms)))
         return {"total": ms[0], "plan": ms[1], "recur": ms[2], "tracks": ms[3]}
