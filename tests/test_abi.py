@@ -1,0 +1,87 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol the header declares, its host-side
+helpers agree with the oracle, and it FAILS LOUDLY (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "plaac_native.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(plaac_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(native):
+    L = native.load()
+    declared = header_functions()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(native.EXPORTS) == declared
+
+
+def test_struct_layouts(native):
+    L = native.load()
+    assert L.plaac_abi_version() == 1
+    assert L.plaac_sizeof_row() == 160 == native.ROW_DTYPE.itemsize
+    assert L.plaac_sizeof_params() == C.sizeof(native.Params)
+
+
+def test_params_init_matches_oracle_bit_for_bit(native, oracle):
+    rng = np.random.default_rng(0)
+    cases = [dict(), dict(alpha=0.5, bgcounts=rng.integers(1, 10**6, 22).astype(float)),
+             dict(alpha=0.0, bgcounts=rng.random(22)), dict(fg=oracle.const_tables()["fg04"], corelength=30),
+             dict(alpha=7.0), dict(ww1=21, ww2=61, adjustprolines=False)]
+    for kw in cases:
+        a, b = native.make_params(**kw), oracle.build_params(**kw)
+        for f in ("fg", "bgscer", "bgthis", "bg", "llr", "lodpapa", "hydro2", "charge", "loglut", "cc"):
+            assert np.array(getattr(a, f)).tobytes() == np.array(getattr(b, f)).tobytes(), (kw, f)
+        for h in ("hmm1", "hmm0"):
+            for f in ("lt", "li", "le", "lf"):
+                assert np.array(getattr(getattr(a, h), f)).tobytes() == np.array(
+                    getattr(getattr(b, h), f)).tobytes(), (kw, h, f)
+        assert (a.corelength, a.ww1, a.ww2, a.ww3, a.adjustprolines, a.alpha) == (
+            b.corelength, b.ww1, b.ww2, b.ww3, b.adjustprolines, b.alpha)
+        assert a.big_neg == -1000000.0
+
+
+def test_params_init_rejects_bad_arguments(native):
+    with pytest.raises(native.PlaacError):
+        native.make_params(corelength=0)
+    with pytest.raises(native.PlaacError):
+        native.make_params(ww1=0)
+
+
+def test_builtin_tables_and_encode(native, oracle):
+    t, u = native.builtin_tables(), oracle.const_tables()
+    for k in ("bg_scer", "fg28", "fg04"):
+        assert np.array_equal(t[k], u[k])
+    s = bytes(range(256))
+    assert np.array_equal(native.encode(s), oracle.encode(s))
+    assert native.encode("XACDEFGHIKLMNPQRSTVWY*").tolist() == list(range(22))
+
+
+def test_no_gpu_means_loud_failure_not_fallback(native):
+    """On a machine without a usable gfx950 device the product must refuse to compute."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; covered by the gpu-marked tests")
+    with pytest.raises(native.PlaacError) as e:
+        native.Context(native.make_params())
+    assert e.value.status == native.PLAAC_ERR_DEVICE
+    assert "device" in str(e.value).lower()
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/"""
+    pkg = os.path.join(ROOT, "plaac_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_ctypes" not in src and "plaac_oracle" not in src and "libplaac_oracle" not in src, f

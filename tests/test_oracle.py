@@ -1,0 +1,208 @@
+"""CPU tests of the oracle itself: pinned against the reference's known answers, cross-checked against
+its pure-Python twin, and property-tested (the two disabled debug checks of plaac.java:772-791, 841-848)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, runs_of_ones
+
+
+def params_to_dict(P):
+    def hmm(h):
+        return dict(lt=[list(r) for r in h.lt], li=list(h.li), le=[list(r) for r in h.le], lf=list(h.lf))
+    return dict(corelength=P.corelength, ww1=P.ww1, ww2=P.ww2, ww3=P.ww3, adjustprolines=bool(P.adjustprolines),
+                cc=list(P.cc), llr=list(P.llr), lodpapa=list(P.lodpapa), hydro2=list(P.hydro2),
+                charge=list(P.charge), loglut=list(P.loglut), hmm1=hmm(P.hmm1), hmm0=hmm(P.hmm0))
+
+
+def test_kat28_viterbi_pins_the_oracle(oracle, kat28):
+    """The reference's own 28 PrD annotations (cli/src/scer_fg_28.fasta), valid for fg = prd_freq_scer_04."""
+    recs, rows = kat28
+    fg04 = np.loadtxt(os.path.join(GOLDEN, "prd_freq_scer_04.txt"), usecols=0)
+    assert np.array_equal(fg04, oracle.const_tables()["fg04"])
+    P = oracle.build_params(fg=fg04)
+    codes, offs = oracle.pack([s for _, s in recs])
+    _, tr = oracle.score_batch(P, codes, offs, tracks=True)
+    hits = 0
+    for i, (gene, orf, s, e) in enumerate(rows):
+        v = tr["vit"][int(offs[i]):int(offs[i + 1])]
+        if recs[i][1].endswith("*"):
+            v = v[:-1]
+        hits += (s, e) in runs_of_ones(v)
+    assert hits == 28
+
+
+def test_kat28_is_specific_to_fg04(oracle, kat28):
+    """With the default fg (prd_freq_scer_28) only 12 of the 28 coincide — guards against a
+    KAT that would pass for any table."""
+    recs, rows = kat28
+    codes, offs = oracle.pack([s for _, s in recs])
+    _, tr = oracle.score_batch(oracle.build_params(), codes, offs, tracks=True)
+    hits = 0
+    for i, (_, _, s, e) in enumerate(rows):
+        n = int(offs[i + 1] - offs[i]) - recs[i][1].endswith("*")
+        hits += (s, e) in runs_of_ones(tr["vit"][int(offs[i]):int(offs[i]) + n])
+    assert hits == 12
+
+
+def test_classic_prions_anchors(oracle, classic4):
+    """SURVEY §8 C4 plausibility anchors (not reference output): Sup35p / Ure2p / Rnq1p / Mot3p."""
+    codes, offs = oracle.pack([s for _, s in classic4])
+    rows = oracle.score_batch(oracle.build_params(), codes, offs)
+    one = lambda f, i: int(rows[f][i]) + 1
+    assert [n for n, _ in classic4] == ["Sup35p", "Ure2p", "Rnq1p", "Mot3p"]
+    assert (one("core_start", 0), one("core_end", 0), one("prd_start", 0), one("prd_end", 0)) == (5, 64, 1, 133)
+    assert rows["prot_len"][0] == 685
+    assert (one("core_start", 1), one("core_end", 1), one("prd_end", 1)) == (17, 76, 89)
+    assert (one("core_start", 2), one("core_end", 2), one("prd_start", 2), one("prd_end", 2)) == (218, 277, 124, 405)
+    assert (one("core_start", 3), one("core_end", 3)) == (98, 157)
+    np.testing.assert_allclose(rows["core_score"], [51.215, 29.225, 47.459, 40.751], atol=1e-3)
+    np.testing.assert_allclose(rows["hmm_all"][0], 81.82, atol=1e-2)
+    np.testing.assert_allclose(rows["hmm_vit"][0], 79.60, atol=1e-2)
+    np.testing.assert_allclose(rows["prd_score"][0], 89.773, atol=1e-3)
+
+
+def test_table_setup_details(oracle):
+    P = oracle.build_params()
+    # the four normalisations really change bits: bg_freq_scer sums to 1.0001, fg28 to 0.99999
+    t = oracle.const_tables()
+    assert abs(t["bg_scer"].sum() - 1.0001) < 1e-12 and abs(t["fg28"].sum() - 0.99999) < 1e-12
+    assert abs(sum(P.bg) - 1) < 1e-15 and abs(sum(P.fg) - 1) < 1e-15
+    assert P.llr[0] == 0.0 and P.llr[21] == 0.0 and P.llr[12] > 1.0 and P.llr[14] > 1.0  # N, Q enriched
+    assert P.hydro2[0] == 0.5 and P.hydro2[21] == 0.5  # X and * are 0.5, not 0
+    assert P.lodpapa[0] == 0.0 and P.lodpapa[21] == 0.0
+    assert P.loglut[0] == math.log(2.0) and len(P.loglut) == 4001
+    assert list(P.hmm1.lf) == [0.0, 0.0] and list(P.hmm0.lf) == [0.0, 0.0]  # free end
+    assert P.hmm0.lt[0][1] == -math.inf and P.hmm0.li[1] == -math.inf
+    assert list(P.hmm0.le[0]) == list(P.hmm1.le[0])
+    # alpha outside [0,1] falls back to 1.0 (:444-447)
+    assert oracle.build_params(alpha=1.5).alpha == 1.0 and oracle.build_params(alpha=-0.1).alpha == 1.0
+    # alpha = 0 with an organism background uses that background
+    counts = np.arange(22, dtype=np.float64) + 5
+    P0 = oracle.build_params(alpha=0.0, bgcounts=counts)
+    c = counts.copy()
+    c[0] = c[21] = 0
+    np.testing.assert_allclose(np.array(P0.bgthis), c / c.sum(), rtol=1e-15)
+    np.testing.assert_allclose(np.array(P0.bg)[1:21], (c / c.sum())[1:21], rtol=1e-4)
+
+
+def test_encoding(oracle):
+    s = "XACDEFGHIKLMNPQRSTVWY*acdefghiklmnpqrstvwyxBZUOJ- 1."
+    got = oracle.encode(s).tolist()
+    assert got[:22] == list(range(22))
+    assert got[22:42] == list(range(1, 21))
+    assert got[42:] == [0] * 10
+
+
+def test_logeapeb(oracle):
+    P = oracle.build_params()
+    inf = math.inf
+    assert oracle.logeapeb(P, -inf, -inf) == -inf
+    assert oracle.logeapeb(P, -inf, -3.5) == -3.5 and oracle.logeapeb(P, 2.25, -inf) == 2.25
+    assert oracle.logeapeb(P, 1.0, 1.0) == 1.0 + math.log(2)
+    assert oracle.logeapeb(P, 0.0, -40.0) == 0.0 and 0.0 < oracle.logeapeb(P, 0.0, -30.0) < 1e-12
+    # the table is log(1.0 + exp(-x)), not log1p: it is exactly 0 once 1 + e^-x rounds to 1 (x > ~36.7)
+    assert P.loglut[3600] > 0.0 and all(v == 0.0 for v in P.loglut[3700:])
+    rng = np.random.default_rng(0)
+    for a, b in rng.normal(0, 10, (200, 2)):
+        exact = np.logaddexp(a, b)
+        assert abs(oracle.logeapeb(P, a, b) - exact) < 4e-6  # LUT interpolation error is part of the answer
+        assert oracle.logeapeb(P, a, b) == oracle.logeapeb(P, b, a)
+
+
+def test_hss2_equals_brute_force(oracle):
+    """debug cross-check of plaac.java:772-791 as a property test, incl. exact ties (first window wins)"""
+    rng = np.random.default_rng(1)
+    for trial in range(300):
+        n = int(rng.integers(1, 200))
+        L = int(rng.integers(1, 90))
+        if trial % 3 == 0:
+            seq = rng.integers(0, 2, n).astype(np.float64)  # many exact ties
+        elif trial % 3 == 1:
+            seq = rng.normal(0, 2, n)
+        else:
+            seq = np.where(rng.random(n) < 0.3, -1000000.0, rng.normal(0, 2, n))
+        a, b = oracle.hss2(seq, L, L), oracle.hss_brute(seq, L)
+        assert a.tobytes() == b.tobytes(), (n, L)
+        if L <= n:
+            assert a[1] - a[0] + 1 == L
+        else:
+            assert (a[0], a[1], a[2]) == (-1, -2, -math.inf)
+
+
+def test_python_twin_agrees_bit_for_bit(oracle):
+    from oracle import plaac_oracle_py as twin
+    from plaac_amd import synth
+    rng = np.random.default_rng(2)
+    for kw in (dict(), dict(corelength=20, ww1=11, ww2=21), dict(alpha=0.3, bgcounts=np.arange(1.0, 23.0)),
+               dict(adjustprolines=False, ww1=40, ww2=6)):
+        P = oracle.build_params(**kw)
+        lens = np.array([1, 2, 3, 5, 19, 20, 21, 40, 41, 42, 59, 60, 61, 150, 400])
+        codes, offs = synth.residues(lens, np.array(P.fg), np.array(P.bg), rng)
+        codes[int(offs[13]) + 30:int(offs[13]) + 120] = rng.choice([12, 14, 16, 20, 13], 90)  # force a PrD + prolines
+        rows, tr = oracle.score_batch(P, codes, offs, tracks=True)
+        D = params_to_dict(P)
+        for i in range(len(lens)):
+            x = codes[int(offs[i]):int(offs[i + 1])].tolist()
+            r, t = twin.score_protein(D, x)
+            for k, v in r.items():
+                w = rows[k][i]
+                assert (v == w) or (isinstance(v, float) and math.isnan(v) and math.isnan(w)), (kw, i, k, v, w)
+            for k, v in t.items():
+                w = tr[k][int(offs[i]):int(offs[i + 1])]
+                a = np.asarray(v, dtype=w.dtype)
+                assert a.tobytes() == w.tobytes(), (kw, i, k)
+
+
+def test_batch_semantics(oracle):
+    """one trailing stop is trimmed for scoring (:758), empty / stop-only records are skipped (:762)"""
+    P = oracle.build_params()
+    codes, offs = oracle.pack(["MKVQQQNNN", "MKVQQQNNN*", "MKVQQQNNN**", "", "*"])
+    rows = oracle.score_batch(P, codes, offs)
+    assert rows["prot_len"].tolist() == [9, 9, 10, 0, 0]
+    assert rows[0].tobytes() == rows[1].tobytes()
+    assert rows["llr_start"][0] == -1 and rows["llr_end"][0] == -2 and rows["llr_score"][0] == -math.inf
+    assert rows["core_start"][0] == -1 and math.isnan(rows["core_score"][0]) and rows["prd_score"][0] == 0.0
+    assert rows["papa_cen"][0] == -1 and rows["papa_combo"][0] == -math.inf and math.isnan(rows["papa_prop"][0])
+    # threads do not change anything
+    from plaac_amd import synth
+    c2, o2 = synth.make_batch(2, nprot=200, seed=4)
+    assert oracle.score_batch(P, c2, o2, nthreads=1).tobytes() == oracle.score_batch(P, c2, o2, nthreads=4).tobytes()
+
+
+def test_histogram_rules(oracle):
+    """isvalidprotein (:1732-1739): X/* strictly inside invalidate, a trailing X invalidates, position 0 is free"""
+    h = lambda s: oracle.histogram(*oracle.pack(s))
+    assert h(["MKV*"]).sum() == 4 and h(["MKV*"])[21] == 1
+    assert h(["MKVX"]).sum() == 0 and h(["XMKV"]).sum() == 4 and h(["MK*V"]).sum() == 0
+    assert h(["MKV**"]).sum() == 0 and h(["M"]).sum() == 1 and h(["X"]).sum() == 0 and h(["*"]).sum() == 1
+    assert h(["", "MKV"]).sum() == 3
+    assert h(["mkv", "MKV"])[11] == 2
+
+
+def test_output_invariants_on_synthetic_proteome(oracle):
+    from plaac_amd import synth
+    P = oracle.build_params()
+    codes, offs = synth.make_batch(2, nprot=600, seed=8)
+    rows, tr = oracle.score_batch(P, codes, offs, tracks=True, nthreads=4)
+    has = rows["core_start"] >= 0
+    assert has.sum() > 5
+    assert np.array_equal(has, rows["vit_maxrun"] >= P.corelength)  # debug checks :841-848
+    s = tr["post0"] + tr["post1"]
+    assert np.all(np.abs(s - 1) < 1e-3) and np.any(s != 1.0)  # LUT noise: pairs need not sum to exactly 1
+    # window tracks against a naive numpy evaluation (tolerance: different summation order)
+    i = int(np.argmax(rows["prot_len"]))
+    x = codes[int(offs[i]):int(offs[i + 1])]
+    n, w = len(x), 20
+    hy = np.array(P.hydro2)[x]
+    naive = np.array([hy[max(0, k - w):min(n, k + w + 1)].mean() for k in range(n)])
+    np.testing.assert_allclose(tr["hydro"][int(offs[i]):int(offs[i + 1])], naive, rtol=1e-12)
+    fi = tr["fi"][int(offs[i]):int(offs[i + 1])]
+    wt = 1.0 + np.minimum(np.arange(n), w) + np.minimum(n - 1 - np.arange(n), w)
+    k = n // 2
+    np.testing.assert_allclose(tr["fix2"][int(offs[i]) + k],
+                               (wt[k - w:k + w + 1] * fi[k - w:k + w + 1]).sum() / wt[k - w:k + w + 1].sum(),
+                               rtol=1e-12)
+    assert np.all(np.isnan(tr["fix2"][int(offs[i]):int(offs[i]) + w]))
