@@ -155,8 +155,11 @@ plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *o
 
 /* Same, on buffers already resident in device memory (all pointers are device pointers, including
  * the ones inside *tracks; the tracks struct itself lives on the host). `stream` is a hipStream_t
- * (NULL = the ctx's own stream). Asynchronous: returns after enqueueing; synchronise the stream
- * (or call plaac_ctx_sync) before reading rows. Work buffers are grown on demand and reused. */
+ * (NULL = the ctx's own stream). Asynchronous: returns after enqueueing; all work is ordered after
+ * earlier work on `stream` and before later work on it (internal side streams are forked and joined
+ * with events). Synchronise the stream (or call plaac_ctx_sync when stream == NULL) before reading rows.
+ * d_codes must be 16-byte aligned and readable up to the next 16-byte boundary after total_residues
+ * (true of any hipMalloc / torch allocation). Work buffers are grown on demand and reused. */
 plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,
                                 uint64_t total_residues, plaac_row *d_rows, const plaac_tracks *d_tracks,
                                 void *stream);
@@ -164,13 +167,17 @@ plaac_status plaac_histogram_device(plaac_ctx *ctx, const uint8_t *d_codes, cons
                                     uint32_t nprot, int64_t *d_counts, void *stream);
 plaac_status plaac_ctx_sync(plaac_ctx *ctx);
 
-/* Device time (ms, HIP events on the launch stream) of the kernels of the most recent completed
- * plaac_score_device / plaac_score call: [0] total, [1] sort/plan, [2] recurrence kernel (HMM + windows
- * over prefix sums), [3] window-track kernel (FoldIndex/PAPA). Requires a prior sync. */
-plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[4]);
-/* Same four figures averaged over the most recent `ncalls` scored batches (the ctx keeps the events of
+/* Device time in ms (HIP events recorded on the stream each kernel is launched on) of the most recent
+ * scored batch: [0] whole call (first launch -> all kernels done), [1] plan (length sort),
+ * [2] k_vit (Viterbi / traceback / core), [3] k_fwd (forward [+ backward, posteriors]),
+ * [4] k_win (MW / LLR windows, means), [5] k_tracks (FoldIndex / PAPA window tracks), [6..7] reserved.
+ * The four scoring kernels run concurrently on separate streams (PLAAC_SERIAL_STREAMS=1 in the
+ * environment at ctx creation serialises them for profiling), so [2..5] overlap and do not add up to [0].
+ * Blocks until the batch has completed. */
+plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]);
+/* Same figures averaged over the most recent `ncalls` scored batches (the ctx keeps the events of
  * the last 32). This is how bench.py times the kernels over its whole timed region without a sync per step. */
-plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[4]);
+plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]);
 
 #ifdef __cplusplus
 }

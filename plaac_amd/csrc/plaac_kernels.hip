@@ -6,7 +6,7 @@
 // Kernel map (reference = cli/src/plaac.java):
 //   k_plan_*      length histogram / scan / scatter: descending-length order, so that the 64 lanes
 //                 of a wave run recurrences of similar length and the longest chains start first.
-//   k_recur       "K-A", ONE LANE PER PROTEIN. All order-sensitive serial fp64 chains:
+//   k_vit/k_fwd/k_win  "K-A", ONE LANE PER PROTEIN. All order-sensitive serial fp64 chains:
 //                   Viterbi + traceback            hmm.viterbidecodel   :3077-3121
 //                   forward with the LUT log-sum-exp  hmm.posteriorl    :3354-3375, logeapeb :1024-1047
 //                   hmm0 (degenerates to a running sum)                  :795, SURVEY H4
@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -44,7 +45,7 @@ constexpr int NAA = PLAAC_NAA;
 constexpr int LUTLEN = PLAAC_LUTLEN;
 constexpr int LEN_BINS = 1 << 16; // lengths >= LEN_BINS-1 share the last bin
 
-// per-code row used by k_recur: one LDS row per residue code
+// per-code row used by the K-A kernels: one LDS row per residue code
 enum { R_LE0 = 0, R_LE1 = 1, R_LLR = 2, R_HYD = 3, R_LE0H = 4, R_PAD = 5, R_W = 6 };
 
 struct DevTables {
@@ -119,14 +120,27 @@ __global__ void k_plan_scatter(const uint32_t *__restrict__ neff, uint32_t nprot
 }
 
 // ------------------------------------------------------------------------------------------------
-// K-A: one lane per protein — serial recurrences
+// K-A: one lane per protein — the serial recurrences, split into three independent roles so that
+// the chains of one (long) protein advance concurrently in different waves:
+//   k_vit   Viterbi + traceback + masked core / PRD                    (3 dependent sweeps)
+//   k_fwd   forward recurrence with the LUT log-sum-exp (+ backward / posteriors in track mode)
+//   k_win   MW and LLR prefix-sum windows, mean hydropathy / charge
+// The kernel time is set by the longest protein's chain (n x per-step issue time of ONE wave), so the
+// per-step instruction count of each role and the wave's issue priority matter, not the lane count.
+//
+// Residues are consumed in blocks of 16 steps, phase-locked across the 64 lanes (block boundaries are
+// relative to each protein's start, hence the unaligned 16-byte loads): every lane reloads in the same
+// iteration, the next block is already in flight while the current one is consumed (memory latency stays
+// off the serial chain), and inside the fully unrolled block every byte / bit extraction has an
+// immediate shift. (A per-lane aligned stream would reload in a different iteration per lane, and the
+// wave-wide vmcnt wait would then expose the full memory latency on every step.)
 // ------------------------------------------------------------------------------------------------
-// logeapeb (:1024-1047), branch-free. a==b (incl. -inf,-inf) falls out of the same formula:
+// logeapeb (:1024-1047), branch-free. For the values that occur (no NaN) max/min select exactly the
+// operands the reference's if/else picks. a==b (incl. -inf,-inf) falls out of the same formula:
 // dex=0 gives a + (0*lut[1] + 1*lut[0]) = a + ln 2, and -inf - -inf = NaN fails (c<40) -> hi.
 __device__ __forceinline__ double lse_lut(const double *__restrict__ lut, double a, double b) {
-    const bool agt = a > b;
-    const double hi = agt ? a : b;
-    const double lo = agt ? b : a;
+    const double hi = __builtin_fmax(a, b);
+    const double lo = __builtin_fmin(a, b);
     const double c = hi - lo;
     const bool inrange = c < 40.0;
     const double x = 100.0 * (inrange ? c : 0.0);
@@ -142,191 +156,163 @@ __device__ __forceinline__ uint32_t ld_code(const uint8_t *__restrict__ x, uint3
 }
 
 constexpr int KA_THREADS = 256;
+constexpr int ROWS = NAA + 1; // LDS row 22 duplicates row 0: any byte > 21 is scored as X with one v_min
 
-template <bool TRACKS>
-__global__ __launch_bounds__(KA_THREADS) void k_recur(const uint8_t *__restrict__ codes,
-                                                      const uint64_t *__restrict__ offsets,
-                                                      const uint32_t *__restrict__ neff,
-                                                      const uint32_t *__restrict__ order, uint32_t nprot,
-                                                      const DevTables *__restrict__ T, uint32_t *__restrict__ bits,
-                                                      plaac_row *__restrict__ rows, TrackPtrs tr,
-                                                      double *__restrict__ fwd) {
-    __shared__ double s_lut[LUTLEN + 1];
-    __shared__ double s_row[NAA * R_W];
-    for (int i = threadIdx.x; i < LUTLEN; i += KA_THREADS) s_lut[i] = T->loglut[i];
-    if (threadIdx.x == 0) s_lut[LUTLEN] = 0.0;
-    for (int i = threadIdx.x; i < NAA * R_W; i += KA_THREADS) s_row[i] = (&T->row[0][0])[i];
-    __syncthreads();
+// 16 residues starting at p (any alignment). [lo, end) is the codes buffer; a block that is not wholly
+// inside it (only the first / last few residues of the whole batch) is assembled byte by byte.
+__device__ __noinline__ uint4 load16_edge(const uint8_t *p, const uint8_t *lo, const uint8_t *end) {
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < 16; ++i) {
+        const uint8_t *q = p + i;
+        const uint32_t b = (q >= lo && q < end) ? (uint32_t)*q : 0u;
+        w[i >> 2] |= b << (8 * (i & 3));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint4 load16(const uint8_t *p, const uint8_t *lo, const uint8_t *end) {
+    if (p >= lo && p + 16 <= end) {
+        uint4 v;
+        __builtin_memcpy(&v, p, 16); // one (possibly unaligned) global_load_dwordx4
+        return v;
+    }
+    return load16_edge(p, lo, end);
+}
+// residue j (compile-time after unrolling) of a 16-residue block
+__device__ __forceinline__ uint32_t block_code(const uint4 &c, int j) {
+    const uint32_t w = j < 4 ? c.x : j < 8 ? c.y : j < 12 ? c.z : c.w;
+    const uint32_t b = (w >> (8 * (j & 3))) & 0xffu;
+    return b < 22u ? b : 22u;
+}
 
+// issue priority by chain length: the longest chains define the kernel's duration
+__device__ __forceinline__ void set_wave_priority(uint32_t n) {
+    const uint32_t n0 = __builtin_amdgcn_readfirstlane(n); // lane 0 holds the wave's longest protein
+    if (n0 >= 4096u) __builtin_amdgcn_s_setprio(3);
+    else if (n0 >= 1024u) __builtin_amdgcn_s_setprio(2);
+    else if (n0 >= 256u) __builtin_amdgcn_s_setprio(1);
+}
+
+struct LaneJob {
+    uint32_t p, n;
+    uint64_t off;
+};
+
+__device__ __forceinline__ LaneJob lane_job(const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ neff,
+                                            const uint32_t *__restrict__ order, uint32_t nprot) {
+    LaneJob j{0u, 0u, 0ull};
     const uint32_t gid = blockIdx.x * KA_THREADS + threadIdx.x;
-    if (gid >= nprot) return;
-    const uint32_t p = order[gid];
-    const uint32_t n = neff[p];
-    const uint64_t off = offsets[p];
-    plaac_row *row = rows + p;
+    if (gid < nprot) {
+        j.p = order[gid];
+        j.n = neff[j.p];
+        j.off = offsets[j.p];
+    }
+    return j;
+}
+
+__device__ __forceinline__ void load_rows(double *s_row, const DevTables *__restrict__ T) {
+    for (int i = threadIdx.x; i < ROWS * R_W; i += KA_THREADS) {
+        const int r = i / R_W, k = i - r * R_W;
+        s_row[i] = T->row[r == NAA ? 0 : r][k];
+    }
+}
+
+// ---- role V: Viterbi (:3077-3121), traceback, longest run (:1787-1804), masked core + PRD (:816-880) ----
+template <bool TRACKS>
+__global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ codes,
+                                                    const uint64_t *__restrict__ offsets,
+                                                    const uint32_t *__restrict__ neff,
+                                                    const uint32_t *__restrict__ order, uint32_t nprot,
+                                                    uint64_t total, const DevTables *__restrict__ T,
+                                                    uint32_t *__restrict__ bits, plaac_row *__restrict__ rows,
+                                                    TrackPtrs tr) {
+    __shared__ double s_row[ROWS * R_W];
+    load_rows(s_row, T);
+    __syncthreads();
+    const LaneJob J = lane_job(offsets, neff, order, nprot);
+    const uint32_t n = J.n;
+    set_wave_priority(n);
+    if (blockIdx.x * KA_THREADS + threadIdx.x >= nprot) return;
+    plaac_row *row = rows + J.p;
     if (n == 0) { // skipped record (:762): zero the fields this kernel owns
-        row->llr_score = row->core_score = row->prd_score = row->hmm_all = row->hmm_vit = 0.0;
-        row->fi_meanhydro = row->fi_meancharge = row->fi_meancombo = 0.0;
-        row->mw_score = row->mw_start = row->mw_end = row->llr_start = row->llr_end = 0;
+        row->core_score = row->prd_score = row->hmm_vit = 0.0;
         row->vit_maxrun = row->core_start = row->core_end = row->prd_start = row->prd_end = 0;
-        row->prot_len = 0;
         return;
     }
-    const uint8_t *__restrict__ x = codes + off;
+    const uint8_t *__restrict__ x = codes + J.off;
+    const uint8_t *cend = codes + total;
     // private bit scratch: 2 bits/residue of traceback, later 1 bit/residue of Viterbi path
-    uint32_t *__restrict__ wbits = bits + (off >> 4) + p;
+    uint32_t *__restrict__ wbits = bits + (J.off >> 4) + J.p;
+    const uint32_t nw = (n + 15u) >> 4;
 
     const double lt00 = T->lt[0][0], lt01 = T->lt[0][1], lt10 = T->lt[1][0], lt11 = T->lt[1][1];
     const double lf0 = T->lf[0], lf1 = T->lf[1];
+    const double h0lt = T->h0_lt00;
     const uint32_t c = (uint32_t)T->corelength;
-    const uint32_t mw = n < 80u ? n : 80u; // :769-770
 
-    // ---------------- pass 1: t = 0 .. n-1 --------------------------------------------------
-    double s0 = 0, s1 = 0, a0 = 0, a1 = 0, h0 = 0;
-    double hydsum = 0.0;
-    int chg = 0;
-    int cntL = 0, cntT = 0, mwbest = 0, mwstart = 0;          // MW window (exact integers)
-    double psL = 0.0, psT = 0.0, llrbest = -INFINITY;          // LLR window over prefix sums
-    int llrstart = -1;
-    uint32_t tbw = 0;
-    for (uint32_t t = 0; t < n; ++t) {
-        const uint32_t xc = ld_code(x, t);
-        const double *__restrict__ r = s_row + xc * R_W;
-        const double e0 = r[R_LE0], e1 = r[R_LE1];
-        if (t == 0) {
-            s0 = T->li[0] + e0;
-            s1 = T->li[1] + e1;
-            a0 = s0;
-            a1 = s1;
-            h0 = T->h0_li0 + r[R_LE0H];
-        } else {
-            // Viterbi (:3087-3100): state 0 stays the arg-max on ties (strict >)
-            const double v00 = lt00 + s0, v10 = lt10 + s1, v01 = lt01 + s0, v11 = lt11 + s1;
-            const bool g0 = v10 > v00, g1 = v11 > v01;
-            s0 = (g0 ? v10 : v00) + e0;
-            s1 = (g1 ? v11 : v01) + e1;
-            tbw |= ((uint32_t)g0 | ((uint32_t)g1 << 1)) << (2u * (t & 15u));
-            // forward (:3360-3368): LSE(-inf, u) returns u unchanged, so one LUT-LSE per state
-            const double f0 = lse_lut(s_lut, lt00 + a0, lt10 + a1);
-            const double f1 = lse_lut(s_lut, lt01 + a0, lt11 + a1);
-            if (TRACKS) {
-                fwd[2 * (off + t - 1)] = a0;
-                fwd[2 * (off + t - 1) + 1] = a1;
-            }
-            a0 = f0 + e0;
-            a1 = f1 + e1;
-            h0 = (T->h0_lt00 + h0) + r[R_LE0H];
-        }
-        if ((t & 15u) == 15u || t == n - 1) {
-            wbits[t >> 4] = tbw;
-            tbw = 0;
-        }
-        hydsum = hydsum + r[R_HYD];                                  // mean (:1584-1588)
-        chg += (xc == 3u || xc == 4u) ? 1 : ((xc == 9u || xc == 15u) ? -1 : 0);
-        // MW (:767-771): counts of N (12) and Q (14)
-        cntL += (xc == 12u || xc == 14u) ? 1 : 0;
-        if (t >= mw) {
-            const uint32_t xo = ld_code(x, t - mw);
-            cntT += (xo == 12u || xo == 14u) ? 1 : 0;
-        }
-        if (t + 1 >= mw) {
-            const int d = cntL - cntT;
-            if (t + 1 == mw || d > mwbest) {
-                mwbest = d;
-                mwstart = (int)(t + 1 - mw);
-            }
-        }
-        // LLR (:782-783): psum[i+1] = psum[i] + llr[x_i]; the trailing prefix sum is the same chain c steps later
-        psL = psL + r[R_LLR];
-        if (t >= c) psT = psT + s_row[ld_code(x, t - c) * R_W + R_LLR];
-        if (t + 1 >= c) {
-            const double d = (t + 1 == c) ? psL : psL - psT;
-            if (t + 1 == c || d > llrbest) {
-                llrbest = d;
-                llrstart = (int)(t + 1 - c);
-            }
-        }
-    }
-    if (TRACKS) {
-        fwd[2 * (off + n - 1)] = a0;
-        fwd[2 * (off + n - 1) + 1] = a1;
-    }
-    // end of Viterbi (:3102-3109) and of forward (:3369-3375)
-    const double vend0 = s0 + lf0, vend1 = s1 + lf1;
-    uint32_t state = vend1 > vend0 ? 1u : 0u;
-    const double lvit1 = state ? vend1 : vend0;
-    const double lmarg1 = lse_lut(s_lut, a0 + lf0, a1 + lf1);
-    const double l0 = h0 + T->h0_lf0;
-    row->hmm_all = lmarg1 - l0;
-    row->hmm_vit = lvit1 - l0;
-    row->prot_len = (int32_t)n;
-    row->mw_score = mwbest;
-    row->mw_start = mwstart;
-    row->mw_end = mwstart + (int)mw - 1;
-    row->llr_score = llrbest;
-    row->llr_start = llrstart;
-    row->llr_end = llrstart < 0 ? -2 : llrstart + (int)c - 1;
+    // ---------------- sweep 1: t = 0 .. n-1 ----------------
+    double s0 = 0.0, s1 = 0.0, h0 = 0.0;
     {
-        const double meanhydro = (1.0 * hydsum) / (double)(int)n;
-        const double meancharge = (1.0 * (double)chg) / (double)(int)n;
-        row->fi_meanhydro = meanhydro;
-        row->fi_meancharge = meancharge;
-        row->fi_meancombo = (T->cc[2] + T->cc[1] * fabs(meancharge)) + T->cc[0] * meanhydro; // :4885
-    }
-
-    // ---------------- pass 2: traceback t = n-1 .. 0 (:3111-3113), longest run (:1787-1804) ----
-    {
-        // (track mode) backward recurrence and posteriors run in the same reverse sweep (:3377-3405)
-        double b0 = lf0, b1 = lf1, lpseq = 0.0;
-        if (TRACKS) {
-            // lpseq needs b[.][0], i.e. a full backward sweep first
-            double q0 = lf0, q1 = lf1;
-            for (uint32_t t = n - 1; t >= 1; --t) {
-                const double *__restrict__ r = s_row + ld_code(x, t) * R_W;
-                const double u0 = (lt00 + q0) + r[R_LE0], u1 = (lt01 + q1) + r[R_LE1];
-                const double w0 = (lt10 + q0) + r[R_LE0], w1 = (lt11 + q1) + r[R_LE1];
-                q0 = lse_lut(s_lut, u0, u1);
-                q1 = lse_lut(s_lut, w0, w1);
-            }
-            lpseq = lse_lut(s_lut, fwd[2 * off] + q0, fwd[2 * off + 1] + q1);
-        }
-        int cur = 0, maxrun = 0;
-        uint32_t vw = 0; // Viterbi-path bits of the current 16-residue word
-        uint32_t word = wbits[(n - 1) >> 4];
-        for (uint32_t t = n - 1;; --t) {
-            // here `state` = vit[t]
-            vw |= state << (t & 15u);
-            cur = state ? cur + 1 : 0;
-            maxrun = cur > maxrun ? cur : maxrun;
-            if (TRACKS) {
-                const double fa0 = fwd[2 * (off + t)], fa1 = fwd[2 * (off + t) + 1];
-                const double pp0 = exp((fa0 + b0) - lpseq), pp1 = exp((fa1 + b1) - lpseq);
-                tr.post0[off + t] = pp0;
-                tr.post1[off + t] = pp1;
-                tr.map[off + t] = pp1 > pp0 ? 1 : 0; // MAP ties -> 0 (:4039)
-                tr.vit[off + t] = (uint8_t)state;
-                if (t > 0) {
-                    const double *__restrict__ r = s_row + ld_code(x, t) * R_W;
-                    const double u0 = (lt00 + b0) + r[R_LE0], u1 = (lt01 + b1) + r[R_LE1];
-                    const double w0 = (lt10 + b0) + r[R_LE0], w1 = (lt11 + b1) + r[R_LE1];
-                    b0 = lse_lut(s_lut, u0, u1);
-                    b1 = lse_lut(s_lut, w0, w1);
+        uint4 nxt = load16(x, codes, cend);
+        for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
+            const uint4 cur = nxt;
+            if (t0 + 16u < n) nxt = load16(x + t0 + 16u, codes, cend);
+            uint32_t tbw = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t t = t0 + (uint32_t)j;
+                if (t < n) {
+                    const double *__restrict__ r = s_row + block_code(cur, j) * R_W;
+                    const double e0 = r[R_LE0], e1 = r[R_LE1], eh = r[R_LE0H];
+                    if (j == 0 && t0 == 0u) {
+                        s0 = T->li[0] + e0;
+                        s1 = T->li[1] + e1;
+                        h0 = T->h0_li0 + eh;
+                    } else {
+                        // (:3087-3100): state 0 stays the arg-max on ties (strict >)
+                        const double v00 = lt00 + s0, v10 = lt10 + s1, v01 = lt01 + s0, v11 = lt11 + s1;
+                        const bool g0 = v10 > v00, g1 = v11 > v01;
+                        s0 = (g0 ? v10 : v00) + e0;
+                        s1 = (g1 ? v11 : v01) + e1;
+                        h0 = (h0lt + h0) + eh; // hmm0: Viterbi == forward == running sum
+                        tbw |= ((uint32_t)g0 | ((uint32_t)g1 << 1)) << (2 * j);
+                    }
                 }
             }
-            const uint32_t tbits = (word >> (2u * (t & 15u))) & 3u;
-            const uint32_t prev = (tbits >> state) & 1u; // tb[vit[t]][t]
-            if ((t & 15u) == 0u) {
-                wbits[t >> 4] = vw; // this word now holds vit[16j..16j+15]
-                vw = 0;
-                if (t == 0) break;
-                word = wbits[(t - 1) >> 4];
+            wbits[t0 >> 4] = tbw;
+        }
+    }
+    // end of Viterbi (:3102-3109)
+    const double vend0 = s0 + lf0, vend1 = s1 + lf1;
+    uint32_t state = vend1 > vend0 ? 1u : 0u;
+    row->hmm_vit = (state ? vend1 : vend0) - (h0 + T->h0_lf0);
+
+    // ---------------- sweep 2: traceback t = n-1 .. 0 (:3111-3113), longest run ----------------
+    {
+        int cur = 0, maxrun = 0;
+        uint32_t wnext = wbits[nw - 1u]; // traceback words are prefetched one block ahead
+        for (uint32_t wi = nw; wi-- > 0u;) {
+            const uint32_t word = wnext;
+            if (wi > 0u) wnext = wbits[wi - 1u];
+            const uint32_t t0 = wi << 4;
+            uint32_t vw = 0; // Viterbi-path bits of this 16-residue block
+#pragma unroll
+            for (int j = 15; j >= 0; --j) {
+                const uint32_t t = t0 + (uint32_t)j;
+                if (t < n) {
+                    // here `state` = vit[t]
+                    vw |= state << j;
+                    cur = state ? cur + 1 : 0;
+                    maxrun = cur > maxrun ? cur : maxrun;
+                    if (TRACKS) tr.vit[J.off + t] = (uint8_t)state;
+                    state = (word >> (2 * j + (int)state)) & 1u; // tb[vit[t]][t] = vit[t-1]
+                }
             }
-            state = prev;
+            wbits[wi] = vw; // this word now holds vit[16*wi .. 16*wi+15]
         }
         row->vit_maxrun = maxrun;
     }
 
-    // ---------------- pass 3: masked core window + PRD (:818-880) ---------------------------
+    // ---------------- sweep 3: masked core window + PRD (:818-880) ----------------
     {
         const double big_neg = T->big_neg;
         double mL = 0.0, mT = 0.0, best = -INFINITY;
@@ -334,41 +320,64 @@ __global__ __launch_bounds__(KA_THREADS) void k_recur(const uint8_t *__restrict_
         bool inrun = false, flag = false;
         int runstart = 0, prds = -1, prde = -2;
         double runsum = 0.0, prdsum = 0.0;
-        uint32_t wl = 0, wt_ = 0;
-        for (uint32_t t = 0; t < n; ++t) {
-            if ((t & 15u) == 0u) wl = wbits[t >> 4];
-            const uint32_t v = (wl >> (t & 15u)) & 1u;
-            const double lv = s_row[ld_code(x, t) * R_W + R_LLR];
-            mL = mL + (v ? lv : big_neg);
-            if (t >= c) {
-                const uint32_t to = t - c;
-                if ((to & 15u) == 0u || t == c) wt_ = wbits[to >> 4];
-                const uint32_t vo = (wt_ >> (to & 15u)) & 1u;
-                mT = mT + (vo ? s_row[ld_code(x, to) * R_W + R_LLR] : big_neg);
+        // lead stream: residues + path bits of block t0; trailing stream: the same, c steps later, i.e. the
+        // 16 positions s .. s+15 with s = t0 - c. Both are fetched one block ahead.
+        uint4 nxt = load16(x, codes, cend), tnxt = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t wlnext = wbits[0], plo = 0u, phi = 0u;
+        auto prefetch_trail = [&](int s) { // block starting at position s (>= -15) of this protein
+            tnxt = load16(x + s, codes, cend);
+            const uint32_t w0 = s >= 0 ? (uint32_t)s >> 4 : 0u;
+            plo = wbits[w0];
+            phi = (s >= 0 && w0 + 1u < nw) ? wbits[w0 + 1u] : 0u;
+        };
+        if (15 >= (int)c) prefetch_trail(-(int)c);
+        for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
+            const uint4 cur = nxt, tcur = tnxt;
+            const uint32_t wl = wlnext;
+            const int s = (int)t0 - (int)c;
+            const uint32_t tv = s >= 0 ? ((plo | (phi << 16)) >> (s & 15)) : (s > -16 ? (plo << (-s)) : 0u);
+            if (t0 + 16u < n) {
+                nxt = load16(x + t0 + 16u, codes, cend);
+                wlnext = wbits[(t0 >> 4) + 1u];
+                if (s + 31 >= 0) prefetch_trail(s + 16);
             }
-            // run bookkeeping: PRD = maximal Viterbi run around the core, PRDscore = its left-to-right sum
-            if (v) {
-                if (!inrun) {
-                    inrun = true;
-                    runstart = (int)t;
-                    runsum = 0.0;
-                    flag = false;
-                }
-                runsum = runsum + lv;
-            } else if (inrun) {
-                if (flag) {
-                    prds = runstart;
-                    prde = (int)t - 1;
-                    prdsum = runsum;
-                }
-                inrun = false;
-            }
-            if (t + 1 >= c) {
-                const double d = (t + 1 == c) ? mL : mL - mT;
-                if (t + 1 == c || d > best) {
-                    best = d;
-                    bstart = (int)(t + 1 - c);
-                    flag = v != 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t t = t0 + (uint32_t)j;
+                if (t < n) {
+                    const uint32_t v = (wl >> j) & 1u;
+                    const double lv = s_row[block_code(cur, j) * R_W + R_LLR];
+                    mL = mL + (v ? lv : big_neg); // psum[i+1] = psum[i] + maa3[i]
+                    if (t >= c) {                 // the trailing prefix sum is the same chain, c steps later
+                        const uint32_t vo = (tv >> j) & 1u;
+                        const double lo = s_row[block_code(tcur, j) * R_W + R_LLR];
+                        mT = mT + (vo ? lo : big_neg);
+                    }
+                    // PRD = maximal Viterbi run around the core, PRDscore = its left-to-right sum (:863-872)
+                    if (v) {
+                        if (!inrun) {
+                            inrun = true;
+                            runstart = (int)t;
+                            runsum = 0.0;
+                            flag = false;
+                        }
+                        runsum = runsum + lv;
+                    } else if (inrun) {
+                        if (flag) {
+                            prds = runstart;
+                            prde = (int)t - 1;
+                            prdsum = runsum;
+                        }
+                        inrun = false;
+                    }
+                    if (t + 1 >= c) {
+                        const double d = (t + 1 == c) ? mL : mL - mT;
+                        if (t + 1 == c || d > best) { // strict >: the first window wins ties
+                            best = d;
+                            bstart = (int)(t + 1 - c);
+                            flag = v != 0u;
+                        }
+                    }
                 }
             }
         }
@@ -393,6 +402,190 @@ __global__ __launch_bounds__(KA_THREADS) void k_recur(const uint8_t *__restrict_
             row->prd_end = -2;
         }
     }
+}
+
+// ---- role F: forward (:3354-3375) with logeapeb (:1024-1047); track mode adds backward, posteriors
+//      and the MAP path (:3377-3405, :4032-4045) ----
+template <bool TRACKS>
+__global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ codes,
+                                                    const uint64_t *__restrict__ offsets,
+                                                    const uint32_t *__restrict__ neff,
+                                                    const uint32_t *__restrict__ order, uint32_t nprot,
+                                                    uint64_t total, const DevTables *__restrict__ T,
+                                                    plaac_row *__restrict__ rows, TrackPtrs tr,
+                                                    double *__restrict__ fwd) {
+    __shared__ double s_lut[LUTLEN + 1];
+    __shared__ double s_row[ROWS * R_W];
+    for (int i = threadIdx.x; i < LUTLEN; i += KA_THREADS) s_lut[i] = T->loglut[i];
+    if (threadIdx.x == 0) s_lut[LUTLEN] = 0.0;
+    load_rows(s_row, T);
+    __syncthreads();
+    const LaneJob J = lane_job(offsets, neff, order, nprot);
+    const uint32_t n = J.n;
+    set_wave_priority(n);
+    if (blockIdx.x * KA_THREADS + threadIdx.x >= nprot) return;
+    plaac_row *row = rows + J.p;
+    if (n == 0) {
+        row->hmm_all = 0.0;
+        return;
+    }
+    const uint8_t *__restrict__ x = codes + J.off;
+    const uint8_t *cend = codes + total;
+    const double lt00 = T->lt[0][0], lt01 = T->lt[0][1], lt10 = T->lt[1][0], lt11 = T->lt[1][1];
+    const double lf0 = T->lf[0], lf1 = T->lf[1];
+    const double h0lt = T->h0_lt00;
+
+    double a0 = 0.0, a1 = 0.0, h0 = 0.0;
+    {
+        uint4 nxt = load16(x, codes, cend);
+        for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
+            const uint4 cur = nxt;
+            if (t0 + 16u < n) nxt = load16(x + t0 + 16u, codes, cend);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t t = t0 + (uint32_t)j;
+                if (t < n) {
+                    const double *__restrict__ r = s_row + block_code(cur, j) * R_W;
+                    const double e0 = r[R_LE0], e1 = r[R_LE1], eh = r[R_LE0H];
+                    if (j == 0 && t0 == 0u) {
+                        a0 = T->li[0] + e0;
+                        a1 = T->li[1] + e1;
+                        h0 = T->h0_li0 + eh;
+                    } else {
+                        // (:3360-3368): LSE(-inf, u) returns u unchanged, so one LUT-LSE per state
+                        const double f0 = lse_lut(s_lut, lt00 + a0, lt10 + a1);
+                        const double f1 = lse_lut(s_lut, lt01 + a0, lt11 + a1);
+                        a0 = f0 + e0;
+                        a1 = f1 + e1;
+                        h0 = (h0lt + h0) + eh;
+                    }
+                    if (TRACKS) {
+                        fwd[2 * (J.off + t)] = a0;
+                        fwd[2 * (J.off + t) + 1] = a1;
+                    }
+                }
+            }
+        }
+    }
+    const double lmarg1 = lse_lut(s_lut, a0 + lf0, a1 + lf1); // (:3369-3375)
+    row->hmm_all = lmarg1 - (h0 + T->h0_lf0);
+
+    if (TRACKS) {
+        // lpseq needs b[.][0]: one full backward sweep first, then a second one that emits posteriors
+        double q0 = lf0, q1 = lf1;
+        for (uint32_t t = n - 1; t >= 1; --t) {
+            const double *__restrict__ r = s_row + ld_code(x, t) * R_W;
+            const double u0 = (lt00 + q0) + r[R_LE0], u1 = (lt01 + q1) + r[R_LE1];
+            const double w0 = (lt10 + q0) + r[R_LE0], w1 = (lt11 + q1) + r[R_LE1];
+            q0 = lse_lut(s_lut, u0, u1);
+            q1 = lse_lut(s_lut, w0, w1);
+        }
+        const double lpseq = lse_lut(s_lut, fwd[2 * J.off] + q0, fwd[2 * J.off + 1] + q1);
+        double b0 = lf0, b1 = lf1;
+        for (uint32_t t = n - 1;; --t) {
+            const double fa0 = fwd[2 * (J.off + t)], fa1 = fwd[2 * (J.off + t) + 1];
+            const double pp0 = exp((fa0 + b0) - lpseq), pp1 = exp((fa1 + b1) - lpseq);
+            tr.post0[J.off + t] = pp0;
+            tr.post1[J.off + t] = pp1;
+            tr.map[J.off + t] = pp1 > pp0 ? 1 : 0; // MAP ties -> 0 (:4039)
+            if (t == 0) break;
+            const double *__restrict__ r = s_row + ld_code(x, t) * R_W;
+            const double u0 = (lt00 + b0) + r[R_LE0], u1 = (lt01 + b1) + r[R_LE1];
+            const double w0 = (lt10 + b0) + r[R_LE0], w1 = (lt11 + b1) + r[R_LE1];
+            b0 = lse_lut(s_lut, u0, u1);
+            b1 = lse_lut(s_lut, w0, w1);
+        }
+    }
+}
+
+// ---- role W: MW (:767-771) and LLR (:782-783) windows over prefix sums (hss2 :1206-1257 with
+//      min == max), mean hydropathy / charge / FoldIndex (:4877-4885) ----
+__global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ codes,
+                                                    const uint64_t *__restrict__ offsets,
+                                                    const uint32_t *__restrict__ neff,
+                                                    const uint32_t *__restrict__ order, uint32_t nprot,
+                                                    uint64_t total, const DevTables *__restrict__ T,
+                                                    plaac_row *__restrict__ rows) {
+    __shared__ double s_row[ROWS * R_W];
+    load_rows(s_row, T);
+    __syncthreads();
+    const LaneJob J = lane_job(offsets, neff, order, nprot);
+    const uint32_t n = J.n;
+    set_wave_priority(n);
+    if (blockIdx.x * KA_THREADS + threadIdx.x >= nprot) return;
+    plaac_row *row = rows + J.p;
+    if (n == 0) {
+        row->llr_score = row->fi_meanhydro = row->fi_meancharge = row->fi_meancombo = 0.0;
+        row->mw_score = row->mw_start = row->mw_end = row->llr_start = row->llr_end = 0;
+        row->prot_len = 0;
+        return;
+    }
+    const uint8_t *__restrict__ x = codes + J.off;
+    const uint8_t *cend = codes + total;
+    const uint32_t c = (uint32_t)T->corelength;
+    const uint32_t mw = n < 80u ? n : 80u; // :769-770 (a protein shorter than 80 has a single window)
+
+    double hydsum = 0.0;
+    int chg = 0;
+    int cntL = 0, cntT = 0, mwbest = 0, mwstart = 0;  // MW window: exact integers
+    double psL = 0.0, psT = 0.0, llrbest = -INFINITY; // LLR window over prefix sums
+    int llrstart = -1;
+    // three phase-locked streams: residues at t, at t - c (LLR window) and at t - 80 (MW window)
+    uint4 nxt = load16(x, codes, cend), cnxt = make_uint4(0u, 0u, 0u, 0u), mnxt = cnxt;
+    if (15 >= (int)c) cnxt = load16(x - (int)c, codes, cend);
+    for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
+        const uint4 cur = nxt, ccur = cnxt, mcur = mnxt;
+        if (t0 + 16u < n) {
+            nxt = load16(x + t0 + 16u, codes, cend);
+            const int sc = (int)t0 + 16 - (int)c, sm = (int)t0 + 16 - 80;
+            if (sc + 15 >= 0) cnxt = load16(x + sc, codes, cend);
+            if (sm + 15 >= 0) mnxt = load16(x + sm, codes, cend);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t t = t0 + (uint32_t)j;
+            if (t < n) {
+                const uint32_t xc = block_code(cur, j);
+                const double *__restrict__ r = s_row + xc * R_W;
+                hydsum = hydsum + r[R_HYD]; // mean (:1584-1588)
+                chg += (xc == 3u || xc == 4u) ? 1 : ((xc == 9u || xc == 15u) ? -1 : 0);
+                cntL += (xc == 12u || xc == 14u) ? 1 : 0; // N, Q
+                if (t >= 80u) { // only reached when n > 80, i.e. mw == 80
+                    const uint32_t xo = block_code(mcur, j);
+                    cntT += (xo == 12u || xo == 14u) ? 1 : 0;
+                }
+                if (t + 1 >= mw) {
+                    const int d = cntL - cntT;
+                    if (t + 1 == mw || d > mwbest) {
+                        mwbest = d;
+                        mwstart = (int)(t + 1 - mw);
+                    }
+                }
+                // psum[i+1] = psum[i] + llr[x_i]; the trailing prefix sum is the same chain c steps later
+                psL = psL + r[R_LLR];
+                if (t >= c) psT = psT + s_row[block_code(ccur, j) * R_W + R_LLR];
+                if (t + 1 >= c) {
+                    const double d = (t + 1 == c) ? psL : psL - psT;
+                    if (t + 1 == c || d > llrbest) {
+                        llrbest = d;
+                        llrstart = (int)(t + 1 - c);
+                    }
+                }
+            }
+        }
+    }
+    row->prot_len = (int32_t)n;
+    row->mw_score = mwbest;
+    row->mw_start = mwstart;
+    row->mw_end = mwstart + (int)mw - 1;
+    row->llr_score = llrbest;
+    row->llr_start = llrstart;
+    row->llr_end = llrstart < 0 ? -2 : llrstart + (int)c - 1;
+    const double meanhydro = (1.0 * hydsum) / (double)(int)n;
+    const double meancharge = (1.0 * (double)chg) / (double)(int)n;
+    row->fi_meanhydro = meanhydro;
+    row->fi_meancharge = meancharge;
+    row->fi_meancombo = (T->cc[2] + T->cc[1] * fabs(meancharge)) + T->cc[0] * meanhydro; // :4885
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -703,8 +896,11 @@ struct plaac_ctx {
     unsigned long long *d_counts = nullptr;
     size_t cap_codes = 0, cap_offs = 0, cap_rows = 0, cap_trk = 0;
     static constexpr int EV_SETS = 32; // timings of the last 32 scored batches
-    hipEvent_t ev[EV_SETS][4] = {};
+    static constexpr int EV_PER = 11;  // start, planned, {begin,end} x {vit,fwd,win,tracks}, joined
+    hipEvent_t ev[EV_SETS][EV_PER] = {};
     uint64_t ncalls = 0;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // high-priority side streams of the three K-A roles
+    bool serial = false;                              // PLAAC_SERIAL_STREAMS=1: everything on one stream
     std::string err;
 };
 
@@ -837,6 +1033,15 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        for (auto &a : ctx->aux)
+            if ((e = hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest)) != hipSuccess)
+                return bail("hipStreamCreateWithPriority", e);
+        const char *ser = std::getenv("PLAAC_SERIAL_STREAMS");
+        ctx->serial = ser && ser[0] == '1';
+    }
     for (auto &set : ctx->ev)
         for (auto &ev : set)
             if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
@@ -885,6 +1090,11 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     for (auto &set : ctx->ev)
         for (auto &ev : set)
             if (ev) (void)hipEventDestroy(ev);
+    for (auto &a : ctx->aux)
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -902,6 +1112,7 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     if (!ctx) return PLAAC_ERR_ARG;
     if (nprot == 0) return PLAAC_OK;
     if (!d_offsets || !d_rows || (!d_codes && total_residues)) return fail(ctx, PLAAC_ERR_ARG, "null device buffer");
+    if ((uintptr_t)d_codes & 15u) return fail(ctx, PLAAC_ERR_ARG, "d_codes must be 16-byte aligned");
     TrackPtrs tp{};
     if (d_tracks) {
         tp = TrackPtrs{d_tracks->vit,   d_tracks->map,  d_tracks->charge,     d_tracks->hydro,
@@ -932,21 +1143,42 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     const int wmax = std::max(ctx->params.ww1 / 2, std::max(ctx->params.ww2 / 2, ctx->params.ww3 / 2));
 
     hipEvent_t *evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
-    PL_HIP(ctx, hipEventRecord(evs[0], st));
+    enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10 };
+    PL_HIP(ctx, hipEventRecord(evs[E_START], st));
     PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * LEN_BINS, st));
     const unsigned pb = (nprot + 255u) / 256u;
     hipLaunchKernelGGL(k_plan_lengths, dim3(pb), dim3(256), 0, st, d_codes, d_offsets, nprot, ctx->d_neff, ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scatter, dim3(pb), dim3(256), 0, st, ctx->d_neff, nprot, ctx->d_hist, ctx->d_order);
-    PL_HIP(ctx, hipEventRecord(evs[1], st));
+    PL_HIP(ctx, hipEventRecord(evs[E_PLAN], st));
+    // The three K-A roles and K-B are independent given the plan: fork them onto side streams so the long
+    // serial chains (which set the wall time) overlap each other and the throughput-bound window kernel.
+    hipStream_t sv = ctx->serial ? st : ctx->aux[0], sf = ctx->serial ? st : ctx->aux[1],
+                sw = ctx->serial ? st : ctx->aux[2];
+    if (!ctx->serial)
+        for (hipStream_t a : {sv, sf, sw}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PLAN], 0));
     const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
+    PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
     if (d_tracks)
-        hipLaunchKernelGGL(k_recur<true>, dim3(ab), dim3(KA_THREADS), 0, st, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, ctx->d_tab, ctx->d_bits, d_rows, tp, ctx->d_fwd);
+        hipLaunchKernelGGL(k_vit<true>, dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
+                           ctx->d_order, nprot, total_residues, ctx->d_tab, ctx->d_bits, d_rows, tp);
     else
-        hipLaunchKernelGGL(k_recur<false>, dim3(ab), dim3(KA_THREADS), 0, st, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, ctx->d_tab, ctx->d_bits, d_rows, tp, (double *)nullptr);
-    PL_HIP(ctx, hipEventRecord(evs[2], st));
+        hipLaunchKernelGGL(k_vit<false>, dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
+                           ctx->d_order, nprot, total_residues, ctx->d_tab, ctx->d_bits, d_rows, tp);
+    PL_HIP(ctx, hipEventRecord(evs[E_VIT + 1], sv));
+    PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
+    if (d_tracks)
+        hipLaunchKernelGGL(k_fwd<true>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
+                           ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp, ctx->d_fwd);
+    else
+        hipLaunchKernelGGL(k_fwd<false>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
+                           ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp, (double *)nullptr);
+    PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
+    PL_HIP(ctx, hipEventRecord(evs[E_WIN], sw));
+    hipLaunchKernelGGL(k_win, dim3(ab), dim3(KA_THREADS), 0, sw, d_codes, d_offsets, ctx->d_neff, ctx->d_order, nprot,
+                       total_residues, ctx->d_tab, d_rows);
+    PL_HIP(ctx, hipEventRecord(evs[E_WIN + 1], sw));
+    PL_HIP(ctx, hipEventRecord(evs[E_TRK], st));
 #define LAUNCH_KB(RING)                                                                                            \
     do {                                                                                                           \
         if (d_tracks)                                                                                              \
@@ -960,35 +1192,38 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     else if (wmax <= 96) LAUNCH_KB(256);
     else LAUNCH_KB(1024);
 #undef LAUNCH_KB
-    PL_HIP(ctx, hipEventRecord(evs[3], st));
+    PL_HIP(ctx, hipEventRecord(evs[E_TRK + 1], st));
+    if (!ctx->serial)
+        for (int done : {E_VIT + 1, E_FWD + 1, E_WIN + 1}) PL_HIP(ctx, hipStreamWaitEvent(st, evs[done], 0));
+    PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->ncalls++;
     return PLAAC_OK;
 }
 
-plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[4]) {
+plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
     if (!ctx || !ms) return PLAAC_ERR_ARG;
     if (ctx->ncalls == 0) return fail(ctx, PLAAC_ERR_ARG, "no scored batch to time yet");
     if (ncalls == 0) ncalls = 1;
     if (ncalls > plaac_ctx::EV_SETS) ncalls = plaac_ctx::EV_SETS;
     if (ncalls > ctx->ncalls) ncalls = (uint32_t)ctx->ncalls;
     PL_HIP(ctx, hipSetDevice(ctx->device));
-    double acc[4] = {0, 0, 0, 0};
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static const int pairs[6][2] = {{0, 10}, {0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}};
     for (uint32_t k = 0; k < ncalls; ++k) {
         hipEvent_t *evs = ctx->ev[(ctx->ncalls - 1 - k) % plaac_ctx::EV_SETS];
-        float t[4];
-        PL_HIP(ctx, hipEventSynchronize(evs[3]));
-        PL_HIP(ctx, hipEventElapsedTime(&t[0], evs[0], evs[3]));
-        PL_HIP(ctx, hipEventElapsedTime(&t[1], evs[0], evs[1]));
-        PL_HIP(ctx, hipEventElapsedTime(&t[2], evs[1], evs[2]));
-        PL_HIP(ctx, hipEventElapsedTime(&t[3], evs[2], evs[3]));
-        for (int i = 0; i < 4; ++i) acc[i] += t[i];
+        PL_HIP(ctx, hipEventSynchronize(evs[10]));
+        for (int i = 0; i < 6; ++i) {
+            float t = 0.f;
+            PL_HIP(ctx, hipEventElapsedTime(&t, evs[pairs[i][0]], evs[pairs[i][1]]));
+            acc[i] += t;
+        }
     }
-    for (int i = 0; i < 4; ++i) ms[i] = (float)(acc[i] / ncalls);
+    for (int i = 0; i < 8; ++i) ms[i] = (float)(acc[i] / ncalls);
     return PLAAC_OK;
 }
 
-plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[4]) { return plaac_timings_mean(ctx, 1, ms); }
+plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]) { return plaac_timings_mean(ctx, 1, ms); }
 
 plaac_status plaac_histogram_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
                                     uint32_t nprot, int64_t *d_counts, void *stream_) {
@@ -1018,7 +1253,7 @@ static plaac_status stage_in(plaac_ctx *ctx, const uint8_t *codes, const uint64_
     for (uint64_t i = 0; i < total; ++i)
         if (codes[i] > 21) return fail(ctx, PLAAC_ERR_ARG, "residue code > 21");
     plaac_status rc;
-    if ((rc = grow(ctx, ctx->d_codes, ctx->cap_codes, (size_t)total + 16)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, ctx->d_codes, ctx->cap_codes, (size_t)total + 64)) != PLAAC_OK) return rc;
     if ((rc = grow(ctx, ctx->d_offsets, ctx->cap_offs, (size_t)nprot + 1)) != PLAAC_OK) return rc;
     if (total) PL_HIP(ctx, hipMemcpyAsync(ctx->d_codes, codes, total, hipMemcpyHostToDevice, ctx->stream));
     PL_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, sizeof(uint64_t) * ((size_t)nprot + 1), hipMemcpyHostToDevice,

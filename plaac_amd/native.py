@@ -238,8 +238,8 @@ class Context:
         self._check(self._L.plaac_ctx_sync(self._h))
 
     def last_timings(self, ncalls=1):
-        """device ms (HIP events on the launch stream), mean over the last `ncalls` scored batches:
-        total, plan (sort), recurrence kernel, window-track kernel"""
-        ms = (C.c_float * 4)()
+        """device ms (HIP events on each kernel's launch stream), mean over the last `ncalls` scored batches.
+        The four scoring kernels overlap on separate streams, so they do not add up to `total`."""
+        ms = (C.c_float * 8)()
         self._check(self._L.plaac_timings_mean(self._h, int(ncalls), C.addressof(ms)))
-        return {"total": ms[0], "plan": ms[1], "recur": ms[2], "tracks": ms[3]}
+        return {"total": ms[0], "plan": ms[1], "vit": ms[2], "fwd": ms[3], "win": ms[4], "tracks": ms[5]}
