@@ -1,0 +1,75 @@
+/*
+ * plaac_host.h — host-side text I/O of the PLAAC engine (part of libplaac_native.so, no device code).
+ *
+ * These helpers reproduce the reference's input and output contracts around the scoring kernels
+ * (reference = cli/src/plaac.java of whitehead/plaac):
+ *   fastareader                :4302-4375  record splitting quirks
+ *   read_aa_params / print_aa_params  :2684-2713 / :2665-2669   the -B / -F / -b file format
+ *   System.out.format rows     :899-945 (summary, 38 columns), :635-645 (per-residue tracks)
+ *   "## parameters at run-time" block :503-514, aaparams2string :2717-2723
+ * Number formatting follows java.util.Formatter (HALF_UP on the exact decimal expansion, "NaN",
+ * "Infinity"), not C printf.
+ * C linkage so that the C++ CLI, a JNI shim and ctypes tests share one implementation.
+ */
+#ifndef PLAAC_HOST_H
+#define PLAAC_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "plaac_native.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A FASTA file split into records exactly as fastareader does, residues already encoded (plaac_encode).
+ * codes/offsets are a ready-made UNTRIMMED batch for plaac_histogram / plaac_score. */
+typedef struct plaac_fasta {
+    uint32_t nrec;
+    uint64_t nres;
+    uint8_t *codes;     /* nres bytes                                  */
+    uint64_t *offsets;  /* nrec + 1                                    */
+    char *names;        /* all headers, NUL-separated                  */
+    uint64_t *name_off; /* nrec + 1 offsets into names                 */
+} plaac_fasta;
+
+/* Reads `path`. Returns PLAAC_ERR_IO when the file cannot be opened (the reference prints
+ * "# Couldn't open <file>" to stdout and carries on with no records; the CLI mirrors that). */
+plaac_status plaac_fasta_read(const char *path, plaac_fasta **out);
+void plaac_fasta_free(plaac_fasta *f);
+
+/* -B / -F parameter files: 22 lines, first token = number (:2684-2713).
+ * warn_line (nullable, >= 22 ints): set to 1 where the optional "# name" column disagrees with the alphabet. */
+plaac_status plaac_read_aa_params(const char *path, double vec[PLAAC_NAA], int *warn_line);
+
+/* java.util.Formatter "%.<decimals>f" of v into buf (cap >= 400). Returns the length written. */
+int plaac_format_fixed(double v, int decimals, char *buf, size_t cap);
+/* java.lang.Double.toString(v) (used for alpha in the parameter block). */
+int plaac_format_double_tostring(double v, char *buf, size_t cap);
+
+/* One line of the per-protein summary table, without the trailing newline (:899-945).
+ * codes = the record's UNTRIMMED codes, reclen their number. Returns the length, or -1 if cap is too small.
+ * Records with row->prot_len == 0 produce no line (returns 0). */
+long plaac_format_summary_row(const plaac_row *row, const char *name, const uint8_t *codes, uint64_t reclen,
+                              int corelength, int ww2, char *buf, size_t cap);
+/* header line of the summary table (:715-719) and of the per-residue table (:603-605), no newline */
+const char *plaac_summary_header(void);
+const char *plaac_tracks_header(void);
+
+/* All per-residue lines of one protein plus the closing line of 56 '#' (:635-645), newline-terminated.
+ * `first` = index of the record's first residue in the track arrays. Returns the length or -1. */
+long plaac_format_track_rows(const plaac_tracks *tracks, uint64_t first, const uint8_t *codes, uint32_t n,
+                             const char *order_id, const char *name, char *buf, size_t cap);
+/* worst-case bytes plaac_format_track_rows needs for a protein of n residues */
+size_t plaac_track_rows_bound(uint32_t n, size_t id_len, size_t name_len);
+
+/* "## parameters at run-time" block (:503-514), newline-terminated. Returns the length or -1. */
+long plaac_format_param_block(const plaac_params *p, char *buf, size_t cap);
+/* the 22 lines "%.6f # %s" of print_aa_params (:2665-2669). Returns the length or -1. */
+long plaac_format_aa_params(const double vec[PLAAC_NAA], char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLAAC_HOST_H */

@@ -1,0 +1,453 @@
+// plaac_io.cpp — host text I/O of libplaac_native.so (see include/plaac_host.h). No device code.
+//
+// Reference behaviour reproduced here (cli/src/plaac.java):
+//   fastareader :4302-4375 — header = line starting with '>'; sequence lines are concatenated until a
+//       blank line or the next header; after a blank line the rest of the record is skipped; the name of the
+//       first record (and of any record found after a blank line) is trimmed, names met while reading a
+//       sequence are not; line content is never trimmed (blanks become X).
+//   java.util.Formatter %.Nf — FormattedFloatingDecimal: take the SHORTEST decimal digit string that
+//       identifies the double (what Double.toString prints), then round HALF_UP at the requested place
+//       (so 0.0045 -> "0.005" although the double is 0.004499999...; C printf gives "0.004").
+#include "plaac_host.h"
+
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+const char kAlphabet[] = "XACDEFGHIKLMNPQRSTVWY*"; // aanames (:26)
+
+// shortest round-trip digits of |v| (finite, non-zero): value = 0.d1d2...dn x 10^decexp
+struct Digits {
+    std::string d;
+    int decexp;
+};
+
+Digits shortest_digits(double av) {
+    char tmp[64];
+    auto r = std::to_chars(tmp, tmp + sizeof tmp, av, std::chars_format::scientific);
+    std::string s(tmp, r.ptr);
+    const size_t epos = s.find('e');
+    std::string mant = s.substr(0, epos);
+    const int e10 = std::atoi(s.c_str() + epos + 1);
+    Digits out;
+    for (char c : mant)
+        if (c != '.') out.d.push_back(c);
+    while (out.d.size() > 1 && out.d.back() == '0') out.d.pop_back();
+    out.decexp = e10 + 1;
+    return out;
+}
+
+// FormattedFloatingDecimal.applyPrecision: keep `keep` leading digits, HALF_UP on the next one
+void round_half_up(Digits &g, int keep) {
+    const int n = (int)g.d.size();
+    if (keep >= n || keep < 0) return;
+    if (keep == 0) {
+        if (g.d[0] >= '5') {
+            g.d = "1";
+            g.decexp += 1;
+        } else {
+            g.d = "0";
+        }
+        return;
+    }
+    const bool up = g.d[keep] >= '5';
+    g.d.resize(keep);
+    if (!up) return;
+    int i = keep - 1;
+    while (i >= 0 && g.d[i] == '9') g.d[i--] = '0';
+    if (i >= 0) {
+        g.d[i]++;
+    } else {
+        g.d.insert(g.d.begin(), '1');
+        g.d.resize(keep);
+        g.decexp += 1;
+    }
+}
+
+std::string fixed_string(double v, int decimals) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
+    std::string out;
+    if (std::signbit(v)) out.push_back('-');
+    const double av = std::fabs(v);
+    Digits g{"0", 1};
+    if (av != 0.0) {
+        g = shortest_digits(av);
+        round_half_up(g, g.decexp + decimals);
+    }
+    // integer part
+    if (g.decexp <= 0 || g.d == "0") {
+        out.push_back('0');
+    } else {
+        for (int i = 0; i < g.decexp; ++i) out.push_back(i < (int)g.d.size() ? g.d[i] : '0');
+    }
+    if (decimals > 0) {
+        out.push_back('.');
+        for (int k = 0; k < decimals; ++k) {
+            const int idx = g.decexp + k; // digit index of the k-th decimal
+            char c = '0';
+            if (g.d != "0" && idx >= 0 && idx < (int)g.d.size()) c = g.d[idx];
+            out.push_back(c);
+        }
+    }
+    return out;
+}
+
+// java.lang.Double.toString
+std::string java_double_tostring(double v) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
+    std::string out;
+    if (std::signbit(v)) out.push_back('-');
+    const double av = std::fabs(v);
+    if (av == 0.0) return out + "0.0";
+    Digits g = shortest_digits(av);
+    if (av >= 1e-3 && av < 1e7) {
+        if (g.decexp <= 0) {
+            out += "0.";
+            out.append((size_t)(-g.decexp), '0');
+            out += g.d;
+        } else {
+            for (int i = 0; i < g.decexp; ++i) out.push_back(i < (int)g.d.size() ? g.d[i] : '0');
+            out.push_back('.');
+            if ((int)g.d.size() > g.decexp) out += g.d.substr((size_t)g.decexp);
+            else out.push_back('0');
+        }
+    } else {
+        out.push_back(g.d[0]);
+        out.push_back('.');
+        if (g.d.size() > 1) out += g.d.substr(1);
+        else out.push_back('0');
+        out += "E" + std::to_string(g.decexp - 1);
+    }
+    return out;
+}
+
+// String.trim(): strip chars <= ' ' at both ends
+std::string java_trim(const std::string &s) {
+    size_t b = 0, e = s.size();
+    while (b < e && (unsigned char)s[b] <= ' ') ++b;
+    while (e > b && (unsigned char)s[e - 1] <= ' ') --e;
+    return s.substr(b, e - b);
+}
+
+// BufferedReader.readLine over an in-memory file: terminators \n, \r, \r\n
+struct LineReader {
+    const std::string &buf;
+    size_t pos = 0;
+    explicit LineReader(const std::string &b) : buf(b) {}
+    bool next(std::string &line) {
+        if (pos >= buf.size()) return false;
+        size_t e = pos;
+        while (e < buf.size() && buf[e] != '\n' && buf[e] != '\r') ++e;
+        line.assign(buf, pos, e - pos);
+        if (e < buf.size()) {
+            if (buf[e] == '\r' && e + 1 < buf.size() && buf[e + 1] == '\n') ++e;
+            ++e;
+        }
+        pos = e;
+        return true;
+    }
+};
+
+bool slurp(const char *path, std::string &out) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return false;
+    char chunk[1 << 16];
+    size_t n;
+    while ((n = std::fread(chunk, 1, sizeof chunk, f)) > 0) out.append(chunk, n);
+    std::fclose(f);
+    return true;
+}
+
+// submatrix(int[], r1, r2) clamps (:1445-1456)
+void clamp_range(int m, int &r1, int &r2) {
+    if (r1 < 0) r1 = 0;
+    if (r2 < r1) r2 = r1;
+    if (r1 >= m) r1 = m - 1;
+    if (r2 >= m) r2 = m - 1;
+}
+
+void append_aa(std::string &out, const uint8_t *aa, int m, int r1, int r2) {
+    clamp_range(m, r1, r2);
+    for (int i = r1; i <= r2; ++i) out.push_back(kAlphabet[aa[i] <= 21 ? aa[i] : 0]);
+}
+
+long emit(const std::string &s, char *buf, size_t cap) {
+    if (s.size() + 1 > cap) return -1;
+    std::memcpy(buf, s.data(), s.size());
+    buf[s.size()] = '\0';
+    return (long)s.size();
+}
+
+double inf2nan(double x) { return std::isinf(x) ? std::nan("") : x; } // (:1008)
+
+} // namespace
+
+extern "C" {
+
+plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
+    if (!path || !out) return PLAAC_ERR_ARG;
+    *out = nullptr;
+    std::string file;
+    if (!slurp(path, file)) return PLAAC_ERR_IO;
+    std::vector<uint64_t> offs{0}, noffs{0};
+    std::string names, codes_txt;
+    LineReader rd(file);
+    std::string line, name, seq;
+    bool ondeck = false;
+    for (;;) {
+        if (!ondeck) { // hasmorefastas (:4355-4372): skip to the next header, its name is trimmed
+            bool found = false;
+            while (rd.next(line)) {
+                if (!line.empty() && line[0] == '>') {
+                    name = java_trim(line).substr(1);
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) break;
+        }
+        // nextfasta (:4325-4348)
+        seq.clear();
+        std::string nextname;
+        ondeck = false;
+        while (rd.next(line)) {
+            if (line.empty()) break; // blank line ends the record; the remainder is skipped
+            if (line[0] == '>') {
+                ondeck = true;
+                nextname = line.substr(1); // not trimmed
+                break;
+            }
+            seq += line;
+        }
+        names += name;
+        names.push_back('\0');
+        noffs.push_back(names.size());
+        codes_txt += seq;
+        offs.push_back(codes_txt.size());
+        if (ondeck) name = nextname;
+    }
+    plaac_fasta *f = (plaac_fasta *)std::calloc(1, sizeof(plaac_fasta));
+    if (!f) return PLAAC_ERR_NOMEM;
+    f->nrec = (uint32_t)(offs.size() - 1);
+    f->nres = codes_txt.size();
+    f->codes = (uint8_t *)std::malloc(codes_txt.size() + 64);
+    f->offsets = (uint64_t *)std::malloc(offs.size() * sizeof(uint64_t));
+    f->names = (char *)std::malloc(names.size() + 1);
+    f->name_off = (uint64_t *)std::malloc(noffs.size() * sizeof(uint64_t));
+    if (!f->codes || !f->offsets || !f->names || !f->name_off) {
+        plaac_fasta_free(f);
+        return PLAAC_ERR_NOMEM;
+    }
+    plaac_encode(codes_txt.data(), codes_txt.size(), f->codes);
+    std::memcpy(f->offsets, offs.data(), offs.size() * sizeof(uint64_t));
+    std::memcpy(f->names, names.data(), names.size());
+    f->names[names.size()] = '\0';
+    std::memcpy(f->name_off, noffs.data(), noffs.size() * sizeof(uint64_t));
+    *out = f;
+    return PLAAC_OK;
+}
+
+void plaac_fasta_free(plaac_fasta *f) {
+    if (!f) return;
+    std::free(f->codes);
+    std::free(f->offsets);
+    std::free(f->names);
+    std::free(f->name_off);
+    std::free(f);
+}
+
+plaac_status plaac_read_aa_params(const char *path, double vec[PLAAC_NAA], int *warn_line) {
+    if (!path || !vec) return PLAAC_ERR_ARG;
+    for (int i = 0; i < PLAAC_NAA; ++i) {
+        vec[i] = 0.0;
+        if (warn_line) warn_line[i] = 0;
+    }
+    std::string file;
+    if (!slurp(path, file)) return PLAAC_ERR_IO;
+    LineReader rd(file);
+    std::string line;
+    for (int i = 0; i < PLAAC_NAA; ++i) {
+        if (!rd.next(line)) return PLAAC_ERR_ARG; // the reference throws on a short file
+        std::vector<std::string> tok; // StringTokenizer: split on blanks, tabs, newlines, form feeds
+        size_t p = 0;
+        while (p < line.size()) {
+            while (p < line.size() && std::strchr(" \t\n\r\f", line[p])) ++p;
+            size_t q = p;
+            while (q < line.size() && !std::strchr(" \t\n\r\f", line[q])) ++q;
+            if (q > p) tok.push_back(line.substr(p, q - p));
+            p = q;
+        }
+        if (tok.empty()) return PLAAC_ERR_ARG;
+        char *endp = nullptr;
+        vec[i] = std::strtod(tok[0].c_str(), &endp);
+        if (endp == tok[0].c_str()) return PLAAC_ERR_ARG;
+        if (tok.size() > 2 && warn_line && tok[2][0] != kAlphabet[i]) warn_line[i] = 1;
+    }
+    return PLAAC_OK;
+}
+
+int plaac_format_fixed(double v, int decimals, char *buf, size_t cap) {
+    return (int)emit(fixed_string(v, decimals), buf, cap);
+}
+
+int plaac_format_double_tostring(double v, char *buf, size_t cap) {
+    return (int)emit(java_double_tostring(v), buf, cap);
+}
+
+const char *plaac_summary_header(void) {
+    return "SEQid\tMW\tMWstart\tMWend\tMWlen\tLLR\tLLRstart\tLLRend\tLLRlen\tNLLR\tVITmaxrun\tCOREscore\tCOREstart\t"
+           "COREend\tCORElen\tPRDscore\tPRDstart\tPRDend\tPRDlen\tPROTlen\tHMMall\tHMMvit\tCOREaa\tSTARTaa\tENDaa\t"
+           "PRDaa\tFInumaa\tFImeanhydro\tFImeancharge\tFImeancombo\tFImaxrun\tPAPAcombo\tPAPAprop\tPAPAfi\tPAPAllr\t"
+           "PAPAllr2\tPAPAcen\tPAPAaa";
+}
+
+const char *plaac_tracks_header(void) {
+    return "ORDER\tSEQid\tAANUM\tAA\tVIT\tMAP\tCHARGE\tHYDRO\tFI\tPLAAC\tPAPA\tFIx2\tPLAACx2\tPAPAx2\tHMM.background\t"
+           "HMM.PrD-like";
+}
+
+long plaac_format_summary_row(const plaac_row *r, const char *name, const uint8_t *codes, uint64_t reclen,
+                              int corelength, int ww2, char *buf, size_t cap) {
+    if (!r || !name || !buf) return -1;
+    if (r->prot_len <= 0) return 0; // skipped record (:762)
+    const int n = r->prot_len;
+    (void)reclen;
+    std::string s(name);
+    auto I = [&](long v) { s += '\t'; s += std::to_string(v); };
+    auto F = [&](double v) { s += '\t'; s += fixed_string(v, 3); };
+    // one-based indices; the -1/-2 sentinels are shifted too, as the reference does (:902-913)
+    I(r->mw_score);
+    I(r->mw_start + 1);
+    I(r->mw_end + 1);
+    I(r->mw_end - r->mw_start + 1);
+    F(inf2nan(r->llr_score));
+    I(r->llr_start + 1);
+    I(r->llr_end + 1);
+    I(r->llr_end - r->llr_start + 1);
+    F(inf2nan(r->llr_score) / (double)(r->llr_end - r->llr_start + 1)); // NLLR (:907)
+    I(r->vit_maxrun);
+    F(inf2nan(r->core_score));
+    I(r->core_start + 1);
+    I(r->core_end + 1);
+    I(r->core_end - r->core_start + 1);
+    F(r->prd_score);
+    I(r->prd_start + 1);
+    I(r->prd_end + 1);
+    I(r->prd_end - r->prd_start + 1);
+    I(n);
+    F(r->hmm_all);
+    F(r->hmm_vit);
+    s += '\t';
+    if (r->prd_end - r->prd_start + 1 >= corelength) { // (:915-922)
+        append_aa(s, codes, n, r->core_start, r->core_end);
+        s += '\t';
+        append_aa(s, codes, n, r->prd_start, r->prd_start + 14);
+        s += '\t';
+        append_aa(s, codes, n, r->prd_end - 14, r->prd_end);
+        s += '\t';
+        append_aa(s, codes, n, r->prd_start, r->prd_end);
+    } else {
+        s += "-\t-\t-\t-";
+    }
+    I(r->fi_numaa);
+    F(r->fi_meanhydro);
+    F(r->fi_meancharge);
+    F(r->fi_meancombo);
+    I(r->fi_maxrun);
+    F(inf2nan(r->papa_combo));
+    F(r->papa_prop);
+    F(r->papa_fi);
+    F(r->papa_llr);
+    F(r->papa_llr2);
+    I(r->papa_cen + 1);
+    s += '\t';
+    append_aa(s, codes, n, r->papa_cen - ww2 / 2, r->papa_cen + ww2 / 2); // (:944)
+    return emit(s, buf, cap);
+}
+
+size_t plaac_track_rows_bound(uint32_t n, size_t id_len, size_t name_len) {
+    return (size_t)n * (id_len + name_len + 400) + 128;
+}
+
+long plaac_format_track_rows(const plaac_tracks *t, uint64_t first, const uint8_t *codes, uint32_t n,
+                             const char *order_id, const char *name, char *buf, size_t cap) {
+    if (!t || !codes || !order_id || !name || !buf) return -1;
+    std::string s;
+    s.reserve((size_t)n * 160 + 64);
+    static const int prec[8] = {4, 4, 8, 4, 8, 8, 4, 8}; // (:638)
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t k = first + i;
+        s += order_id;
+        s += '\t';
+        s += name;
+        s += '\t';
+        s += std::to_string(i + 1);
+        s += '\t';
+        s += kAlphabet[codes[i] <= 21 ? codes[i] : 0];
+        s += '\t';
+        s += std::to_string((int)t->vit[k]);
+        s += '\t';
+        s += std::to_string((int)t->map[k]);
+        const double v[8] = {t->charge[k], t->hydro[k], t->fi[k], t->plaacllr[k], t->papa[k], t->fix2[k],
+                             t->plaacllrx2[k], t->papax2[k]};
+        for (int j = 0; j < 8; ++j) {
+            s += '\t';
+            s += fixed_string(v[j], prec[j]);
+        }
+        s += '\t';
+        s += fixed_string(t->post0[k], 4);
+        s += '\t';
+        s += fixed_string(t->post1[k], 4);
+        s += '\n';
+    }
+    s += "########################################################\n";
+    return emit(s, buf, cap);
+}
+
+long plaac_format_param_block(const plaac_params *p, char *buf, size_t cap) {
+    if (!p || !buf) return -1;
+    auto aa = [](const double *v) {
+        std::string s;
+        for (int i = 0; i < PLAAC_NAA; ++i) {
+            s.push_back(kAlphabet[i]);
+            s.push_back('=');
+            s += fixed_string(v[i], 5);
+            s.push_back(';');
+        }
+        return s;
+    };
+    std::string s = "############################ parameters at run-time ####################################\n";
+    s += "## alpha=" + java_double_tostring(p->alpha) + "; corelength=" + std::to_string(p->corelength) +
+         "; ww1=" + std::to_string(p->ww1) + "; ww2=" + std::to_string(p->ww2) + "; ww3=" + std::to_string(p->ww3) +
+         "; adjustprolines=" + (p->adjustprolines ? "true" : "false") + ";\n";
+    s += "## fg_used: {" + aa(p->fg) + "}\n";
+    s += "## bg_scer: {" + aa(p->bgscer) + "}\n";
+    s += "## bg_input: {" + aa(p->bgthis) + "}\n";
+    s += "## bg_used: {" + aa(p->bg) + "}\n";
+    s += "## plaac_llr: {" + aa(p->llr) + "}\n";
+    s += "## papa_lods: {" + aa(p->lodpapa) + "}\n";
+    s += "#######################################################################################\n";
+    return emit(s, buf, cap);
+}
+
+long plaac_format_aa_params(const double vec[PLAAC_NAA], char *buf, size_t cap) {
+    if (!vec || !buf) return -1;
+    std::string s;
+    for (int i = 0; i < PLAAC_NAA; ++i) {
+        s += fixed_string(vec[i], 6);
+        s += " # ";
+        s.push_back(kAlphabet[i]);
+        s.push_back('\n');
+    }
+    return emit(s, buf, cap);
+}
+
+} // extern "C"

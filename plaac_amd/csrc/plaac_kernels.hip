@@ -839,6 +839,332 @@ __global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes
 }
 
 // ------------------------------------------------------------------------------------------------
+// K-B fast path: all three half-windows equal 20 (the default ww = 41, also ww = 40).
+// Two consecutive positions per lane (128 positions per iteration): the 42 values under the union of the
+// two windows are read once and feed both fixed-order 41-term sums, which halves the LDS traffic and makes
+// the loop fp64-VALU-bound instead of LDS-bound. Values live in LDS split by position parity so that
+// lane l reads [base + l + m] with an immediate offset m (conflict-free, no address arithmetic); the
+// first 24 slots of every sub-ring are mirrored behind it so that base + m never has to wrap.
+// Charge sums are exact integers -> prefix counts (wave scan) instead of 41 adds. The weights of the
+// second smoothing depend only on the position, so weight*value is formed once per position.
+// ------------------------------------------------------------------------------------------------
+constexpr int TW = 20;           // half window
+constexpr int TC = 128;          // positions per iteration (2 per lane)
+constexpr int TRB = 128;         // sub-ring entries per parity class
+constexpr int TMIR = 24;         // mirrored head
+constexpr int TSUB = TRB + TMIR; // 152
+
+__device__ __forceinline__ uint32_t load4(const uint8_t *p, const uint8_t *lo, const uint8_t *end) {
+    if (p >= lo && p + 4 <= end) {
+        uint32_t v;
+        __builtin_memcpy(&v, p, 4);
+        return v;
+    }
+    uint32_t v = 0u;
+    for (int i = 0; i < 4; ++i) {
+        const uint8_t *q = p + i;
+        v |= ((q >= lo && q < end) ? (uint32_t)*q : 0u) << (8 * i);
+    }
+    return v;
+}
+
+// spread the 32 bits of x to the even bit positions of a 64-bit word
+__device__ __forceinline__ unsigned long long spread32(unsigned long long x) {
+    x &= 0xffffffffull;
+    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
+enum { RG_H = 0, RG_L = 1, RG_P = 2, RG_WF = 3, RG_WL = 4, RG_WP = 5, RG_N = 6 };
+__device__ __forceinline__ void ring_put(double (*R)[2][TSUB], int a, int cls, int idx, double v) {
+    R[a][cls][idx] = v;
+    if (idx < TMIR) R[a][cls][idx + TRB] = v;
+}
+
+// The two 41-term sums of positions I and I+1 (I even) for THREE tracks at once (rings A, A+1, A+2 of
+// `R`), each in increasing position order: s[.][0] over I-20..I+20, s[.][1] over I-19..I+21.
+// base = slot of position I-20 in the even sub-ring. Partially unrolled on purpose: a fully unrolled body
+// lets the scheduler hoist all 126 LDS reads and spill.
+__device__ __forceinline__ void window_pairs3(const double (*R)[2][TSUB], int A, int base, double (&s)[3][2]) {
+    const double *__restrict__ E0 = &R[A][0][base], *__restrict__ O0 = &R[A][1][base];
+    const double *__restrict__ E1 = &R[A + 1][0][base], *__restrict__ O1 = &R[A + 1][1][base];
+    const double *__restrict__ E2 = &R[A + 2][0][base], *__restrict__ O2 = &R[A + 2][1][base];
+    double a00 = 0.0 + E0[0], a01 = 0.0, a10 = 0.0 + E1[0], a11 = 0.0, a20 = 0.0 + E2[0], a21 = 0.0;
+#pragma unroll 4
+    for (int m = 0; m < TW; ++m) {
+        const double o0 = O0[m], e0 = E0[m + 1], o1 = O1[m], e1 = E1[m + 1], o2 = O2[m], e2 = E2[m + 1];
+        a00 = a00 + o0;
+        a01 = a01 + o0;
+        a10 = a10 + o1;
+        a11 = a11 + o1;
+        a20 = a20 + o2;
+        a21 = a21 + o2;
+        a00 = a00 + e0;
+        a01 = a01 + e0;
+        a10 = a10 + e1;
+        a11 = a11 + e1;
+        a20 = a20 + e2;
+        a21 = a21 + e2;
+    }
+    s[0][0] = a00;
+    s[0][1] = a01 + O0[TW];
+    s[1][0] = a10;
+    s[1][1] = a11 + O1[TW];
+    s[2][0] = a20;
+    s[2][1] = a21 + O2[TW];
+}
+
+template <bool TRACKS>
+__global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ codes,
+                                                 const uint64_t *__restrict__ offsets,
+                                                 const uint32_t *__restrict__ neff,
+                                                 const uint32_t *__restrict__ order, uint32_t nprot, uint64_t total,
+                                                 const DevTables *__restrict__ T, plaac_row *__restrict__ rows,
+                                                 TrackPtrs tr) {
+    __shared__ double t_hyd[ROWS], t_llr[ROWS], t_lod[ROWS];
+    __shared__ int t_chg[ROWS];
+    // rings: mapped inputs hydro/llr/papa (0.0 outside [0,n)), then weight * first-level FoldIndex/llr/papa
+    __shared__ double ring[RG_N][2][TSUB];
+    __shared__ int pre[256]; // pre[q & 255] = charge sum of positions < q
+
+    const int lane = threadIdx.x;
+    const uint32_t p = order[blockIdx.x];
+    const int n = (int)neff[p];
+    plaac_row *row = rows + p;
+    if (n == 0) {
+        if (lane == 0) {
+            row->papa_combo = row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = 0.0;
+            row->fi_numaa = row->fi_maxrun = row->papa_cen = 0;
+        }
+        return;
+    }
+    if (lane < ROWS) {
+        const int k = lane == NAA ? 0 : lane;
+        t_hyd[lane] = T->hyd[k];
+        t_llr[lane] = T->llr[k];
+        t_lod[lane] = T->lod[k];
+        t_chg[lane] = T->chg[k];
+    }
+    for (int i = lane; i < RG_N * 2 * TSUB; i += 64) (&ring[0][0][0])[i] = 0.0;
+    for (int i = lane; i < 256; i += 64) pre[i] = 0;
+
+    const uint64_t off = offsets[p];
+    const uint8_t *__restrict__ x = codes + off;
+    const uint8_t *cend = codes + total;
+    const int ww1 = T->ww1, ww2 = T->ww2;
+    const int we = n - 1 < TW ? n - 1 : TW; // w = ww/2 clamped to n-1 (:2588-2589)
+    const bool adjust = T->adjustprolines != 0;
+    const double cc0 = T->cc[0], cc1 = T->cc[1], cc2 = T->cc[2];
+    int halfw = (ww1 - 1) / 2; // FoldIndex run scan domain (:5010-5013)
+    if (halfw > n / 2) halfw = n / 2;
+    const int dlo = halfw, dhi = n - halfw - 1;
+    const int plo = (ww2 - 1) / 2, phi = n - (ww2 - 1) / 2; // PAPA centres k in [plo, phi) (:4942)
+
+    double pbest = -INFINITY, pfi = 0.0, pll2 = 0.0;
+    int pcen = -1;
+    bool run_open = false;
+    int run_start = 0, numaa = 0, maxlen = 0, carry = 0;
+    auto close_run = [&](int s, int e) {
+        if (s == dlo) s = 0;
+        if (e == dhi) e = n - 1;
+        const int len = e - s + 1;
+        if (len >= 5) {
+            numaa += len;
+            maxlen = len > maxlen ? len : maxlen;
+        }
+    };
+    auto scan_mask = [&](unsigned long long m, int base) { // FoldIndex<0 runs (:5020-5058), wave-uniform
+        if (run_open) {
+            const int t1 = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
+            if (t1 < 64) {
+                close_run(run_start, base + t1 - 1);
+                run_open = false;
+                m &= ~((1ull << t1) - 1ull);
+            } else {
+                m = 0ull;
+            }
+        }
+        while (m) {
+            const int s = __builtin_ctzll(m);
+            const unsigned long long rest = ~(m >> s);
+            const int len = rest == 0ull ? 64 - s : __builtin_ctzll(rest);
+            if (s + len >= 64) {
+                run_open = true;
+                run_start = base + s;
+                break;
+            }
+            close_run(base + s, base + s + len - 1);
+            m &= ~(((1ull << len) - 1ull) << s);
+        }
+    };
+    __syncthreads();
+
+    const int nchunks = (n + 2 * TW + TC - 1) / TC;
+    for (int k = 0; k < nchunks; ++k) {
+        // ---- stage 0: residues -> mapped inputs at q0 = 128k + 2*lane and q0 + 1
+        {
+            const int q0 = TC * k + 2 * lane;
+            double vh0 = 0.0, vl0 = 0.0, vp0 = 0.0, vh1 = 0.0, vl1 = 0.0, vp1 = 0.0;
+            int c0 = 0, c1 = 0;
+            if (q0 < n) {
+                const uint32_t w = load4(x + q0 - 2, codes, cend); // residues q0-2 .. q0+1
+                const uint32_t bm2 = w & 0xffu, bm1 = (w >> 8) & 0xffu;
+                uint32_t b0 = (w >> 16) & 0xffu, b1 = w >> 24;
+                b0 = b0 < 22u ? b0 : 22u;
+                b1 = b1 < 22u ? b1 : 22u;
+                const bool pm2 = q0 >= 2 && bm2 == 13u, pm1 = q0 >= 1 && bm1 == 13u;
+                vh0 = t_hyd[b0];
+                vl0 = t_llr[b0];
+                c0 = t_chg[b0];
+                // only the first P of PP / PxP scores (:2653-2654); absolute neighbours p-1, p-2
+                vp0 = (adjust && b0 == 13u && (pm1 || pm2)) ? 0.0 : t_lod[b0];
+                if (q0 + 1 < n) {
+                    vh1 = t_hyd[b1];
+                    vl1 = t_llr[b1];
+                    c1 = t_chg[b1];
+                    vp1 = (adjust && b1 == 13u && (b0 == 13u || pm1)) ? 0.0 : t_lod[b1];
+                }
+            }
+            const int idx = (q0 >> 1) & (TRB - 1);
+            ring_put(ring, RG_H, 0, idx, vh0);
+            ring_put(ring, RG_H, 1, idx, vh1);
+            ring_put(ring, RG_L, 0, idx, vl0);
+            ring_put(ring, RG_L, 1, idx, vl1);
+            ring_put(ring, RG_P, 0, idx, vp0);
+            ring_put(ring, RG_P, 1, idx, vp1);
+            // charge prefix counts: inclusive wave scan of the per-lane pair sums
+            int s = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(s, d);
+                if (lane >= d) s += o;
+            }
+            pre[(q0 + 1) & 255] = carry + s - c1;
+            pre[(q0 + 2) & 255] = carry + s;
+            carry += __shfl(s, 63);
+        }
+        __syncthreads();
+        // ---- stage 1: first-level tracks at i0 = 128k + 2*lane - 20 and i0 + 1
+        {
+            const int i0 = TC * k + 2 * lane - TW;
+            const int base = ((i0 - TW) >> 1) & (TRB - 1);
+            double sums[3][2];
+            window_pairs3(ring, RG_H, base, sums);
+            double wfi[2] = {0.0, 0.0}, wll[2] = {0.0, 0.0}, wpa[2] = {0.0, 0.0};
+            bool neg[2] = {false, false};
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int i = i0 + b;
+                if (i >= 0 && i < n) {
+                    const int lo = imax(i - TW, 0), hi = imin(i + TW, n - 1);
+                    const double cnt = (double)(hi - lo + 1);
+                    const int csum = pre[(hi + 1) & 255] - pre[lo & 255];
+                    const double hydro = sums[0][b] / cnt;
+                    const double charge = (double)csum / cnt;
+                    const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
+                    const double llr1 = sums[1][b] / cnt;
+                    const double papa = sums[2][b] / cnt;
+                    const double wt = (double)(1 + imin(i, we) + imin(n - i - 1, we));
+                    wfi[b] = wt * fi;
+                    wll[b] = wt * llr1;
+                    wpa[b] = wt * papa;
+                    neg[b] = (fi < 0.0) && i >= dlo && i <= dhi;
+                    if (TRACKS) {
+                        tr.charge[off + i] = charge;
+                        tr.hydro[off + i] = hydro;
+                        tr.fi[off + i] = fi;
+                        tr.plaacllr[off + i] = llr1;
+                        tr.papa[off + i] = papa;
+                    }
+                }
+            }
+            const int idx = (i0 >> 1) & (TRB - 1);
+            ring_put(ring, RG_WF, 0, idx, wfi[0]);
+            ring_put(ring, RG_WF, 1, idx, wfi[1]);
+            ring_put(ring, RG_WL, 0, idx, wll[0]);
+            ring_put(ring, RG_WL, 1, idx, wll[1]);
+            ring_put(ring, RG_WP, 0, idx, wpa[0]);
+            ring_put(ring, RG_WP, 1, idx, wpa[1]);
+            // position-ordered 128-bit mask of FoldIndex < 0: even positions from lanes' first output
+            const unsigned long long me = __ballot(neg[0]), mo = __ballot(neg[1]);
+            const int pbase = TC * k - TW;
+            scan_mask(spread32(me) | (spread32(mo) << 1), pbase);
+            scan_mask(spread32(me >> 32) | (spread32(mo >> 32) << 1), pbase + 64);
+        }
+        __syncthreads();
+        // ---- stage 2: weighted second smoothing at i0 = 128k + 2*lane - 40 and i0 + 1, PAPA arg-max
+        {
+            const int i0 = TC * k + 2 * lane - 2 * TW;
+            const int base = ((i0 - TW) >> 1) & (TRB - 1);
+            double sums[3][2];
+            window_pairs3(ring, RG_WF, base, sums);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int i = i0 + b;
+                if (i >= 0 && i < n) {
+                    double fix2 = __builtin_nan(""), llx2 = fix2, pax2 = fix2;
+                    if (i >= we && i <= n - we - 1) {
+                        const double den = (double)((2 * we + 1) + sum_min_left(i, we) + sum_min_left(n - 1 - i, we));
+                        fix2 = sums[0][b] / den;
+                        llx2 = sums[1][b] / den;
+                        pax2 = sums[2][b] / den;
+                    }
+                    if (TRACKS) {
+                        tr.fix2[off + i] = fix2;
+                        tr.plaacllrx2[off + i] = llx2;
+                        tr.papax2[off + i] = pax2;
+                    }
+                    if (i >= plo && i < phi && (pax2 > pbest) && (fix2 < 0.0)) { // papamode 1 (:4942-4948)
+                        pbest = pax2;
+                        pcen = i;
+                        pfi = fix2;
+                        pll2 = llx2;
+                    }
+                }
+            }
+        }
+    }
+    if (run_open) close_run(run_start, dhi);
+
+    // wave arg-max: largest papax2, smallest centre among equals (first max of the serial loop)
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double ob = __shfl_xor(pbest, d);
+        const int oc = __shfl_xor(pcen, d);
+        const double ofi = __shfl_xor(pfi, d), oll2 = __shfl_xor(pll2, d);
+        const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
+        if (take) {
+            pbest = ob;
+            pcen = oc;
+            pfi = ofi;
+            pll2 = oll2;
+        }
+    }
+    if (lane == 0) {
+        row->fi_numaa = numaa;
+        row->fi_maxrun = maxlen;
+        row->papa_cen = pcen;
+        if (pcen >= 0) {
+            // PAPAllr = first-level PLAAC-LLR at the centre: recomputed here (same fixed-order sum)
+            double s = 0.0;
+            const int lo = imax(pcen - TW, 0), hi = imin(pcen + TW, n - 1);
+            for (int q = lo; q <= hi; ++q) s = s + T->llr[ld_code(x, (uint32_t)q)];
+            row->papa_combo = pbest;
+            row->papa_prop = pbest;
+            row->papa_fi = pfi;
+            row->papa_llr = s / (double)(hi - lo + 1);
+            row->papa_llr2 = pll2;
+        } else {
+            row->papa_combo = -INFINITY;
+            row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // histogram over valid records (:1698-1706, :1732-1739); one wave per record, grid-stride
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hist(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets,
@@ -901,6 +1227,7 @@ struct plaac_ctx {
     uint64_t ncalls = 0;
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // high-priority side streams of the three K-A roles
     bool serial = false;                              // PLAAC_SERIAL_STREAMS=1: everything on one stream
+    bool generic_tracks = false;                      // PLAAC_GENERIC_TRACKS=1: never use the ww=41 fast path
     std::string err;
 };
 
@@ -1041,6 +1368,8 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
                 return bail("hipStreamCreateWithPriority", e);
         const char *ser = std::getenv("PLAAC_SERIAL_STREAMS");
         ctx->serial = ser && ser[0] == '1';
+        const char *gen = std::getenv("PLAAC_GENERIC_TRACKS");
+        ctx->generic_tracks = gen && gen[0] == '1';
     }
     for (auto &set : ctx->ev)
         for (auto &ev : set)
@@ -1188,7 +1517,16 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
             hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,          \
                                ctx->d_neff, ctx->d_order, nprot, ctx->d_tab, d_rows, tp);                          \
     } while (0)
-    if (wmax <= 32) LAUNCH_KB(128);
+    const bool fast20 = ctx->params.ww1 / 2 == TW && ctx->params.ww2 / 2 == TW && ctx->params.ww3 / 2 == TW &&
+                        !ctx->generic_tracks;
+    if (fast20) {
+        if (d_tracks)
+            hipLaunchKernelGGL(k_tracks20<true>, dim3(nprot), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
+                               ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
+        else
+            hipLaunchKernelGGL(k_tracks20<false>, dim3(nprot), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
+                               ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
+    } else if (wmax <= 32) LAUNCH_KB(128);
     else if (wmax <= 96) LAUNCH_KB(256);
     else LAUNCH_KB(1024);
 #undef LAUNCH_KB

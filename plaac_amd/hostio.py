@@ -1,0 +1,134 @@
+"""ctypes binding of include/plaac_host.h: the FASTA reader and the Java-compatible text formatting
+that live in libplaac_native.so (C++). Python adds nothing but marshalling."""
+import ctypes as C
+
+import numpy as np
+
+from . import native
+
+
+class _Fasta(C.Structure):
+    _fields_ = [("nrec", C.c_uint32), ("nres", C.c_uint64), ("codes", C.POINTER(C.c_uint8)),
+                ("offsets", C.POINTER(C.c_uint64)), ("names", C.POINTER(C.c_char)),
+                ("name_off", C.POINTER(C.c_uint64))]
+
+
+HOST_EXPORTS = (
+    "plaac_fasta_read", "plaac_fasta_free", "plaac_read_aa_params", "plaac_format_fixed",
+    "plaac_format_double_tostring", "plaac_format_summary_row", "plaac_summary_header", "plaac_tracks_header",
+    "plaac_format_track_rows", "plaac_track_rows_bound", "plaac_format_param_block", "plaac_format_aa_params",
+)
+
+_ready = False
+
+
+def _lib():
+    global _ready
+    L = native.load()
+    if not _ready:
+        L.plaac_fasta_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(_Fasta))]
+        L.plaac_fasta_free.argtypes = [C.POINTER(_Fasta)]
+        L.plaac_fasta_free.restype = None
+        L.plaac_read_aa_params.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
+        L.plaac_format_fixed.argtypes = [C.c_double, C.c_int, C.c_char_p, C.c_size_t]
+        L.plaac_format_double_tostring.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
+        L.plaac_format_summary_row.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
+                                               C.c_char_p, C.c_size_t]
+        L.plaac_format_summary_row.restype = C.c_long
+        L.plaac_summary_header.restype = C.c_char_p
+        L.plaac_tracks_header.restype = C.c_char_p
+        L.plaac_format_track_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p,
+                                              C.c_char_p, C.c_size_t]
+        L.plaac_format_track_rows.restype = C.c_long
+        L.plaac_track_rows_bound.argtypes = [C.c_uint32, C.c_size_t, C.c_size_t]
+        L.plaac_track_rows_bound.restype = C.c_size_t
+        L.plaac_format_param_block.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.plaac_format_param_block.restype = C.c_long
+        L.plaac_format_aa_params.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.plaac_format_aa_params.restype = C.c_long
+        _ready = True
+    return L
+
+
+def read_fasta(path):
+    """-> (names list[bytes], codes u8, offsets u64) exactly as the reference's fastareader splits the file"""
+    pf = C.POINTER(_Fasta)()
+    st = _lib().plaac_fasta_read(str(path).encode(), C.byref(pf))
+    if st != native.PLAAC_OK:
+        raise native.PlaacError(st, "cannot read " + str(path))
+    f = pf.contents
+    n = f.nrec
+    codes = np.ctypeslib.as_array(f.codes, shape=(max(int(f.nres), 1),))[:int(f.nres)].copy()
+    offs = np.ctypeslib.as_array(f.offsets, shape=(n + 1,)).copy()
+    noff = np.ctypeslib.as_array(f.name_off, shape=(n + 1,)).copy()
+    blob = C.string_at(f.names, int(noff[-1]))
+    names = [blob[int(noff[i]):int(noff[i + 1]) - 1] for i in range(n)]
+    _lib().plaac_fasta_free(pf)
+    return names, codes, offs
+
+
+def read_aa_params(path):
+    vec = np.zeros(22)
+    warn = np.zeros(22, dtype=np.int32)
+    st = _lib().plaac_read_aa_params(str(path).encode(), vec.ctypes.data, warn.ctypes.data)
+    if st != native.PLAAC_OK:
+        raise native.PlaacError(st, "cannot read " + str(path))
+    return vec, warn
+
+
+def format_fixed(v, decimals):
+    buf = C.create_string_buffer(512)
+    _lib().plaac_format_fixed(float(v), int(decimals), buf, 512)
+    return buf.value.decode()
+
+
+def double_tostring(v):
+    buf = C.create_string_buffer(64)
+    _lib().plaac_format_double_tostring(float(v), buf, 64)
+    return buf.value.decode()
+
+
+def summary_header():
+    return _lib().plaac_summary_header().decode()
+
+
+def tracks_header():
+    return _lib().plaac_tracks_header().decode()
+
+
+def format_summary_row(row, name, codes, corelength=60, ww2=41):
+    """row: one element of a ROW_DTYPE array; codes: the record's untrimmed codes"""
+    r = np.array([row], dtype=native.ROW_DTYPE)
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    cap = 3 * len(codes) + len(name) + 4096
+    buf = C.create_string_buffer(cap)
+    k = _lib().plaac_format_summary_row(r.ctypes.data, name if isinstance(name, bytes) else name.encode(),
+                                        codes.ctypes.data, len(codes), corelength, ww2, buf, cap)
+    if k < 0:
+        raise RuntimeError("summary row buffer too small")
+    return buf.raw[:k].decode()
+
+
+def format_track_rows(tracks, first, codes, n, order_id, name):
+    T = native.Tracks(**{k: tracks[k].ctypes.data for k in native.TRACK_U8 + native.TRACK_F64})
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    cap = _lib().plaac_track_rows_bound(n, len(order_id), len(name))
+    buf = C.create_string_buffer(cap)
+    k = _lib().plaac_format_track_rows(C.addressof(T), first, codes.ctypes.data, n, order_id.encode(), name.encode(),
+                                       buf, cap)
+    if k < 0:
+        raise RuntimeError("track rows buffer too small")
+    return buf.raw[:k].decode()
+
+
+def format_param_block(P):
+    buf = C.create_string_buffer(16384)
+    k = _lib().plaac_format_param_block(C.addressof(P), buf, 16384)
+    return buf.raw[:k].decode()
+
+
+def format_aa_params(vec):
+    vec = np.ascontiguousarray(vec, dtype=np.float64)
+    buf = C.create_string_buffer(2048)
+    k = _lib().plaac_format_aa_params(vec.ctypes.data, buf, 2048)
+    return buf.raw[:k].decode()

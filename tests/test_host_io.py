@@ -1,0 +1,180 @@
+"""CPU tests of the host text I/O in libplaac_native.so (include/plaac_host.h): fastareader quirks
+(SURVEY.md §9.A), java.util.Formatter number formatting (§9.F), the summary / track / parameter text."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+@pytest.fixture(scope="module")
+def io(native):
+    from plaac_amd import hostio
+    hostio._lib()
+    return hostio
+
+
+def test_host_header_exports(native):
+    L = native.load()
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "plaac_host.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(plaac_[a-z0-9_]+)\s*\(", txt)))
+    from plaac_amd import hostio
+    assert declared == sorted(hostio.HOST_EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_java_fixed_formatting(io):
+    f = io.format_fixed
+    assert f(51.21464835140835, 3) == "51.215"
+    assert f(float("nan"), 3) == "NaN"
+    assert f(float("inf"), 3) == "Infinity" and f(float("-inf"), 3) == "-Infinity"
+    assert f(0.0, 3) == "0.000" and f(-0.0, 3) == "-0.000"
+    # HALF_UP on exact binary ties (C printf would round half-to-even: 0.062)
+    assert f(0.0625, 3) == "0.063" and f(-0.0625, 3) == "-0.063" and f(0.1875, 3) == "0.188"
+    # HALF_UP on the SHORTEST decimal repr, like java.util.Formatter: 0.0045 is 0.004499999... in binary
+    assert f(0.0045, 3) == "0.005" and f(9 / 2000, 3) == "0.005" and f(1.0005, 3) == "1.001"
+    assert f(1.005, 2) == "1.01"
+    assert f(0.0004, 3) == "0.000" and f(0.0005, 3) == "0.001" and f(-0.0004, 3) == "-0.000"
+    assert f(0.9996, 3) == "1.000" and f(9.9995, 3) == "10.000" and f(999.9999, 3) == "1000.000"
+    assert f(1e-9, 3) == "0.000" and f(123456789.125, 3) == "123456789.125"
+    assert f(-1.151, 3) == "-1.151" and f(2.0, 4) == "2.0000" and f(0.00000001234, 8) == "0.00000001"
+    assert f(1e21, 3) == "1000000000000000000000.000"
+    rng = np.random.default_rng(0)
+    for v in np.concatenate([rng.normal(0, 50, 2000), rng.random(2000) * 1e-3]):
+        for d in (3, 4, 8):
+            # away from decimal ties Java and C agree
+            assert f(v, d) == ("%.*f" % (d, v)), (v, d)
+
+
+def test_java_double_tostring(io):
+    t = io.double_tostring
+    assert [t(v) for v in (1.0, 0.5, 0.25, 0.1, 0.0, 100.0, 0.001, 1234567.0)] == \
+        ["1.0", "0.5", "0.25", "0.1", "0.0", "100.0", "0.001", "1234567.0"]
+    assert t(0.0001) == "1.0E-4" and t(1e7) == "1.0E7" and t(1.5e-5) == "1.5E-5"
+
+
+def test_fastareader_quirks(io, tmp_path):
+    p = tmp_path / "q.fa"
+    p.write_bytes(b"junk before first header\n"
+                  b">first  \r\n"           # first name is trimmed, \r\n is a line end
+                  b"MKV\n"
+                  b"QQ N\n"                 # embedded blank stays (-> X)
+                  b">second \n"             # later names are NOT trimmed
+                  b"acd\n"
+                  b"\n"                     # blank line ends the record ...
+                  b"EFG\n"                  # ... and the rest is skipped
+                  b">third\n"
+                  b">fourth\n"              # third has an empty sequence
+                  b"WY*\n"
+                  b"   \n"                  # a line of blanks is sequence, not a terminator
+                  b"K")                     # no final newline
+    names, codes, offs = io.read_fasta(p)
+    assert names == [b"first", b"second ", b"third", b"fourth"]
+    seqs = [bytes(codes[int(offs[i]):int(offs[i + 1])]) for i in range(4)]
+    enc = lambda s: bytes(__import__("plaac_amd").native.encode(s))
+    assert seqs == [enc("MKVQQ N"), enc("acd"), b"", enc("WY*   K")]
+    assert seqs[0][5] == 0  # the blank became X
+
+
+def test_fasta_matches_simple_reader_on_fixtures(io, classic4, kat28, native):
+    for path, recs in ((os.path.join(GOLDEN, "four_classic_prions.fasta"), classic4),
+                       (os.path.join(GOLDEN, "kat28.fasta"), kat28[0])):
+        names, codes, offs = io.read_fasta(path)
+        assert [n.decode() for n in names] == [n for n, _ in recs]
+        c2, o2 = native.pack([s for _, s in recs])
+        assert np.array_equal(codes, c2) and np.array_equal(offs, o2)
+
+
+def test_missing_file_is_an_io_error(io, native):
+    with pytest.raises(native.PlaacError) as e:
+        io.read_fasta("/nonexistent/x.fa")
+    assert e.value.status == native.PLAAC_ERR_IO
+
+
+def test_read_aa_params(io, tmp_path, oracle):
+    vec, warn = io.read_aa_params(os.path.join(GOLDEN, "prd_freq_scer_04.txt"))
+    assert np.array_equal(vec, oracle.const_tables()["fg04"]) and not warn.any()
+    p = tmp_path / "bg.txt"
+    p.write_text("".join("%d.000000 # %s\n" % (i * 7, a) for i, a in enumerate("XACDEFGHIKLMNPQRSTVWY*")))
+    vec, warn = io.read_aa_params(p)
+    assert vec.tolist() == [i * 7.0 for i in range(22)] and not warn.any()
+    p.write_text("".join("%d # %s\n" % (i, a) for i, a in enumerate("XACDEFGHIKLMNPQRSTVYW*")))
+    _, warn = io.read_aa_params(p)
+    assert warn.nonzero()[0].tolist() == [19, 20]
+    # round trip with the -b dump format (print_aa_params)
+    txt = io.format_aa_params(np.arange(22) * 1000.5)
+    assert txt.splitlines()[1] == "1000.500000 # A" and len(txt.splitlines()) == 22
+    p.write_text(txt)
+    assert np.array_equal(io.read_aa_params(p)[0], np.arange(22) * 1000.5)
+
+
+def test_summary_row_text(io, oracle, classic4):
+    """format a Sup35p row produced by the oracle (tests may use it) and check every column"""
+    codes, offs = oracle.pack([s for _, s in classic4])
+    rows = oracle.score_batch(oracle.build_params(), codes, offs)
+    line = io.format_summary_row(rows[0], "Sup35p", codes[int(offs[0]):int(offs[1])])
+    col = dict(zip(io.summary_header().split("\t"), line.split("\t")))
+    assert len(line.split("\t")) == 38 == len(io.summary_header().split("\t"))
+    assert col["SEQid"] == "Sup35p" and col["PROTlen"] == "685"
+    assert (col["COREstart"], col["COREend"], col["CORElen"]) == ("5", "64", "60")
+    assert (col["PRDstart"], col["PRDend"], col["PRDlen"]) == ("1", "133", "133")
+    assert col["COREscore"] == "51.215" and col["LLR"] == "51.215" and col["NLLR"] == "0.854"
+    assert col["HMMall"] == "81.820" and col["HMMvit"] == "79.598" and col["PRDscore"] == "89.773"
+    seq = classic4[0][1]
+    assert col["COREaa"] == seq[4:64] and col["PRDaa"] == seq[0:133]
+    assert col["STARTaa"] == seq[0:15] and col["ENDaa"] == seq[118:133]
+    cen = int(col["PAPAcen"])
+    assert col["PAPAaa"] == seq[cen - 1 - 20:cen - 1 + 21]
+    assert (col["MWstart"], col["MWend"], col["MWlen"]) == ("4", "83", "80") and col["MW"] == "38"
+
+
+def test_summary_row_sentinels(io, oracle):
+    """no core / n < c: start 0, end -1, len 0, NaN scores, '-' strings, PAPAaa = first <= 20 residues"""
+    codes, offs = oracle.pack(["MKVLAAGIVGLDEE", "mkvl*", "*"])
+    rows = oracle.score_batch(oracle.build_params(), codes, offs)
+    cols = io.format_summary_row(rows[0], "short", codes[int(offs[0]):int(offs[1])]).split("\t")
+    col = dict(zip(io.summary_header().split("\t"), cols))
+    assert (col["LLR"], col["LLRstart"], col["LLRend"], col["LLRlen"], col["NLLR"]) == ("NaN", "0", "-1", "0", "NaN")
+    assert (col["COREscore"], col["COREstart"], col["COREend"], col["CORElen"]) == ("NaN", "0", "-1", "0")
+    assert (col["PRDscore"], col["PRDstart"], col["PRDend"], col["PRDlen"]) == ("0.000", "0", "-1", "0")
+    assert (col["COREaa"], col["STARTaa"], col["ENDaa"], col["PRDaa"]) == ("-", "-", "-", "-")
+    assert col["PAPAcombo"] == "NaN" and col["PAPAprop"] == "NaN" and col["PAPAcen"] == "0"
+    assert col["PAPAaa"] == "MKVLAAGIVGLDEE" and col["MWlen"] == "14"
+    # lower case is printed upper case, the trimmed stop is not part of the protein
+    line = io.format_summary_row(rows[1], "lc", codes[int(offs[1]):int(offs[2])])
+    assert line.split("\t")[-1] == "MKVL" and line.split("\t")[19] == "4"
+    # a stop-only record yields no line
+    assert io.format_summary_row(rows[2], "stop", codes[int(offs[2]):int(offs[3])]) == ""
+
+
+def test_track_rows_text(io, oracle):
+    seq = "MQNQQNYQQGGYNNSS" * 6
+    codes, offs = oracle.pack([seq])
+    rows, tr = oracle.score_batch(oracle.build_params(), codes, offs, tracks=True)
+    txt = io.format_track_rows(tr, 0, codes, len(seq), "7", "my name")
+    lines = txt.split("\n")
+    assert lines[-1] == "" and lines[-2] == "#" * 56 and len(lines) == len(seq) + 2
+    assert len(io.tracks_header().split("\t")) == 16
+    f = lines[0].split("\t")
+    assert len(f) == 16 and f[:4] == ["7", "my name", "1", "M"] and f[4] in "01" and f[5] in "01"
+    assert f[11] == "NaN" and f[12] == "NaN" and f[13] == "NaN"  # x2 tracks are NaN within 20 of the ends
+    mid = lines[48].split("\t")
+    assert mid[2] == "49" and mid[3] == seq[48]
+    assert mid[6] == io.format_fixed(tr["charge"][48], 4) and mid[8] == io.format_fixed(tr["fi"][48], 8)
+    assert abs(float(mid[14]) + float(mid[15]) - 1.0) < 2e-3
+
+
+def test_param_block_text(io, native):
+    P = native.make_params(alpha=0.5, bgcounts=np.arange(22.0) + 1, corelength=30, ww1=21, ww2=31)
+    lines = io.format_param_block(P).split("\n")
+    assert lines[0].startswith("####") and "parameters at run-time" in lines[0]
+    assert lines[1] == "## alpha=0.5; corelength=30; ww1=21; ww2=31; ww3=31; adjustprolines=true;"
+    assert lines[2].startswith("## fg_used: {X=0.00001;A=0.04865;C=0.00219;") and lines[2].endswith(";}")
+    assert [l.split(":")[0] for l in lines[2:8]] == ["## fg_used", "## bg_scer", "## bg_input", "## bg_used",
+                                                     "## plaac_llr", "## papa_lods"]
+    assert lines[4].startswith("## bg_input: {X=0.00000;A=0.00870;")  # X and * zeroed, rest normalised
+    assert lines[8] == "#" * 87
