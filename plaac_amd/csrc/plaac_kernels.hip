@@ -217,6 +217,85 @@ __device__ __forceinline__ void load_rows(double *s_row, const DevTables *__rest
 }
 
 // ---- role V: Viterbi (:3077-3121), traceback, longest run (:1787-1804), masked core + PRD (:816-880) ----
+// Every sweep has a guard-free straight-line body for blocks that lie wholly inside the lane's protein
+// (all but the last block of each lane) so that the LDS lookups of later steps can be hoisted above the
+// serial chain, and a guarded body for the last, partial block.
+struct VitState {
+    double s0, s1, h0;
+};
+
+template <bool GUARD>
+__device__ __forceinline__ uint32_t vit_block(VitState &S, const double *__restrict__ s_row, const uint4 cur,
+                                              uint32_t t0, uint32_t n, double lt00, double lt01, double lt10,
+                                              double lt11, double h0lt, int jfirst) {
+    uint32_t tbw = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < jfirst) continue; // the very first residue (t = 0) is the initialisation, not a step
+        if (!GUARD || t0 + (uint32_t)j < n) {
+            const double *__restrict__ r = s_row + block_code(cur, j) * R_W;
+            const double e0 = r[R_LE0], e1 = r[R_LE1], eh = r[R_LE0H];
+            // (:3087-3100): state 0 stays the arg-max on ties (strict >)
+            const double v00 = lt00 + S.s0, v10 = lt10 + S.s1, v01 = lt01 + S.s0, v11 = lt11 + S.s1;
+            const bool g0 = v10 > v00, g1 = v11 > v01;
+            S.s0 = (g0 ? v10 : v00) + e0;
+            S.s1 = (g1 ? v11 : v01) + e1;
+            S.h0 = (h0lt + S.h0) + eh; // hmm0: Viterbi == forward == running sum
+            tbw |= ((uint32_t)g0 | ((uint32_t)g1 << 1)) << (2 * j);
+        }
+    }
+    return tbw;
+}
+
+template <bool GUARD, bool TRACKS>
+__device__ __forceinline__ uint32_t traceback_block(uint32_t &state, int &cur, int &maxrun, uint32_t word,
+                                                    uint32_t t0, uint32_t n, uint8_t *__restrict__ vit_out) {
+    uint32_t vw = 0;
+#pragma unroll
+    for (int j = 15; j >= 0; --j) {
+        if (!GUARD || t0 + (uint32_t)j < n) {
+            // here `state` = vit[t]
+            vw |= state << j;
+            cur = state ? cur + 1 : 0;
+            maxrun = cur > maxrun ? cur : maxrun;
+            if (TRACKS) vit_out[t0 + (uint32_t)j] = (uint8_t)state;
+            state = (word >> (2 * j + (int)state)) & 1u; // tb[vit[t]][t] = vit[t-1]
+        }
+    }
+    return vw;
+}
+
+struct CoreState {
+    double mL, mT, best;
+    int bstart;
+};
+
+// STEADY: the whole block has t >= c, i.e. both prefix-sum chains run and every step closes a window
+template <bool GUARD, bool STEADY>
+__device__ __forceinline__ void core_block(CoreState &S, const double *__restrict__ s_row, const uint4 cur,
+                                           const uint4 tcur, uint32_t wl, uint32_t tv, uint32_t t0, uint32_t n,
+                                           uint32_t c, double big_neg) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t t = t0 + (uint32_t)j;
+        if (!GUARD || t < n) {
+            const double lv = s_row[block_code(cur, j) * R_W + R_LLR];
+            S.mL = S.mL + (((wl >> j) & 1u) ? lv : big_neg); // psum[i+1] = psum[i] + maa3[i]
+            if (STEADY || t >= c) {                           // same chain, c steps later
+                const double lo = s_row[block_code(tcur, j) * R_W + R_LLR];
+                S.mT = S.mT + (((tv >> j) & 1u) ? lo : big_neg);
+            }
+            if (STEADY || t + 1 >= c) {
+                const bool first = !STEADY && t + 1 == c;
+                const double d = first ? S.mL : S.mL - S.mT;
+                const bool upd = first || d > S.best; // strict >: the first window wins ties
+                S.best = upd ? d : S.best;
+                S.bstart = upd ? (int)(t + 1 - c) : S.bstart;
+            }
+        }
+    }
+}
+
 template <bool TRACKS>
 __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
@@ -250,76 +329,50 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     const uint32_t c = (uint32_t)T->corelength;
 
     // ---------------- sweep 1: t = 0 .. n-1 ----------------
-    double s0 = 0.0, s1 = 0.0, h0 = 0.0;
+    VitState V;
     {
         uint4 nxt = load16(x, codes, cend);
+        {
+            const double *__restrict__ r = s_row + block_code(nxt, 0) * R_W;
+            V.s0 = T->li[0] + r[R_LE0];
+            V.s1 = T->li[1] + r[R_LE1];
+            V.h0 = T->h0_li0 + r[R_LE0H];
+        }
         for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
             const uint4 cur = nxt;
             if (t0 + 16u < n) nxt = load16(x + t0 + 16u, codes, cend);
-            uint32_t tbw = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t t = t0 + (uint32_t)j;
-                if (t < n) {
-                    const double *__restrict__ r = s_row + block_code(cur, j) * R_W;
-                    const double e0 = r[R_LE0], e1 = r[R_LE1], eh = r[R_LE0H];
-                    if (j == 0 && t0 == 0u) {
-                        s0 = T->li[0] + e0;
-                        s1 = T->li[1] + e1;
-                        h0 = T->h0_li0 + eh;
-                    } else {
-                        // (:3087-3100): state 0 stays the arg-max on ties (strict >)
-                        const double v00 = lt00 + s0, v10 = lt10 + s1, v01 = lt01 + s0, v11 = lt11 + s1;
-                        const bool g0 = v10 > v00, g1 = v11 > v01;
-                        s0 = (g0 ? v10 : v00) + e0;
-                        s1 = (g1 ? v11 : v01) + e1;
-                        h0 = (h0lt + h0) + eh; // hmm0: Viterbi == forward == running sum
-                        tbw |= ((uint32_t)g0 | ((uint32_t)g1 << 1)) << (2 * j);
-                    }
-                }
-            }
+            uint32_t tbw;
+            if (t0 == 0u) tbw = vit_block<true>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 1);
+            else if (t0 + 16u <= n) tbw = vit_block<false>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0);
+            else tbw = vit_block<true>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0);
             wbits[t0 >> 4] = tbw;
         }
     }
     // end of Viterbi (:3102-3109)
-    const double vend0 = s0 + lf0, vend1 = s1 + lf1;
+    const double vend0 = V.s0 + lf0, vend1 = V.s1 + lf1;
     uint32_t state = vend1 > vend0 ? 1u : 0u;
-    row->hmm_vit = (state ? vend1 : vend0) - (h0 + T->h0_lf0);
+    row->hmm_vit = (state ? vend1 : vend0) - (V.h0 + T->h0_lf0);
 
     // ---------------- sweep 2: traceback t = n-1 .. 0 (:3111-3113), longest run ----------------
     {
         int cur = 0, maxrun = 0;
         uint32_t wnext = wbits[nw - 1u]; // traceback words are prefetched one block ahead
+        uint8_t *vit_out = TRACKS ? tr.vit + J.off : nullptr;
         for (uint32_t wi = nw; wi-- > 0u;) {
             const uint32_t word = wnext;
             if (wi > 0u) wnext = wbits[wi - 1u];
             const uint32_t t0 = wi << 4;
-            uint32_t vw = 0; // Viterbi-path bits of this 16-residue block
-#pragma unroll
-            for (int j = 15; j >= 0; --j) {
-                const uint32_t t = t0 + (uint32_t)j;
-                if (t < n) {
-                    // here `state` = vit[t]
-                    vw |= state << j;
-                    cur = state ? cur + 1 : 0;
-                    maxrun = cur > maxrun ? cur : maxrun;
-                    if (TRACKS) tr.vit[J.off + t] = (uint8_t)state;
-                    state = (word >> (2 * j + (int)state)) & 1u; // tb[vit[t]][t] = vit[t-1]
-                }
-            }
+            const uint32_t vw = (t0 + 16u <= n) ? traceback_block<false, TRACKS>(state, cur, maxrun, word, t0, n, vit_out)
+                                                : traceback_block<true, TRACKS>(state, cur, maxrun, word, t0, n, vit_out);
             wbits[wi] = vw; // this word now holds vit[16*wi .. 16*wi+15]
         }
         row->vit_maxrun = maxrun;
     }
 
-    // ---------------- sweep 3: masked core window + PRD (:818-880) ----------------
+    // ---------------- sweep 3: masked core window (:818-833) ----------------
+    CoreState C{0.0, 0.0, -INFINITY, -1};
+    const double big_neg = T->big_neg;
     {
-        const double big_neg = T->big_neg;
-        double mL = 0.0, mT = 0.0, best = -INFINITY;
-        int bstart = -1;
-        bool inrun = false, flag = false;
-        int runstart = 0, prds = -1, prde = -2;
-        double runsum = 0.0, prdsum = 0.0;
         // lead stream: residues + path bits of block t0; trailing stream: the same, c steps later, i.e. the
         // 16 positions s .. s+15 with s = t0 - c. Both are fetched one block ahead.
         uint4 nxt = load16(x, codes, cend), tnxt = make_uint4(0u, 0u, 0u, 0u);
@@ -341,71 +394,69 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
                 wlnext = wbits[(t0 >> 4) + 1u];
                 if (s + 31 >= 0) prefetch_trail(s + 16);
             }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t t = t0 + (uint32_t)j;
-                if (t < n) {
-                    const uint32_t v = (wl >> j) & 1u;
-                    const double lv = s_row[block_code(cur, j) * R_W + R_LLR];
-                    mL = mL + (v ? lv : big_neg); // psum[i+1] = psum[i] + maa3[i]
-                    if (t >= c) {                 // the trailing prefix sum is the same chain, c steps later
-                        const uint32_t vo = (tv >> j) & 1u;
-                        const double lo = s_row[block_code(tcur, j) * R_W + R_LLR];
-                        mT = mT + (vo ? lo : big_neg);
-                    }
-                    // PRD = maximal Viterbi run around the core, PRDscore = its left-to-right sum (:863-872)
-                    if (v) {
-                        if (!inrun) {
-                            inrun = true;
-                            runstart = (int)t;
-                            runsum = 0.0;
-                            flag = false;
-                        }
-                        runsum = runsum + lv;
-                    } else if (inrun) {
-                        if (flag) {
-                            prds = runstart;
-                            prde = (int)t - 1;
-                            prdsum = runsum;
-                        }
-                        inrun = false;
-                    }
-                    if (t + 1 >= c) {
-                        const double d = (t + 1 == c) ? mL : mL - mT;
-                        if (t + 1 == c || d > best) { // strict >: the first window wins ties
-                            best = d;
-                            bstart = (int)(t + 1 - c);
-                            flag = v != 0u;
-                        }
-                    }
-                }
+            const bool full = t0 + 16u <= n;
+            if (t0 >= c) { // wave-uniform
+                if (full) core_block<false, true>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
+                else core_block<true, true>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
+            } else {
+                core_block<true, false>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
             }
         }
-        if (inrun && flag) {
-            prds = runstart;
-            prde = (int)n - 1;
-            prdsum = runsum;
-        }
-        if (best > big_neg / 2) { // :861
-            row->core_score = best;
-            row->core_start = bstart;
-            row->core_end = bstart + (int)c - 1;
-            row->prd_score = prdsum;
-            row->prd_start = prds;
-            row->prd_end = prde;
-        } else { // :873-880
-            row->core_score = __builtin_nan("");
-            row->core_start = -1;
-            row->core_end = -2;
-            row->prd_score = 0.0;
-            row->prd_start = -1;
-            row->prd_end = -2;
-        }
+    }
+    if (C.best > big_neg / 2) { // :861 — a core exists; expand it to the whole Viterbi run (:863-866)
+        auto bit = [&](int q) { return (wbits[(uint32_t)q >> 4] >> (q & 15)) & 1u; };
+        int a = C.bstart, z = C.bstart + (int)c - 1;
+        while (a > 0 && bit(a - 1)) --a;
+        while (z + 1 < (int)n && bit(z + 1)) ++z;
+        double prd = 0.0; // PRDscore: left-to-right sum over the run (:870-872)
+        for (int k = a; k <= z; ++k) prd = prd + s_row[ld_code(x, (uint32_t)k) * R_W + R_LLR];
+        row->core_score = C.best;
+        row->core_start = C.bstart;
+        row->core_end = C.bstart + (int)c - 1;
+        row->prd_score = prd;
+        row->prd_start = a;
+        row->prd_end = z;
+    } else { // :873-880
+        row->core_score = __builtin_nan("");
+        row->core_start = -1;
+        row->core_end = -2;
+        row->prd_score = 0.0;
+        row->prd_start = -1;
+        row->prd_end = -2;
     }
 }
 
 // ---- role F: forward (:3354-3375) with logeapeb (:1024-1047); track mode adds backward, posteriors
 //      and the MAP path (:3377-3405, :4032-4045) ----
+struct FwdState {
+    double a0, a1, h0;
+};
+
+template <bool GUARD, bool TRACKS>
+__device__ __forceinline__ void fwd_block(FwdState &S, const double *__restrict__ s_row,
+                                          const double *__restrict__ s_lut, const uint4 cur, uint32_t t0, uint32_t n,
+                                          double lt00, double lt01, double lt10, double lt11, double h0lt, int jfirst,
+                                          double *__restrict__ fwd_out) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < jfirst) continue;
+        if (!GUARD || t0 + (uint32_t)j < n) {
+            const double *__restrict__ r = s_row + block_code(cur, j) * R_W;
+            const double e0 = r[R_LE0], e1 = r[R_LE1], eh = r[R_LE0H];
+            // (:3360-3368): LSE(-inf, u) returns u unchanged, so one LUT-LSE per state
+            const double f0 = lse_lut(s_lut, lt00 + S.a0, lt10 + S.a1);
+            const double f1 = lse_lut(s_lut, lt01 + S.a0, lt11 + S.a1);
+            S.a0 = f0 + e0;
+            S.a1 = f1 + e1;
+            S.h0 = (h0lt + S.h0) + eh;
+            if (TRACKS) {
+                fwd_out[2 * (t0 + (uint32_t)j)] = S.a0;
+                fwd_out[2 * (t0 + (uint32_t)j) + 1] = S.a1;
+            }
+        }
+    }
+}
+
 template <bool TRACKS>
 __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
@@ -434,41 +485,32 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
     const double lt00 = T->lt[0][0], lt01 = T->lt[0][1], lt10 = T->lt[1][0], lt11 = T->lt[1][1];
     const double lf0 = T->lf[0], lf1 = T->lf[1];
     const double h0lt = T->h0_lt00;
+    double *fwd_out = TRACKS ? fwd + 2 * J.off : nullptr;
 
-    double a0 = 0.0, a1 = 0.0, h0 = 0.0;
+    FwdState F;
     {
         uint4 nxt = load16(x, codes, cend);
+        {
+            const double *__restrict__ r = s_row + block_code(nxt, 0) * R_W;
+            F.a0 = T->li[0] + r[R_LE0];
+            F.a1 = T->li[1] + r[R_LE1];
+            F.h0 = T->h0_li0 + r[R_LE0H];
+            if (TRACKS) {
+                fwd_out[0] = F.a0;
+                fwd_out[1] = F.a1;
+            }
+        }
         for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
             const uint4 cur = nxt;
             if (t0 + 16u < n) nxt = load16(x + t0 + 16u, codes, cend);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t t = t0 + (uint32_t)j;
-                if (t < n) {
-                    const double *__restrict__ r = s_row + block_code(cur, j) * R_W;
-                    const double e0 = r[R_LE0], e1 = r[R_LE1], eh = r[R_LE0H];
-                    if (j == 0 && t0 == 0u) {
-                        a0 = T->li[0] + e0;
-                        a1 = T->li[1] + e1;
-                        h0 = T->h0_li0 + eh;
-                    } else {
-                        // (:3360-3368): LSE(-inf, u) returns u unchanged, so one LUT-LSE per state
-                        const double f0 = lse_lut(s_lut, lt00 + a0, lt10 + a1);
-                        const double f1 = lse_lut(s_lut, lt01 + a0, lt11 + a1);
-                        a0 = f0 + e0;
-                        a1 = f1 + e1;
-                        h0 = (h0lt + h0) + eh;
-                    }
-                    if (TRACKS) {
-                        fwd[2 * (J.off + t)] = a0;
-                        fwd[2 * (J.off + t) + 1] = a1;
-                    }
-                }
-            }
+            if (t0 == 0u) fwd_block<true, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 1, fwd_out);
+            else if (t0 + 16u <= n)
+                fwd_block<false, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0, fwd_out);
+            else fwd_block<true, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0, fwd_out);
         }
     }
-    const double lmarg1 = lse_lut(s_lut, a0 + lf0, a1 + lf1); // (:3369-3375)
-    row->hmm_all = lmarg1 - (h0 + T->h0_lf0);
+    const double lmarg1 = lse_lut(s_lut, F.a0 + lf0, F.a1 + lf1); // (:3369-3375)
+    row->hmm_all = lmarg1 - (F.h0 + T->h0_lf0);
 
     if (TRACKS) {
         // lpseq needs b[.][0]: one full backward sweep first, then a second one that emits posteriors
@@ -480,10 +522,10 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
             q0 = lse_lut(s_lut, u0, u1);
             q1 = lse_lut(s_lut, w0, w1);
         }
-        const double lpseq = lse_lut(s_lut, fwd[2 * J.off] + q0, fwd[2 * J.off + 1] + q1);
+        const double lpseq = lse_lut(s_lut, fwd_out[0] + q0, fwd_out[1] + q1);
         double b0 = lf0, b1 = lf1;
         for (uint32_t t = n - 1;; --t) {
-            const double fa0 = fwd[2 * (J.off + t)], fa1 = fwd[2 * (J.off + t) + 1];
+            const double fa0 = fwd_out[2 * t], fa1 = fwd_out[2 * t + 1];
             const double pp0 = exp((fa0 + b0) - lpseq), pp1 = exp((fa1 + b1) - lpseq);
             tr.post0[J.off + t] = pp0;
             tr.post1[J.off + t] = pp1;
@@ -500,6 +542,53 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
 
 // ---- role W: MW (:767-771) and LLR (:782-783) windows over prefix sums (hss2 :1206-1257 with
 //      min == max), mean hydropathy / charge / FoldIndex (:4877-4885) ----
+struct WinState {
+    double hydsum, psL, psT, llrbest;
+    int chg, cntL, cntT, mwbest, mwstart, llrstart;
+};
+
+__device__ __forceinline__ int is_nq(uint32_t c) { return (c == 12u || c == 14u) ? 1 : 0; }
+
+// STEADY: the whole block has t >= max(c, 80): both trailing streams run and every step closes both windows
+template <bool GUARD, bool STEADY>
+__device__ __forceinline__ void win_block(WinState &S, const double *__restrict__ s_row, const uint4 cur,
+                                          const uint4 ccur, const uint4 mcur, uint32_t t0, uint32_t n, uint32_t c,
+                                          uint32_t mw) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t t = t0 + (uint32_t)j;
+        if (!GUARD || t < n) {
+            const uint32_t xc = block_code(cur, j);
+            const double *__restrict__ r = s_row + xc * R_W;
+            S.hydsum = S.hydsum + r[R_HYD]; // mean (:1584-1588)
+            S.chg += (xc == 3u || xc == 4u) ? 1 : ((xc == 9u || xc == 15u) ? -1 : 0);
+            S.cntL += is_nq(xc);
+            if (STEADY || t >= 80u) S.cntT += is_nq(block_code(mcur, j)); // only reached when mw == 80
+            if (STEADY) {
+                const int d = S.cntL - S.cntT;
+                const bool upd = d > S.mwbest;
+                S.mwbest = upd ? d : S.mwbest;
+                S.mwstart = upd ? (int)(t + 1u - 80u) : S.mwstart;
+            } else {
+                const int d = S.cntL - S.cntT;
+                const bool upd = (t + 1 >= mw) && (t + 1 == mw || d > S.mwbest);
+                S.mwbest = upd ? d : S.mwbest;
+                S.mwstart = upd ? (int)(t + 1 - mw) : S.mwstart;
+            }
+            // psum[i+1] = psum[i] + llr[x_i]; the trailing prefix sum is the same chain c steps later
+            S.psL = S.psL + r[R_LLR];
+            if (STEADY || t >= c) S.psT = S.psT + s_row[block_code(ccur, j) * R_W + R_LLR];
+            if (STEADY || t + 1 >= c) {
+                const bool first = !STEADY && t + 1 == c;
+                const double d = first ? S.psL : S.psL - S.psT;
+                const bool upd = first || d > S.llrbest;
+                S.llrbest = upd ? d : S.llrbest;
+                S.llrstart = upd ? (int)(t + 1 - c) : S.llrstart;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
@@ -524,12 +613,9 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
     const uint8_t *cend = codes + total;
     const uint32_t c = (uint32_t)T->corelength;
     const uint32_t mw = n < 80u ? n : 80u; // :769-770 (a protein shorter than 80 has a single window)
+    const uint32_t steady_from = c > 80u ? c : 80u;
 
-    double hydsum = 0.0;
-    int chg = 0;
-    int cntL = 0, cntT = 0, mwbest = 0, mwstart = 0;  // MW window: exact integers
-    double psL = 0.0, psT = 0.0, llrbest = -INFINITY; // LLR window over prefix sums
-    int llrstart = -1;
+    WinState W{0.0, 0.0, 0.0, -INFINITY, 0, 0, 0, 0, 0, -1};
     // three phase-locked streams: residues at t, at t - c (LLR window) and at t - 80 (MW window)
     uint4 nxt = load16(x, codes, cend), cnxt = make_uint4(0u, 0u, 0u, 0u), mnxt = cnxt;
     if (15 >= (int)c) cnxt = load16(x - (int)c, codes, cend);
@@ -541,48 +627,23 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
             if (sc + 15 >= 0) cnxt = load16(x + sc, codes, cend);
             if (sm + 15 >= 0) mnxt = load16(x + sm, codes, cend);
         }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t t = t0 + (uint32_t)j;
-            if (t < n) {
-                const uint32_t xc = block_code(cur, j);
-                const double *__restrict__ r = s_row + xc * R_W;
-                hydsum = hydsum + r[R_HYD]; // mean (:1584-1588)
-                chg += (xc == 3u || xc == 4u) ? 1 : ((xc == 9u || xc == 15u) ? -1 : 0);
-                cntL += (xc == 12u || xc == 14u) ? 1 : 0; // N, Q
-                if (t >= 80u) { // only reached when n > 80, i.e. mw == 80
-                    const uint32_t xo = block_code(mcur, j);
-                    cntT += (xo == 12u || xo == 14u) ? 1 : 0;
-                }
-                if (t + 1 >= mw) {
-                    const int d = cntL - cntT;
-                    if (t + 1 == mw || d > mwbest) {
-                        mwbest = d;
-                        mwstart = (int)(t + 1 - mw);
-                    }
-                }
-                // psum[i+1] = psum[i] + llr[x_i]; the trailing prefix sum is the same chain c steps later
-                psL = psL + r[R_LLR];
-                if (t >= c) psT = psT + s_row[block_code(ccur, j) * R_W + R_LLR];
-                if (t + 1 >= c) {
-                    const double d = (t + 1 == c) ? psL : psL - psT;
-                    if (t + 1 == c || d > llrbest) {
-                        llrbest = d;
-                        llrstart = (int)(t + 1 - c);
-                    }
-                }
-            }
+        const bool full = t0 + 16u <= n;
+        if (t0 >= steady_from) { // wave-uniform
+            if (full) win_block<false, true>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
+            else win_block<true, true>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
+        } else {
+            win_block<true, false>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
         }
     }
     row->prot_len = (int32_t)n;
-    row->mw_score = mwbest;
-    row->mw_start = mwstart;
-    row->mw_end = mwstart + (int)mw - 1;
-    row->llr_score = llrbest;
-    row->llr_start = llrstart;
-    row->llr_end = llrstart < 0 ? -2 : llrstart + (int)c - 1;
-    const double meanhydro = (1.0 * hydsum) / (double)(int)n;
-    const double meancharge = (1.0 * (double)chg) / (double)(int)n;
+    row->mw_score = W.mwbest;
+    row->mw_start = W.mwstart;
+    row->mw_end = W.mwstart + (int)mw - 1;
+    row->llr_score = W.llrbest;
+    row->llr_start = W.llrstart;
+    row->llr_end = W.llrstart < 0 ? -2 : W.llrstart + (int)c - 1;
+    const double meanhydro = (1.0 * W.hydsum) / (double)(int)n;
+    const double meancharge = (1.0 * (double)W.chg) / (double)(int)n;
     row->fi_meanhydro = meanhydro;
     row->fi_meancharge = meancharge;
     row->fi_meancombo = (T->cc[2] + T->cc[1] * fabs(meancharge)) + T->cc[0] * meanhydro; // :4885
