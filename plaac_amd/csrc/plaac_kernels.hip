@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 
 #include <cmath>
 #include <cstdint>
@@ -901,19 +902,27 @@ __global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes
 
 // ------------------------------------------------------------------------------------------------
 // K-B fast path: all three half-windows equal 20 (the default ww = 41, also ww = 40).
-// Two consecutive positions per lane (128 positions per iteration): the 42 values under the union of the
-// two windows are read once and feed both fixed-order 41-term sums, which halves the LDS traffic and makes
-// the loop fp64-VALU-bound instead of LDS-bound. Values live in LDS split by position parity so that
-// lane l reads [base + l + m] with an immediate offset m (conflict-free, no address arithmetic); the
-// first 24 slots of every sub-ring are mirrored behind it so that base + m never has to wrap.
+// FOUR consecutive positions per lane (256 positions per iteration): the 44 values under the union of the
+// four windows are read once and feed all four fixed-order 41-term sums (0.27 LDS values per add instead
+// of 1), which makes the loop fp64-VALU-bound instead of LDS-bound. Values live in LDS split by position
+// mod 4 so that lane l reads [base + l + g] with an immediate offset g (conflict-free, no address
+// arithmetic); the first 12 slots of every sub-ring are mirrored behind it so base + g never wraps.
 // Charge sums are exact integers -> prefix counts (wave scan) instead of 41 adds. The weights of the
-// second smoothing depend only on the position, so weight*value is formed once per position.
+// second smoothing depend only on the position, so weight*value is formed once per position. The four
+// (three) quotients of a position share their denominator: one reciprocal refinement, then a 3-instruction
+// correctly rounded quotient each (the same FMA sequence the compiler emits for a double division, minus the
+// range scaling that small-integer denominators never need).
+// Each block scores 16 proteins (descending-length order, stride gridDim.x, so every block gets the same mix of
+// long and short ones) and prefetches the next protein's metadata, so the dependent
+// order->length->offset->residues load chain is off the path.
 // ------------------------------------------------------------------------------------------------
-constexpr int TW = 20;           // half window
-constexpr int TC = 128;          // positions per iteration (2 per lane)
-constexpr int TRB = 128;         // sub-ring entries per parity class
-constexpr int TMIR = 24;         // mirrored head
-constexpr int TSUB = TRB + TMIR; // 152
+constexpr int TW = 20;             // half window
+constexpr int TB = 4;              // positions per lane
+constexpr int TC = 64 * TB;        // 256 positions per iteration
+constexpr int TRB = 76;            // sub-ring entries per class (>= (TC + 2*TW) / TB = 74)
+constexpr int TMIR = 12;           // mirrored head (max read offset is 10)
+constexpr int TSUB = TRB + TMIR;   // 88
+enum { RG_H = 0, RG_L = 1, RG_P = 2, RG_WF = 3, RG_WL = 4, RG_WP = 5, RG_N = 6 };
 
 __device__ __forceinline__ uint32_t load4(const uint8_t *p, const uint8_t *lo, const uint8_t *end) {
     if (p >= lo && p + 4 <= end) {
@@ -929,55 +938,73 @@ __device__ __forceinline__ uint32_t load4(const uint8_t *p, const uint8_t *lo, c
     return v;
 }
 
-// spread the 32 bits of x to the even bit positions of a 64-bit word
-__device__ __forceinline__ unsigned long long spread32(unsigned long long x) {
-    x &= 0xffffffffull;
-    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
-    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
-    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
-    x = (x | (x << 2)) & 0x3333333333333333ull;
-    x = (x | (x << 1)) & 0x5555555555555555ull;
-    return x;
+// sum over p in [i-w, i+w] of min(p, w), for i >= w: every term is w except the first m = max(0, 2w-i),
+// which fall short of w by m, m-1, ..., 1
+__device__ __forceinline__ int window_weight_side(int i, int w) {
+    const int m = imax(0, 2 * w - i);
+    return (2 * w + 1) * w - ((m * (m + 1)) >> 1);
 }
 
-enum { RG_H = 0, RG_L = 1, RG_P = 2, RG_WF = 3, RG_WL = 4, RG_WP = 5, RG_N = 6 };
-__device__ __forceinline__ void ring_put(double (*R)[2][TSUB], int a, int cls, int idx, double v) {
-    R[a][cls][idx] = v;
-    if (idx < TMIR) R[a][cls][idx + TRB] = v;
-}
-
-// The two 41-term sums of positions I and I+1 (I even) for THREE tracks at once (rings A, A+1, A+2 of
-// `R`), each in increasing position order: s[.][0] over I-20..I+20, s[.][1] over I-19..I+21.
-// base = slot of position I-20 in the even sub-ring. Partially unrolled on purpose: a fully unrolled body
-// lets the scheduler hoist all 126 LDS reads and spill.
-__device__ __forceinline__ void window_pairs3(const double (*R)[2][TSUB], int A, int base, double (&s)[3][2]) {
-    const double *__restrict__ E0 = &R[A][0][base], *__restrict__ O0 = &R[A][1][base];
-    const double *__restrict__ E1 = &R[A + 1][0][base], *__restrict__ O1 = &R[A + 1][1][base];
-    const double *__restrict__ E2 = &R[A + 2][0][base], *__restrict__ O2 = &R[A + 2][1][base];
-    double a00 = 0.0 + E0[0], a01 = 0.0, a10 = 0.0 + E1[0], a11 = 0.0, a20 = 0.0 + E2[0], a21 = 0.0;
-#pragma unroll 4
-    for (int m = 0; m < TW; ++m) {
-        const double o0 = O0[m], e0 = E0[m + 1], o1 = O1[m], e1 = E1[m + 1], o2 = O2[m], e2 = E2[m + 1];
-        a00 = a00 + o0;
-        a01 = a01 + o0;
-        a10 = a10 + o1;
-        a11 = a11 + o1;
-        a20 = a20 + o2;
-        a21 = a21 + o2;
-        a00 = a00 + e0;
-        a01 = a01 + e0;
-        a10 = a10 + e1;
-        a11 = a11 + e1;
-        a20 = a20 + e2;
-        a21 = a21 + e2;
+// Correctly rounded a/d for several numerators sharing one small positive integer-valued denominator.
+struct SharedDiv {
+    double d, y;
+    __device__ __forceinline__ explicit SharedDiv(double den) : d(den) {
+        const double y0 = __builtin_amdgcn_rcp(den);
+        const double e0 = __builtin_fma(-den, y0, 1.0);
+        const double y1 = __builtin_fma(y0, e0, y0);
+        const double e1 = __builtin_fma(-den, y1, 1.0);
+        y = __builtin_fma(y1, e1, y1);
     }
-    s[0][0] = a00;
-    s[0][1] = a01 + O0[TW];
-    s[1][0] = a10;
-    s[1][1] = a11 + O1[TW];
-    s[2][0] = a20;
-    s[2][1] = a21 + O2[TW];
+    __device__ __forceinline__ double operator()(double a) const {
+        const double q0 = a * y;
+        const double r = __builtin_fma(-d, q0, a);
+        return __builtin_fma(r, y, q0);
+    }
+};
+
+// The four 41-term sums of positions I .. I+3 (I = 0 mod 4) for THREE tracks at once (rings A, A+1, A+2),
+// each in increasing position order: s[track][b] over I+b-20 .. I+b+20. base = slot of position I-20 in the
+// class-0 sub-ring; value e of the union (e = 0..43) is class e&3, slot base + (e>>2).
+__device__ __forceinline__ void window_quads3(const double (*R)[TB][TSUB], int A, int base, double (&s)[3][4]) {
+    double acc[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double v0 = R[A + a][0][base], v1 = R[A + a][1][base], v2 = R[A + a][2][base], v3 = R[A + a][3][base];
+        // e = 0..3: window b starts at e = b
+        acc[a][0] = ((0.0 + v0) + v1) + v2;
+        acc[a][0] = acc[a][0] + v3;
+        acc[a][1] = (0.0 + v1) + v2;
+        acc[a][1] = acc[a][1] + v3;
+        acc[a][2] = (0.0 + v2) + v3;
+        acc[a][3] = 0.0 + v3;
+    }
+#pragma unroll 3
+    for (int g = 1; g <= 9; ++g) { // e = 4g .. 4g+3 lies in all four windows
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v0 = R[A + a][0][base + g], v1 = R[A + a][1][base + g], v2 = R[A + a][2][base + g],
+                         v3 = R[A + a][3][base + g];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                acc[a][b] = acc[a][b] + v0;
+                acc[a][b] = acc[a][b] + v1;
+                acc[a][b] = acc[a][b] + v2;
+                acc[a][b] = acc[a][b] + v3;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { // e = 40..43: window b ends at e = 40 + b
+        const double v0 = R[A + a][0][base + 10], v1 = R[A + a][1][base + 10], v2 = R[A + a][2][base + 10],
+                     v3 = R[A + a][3][base + 10];
+        s[a][0] = acc[a][0] + v0;
+        s[a][1] = (acc[a][1] + v0) + v1;
+        s[a][2] = ((acc[a][2] + v0) + v1) + v2;
+        s[a][3] = (((acc[a][3] + v0) + v1) + v2) + v3;
+    }
 }
+
+constexpr int KB_PROTEINS_PER_BLOCK = 16; // blocks retire regularly, so the K-A kernels' blocks keep getting slots
 
 template <bool TRACKS>
 __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ codes,
@@ -989,20 +1016,10 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
     __shared__ double t_hyd[ROWS], t_llr[ROWS], t_lod[ROWS];
     __shared__ int t_chg[ROWS];
     // rings: mapped inputs hydro/llr/papa (0.0 outside [0,n)), then weight * first-level FoldIndex/llr/papa
-    __shared__ double ring[RG_N][2][TSUB];
-    __shared__ int pre[256]; // pre[q & 255] = charge sum of positions < q
+    __shared__ double ring[RG_N][TB][TSUB];
+    __shared__ int pre[512]; // pre[q & 511] = charge sum of positions < q
 
     const int lane = threadIdx.x;
-    const uint32_t p = order[blockIdx.x];
-    const int n = (int)neff[p];
-    plaac_row *row = rows + p;
-    if (n == 0) {
-        if (lane == 0) {
-            row->papa_combo = row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = 0.0;
-            row->fi_numaa = row->fi_maxrun = row->papa_cen = 0;
-        }
-        return;
-    }
     if (lane < ROWS) {
         const int k = lane == NAA ? 0 : lane;
         t_hyd[lane] = T->hyd[k];
@@ -1010,131 +1027,149 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
         t_lod[lane] = T->lod[k];
         t_chg[lane] = T->chg[k];
     }
-    for (int i = lane; i < RG_N * 2 * TSUB; i += 64) (&ring[0][0][0])[i] = 0.0;
-    for (int i = lane; i < 256; i += 64) pre[i] = 0;
-
-    const uint64_t off = offsets[p];
-    const uint8_t *__restrict__ x = codes + off;
     const uint8_t *cend = codes + total;
     const int ww1 = T->ww1, ww2 = T->ww2;
-    const int we = n - 1 < TW ? n - 1 : TW; // w = ww/2 clamped to n-1 (:2588-2589)
     const bool adjust = T->adjustprolines != 0;
     const double cc0 = T->cc[0], cc1 = T->cc[1], cc2 = T->cc[2];
-    int halfw = (ww1 - 1) / 2; // FoldIndex run scan domain (:5010-5013)
-    if (halfw > n / 2) halfw = n / 2;
-    const int dlo = halfw, dhi = n - halfw - 1;
-    const int plo = (ww2 - 1) / 2, phi = n - (ww2 - 1) / 2; // PAPA centres k in [plo, phi) (:4942)
 
-    double pbest = -INFINITY, pfi = 0.0, pll2 = 0.0;
-    int pcen = -1;
-    bool run_open = false;
-    int run_start = 0, numaa = 0, maxlen = 0, carry = 0;
-    auto close_run = [&](int s, int e) {
-        if (s == dlo) s = 0;
-        if (e == dhi) e = n - 1;
-        const int len = e - s + 1;
-        if (len >= 5) {
-            numaa += len;
-            maxlen = len > maxlen ? len : maxlen;
-        }
-    };
-    auto scan_mask = [&](unsigned long long m, int base) { // FoldIndex<0 runs (:5020-5058), wave-uniform
-        if (run_open) {
-            const int t1 = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
-            if (t1 < 64) {
-                close_run(run_start, base + t1 - 1);
-                run_open = false;
-                m &= ~((1ull << t1) - 1ull);
-            } else {
-                m = 0ull;
-            }
-        }
-        while (m) {
-            const int s = __builtin_ctzll(m);
-            const unsigned long long rest = ~(m >> s);
-            const int len = rest == 0ull ? 64 - s : __builtin_ctzll(rest);
-            if (s + len >= 64) {
-                run_open = true;
-                run_start = base + s;
-                break;
-            }
-            close_run(base + s, base + s + len - 1);
-            m &= ~(((1ull << len) - 1ull) << s);
-        }
-    };
-    __syncthreads();
+    // metadata of the first protein of this block; the next one is prefetched while the current is scored
+    uint32_t b = blockIdx.x;
+    uint32_t p_cur = 0, n_cur = 0, p_nxt = 0;
+    uint64_t off_cur = 0;
+    if (b < nprot) {
+        p_cur = order[b];
+        n_cur = neff[p_cur];
+        off_cur = offsets[p_cur];
+    }
+    if (b + gridDim.x < nprot) p_nxt = order[b + gridDim.x];
 
-    const int nchunks = (n + 2 * TW + TC - 1) / TC;
-    for (int k = 0; k < nchunks; ++k) {
-        // ---- stage 0: residues -> mapped inputs at q0 = 128k + 2*lane and q0 + 1
-        {
-            const int q0 = TC * k + 2 * lane;
-            double vh0 = 0.0, vl0 = 0.0, vp0 = 0.0, vh1 = 0.0, vl1 = 0.0, vp1 = 0.0;
-            int c0 = 0, c1 = 0;
-            if (q0 < n) {
-                const uint32_t w = load4(x + q0 - 2, codes, cend); // residues q0-2 .. q0+1
-                const uint32_t bm2 = w & 0xffu, bm1 = (w >> 8) & 0xffu;
-                uint32_t b0 = (w >> 16) & 0xffu, b1 = w >> 24;
-                b0 = b0 < 22u ? b0 : 22u;
-                b1 = b1 < 22u ? b1 : 22u;
-                const bool pm2 = q0 >= 2 && bm2 == 13u, pm1 = q0 >= 1 && bm1 == 13u;
-                vh0 = t_hyd[b0];
-                vl0 = t_llr[b0];
-                c0 = t_chg[b0];
-                // only the first P of PP / PxP scores (:2653-2654); absolute neighbours p-1, p-2
-                vp0 = (adjust && b0 == 13u && (pm1 || pm2)) ? 0.0 : t_lod[b0];
-                if (q0 + 1 < n) {
-                    vh1 = t_hyd[b1];
-                    vl1 = t_llr[b1];
-                    c1 = t_chg[b1];
-                    vp1 = (adjust && b1 == 13u && (b0 == 13u || pm1)) ? 0.0 : t_lod[b1];
-                }
-            }
-            const int idx = (q0 >> 1) & (TRB - 1);
-            ring_put(ring, RG_H, 0, idx, vh0);
-            ring_put(ring, RG_H, 1, idx, vh1);
-            ring_put(ring, RG_L, 0, idx, vl0);
-            ring_put(ring, RG_L, 1, idx, vl1);
-            ring_put(ring, RG_P, 0, idx, vp0);
-            ring_put(ring, RG_P, 1, idx, vp1);
-            // charge prefix counts: inclusive wave scan of the per-lane pair sums
-            int s = c0 + c1;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(s, d);
-                if (lane >= d) s += o;
-            }
-            pre[(q0 + 1) & 255] = carry + s - c1;
-            pre[(q0 + 2) & 255] = carry + s;
-            carry += __shfl(s, 63);
+    for (; b < nprot; b += gridDim.x) {
+        const uint32_t p = p_cur;
+        const int n = (int)n_cur;
+        const uint64_t off = off_cur;
+        // prefetch: metadata of the next protein, id of the one after
+        const bool has_next = b + gridDim.x < nprot;
+        if (has_next) {
+            p_cur = p_nxt;
+            n_cur = neff[p_nxt];
+            off_cur = offsets[p_nxt];
+            if (b + 2u * gridDim.x < nprot) p_nxt = order[b + 2u * gridDim.x];
         }
+        plaac_row *row = rows + p;
+        if (n == 0) {
+            if (lane == 0) {
+                row->papa_combo = row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = 0.0;
+                row->fi_numaa = row->fi_maxrun = row->papa_cen = 0;
+            }
+            continue;
+        }
+        __syncthreads(); // the previous protein is done with the rings
+        for (int i = lane; i < RG_N * TB * TSUB; i += 64) (&ring[0][0][0])[i] = 0.0;
+        for (int i = lane; i < 512; i += 64) pre[i] = 0;
+
+        const uint8_t *__restrict__ x = codes + off;
+        const int we = n - 1 < TW ? n - 1 : TW; // w = ww/2 clamped to n-1 (:2588-2589)
+        int halfw = (ww1 - 1) / 2;              // FoldIndex run scan domain (:5010-5013)
+        if (halfw > n / 2) halfw = n / 2;
+        const int dlo = halfw, dhi = n - halfw - 1;
+        const int plo = (ww2 - 1) / 2, phi = n - (ww2 - 1) / 2; // PAPA centres k in [plo, phi) (:4942)
+
+        double pbest = -INFINITY, pfi = 0.0, pll2 = 0.0;
+        int pcen = -1;
+        int numaa = 0, maxlen = 0, carry = 0;      // numaa / maxlen: per-lane partials, reduced at the end
+        int last_zero = INT_MIN, last_flag = 0;     // wave-uniform carries of the FoldIndex run scan
         __syncthreads();
-        // ---- stage 1: first-level tracks at i0 = 128k + 2*lane - 20 and i0 + 1
-        {
-            const int i0 = TC * k + 2 * lane - TW;
-            const int base = ((i0 - TW) >> 1) & (TRB - 1);
-            double sums[3][2];
-            window_pairs3(ring, RG_H, base, sums);
-            double wfi[2] = {0.0, 0.0}, wll[2] = {0.0, 0.0}, wpa[2] = {0.0, 0.0};
-            bool neg[2] = {false, false};
+
+        const int nchunks = (n + 2 * TW + TC - 1) / TC;
+        // ring slot of entry number e (= position >> 2): (e mod TRB); per iteration the entry numbers advance by 64
+        int slot_in = 0;                      // slot of entry 64k (stage 0 writes entries 64k + lane)
+        int slot_l1 = TRB - 10;               // slot of entry 64k - 10 (stage 1 reads from position 256k - 40)
+        int slot_w1 = TRB - 5;                // slot of entry 64k - 5  (stage 1 writes position 256k - 20)
+        int slot_l2 = TRB - 15;               // slot of entry 64k - 15 (stage 2 reads from position 256k - 60)
+        auto wrap = [](int s) { return s >= TRB ? s - TRB : s; };
+        for (int k = 0; k < nchunks; ++k) {
+            // ---- stage 0: residues -> mapped inputs at q0 = 256k + 4*lane .. q0 + 3
+            {
+                const int q0 = TC * k + 4 * lane;
+                double vh[4] = {0.0, 0.0, 0.0, 0.0}, vl[4] = {0.0, 0.0, 0.0, 0.0}, vp[4] = {0.0, 0.0, 0.0, 0.0};
+                int ch[4] = {0, 0, 0, 0};
+                if (q0 < n) {
+                    const uint32_t w = load4(x + q0, codes, cend);         // residues q0 .. q0+3
+                    const uint32_t wm = load4(x + q0 - 2, codes, cend);    // residues q0-2, q0-1 (low bytes)
+                    uint32_t cb[6];
+                    cb[0] = q0 >= 2 ? (wm & 0xffu) : 255u;
+                    cb[1] = q0 >= 1 ? ((wm >> 8) & 0xffu) : 255u;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int i = i0 + b;
-                if (i >= 0 && i < n) {
+                    for (int j = 0; j < 4; ++j) cb[2 + j] = (w >> (8 * j)) & 0xffu;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (q0 + j < n) {
+                            const uint32_t c = cb[2 + j] < 22u ? cb[2 + j] : 22u;
+                            vh[j] = t_hyd[c];
+                            vl[j] = t_llr[c];
+                            ch[j] = t_chg[c];
+                            // only the first P of PP / PxP scores (:2653-2654); absolute neighbours p-1, p-2
+                            const bool dup = adjust && c == 13u && (cb[1 + j] == 13u || cb[j] == 13u);
+                            vp[j] = dup ? 0.0 : t_lod[c];
+                        }
+                    }
+                }
+                const int idx = wrap(slot_in + lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ring[RG_H][j][idx] = vh[j];
+                    ring[RG_L][j][idx] = vl[j];
+                    ring[RG_P][j][idx] = vp[j];
+                }
+                if (idx < TMIR) { // mirrored head: one branch for all twelve copies
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ring[RG_H][j][idx + TRB] = vh[j];
+                        ring[RG_L][j][idx + TRB] = vl[j];
+                        ring[RG_P][j][idx + TRB] = vp[j];
+                    }
+                }
+                // charge prefix counts: inclusive wave scan of the per-lane sums
+                int s = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(s, d);
+                    if (lane >= d) s += o;
+                }
+                const int before = carry + s - ((ch[0] + ch[1]) + (ch[2] + ch[3]));
+                pre[(q0 + 1) & 511] = before + ch[0];
+                pre[(q0 + 2) & 511] = before + ch[0] + ch[1];
+                pre[(q0 + 3) & 511] = before + ch[0] + ch[1] + ch[2];
+                pre[(q0 + 4) & 511] = carry + s;
+                carry += __shfl(s, 63);
+            }
+            __syncthreads();
+            // ---- stage 1: first-level tracks at i0 = 256k + 4*lane - 20 .. i0 + 3
+            {
+                const int i0 = TC * k + 4 * lane - TW;
+                double sums[3][4];
+                window_quads3(ring, RG_H, wrap(slot_l1 + lane), sums);
+                double wfi[4], wll[4], wpa[4];
+                int zpos[4]; // position if FoldIndex >= 0 there (or outside the scan domain), else "none"
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j;
+                    const bool live = i >= 0 && i < n;
                     const int lo = imax(i - TW, 0), hi = imin(i + TW, n - 1);
-                    const double cnt = (double)(hi - lo + 1);
-                    const int csum = pre[(hi + 1) & 255] - pre[lo & 255];
-                    const double hydro = sums[0][b] / cnt;
-                    const double charge = (double)csum / cnt;
+                    const SharedDiv div(live ? (double)(hi - lo + 1) : 1.0);
+                    const int csum = pre[(hi + 1) & 511] - pre[lo & 511];
+                    const double hydro = div(sums[0][j]);
+                    const double charge = div((double)csum);
                     const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
-                    const double llr1 = sums[1][b] / cnt;
-                    const double papa = sums[2][b] / cnt;
+                    const double llr1 = div(sums[1][j]);
+                    const double papa = div(sums[2][j]);
                     const double wt = (double)(1 + imin(i, we) + imin(n - i - 1, we));
-                    wfi[b] = wt * fi;
-                    wll[b] = wt * llr1;
-                    wpa[b] = wt * papa;
-                    neg[b] = (fi < 0.0) && i >= dlo && i <= dhi;
-                    if (TRACKS) {
+                    wfi[j] = live ? wt * fi : 0.0;
+                    wll[j] = live ? wt * llr1 : 0.0;
+                    wpa[j] = live ? wt * papa : 0.0;
+                    const bool neg = live && (fi < 0.0) && i >= dlo && i <= dhi;
+                    zpos[j] = neg ? INT_MIN : i;
+                    if (TRACKS && live) {
                         tr.charge[off + i] = charge;
                         tr.hydro[off + i] = hydro;
                         tr.fi[off + i] = fi;
@@ -1142,85 +1177,133 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
                         tr.papa[off + i] = papa;
                     }
                 }
-            }
-            const int idx = (i0 >> 1) & (TRB - 1);
-            ring_put(ring, RG_WF, 0, idx, wfi[0]);
-            ring_put(ring, RG_WF, 1, idx, wfi[1]);
-            ring_put(ring, RG_WL, 0, idx, wll[0]);
-            ring_put(ring, RG_WL, 1, idx, wll[1]);
-            ring_put(ring, RG_WP, 0, idx, wpa[0]);
-            ring_put(ring, RG_WP, 1, idx, wpa[1]);
-            // position-ordered 128-bit mask of FoldIndex < 0: even positions from lanes' first output
-            const unsigned long long me = __ballot(neg[0]), mo = __ballot(neg[1]);
-            const int pbase = TC * k - TW;
-            scan_mask(spread32(me) | (spread32(mo) << 1), pbase);
-            scan_mask(spread32(me >> 32) | (spread32(mo >> 32) << 1), pbase + 64);
-        }
-        __syncthreads();
-        // ---- stage 2: weighted second smoothing at i0 = 128k + 2*lane - 40 and i0 + 1, PAPA arg-max
-        {
-            const int i0 = TC * k + 2 * lane - 2 * TW;
-            const int base = ((i0 - TW) >> 1) & (TRB - 1);
-            double sums[3][2];
-            window_pairs3(ring, RG_WF, base, sums);
+                const int idx = wrap(slot_w1 + lane);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int i = i0 + b;
-                if (i >= 0 && i < n) {
-                    double fix2 = __builtin_nan(""), llx2 = fix2, pax2 = fix2;
-                    if (i >= we && i <= n - we - 1) {
-                        const double den = (double)((2 * we + 1) + sum_min_left(i, we) + sum_min_left(n - 1 - i, we));
-                        fix2 = sums[0][b] / den;
-                        llx2 = sums[1][b] / den;
-                        pax2 = sums[2][b] / den;
+                for (int j = 0; j < 4; ++j) {
+                    ring[RG_WF][j][idx] = wfi[j];
+                    ring[RG_WL][j][idx] = wll[j];
+                    ring[RG_WP][j][idx] = wpa[j];
+                }
+                if (idx < TMIR) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ring[RG_WF][j][idx + TRB] = wfi[j];
+                        ring[RG_WL][j][idx + TRB] = wll[j];
+                        ring[RG_WP][j][idx + TRB] = wpa[j];
                     }
-                    if (TRACKS) {
+                }
+                // FoldIndex<0 runs (:5020-5058), position-parallel: a run is accounted where it ENDS, i.e. at a
+                // position q without the flag whose predecessor has it; its start is one past the last unflagged
+                // position before q (running max of unflagged positions: in-lane, wave max-scan, carry).
+                {
+                    const int lanemax = imax(imax(zpos[0], zpos[1]), imax(zpos[2], zpos[3]));
+                    int sc = lanemax;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int o = __shfl_up(sc, d);
+                        if (lane >= d) sc = imax(sc, o);
+                    }
+                    int before = __shfl_up(sc, 1); // last unflagged position before this lane's first position
+                    if (lane == 0) before = INT_MIN;
+                    before = imax(before, last_zero);
+                    int prevflag = __shfl_up(zpos[3] == INT_MIN ? 1 : 0, 1);
+                    if (lane == 0) prevflag = last_flag;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool flagged = zpos[j] == INT_MIN;
+                        if (!flagged && prevflag) { // a run [before+1, q-1] just ended
+                            int rs = before + 1, re = i0 + j - 1;
+                            if (rs == dlo) rs = 0;
+                            if (re == dhi) re = n - 1;
+                            const int len = re - rs + 1;
+                            if (len >= 5) {
+                                numaa += len;
+                                maxlen = imax(maxlen, len);
+                            }
+                        }
+                        before = imax(before, zpos[j]);
+                        prevflag = flagged ? 1 : 0;
+                    }
+                    last_zero = imax(last_zero, __shfl(sc, 63));
+                    last_flag = __shfl(prevflag, 63);
+                }
+            }
+            __syncthreads();
+            // ---- stage 2: weighted second smoothing at i0 = 256k + 4*lane - 40 .. i0 + 3, PAPA arg-max
+            {
+                const int i0 = TC * k + 4 * lane - 2 * TW;
+                double sums[3][4];
+                window_quads3(ring, RG_WF, wrap(slot_l2 + lane), sums);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j;
+                    const bool valid = i >= we && i <= n - we - 1; // implies 0 <= i < n
+                    const int den = (2 * we + 1) + window_weight_side(i, we) + window_weight_side(n - 1 - i, we);
+                    const SharedDiv div(valid ? (double)den : 1.0);
+                    const double fix2 = valid ? div(sums[0][j]) : __builtin_nan("");
+                    const double llx2 = valid ? div(sums[1][j]) : __builtin_nan("");
+                    const double pax2 = valid ? div(sums[2][j]) : __builtin_nan("");
+                    if (TRACKS && i >= 0 && i < n) {
                         tr.fix2[off + i] = fix2;
                         tr.plaacllrx2[off + i] = llx2;
                         tr.papax2[off + i] = pax2;
                     }
-                    if (i >= plo && i < phi && (pax2 > pbest) && (fix2 < 0.0)) { // papamode 1 (:4942-4948)
-                        pbest = pax2;
-                        pcen = i;
-                        pfi = fix2;
-                        pll2 = llx2;
-                    }
+                    // papamode 1 (:4942-4948): NaNs fail both comparisons
+                    const bool upd = i >= plo && i < phi && (pax2 > pbest) && (fix2 < 0.0);
+                    pbest = upd ? pax2 : pbest;
+                    pcen = upd ? i : pcen;
+                    pfi = upd ? fix2 : pfi;
+                    pll2 = upd ? llx2 : pll2;
                 }
             }
+            slot_in = wrap(slot_in + 64);
+            slot_l1 = wrap(slot_l1 + 64);
+            slot_w1 = wrap(slot_w1 + 64);
+            slot_l2 = wrap(slot_l2 + 64);
         }
-    }
-    if (run_open) close_run(run_start, dhi);
-
-    // wave arg-max: largest papax2, smallest centre among equals (first max of the serial loop)
-    for (int d = 32; d >= 1; d >>= 1) {
-        const double ob = __shfl_xor(pbest, d);
-        const int oc = __shfl_xor(pcen, d);
-        const double ofi = __shfl_xor(pfi, d), oll2 = __shfl_xor(pll2, d);
-        const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
-        if (take) {
-            pbest = ob;
-            pcen = oc;
-            pfi = ofi;
-            pll2 = oll2;
+        // wave arg-max: largest papax2, smallest centre among equals (first max of the serial loop)
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ob = __shfl_xor(pbest, d);
+            const int oc = __shfl_xor(pcen, d);
+            const double ofi = __shfl_xor(pfi, d), oll2 = __shfl_xor(pll2, d);
+            const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
+            if (take) {
+                pbest = ob;
+                pcen = oc;
+                pfi = ofi;
+                pll2 = oll2;
+            }
         }
-    }
-    if (lane == 0) {
-        row->fi_numaa = numaa;
-        row->fi_maxrun = maxlen;
-        row->papa_cen = pcen;
+        for (int d = 32; d >= 1; d >>= 1) { // FoldIndex run statistics: sum / max over lanes
+            numaa += __shfl_xor(numaa, d);
+            maxlen = imax(maxlen, __shfl_xor(maxlen, d));
+        }
+        // PAPAllr = first-level PLAAC-LLR at the centre, recomputed: lanes fetch the 41 taps in parallel,
+        // the fixed-order sum runs over lane broadcasts (out-of-range taps add +0.0)
+        double papallr = __builtin_nan("");
         if (pcen >= 0) {
-            // PAPAllr = first-level PLAAC-LLR at the centre: recomputed here (same fixed-order sum)
+            const int q = pcen - TW + lane;
+            const double v = (lane <= 2 * TW && q >= 0 && q < n) ? t_llr[ld_code(x, (uint32_t)q)] : 0.0;
             double s = 0.0;
+#pragma unroll
+            for (int j = 0; j <= 2 * TW; ++j) s = s + __shfl(v, j);
             const int lo = imax(pcen - TW, 0), hi = imin(pcen + TW, n - 1);
-            for (int q = lo; q <= hi; ++q) s = s + T->llr[ld_code(x, (uint32_t)q)];
-            row->papa_combo = pbest;
-            row->papa_prop = pbest;
-            row->papa_fi = pfi;
-            row->papa_llr = s / (double)(hi - lo + 1);
-            row->papa_llr2 = pll2;
-        } else {
-            row->papa_combo = -INFINITY;
-            row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
+            papallr = s / (double)(hi - lo + 1);
+        }
+        if (lane == 0) {
+            row->fi_numaa = numaa;
+            row->fi_maxrun = maxlen;
+            row->papa_cen = pcen;
+            if (pcen >= 0) {
+                row->papa_combo = pbest;
+                row->papa_prop = pbest;
+                row->papa_fi = pfi;
+                row->papa_llr = papallr;
+                row->papa_llr2 = pll2;
+            } else {
+                row->papa_combo = -INFINITY;
+                row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
+            }
         }
     }
 }
@@ -1267,6 +1350,7 @@ __global__ __launch_bounds__(256) void k_hist(const uint8_t *__restrict__ codes,
 // ------------------------------------------------------------------------------------------------
 struct plaac_ctx {
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     DevTables *d_tab = nullptr;
     plaac_params params;
@@ -1414,6 +1498,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         g_create_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
         plaac_ctx_destroy(ctx);
@@ -1581,11 +1666,12 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     const bool fast20 = ctx->params.ww1 / 2 == TW && ctx->params.ww2 / 2 == TW && ctx->params.ww3 / 2 == TW &&
                         !ctx->generic_tracks;
     if (fast20) {
+        const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
         if (d_tracks)
-            hipLaunchKernelGGL(k_tracks20<true>, dim3(nprot), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
+            hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
                                ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
         else
-            hipLaunchKernelGGL(k_tracks20<false>, dim3(nprot), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
+            hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
                                ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
     } else if (wmax <= 32) LAUNCH_KB(128);
     else if (wmax <= 96) LAUNCH_KB(256);
