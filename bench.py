@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--nprot", type=int, default=0, help="sequences per GPU (default: config 4 -> 1,250,000)")
     ap.add_argument("--tracks", action="store_true", help="per-residue track mode (82 B/residue written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
+                    "'gloo' + --one-device lets two ranks share one GPU for a plumbing check")
+    ap.add_argument("--one-device", action="store_true", help="TEST ONLY: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -43,7 +46,9 @@ def main():
     from plaac_amd import dist as pdist
     from plaac_amd import native, synth
 
-    rank, local_rank, world = pdist.init_process_group()
+    rank, local_rank, world = pdist.init_process_group(args.backend)
+    if args.one_device:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -127,10 +132,20 @@ def main():
     }
     path_bytes = total * (1 + tb) + nprot * 168
     achieved = kbytes[dom] / (dom_ms * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; tools/pmc.sh
+    # collects FETCH_SIZE / WRITE_SIZE for this same workload and leaves the per-launch byte counts here
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            tj = json.load(fh)
+        if tj.get("workload") == [args.config, nprot, bool(args.tracks)]:
+            traffic = tj["bytes_per_launch"].get(dom)
+    except (OSError, ValueError, KeyError):
+        pass
     path_ms = ktimes["total"]
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
         "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
         "kernels_overlap": "k_vit, k_fwd, k_win, k_tracks run concurrently on 4 HIP streams; total = first launch -> join",
         "path_achieved_GBps": round(path_bytes / (path_ms * 1e-3) / 1e9, 3),
@@ -149,22 +164,24 @@ def main():
         Po = oc.build_params()
         ncores = os.cpu_count() or 1
         nthreads = min(ncores, 256)
-        n_s = min(nprot, 60000)
+        n_s = min(nprot, 250000)
         off_h = offsets[:n_s + 1].cpu().numpy().astype(np.uint64)
         codes_h = codes[:int(off_h[-1])].cpu().numpy()
-        n_1 = min(n_s, 4000)
+        n_1 = min(n_s, 8000)
+        oc.score_batch(Po, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)  # scratch warm-up
         t1 = time.perf_counter()
         oc.score_batch(Po, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)
         dt1 = time.perf_counter() - t1
-        oc.score_batch(Po, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=nthreads)  # thread-pool warm-up
+        oc.score_batch(Po, codes_h, off_h, nthreads=nthreads)  # thread-pool and per-thread scratch warm-up
         t1 = time.perf_counter()
         want = oc.score_batch(Po, codes_h, off_h, nthreads=nthreads)
         dtn = time.perf_counter() - t1
         got = rows[:n_s * native.ROW_BYTES].cpu().numpy().view(native.ROW_DTYPE)
         cpu = {
             "value": round(int(off_h[-1]) / dtn, 1), "unit": "residues/s", "cores": nthreads, "kind": "port",
-            "sample": "first %d sequences (%d residues) of rank 0's shard, all host threads; oracle/plaac_oracle.c "
-                      "(dead work of the Java reference omitted)" % (n_s, int(off_h[-1])),
+            "sample": "first %d sequences (%d residues) of rank 0's shard on %d OpenMP threads, second of two runs; "
+                      "value_1core = first %d sequences on 1 thread; oracle/plaac_oracle.c restatement (not the Java "
+                      "reference: no JVM on this box; its dead work omitted)" % (n_s, int(off_h[-1]), nthreads, n_1),
             "value_1core": round(int(off_h[n_1]) / dt1, 1),
             "gpu_rows_match_oracle": bool(got.tobytes() == want.tobytes()),
         }

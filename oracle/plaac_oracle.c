@@ -201,7 +201,7 @@ double oracle_logeapeb(const double *lut, double a, double b) {
 }
 
 /* hss2(seq,min,max), plaac.java:1206-1257, general form (the drivers only call it with min==max) */
-void oracle_hss2(const double *seq, int n, int minlength, int maxlength, double out[3]) {
+static void hss2_buf(const double *seq, int n, int minlength, int maxlength, double out[3], double *psum) {
     if (minlength > n || minlength > maxlength) {
         out[0] = -1.0;
         out[1] = -2.0;
@@ -209,7 +209,6 @@ void oracle_hss2(const double *seq, int n, int minlength, int maxlength, double 
         return;
     }
     if (maxlength > n) maxlength = n;
-    double *psum = (double *)malloc(sizeof(double) * ((size_t)n + 1));
     psum[0] = 0;
     for (int i = 0; i < n; i++) psum[i + 1] = psum[i] + seq[i];
     int beststart = 0, beststop = minlength - 1, curstart = 0, newstart = 0;
@@ -231,10 +230,15 @@ void oracle_hss2(const double *seq, int n, int minlength, int maxlength, double 
             beststart = curstart;
         }
     }
-    free(psum);
     out[0] = beststart;
     out[1] = beststop;
     out[2] = best;
+}
+
+void oracle_hss2(const double *seq, int n, int minlength, int maxlength, double out[3]) {
+    double *psum = (double *)malloc(sizeof(double) * ((size_t)(n > 0 ? n : 0) + 1));
+    hss2_buf(seq, n, minlength, maxlength, out, psum);
+    free(psum);
 }
 
 /* Brute-force fixed-width window over the same rounded prefix sums (the disabled
@@ -314,6 +318,7 @@ static void window_mean_weighted(const double *arr, int n, int ww, double *sa) {
 typedef struct scratch {
     double *d[16];
     int32_t *tb;
+    uint8_t *b[2];
     size_t cap;
 } scratch;
 
@@ -325,12 +330,18 @@ static void scratch_reserve(scratch *S, size_t n) {
     }
     free(S->tb);
     S->tb = (int32_t *)malloc(sizeof(int32_t) * 2 * n);
+    for (int k = 0; k < 2; k++) {
+        free(S->b[k]);
+        S->b[k] = (uint8_t *)malloc(n + 1);
+    }
     S->cap = n;
 }
 
 static void scratch_free(scratch *S) {
     for (int k = 0; k < 16; k++) free(S->d[k]);
     free(S->tb);
+    free(S->b[0]);
+    free(S->b[1]);
     memset(S, 0, sizeof *S);
 }
 
@@ -407,7 +418,7 @@ static void backward_posterior2(const oracle_params *P, const oracle_hmm *h, con
 
 static void score_protein_s(const oracle_params *P, const uint8_t *aa, int n, oracle_row *row, oracle_tracks *tr,
                             scratch *S) {
-    scratch_reserve(S, (size_t)n);
+    if ((size_t)n > S->cap) scratch_reserve(S, (size_t)n + (size_t)n / 4 + 64);
     double *m = S->d[0], *s0 = S->d[1], *s1 = S->d[2], *a0 = S->d[3], *a1 = S->d[4];
     double *hydro = S->d[5], *charge = S->d[6], *fi = S->d[7], *pllr = S->d[8], *papa = S->d[9];
     double *fix2 = S->d[10], *pllrx2 = S->d[11], *papax2 = S->d[12];
@@ -419,20 +430,20 @@ static void score_protein_s(const oracle_params *P, const uint8_t *aa, int n, or
     /* W1: MW, plaac.java:767-771 (qnmask: 1.0 for N=12 and Q=14) */
     for (int i = 0; i < n; i++) m[i] = (aa[i] == 12 || aa[i] == 14) ? 1.0 : 0.0;
     int mw = n < 80 ? n : 80;
-    oracle_hss2(m, n, mw, mw, hs);
+    hss2_buf(m, n, mw, mw, hs, S->d[15]);
     row->mw_score = (int32_t)hs[2]; /* (int) inf2nan(.) :901; never infinite since mw<=n */
     row->mw_start = (int32_t)hs[0];
     row->mw_end = (int32_t)hs[1];
 
     /* W2: LLR window, :782-783 */
     for (int i = 0; i < n; i++) m[i] = P->llr[aa[i]];
-    oracle_hss2(m, n, c, c, hs);
+    hss2_buf(m, n, c, c, hs, S->d[15]);
     row->llr_score = hs[2];
     row->llr_start = (int32_t)hs[0];
     row->llr_end = (int32_t)hs[1];
 
     /* H1, H2, H4, H5: :794-798 */
-    uint8_t *vit = (uint8_t *)malloc((size_t)n);
+    uint8_t *vit = S->b[0];
     double lvit1 = viterbi2(&P->hmm1, aa, n, s0, s1, S->tb, vit);
     double lmarg1 = forward2(P, &P->hmm1, aa, n, a0, a1);
     if (tr) {
@@ -441,10 +452,9 @@ static void score_protein_s(const oracle_params *P, const uint8_t *aa, int n, or
         memcpy(tr->vit, vit, (size_t)n);
     }
     /* hmm0 through the same general code (it degenerates to a running sum) */
-    uint8_t *vit0 = (uint8_t *)malloc((size_t)n);
+    uint8_t *vit0 = S->b[1];
     double lvit0 = viterbi2(&P->hmm0, aa, n, s0, s1, S->tb, vit0);
     double lmarg0 = forward2(P, &P->hmm0, aa, n, a0, a1);
-    free(vit0);
     row->hmm_all = lmarg1 - lmarg0;
     row->hmm_vit = lvit1 - lvit0;
 
@@ -460,7 +470,7 @@ static void score_protein_s(const oracle_params *P, const uint8_t *aa, int n, or
     row->vit_maxrun = maxrun;
     const double big_neg = -1000000.0;
     for (int i = 0; i < n; i++) m[i] = vit[i] == 0 ? big_neg : P->llr[aa[i]];
-    oracle_hss2(m, n, c, c, hs);
+    hss2_buf(m, n, c, c, hs, S->d[15]);
     int corestart = (int)hs[0], corestop = (int)hs[1];
     int aastart = corestart, aastop = corestop;
     double prdscore = 0;
@@ -483,7 +493,6 @@ static void score_protein_s(const oracle_params *P, const uint8_t *aa, int n, or
     row->prd_score = prdscore;
     row->prd_start = aastart;
     row->prd_end = aastop;
-    free(vit);
 
     /* D1/D2: disorderreport :4877-4887; mean :1584-1588 */
     double sm = 0;
