@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' + --one-device lets two ranks share one GPU for a plumbing check")
     ap.add_argument("--one-device", action="store_true", help="TEST ONLY: every rank uses cuda:0")
+    ap.add_argument("--calibrate", action="store_true", help="after the timed region run the histogram kernel once "
+                    "(it reads exactly R bytes): calibration of FETCH_SIZE for tools/pmc.sh")
     args = ap.parse_args()
 
     import torch
@@ -109,6 +111,10 @@ def main():
     else:
         job_res, job_prot = total, nprot
 
+    if args.calibrate:
+        cnt = torch.zeros(22, dtype=torch.int64, device=dev)
+        ctx.histogram_device(codes.data_ptr(), offsets.data_ptr(), nprot, cnt.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
     if rank != 0:
         ctx.close()
         if world > 1:

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/pmc.sh: per-kernel mean counters, durations, HBM traffic.
+
+FETCH_SIZE / WRITE_SIZE are in KB. MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the
+bytes of a wide coalesced streaming read and other access widths are uncalibrated, so the summary carries
+ (a) the raw figure, (b) the guide's x2-corrected figure (used as `traffic`), and (c) a calibration on this
+repo's own narrow-read pattern: k_hist reads every residue byte exactly twice (validity pass + count pass),
+so its expected fetch is known."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KEYS = ("k_tracks20", "k_tracks<", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
+        "k_plan_scatter")
+
+
+def kernel_key(name):
+    for k in KEYS:
+        if k in name:
+            return k.rstrip("<")
+    return None
+
+
+def main(root):
+    counters = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = kernel_key(r["Kernel_Name"])
+            if k:
+                counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    durations = {}
+    for mode in ("trace_concurrent", "trace_serial"):
+        d = collections.defaultdict(list)
+        for f in glob.glob(os.path.join(root, mode, "*", "*_kernel_trace.csv")):
+            for r in csv.DictReader(open(f)):
+                k = kernel_key(r["Kernel_Name"])
+                if k:
+                    d[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        durations[mode] = {k: {"calls": len(v), "mean_ms": sum(v) / len(v), "min_ms": min(v), "max_ms": max(v)}
+                           for k, v in d.items()}
+    bench = {}
+    for mode in ("trace_concurrent", "trace_serial"):
+        try:
+            bench[mode] = json.loads(open(os.path.join(root, mode + ".json")).read().strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001
+            bench[mode] = {"error": str(e)}
+    mean = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in counters.items()}
+    summary = {"counters_mean_per_launch": mean, "kernel_durations": durations, "bench_lines": bench}
+    cfg = bench.get("trace_serial", {}).get("config", {})
+    R, P = cfg.get("residues_per_gpu"), cfg.get("sequences_per_gpu")
+    traffic = {}
+    for k, c in mean.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            traffic[k] = {"fetch_raw_bytes": c["FETCH_SIZE"] * 1024, "write_bytes": c["WRITE_SIZE"] * 1024,
+                          "hbm_bytes_gfx950_corrected": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024}
+    summary["traffic"] = traffic
+    if R and "k_hist" in traffic:
+        expect = 2 * R + 8 * P
+        summary["fetch_calibration_k_hist"] = {
+            "expected_read_bytes": expect, "fetch_raw_bytes": traffic["k_hist"]["fetch_raw_bytes"],
+            "raw_over_expected": traffic["k_hist"]["fetch_raw_bytes"] / expect}
+    json.dump(summary, open(os.path.join(root, "summary.json"), "w"), indent=1, sort_keys=True)
+    if R:
+        mode = cfg.get("mode") == "tracks"
+        wl = {"cfg2": 2, "cfg3": 3, "cfg4": 4}.get(cfg.get("workload", "")[:4], 4)
+        json.dump({"workload": [wl, P, mode], "source": "tools/pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                   "passes); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md gfx950 correction",
+                   "bytes_per_launch": {k: round(v["hbm_bytes_gfx950_corrected"]) for k, v in traffic.items()}},
+                  open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    for k in sorted(mean):
+        t = traffic.get(k, {})
+        ser = durations.get("trace_serial", {}).get(k, {})
+        print("%-16s serial %.3f ms  fetch_raw %.1f MB  write %.1f MB" % (
+            k, ser.get("mean_ms", float("nan")), t.get("fetch_raw_bytes", 0) / 1e6, t.get("write_bytes", 0) / 1e6))
+    if "fetch_calibration_k_hist" in summary:
+        print("calibration k_hist:", summary["fetch_calibration_k_hist"])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc")
