@@ -155,9 +155,10 @@ plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *o
 
 /* Same, on buffers already resident in device memory (all pointers are device pointers, including
  * the ones inside *tracks; the tracks struct itself lives on the host). `stream` is a hipStream_t
- * (NULL = the ctx's own stream). Asynchronous: returns after enqueueing; all work is ordered after
- * earlier work on `stream` and before later work on it (internal side streams are forked and joined
- * with events). Synchronise the stream (or call plaac_ctx_sync when stream == NULL) before reading rows.
+ * (NULL = the ctx's own stream). All work is ordered after earlier work on `stream` and before later work on
+ * it (internal side streams are forked and joined with events). The call waits once for its own planning
+ * kernels (it needs one number back to size the work buffers) and then returns after enqueueing the scoring
+ * kernels: synchronise the stream (or call plaac_ctx_sync when stream == NULL) before reading rows.
  * d_codes must be 16-byte aligned and readable up to the next 16-byte boundary after total_residues
  * (true of any hipMalloc / torch allocation). Work buffers are grown on demand and reused. */
 plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,

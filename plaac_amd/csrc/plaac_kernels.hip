@@ -178,6 +178,117 @@ __device__ __forceinline__ uint4 load16(const uint8_t *p, const uint8_t *lo, con
     }
     return load16_edge(p, lo, end);
 }
+// ---- group-interleaved copy of the residues for the lane-per-protein kernels ------------------------------
+// Wave-group g = the 64 proteins order[64g .. 64g+63] (similar lengths after the sort). Its residues are
+// re-packed as rows of 64 x 16 bytes: row j holds residues 16j..16j+15 of every lane, lane-major, so a wave's
+// block load is ONE fully coalesced 1 KiB read (instead of 64 scattered 16-byte reads that each drag a
+// whole sector through L2, measured 8-20x over-fetch), and every residue crosses HBM once per sweep.
+// The traceback / Viterbi-path bit words use the same row numbering (one 32-bit word per lane per row).
+// rows[g] = ceil(longest length in group / 16); grow[] = exclusive prefix sum (grow[ngroups] = total rows).
+__global__ void k_group_rows(const uint32_t *__restrict__ neff, const uint32_t *__restrict__ order, uint32_t nprot,
+                             uint32_t ngroups, uint32_t *__restrict__ grow) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint32_t n0 = neff[order[64u * g]]; // descending order: lane 0 is the longest
+    grow[g] = (n0 + 15u) >> 4;
+    (void)nprot;
+}
+
+// single block: in-place exclusive scan of a[0..n), total written to a[n]
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uint32_t n) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t b = tid * per, e = b + per < n ? b + per : n;
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += a[i];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (uint32_t i = b; i < e; ++i) {
+        const uint32_t c = a[i];
+        a[i] = run;
+        run += c;
+    }
+    if (tid == 1023u) a[n] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets,
+                                              const uint32_t *__restrict__ neff, const uint32_t *__restrict__ order,
+                                              uint32_t nprot, uint64_t total, const uint32_t *__restrict__ grow,
+                                              uint4 *__restrict__ packed) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= nprot) return;
+    const uint32_t p = order[gid];
+    const uint32_t n = neff[p];
+    const uint8_t *x = codes + offsets[p];
+    const uint8_t *cend = codes + total;
+    uint4 *__restrict__ col = packed + (size_t)grow[gid >> 6] * 64u + (gid & 63u);
+    const uint32_t nj = (n + 15u) >> 4;
+    uint32_t j = 0;
+    for (; j + 4u <= nj; j += 4u) { // four independent 16-byte loads in flight per lane
+        const uint4 v0 = load16(x + 16u * j, codes, cend), v1 = load16(x + 16u * j + 16u, codes, cend),
+                    v2 = load16(x + 16u * j + 32u, codes, cend), v3 = load16(x + 16u * j + 48u, codes, cend);
+        col[(size_t)j * 64u] = v0;
+        col[(size_t)(j + 1u) * 64u] = v1;
+        col[(size_t)(j + 2u) * 64u] = v2;
+        col[(size_t)(j + 3u) * 64u] = v3;
+    }
+    for (; j < nj; ++j) col[(size_t)j * 64u] = load16(x + 16u * j, codes, cend);
+}
+
+// one lane's view of its group's packed rows
+struct PackedLane {
+    const uint4 *__restrict__ pk; // residues: row j at pk[64*j]
+    uint32_t *__restrict__ wb;    // bit words: row j at wb[64*j]
+    __device__ __forceinline__ uint4 chunk(uint32_t j) const { return pk[(size_t)j * 64u]; }
+    __device__ __forceinline__ uint32_t word(uint32_t j) const { return wb[(size_t)j * 64u]; }
+    __device__ __forceinline__ void set_word(uint32_t j, uint32_t v) const { wb[(size_t)j * 64u] = v; }
+    // the 16 residues at positions s .. s+15 (any alignment, s >= -15; positions < 0 read as 0). The byte
+    // shift s & 15 is wave-uniform and loop-invariant for the trailing streams (s = t0 - c).
+    __device__ __forceinline__ uint4 window(int s) const {
+        const int js = s >> 4;
+        const uint32_t sh = (uint32_t)s & 15u;
+        const uint4 lo = js >= 0 ? pk[(size_t)js * 64u] : make_uint4(0u, 0u, 0u, 0u);
+        if (sh == 0u) return lo;
+        const uint4 hi = pk[(size_t)(js + 1) * 64u];
+        const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const uint32_t bs = sh & 3u;
+        uint32_t o[4];
+        switch (sh >> 2) { // wave-uniform
+        case 0:
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], bs);
+            break;
+        case 1:
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __builtin_amdgcn_alignbyte(d[k + 2], d[k + 1], bs);
+            break;
+        case 2:
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __builtin_amdgcn_alignbyte(d[k + 3], d[k + 2], bs);
+            break;
+        default:
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __builtin_amdgcn_alignbyte(d[k + 4], d[k + 3], bs);
+            break;
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    }
+};
+
+__device__ __forceinline__ PackedLane packed_lane(const uint4 *packed, uint32_t *bits, const uint32_t *grow) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const size_t base = (size_t)grow[gid >> 6] * 64u + (gid & 63u);
+    return PackedLane{packed + base, bits + base};
+}
+
 // residue j (compile-time after unrolling) of a 16-residue block
 __device__ __forceinline__ uint32_t block_code(const uint4 &c, int j) {
     const uint32_t w = j < 4 ? c.x : j < 8 ? c.y : j < 12 ? c.z : c.w;
@@ -302,9 +413,10 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
                                                     const uint32_t *__restrict__ order, uint32_t nprot,
-                                                    uint64_t total, const DevTables *__restrict__ T,
-                                                    uint32_t *__restrict__ bits, plaac_row *__restrict__ rows,
-                                                    TrackPtrs tr) {
+                                                    const DevTables *__restrict__ T,
+                                                    const uint4 *__restrict__ packed,
+                                                    const uint32_t *__restrict__ grow, uint32_t *__restrict__ bits,
+                                                    plaac_row *__restrict__ rows, TrackPtrs tr) {
     __shared__ double s_row[ROWS * R_W];
     load_rows(s_row, T);
     __syncthreads();
@@ -319,9 +431,9 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
         return;
     }
     const uint8_t *__restrict__ x = codes + J.off;
-    const uint8_t *cend = codes + total;
-    // private bit scratch: 2 bits/residue of traceback, later 1 bit/residue of Viterbi path
-    uint32_t *__restrict__ wbits = bits + (J.off >> 4) + J.p;
+    // packed residues of this lane + its column of bit words (2 bits/residue of traceback, overwritten in
+    // place by 1 bit/residue of Viterbi path)
+    const PackedLane PL = packed_lane(packed, bits, grow);
     const uint32_t nw = (n + 15u) >> 4;
 
     const double lt00 = T->lt[0][0], lt01 = T->lt[0][1], lt10 = T->lt[1][0], lt11 = T->lt[1][1];
@@ -332,7 +444,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     // ---------------- sweep 1: t = 0 .. n-1 ----------------
     VitState V;
     {
-        uint4 nxt = load16(x, codes, cend);
+        uint4 nxt = PL.chunk(0);
         {
             const double *__restrict__ r = s_row + block_code(nxt, 0) * R_W;
             V.s0 = T->li[0] + r[R_LE0];
@@ -341,12 +453,12 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
         }
         for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
             const uint4 cur = nxt;
-            if (t0 + 16u < n) nxt = load16(x + t0 + 16u, codes, cend);
+            if (t0 + 16u < n) nxt = PL.chunk((t0 >> 4) + 1u);
             uint32_t tbw;
             if (t0 == 0u) tbw = vit_block<true>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 1);
             else if (t0 + 16u <= n) tbw = vit_block<false>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0);
             else tbw = vit_block<true>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0);
-            wbits[t0 >> 4] = tbw;
+            PL.set_word(t0 >> 4, tbw);
         }
     }
     // end of Viterbi (:3102-3109)
@@ -357,15 +469,15 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     // ---------------- sweep 2: traceback t = n-1 .. 0 (:3111-3113), longest run ----------------
     {
         int cur = 0, maxrun = 0;
-        uint32_t wnext = wbits[nw - 1u]; // traceback words are prefetched one block ahead
+        uint32_t wnext = PL.word(nw - 1u); // traceback words are prefetched one block ahead
         uint8_t *vit_out = TRACKS ? tr.vit + J.off : nullptr;
         for (uint32_t wi = nw; wi-- > 0u;) {
             const uint32_t word = wnext;
-            if (wi > 0u) wnext = wbits[wi - 1u];
+            if (wi > 0u) wnext = PL.word(wi - 1u);
             const uint32_t t0 = wi << 4;
             const uint32_t vw = (t0 + 16u <= n) ? traceback_block<false, TRACKS>(state, cur, maxrun, word, t0, n, vit_out)
                                                 : traceback_block<true, TRACKS>(state, cur, maxrun, word, t0, n, vit_out);
-            wbits[wi] = vw; // this word now holds vit[16*wi .. 16*wi+15]
+            PL.set_word(wi, vw); // this word now holds vit[16*wi .. 16*wi+15]
         }
         row->vit_maxrun = maxrun;
     }
@@ -376,13 +488,13 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     {
         // lead stream: residues + path bits of block t0; trailing stream: the same, c steps later, i.e. the
         // 16 positions s .. s+15 with s = t0 - c. Both are fetched one block ahead.
-        uint4 nxt = load16(x, codes, cend), tnxt = make_uint4(0u, 0u, 0u, 0u);
-        uint32_t wlnext = wbits[0], plo = 0u, phi = 0u;
+        uint4 nxt = PL.chunk(0), tnxt = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t wlnext = PL.word(0), plo = 0u, phi = 0u;
         auto prefetch_trail = [&](int s) { // block starting at position s (>= -15) of this protein
-            tnxt = load16(x + s, codes, cend);
+            tnxt = PL.window(s);
             const uint32_t w0 = s >= 0 ? (uint32_t)s >> 4 : 0u;
-            plo = wbits[w0];
-            phi = (s >= 0 && w0 + 1u < nw) ? wbits[w0 + 1u] : 0u;
+            plo = PL.word(w0);
+            phi = (s >= 0 && w0 + 1u < nw) ? PL.word(w0 + 1u) : 0u;
         };
         if (15 >= (int)c) prefetch_trail(-(int)c);
         for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
@@ -391,8 +503,8 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
             const int s = (int)t0 - (int)c;
             const uint32_t tv = s >= 0 ? ((plo | (phi << 16)) >> (s & 15)) : (s > -16 ? (plo << (-s)) : 0u);
             if (t0 + 16u < n) {
-                nxt = load16(x + t0 + 16u, codes, cend);
-                wlnext = wbits[(t0 >> 4) + 1u];
+                nxt = PL.chunk((t0 >> 4) + 1u);
+                wlnext = PL.word((t0 >> 4) + 1u);
                 if (s + 31 >= 0) prefetch_trail(s + 16);
             }
             const bool full = t0 + 16u <= n;
@@ -405,7 +517,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
         }
     }
     if (C.best > big_neg / 2) { // :861 — a core exists; expand it to the whole Viterbi run (:863-866)
-        auto bit = [&](int q) { return (wbits[(uint32_t)q >> 4] >> (q & 15)) & 1u; };
+        auto bit = [&](int q) { return (PL.word((uint32_t)q >> 4) >> (q & 15)) & 1u; };
         int a = C.bstart, z = C.bstart + (int)c - 1;
         while (a > 0 && bit(a - 1)) --a;
         while (z + 1 < (int)n && bit(z + 1)) ++z;
@@ -463,9 +575,10 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
                                                     const uint32_t *__restrict__ order, uint32_t nprot,
-                                                    uint64_t total, const DevTables *__restrict__ T,
-                                                    plaac_row *__restrict__ rows, TrackPtrs tr,
-                                                    double *__restrict__ fwd) {
+                                                    const DevTables *__restrict__ T,
+                                                    const uint4 *__restrict__ packed,
+                                                    const uint32_t *__restrict__ grow, plaac_row *__restrict__ rows,
+                                                    TrackPtrs tr, double *__restrict__ fwd) {
     __shared__ double s_lut[LUTLEN + 1];
     __shared__ double s_row[ROWS * R_W];
     for (int i = threadIdx.x; i < LUTLEN; i += KA_THREADS) s_lut[i] = T->loglut[i];
@@ -482,7 +595,8 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
         return;
     }
     const uint8_t *__restrict__ x = codes + J.off;
-    const uint8_t *cend = codes + total;
+    (void)x;
+    const PackedLane PL = packed_lane(packed, nullptr, grow);
     const double lt00 = T->lt[0][0], lt01 = T->lt[0][1], lt10 = T->lt[1][0], lt11 = T->lt[1][1];
     const double lf0 = T->lf[0], lf1 = T->lf[1];
     const double h0lt = T->h0_lt00;
@@ -490,7 +604,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
 
     FwdState F;
     {
-        uint4 nxt = load16(x, codes, cend);
+        uint4 nxt = PL.chunk(0);
         {
             const double *__restrict__ r = s_row + block_code(nxt, 0) * R_W;
             F.a0 = T->li[0] + r[R_LE0];
@@ -503,7 +617,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
         }
         for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
             const uint4 cur = nxt;
-            if (t0 + 16u < n) nxt = load16(x + t0 + 16u, codes, cend);
+            if (t0 + 16u < n) nxt = PL.chunk((t0 >> 4) + 1u);
             if (t0 == 0u) fwd_block<true, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 1, fwd_out);
             else if (t0 + 16u <= n)
                 fwd_block<false, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0, fwd_out);
@@ -594,8 +708,9 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
                                                     const uint32_t *__restrict__ order, uint32_t nprot,
-                                                    uint64_t total, const DevTables *__restrict__ T,
-                                                    plaac_row *__restrict__ rows) {
+                                                    const DevTables *__restrict__ T,
+                                                    const uint4 *__restrict__ packed,
+                                                    const uint32_t *__restrict__ grow, plaac_row *__restrict__ rows) {
     __shared__ double s_row[ROWS * R_W];
     load_rows(s_row, T);
     __syncthreads();
@@ -610,23 +725,22 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
         row->prot_len = 0;
         return;
     }
-    const uint8_t *__restrict__ x = codes + J.off;
-    const uint8_t *cend = codes + total;
+    const PackedLane PL = packed_lane(packed, nullptr, grow);
     const uint32_t c = (uint32_t)T->corelength;
     const uint32_t mw = n < 80u ? n : 80u; // :769-770 (a protein shorter than 80 has a single window)
     const uint32_t steady_from = c > 80u ? c : 80u;
 
     WinState W{0.0, 0.0, 0.0, -INFINITY, 0, 0, 0, 0, 0, -1};
     // three phase-locked streams: residues at t, at t - c (LLR window) and at t - 80 (MW window)
-    uint4 nxt = load16(x, codes, cend), cnxt = make_uint4(0u, 0u, 0u, 0u), mnxt = cnxt;
-    if (15 >= (int)c) cnxt = load16(x - (int)c, codes, cend);
+    uint4 nxt = PL.chunk(0), cnxt = make_uint4(0u, 0u, 0u, 0u), mnxt = cnxt;
+    if (15 >= (int)c) cnxt = PL.window(-(int)c);
     for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
         const uint4 cur = nxt, ccur = cnxt, mcur = mnxt;
         if (t0 + 16u < n) {
-            nxt = load16(x + t0 + 16u, codes, cend);
+            nxt = PL.chunk((t0 >> 4) + 1u);
             const int sc = (int)t0 + 16 - (int)c, sm = (int)t0 + 16 - 80;
-            if (sc + 15 >= 0) cnxt = load16(x + sc, codes, cend);
-            if (sm + 15 >= 0) mnxt = load16(x + sm, codes, cend);
+            if (sc + 15 >= 0) cnxt = PL.window(sc);
+            if (sm + 15 >= 0) mnxt = PL.window(sm);
         }
         const bool full = t0 + 16u <= n;
         if (t0 >= steady_from) { // wave-uniform
@@ -1355,9 +1469,11 @@ struct plaac_ctx {
     DevTables *d_tab = nullptr;
     plaac_params params;
     // plan / scratch buffers (grown on demand)
-    uint32_t *d_neff = nullptr, *d_order = nullptr, *d_hist = nullptr, *d_bits = nullptr;
+    uint32_t *d_neff = nullptr, *d_order = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
+    uint4 *d_packed = nullptr;
     double *d_fwd = nullptr;
-    size_t cap_prot = 0, cap_bits = 0, cap_fwd = 0;
+    uint32_t *h_pin = nullptr; // pinned word for the one device->host readback of a call (total packed rows)
+    size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_grow = 0, cap_packed = 0;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
     uint64_t *d_offsets = nullptr;
@@ -1525,6 +1641,8 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         return bail("hipMalloc(hist)", e);
     if ((e = hipMalloc((void **)&ctx->d_counts, sizeof(unsigned long long) * NAA)) != hipSuccess)
         return bail("hipMalloc(counts)", e);
+    if ((e = hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc", e);
     plaac_status st = plaac_ctx_set_params(ctx, params);
     if (st != PLAAC_OK) {
         g_create_err = ctx->err;
@@ -1559,7 +1677,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->d_tab,  ctx->d_neff,    ctx->d_order, ctx->d_hist, ctx->d_bits,  ctx->d_fwd,   ctx->d_codes,
-                    ctx->d_offsets, ctx->d_rows, ctx->d_trk8,  ctx->d_trk64, ctx->d_counts};
+                    ctx->d_offsets, ctx->d_rows, ctx->d_trk8,  ctx->d_trk64, ctx->d_counts, ctx->d_grow, ctx->d_packed};
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &set : ctx->ev)
@@ -1603,15 +1722,9 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
 
     plaac_status rc;
     if ((rc = grow(ctx, ctx->d_neff, ctx->cap_prot, (size_t)nprot)) != PLAAC_OK) return rc;
-    {
-        size_t dummy = ctx->d_order ? ctx->cap_prot : 0;
-        if (!ctx->d_order || dummy < nprot) {
-            if (ctx->d_order) PL_HIP(ctx, hipFree(ctx->d_order));
-            ctx->d_order = nullptr;
-            PL_HIP(ctx, hipMalloc((void **)&ctx->d_order, ctx->cap_prot * sizeof(uint32_t)));
-        }
-    }
-    if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, (size_t)(total_residues / 16 + nprot + 2))) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, ctx->d_order, ctx->cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
+    const uint32_t ngroups = (nprot + 63u) / 64u;
+    if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 1)) != PLAAC_OK) return rc;
     if (d_tracks)
         if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, (size_t)(2 * total_residues + 2))) != PLAAC_OK) return rc;
 
@@ -1625,6 +1738,17 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     hipLaunchKernelGGL(k_plan_lengths, dim3(pb), dim3(256), 0, st, d_codes, d_offsets, nprot, ctx->d_neff, ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scatter, dim3(pb), dim3(256), 0, st, ctx->d_neff, nprot, ctx->d_hist, ctx->d_order);
+    // group rows of the interleaved copy; their total is the one value the host needs back (buffer sizes)
+    hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, st, ctx->d_neff, ctx->d_order, nprot,
+                       ngroups, ctx->d_grow);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, ctx->d_grow, ngroups);
+    PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_grow + ngroups, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PL_HIP(ctx, hipStreamSynchronize(st));
+    const size_t total_rows = ctx->h_pin[0];
+    if ((rc = grow(ctx, ctx->d_packed, ctx->cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
+    hipLaunchKernelGGL(k_pack, dim3((nprot + 255u) / 256u), dim3(256), 0, st, d_codes, d_offsets, ctx->d_neff,
+                       ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PLAN], st));
     // The three K-A roles and K-B are independent given the plan: fork them onto side streams so the long
     // serial chains (which set the wall time) overlap each other and the throughput-bound window kernel.
@@ -1636,22 +1760,23 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
     if (d_tracks)
         hipLaunchKernelGGL(k_vit<true>, dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, total_residues, ctx->d_tab, ctx->d_bits, d_rows, tp);
+                           ctx->d_order, nprot, ctx->d_tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, d_rows, tp);
     else
         hipLaunchKernelGGL(k_vit<false>, dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, total_residues, ctx->d_tab, ctx->d_bits, d_rows, tp);
+                           ctx->d_order, nprot, ctx->d_tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, d_rows, tp);
     PL_HIP(ctx, hipEventRecord(evs[E_VIT + 1], sv));
     PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
     if (d_tracks)
         hipLaunchKernelGGL(k_fwd<true>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp, ctx->d_fwd);
+                           ctx->d_order, nprot, ctx->d_tab, ctx->d_packed, ctx->d_grow, d_rows, tp, ctx->d_fwd);
     else
         hipLaunchKernelGGL(k_fwd<false>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp, (double *)nullptr);
+                           ctx->d_order, nprot, ctx->d_tab, ctx->d_packed, ctx->d_grow, d_rows, tp,
+                           (double *)nullptr);
     PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
     PL_HIP(ctx, hipEventRecord(evs[E_WIN], sw));
     hipLaunchKernelGGL(k_win, dim3(ab), dim3(KA_THREADS), 0, sw, d_codes, d_offsets, ctx->d_neff, ctx->d_order, nprot,
-                       total_residues, ctx->d_tab, d_rows);
+                       ctx->d_tab, ctx->d_packed, ctx->d_grow, d_rows);
     PL_HIP(ctx, hipEventRecord(evs[E_WIN + 1], sw));
     PL_HIP(ctx, hipEventRecord(evs[E_TRK], st));
 #define LAUNCH_KB(RING)                                                                                            \

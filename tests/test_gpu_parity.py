@@ -239,3 +239,13 @@ def test_full_size_config2_properties(native, ctx):
     assert np.all(np.abs(s - 1.0) < 1e-3)
     assert np.all(rows["mw_score"] <= np.minimum(n, 80))
     assert np.all((rows["fi_maxrun"] <= n) & (rows["fi_numaa"] <= n))
+
+
+def test_context_reuse_with_growing_and_shrinking_batches(native, oracle, ctx):
+    """work buffers are grown on demand and reused: small -> large -> small -> larger must all stay exact"""
+    from plaac_amd import synth
+    Pn, Po = both_params(native, oracle)
+    ctx.set_params(Pn)
+    for nprot, seed in ((7, 1), (3000, 2), (65, 3), (9000, 4), (1, 5), (640, 6)):
+        codes, offs = synth.make_batch(4, nprot=nprot, seed=seed)
+        assert_rows_equal(ctx.score(codes, offs), oracle.score_batch(Po, codes, offs, nthreads=8), "n=%d" % nprot)
