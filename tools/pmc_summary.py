@@ -14,7 +14,7 @@ import os
 import sys
 
 KEYS = ("k_tracks20", "k_tracks<", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
-        "k_plan_scatter")
+        "k_plan_scatter", "k_pack", "k_group_rows", "k_scan_u32")
 
 
 def kernel_key(name):
