@@ -27,6 +27,24 @@ FP64_VALU_PEAK_GOPS = 39300.0  # 78.6 TFLOP/s vector fp64 counts FMA as 2; this 
 ALGO_OPS_PER_RESIDUE = 470     # non-fusable fp64 ops per residue (summary mode)
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,8 +186,7 @@ def main():
     if not args.no_cpu_baseline:
         from oracle import oracle_ctypes as oc
         Po = oc.build_params()
-        ncores = os.cpu_count() or 1
-        nthreads = min(ncores, 256)
+        nthreads = usable_cores()
         n_s = min(nprot, 250000)
         off_h = offsets[:n_s + 1].cpu().numpy().astype(np.uint64)
         codes_h = codes[:int(off_h[-1])].cpu().numpy()
@@ -205,7 +222,8 @@ def main():
             "mode": "tracks" if args.tracks else "summary", "sequences_per_gpu": nprot,
             "residues_per_gpu": total, "sequences_total": job_prot, "residues_total": job_res,
             "params": "c=60 ww=41 alpha=1.0 fg=prd_freq_scer_28", "sharding": "by sequence, %d rank(s)" % world,
-            "exchange": "RCCL gather of 160 B rows to rank 0" if world > 1 else "none (1 GPU)",
+            "exchange": ("%s gather of 160 B rows to rank 0" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
+            if world > 1 else "none (1 GPU)",
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
