@@ -1483,7 +1483,7 @@ struct plaac_ctx {
     unsigned long long *d_counts = nullptr;
     size_t cap_codes = 0, cap_offs = 0, cap_rows = 0, cap_trk = 0;
     static constexpr int EV_SETS = 32; // timings of the last 32 scored batches
-    static constexpr int EV_PER = 11;  // start, planned, {begin,end} x {vit,fwd,win,tracks}, joined
+    static constexpr int EV_PER = 13;  // start, planned, {begin,end} x {vit,fwd,win,tracks}, joined, {begin,end} pack
     hipEvent_t ev[EV_SETS][EV_PER] = {};
     uint64_t ncalls = 0;
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // high-priority side streams of the three K-A roles
@@ -1731,31 +1731,67 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     const int wmax = std::max(ctx->params.ww1 / 2, std::max(ctx->params.ww2 / 2, ctx->params.ww3 / 2));
 
     hipEvent_t *evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
-    enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10 };
+    enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10, E_PACK = 11 };
+    hipStream_t sv = ctx->serial ? st : ctx->aux[0], sf = ctx->serial ? st : ctx->aux[1],
+                sw = ctx->serial ? st : ctx->aux[2];
+    const bool fast20 = ctx->params.ww1 / 2 == TW && ctx->params.ww2 / 2 == TW && ctx->params.ww3 / 2 == TW &&
+                        !ctx->generic_tracks;
+    auto launch_tracks = [&]() -> plaac_status { // K-B: needs only the order, not the packed copy
+        PL_HIP(ctx, hipEventRecord(evs[E_TRK], st));
+#define LAUNCH_KB(RING)                                                                                            \
+    do {                                                                                                           \
+        if (d_tracks)                                                                                              \
+            hipLaunchKernelGGL((k_tracks<RING, true>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,           \
+                               ctx->d_neff, ctx->d_order, nprot, ctx->d_tab, d_rows, tp);                          \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,          \
+                               ctx->d_neff, ctx->d_order, nprot, ctx->d_tab, d_rows, tp);                          \
+    } while (0)
+        if (fast20) {
+            const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
+            if (d_tracks)
+                hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
+                                   ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
+            else
+                hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
+                                   ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
+        } else if (wmax <= 32) LAUNCH_KB(128);
+        else if (wmax <= 96) LAUNCH_KB(256);
+        else LAUNCH_KB(1024);
+#undef LAUNCH_KB
+        PL_HIP(ctx, hipEventRecord(evs[E_TRK + 1], st));
+        return PLAAC_OK;
+    };
+
     PL_HIP(ctx, hipEventRecord(evs[E_START], st));
     PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * LEN_BINS, st));
     const unsigned pb = (nprot + 255u) / 256u;
     hipLaunchKernelGGL(k_plan_lengths, dim3(pb), dim3(256), 0, st, d_codes, d_offsets, nprot, ctx->d_neff, ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scatter, dim3(pb), dim3(256), 0, st, ctx->d_neff, nprot, ctx->d_hist, ctx->d_order);
+    PL_HIP(ctx, hipEventRecord(evs[E_PLAN], st));
+    // The three K-A roles and K-B are independent given the plan: fork the K-A side onto high-priority streams
+    // so the long serial chains (which set the wall time) overlap each other and the throughput-bound window
+    // kernel. K-B starts right away on the caller's stream; the packing of the K-A input runs beside it.
+    if (!ctx->serial) {
+        if ((rc = launch_tracks()) != PLAAC_OK) return rc;
+        PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PLAN], 0));
+    }
     // group rows of the interleaved copy; their total is the one value the host needs back (buffer sizes)
-    hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, st, ctx->d_neff, ctx->d_order, nprot,
+    PL_HIP(ctx, hipEventRecord(evs[E_PACK], sv));
+    hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, sv, ctx->d_neff, ctx->d_order, nprot,
                        ngroups, ctx->d_grow);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, ctx->d_grow, ngroups);
-    PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_grow + ngroups, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    PL_HIP(ctx, hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, sv, ctx->d_grow, ngroups);
+    PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_grow + ngroups, sizeof(uint32_t), hipMemcpyDeviceToHost, sv));
+    PL_HIP(ctx, hipStreamSynchronize(sv));
     const size_t total_rows = ctx->h_pin[0];
     if ((rc = grow(ctx, ctx->d_packed, ctx->cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
     if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
-    hipLaunchKernelGGL(k_pack, dim3((nprot + 255u) / 256u), dim3(256), 0, st, d_codes, d_offsets, ctx->d_neff,
+    hipLaunchKernelGGL(k_pack, dim3((nprot + 255u) / 256u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
-    PL_HIP(ctx, hipEventRecord(evs[E_PLAN], st));
-    // The three K-A roles and K-B are independent given the plan: fork them onto side streams so the long
-    // serial chains (which set the wall time) overlap each other and the throughput-bound window kernel.
-    hipStream_t sv = ctx->serial ? st : ctx->aux[0], sf = ctx->serial ? st : ctx->aux[1],
-                sw = ctx->serial ? st : ctx->aux[2];
+    PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
     if (!ctx->serial)
-        for (hipStream_t a : {sv, sf, sw}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PLAN], 0));
+        for (hipStream_t a : {sf, sw}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
     const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
     PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
     if (d_tracks)
@@ -1778,33 +1814,11 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     hipLaunchKernelGGL(k_win, dim3(ab), dim3(KA_THREADS), 0, sw, d_codes, d_offsets, ctx->d_neff, ctx->d_order, nprot,
                        ctx->d_tab, ctx->d_packed, ctx->d_grow, d_rows);
     PL_HIP(ctx, hipEventRecord(evs[E_WIN + 1], sw));
-    PL_HIP(ctx, hipEventRecord(evs[E_TRK], st));
-#define LAUNCH_KB(RING)                                                                                            \
-    do {                                                                                                           \
-        if (d_tracks)                                                                                              \
-            hipLaunchKernelGGL((k_tracks<RING, true>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,           \
-                               ctx->d_neff, ctx->d_order, nprot, ctx->d_tab, d_rows, tp);                          \
-        else                                                                                                       \
-            hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,          \
-                               ctx->d_neff, ctx->d_order, nprot, ctx->d_tab, d_rows, tp);                          \
-    } while (0)
-    const bool fast20 = ctx->params.ww1 / 2 == TW && ctx->params.ww2 / 2 == TW && ctx->params.ww3 / 2 == TW &&
-                        !ctx->generic_tracks;
-    if (fast20) {
-        const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
-        if (d_tracks)
-            hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
-                               ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
-        else
-            hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
-                               ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
-    } else if (wmax <= 32) LAUNCH_KB(128);
-    else if (wmax <= 96) LAUNCH_KB(256);
-    else LAUNCH_KB(1024);
-#undef LAUNCH_KB
-    PL_HIP(ctx, hipEventRecord(evs[E_TRK + 1], st));
-    if (!ctx->serial)
+    if (ctx->serial) {
+        if ((rc = launch_tracks()) != PLAAC_OK) return rc;
+    } else {
         for (int done : {E_VIT + 1, E_FWD + 1, E_WIN + 1}) PL_HIP(ctx, hipStreamWaitEvent(st, evs[done], 0));
+    }
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->ncalls++;
@@ -1819,11 +1833,11 @@ plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
     if (ncalls > ctx->ncalls) ncalls = (uint32_t)ctx->ncalls;
     PL_HIP(ctx, hipSetDevice(ctx->device));
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    static const int pairs[6][2] = {{0, 10}, {0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}};
+    static const int pairs[7][2] = {{0, 10}, {0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {11, 12}};
     for (uint32_t k = 0; k < ncalls; ++k) {
         hipEvent_t *evs = ctx->ev[(ctx->ncalls - 1 - k) % plaac_ctx::EV_SETS];
         PL_HIP(ctx, hipEventSynchronize(evs[10]));
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 7; ++i) {
             float t = 0.f;
             PL_HIP(ctx, hipEventElapsedTime(&t, evs[pairs[i][0]], evs[pairs[i][1]]));
             acc[i] += t;
