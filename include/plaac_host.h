@@ -39,6 +39,11 @@ typedef struct plaac_fasta {
 plaac_status plaac_fasta_read(const char *path, plaac_fasta **out);
 void plaac_fasta_free(plaac_fasta *f);
 
+/* Worker threads the host helpers use for parsing / formatting: hardware threads, capped by the cgroup CPU
+ * quota, overridable with PLAAC_THREADS. plaac_fasta_read parses records in parallel (they are independent once
+ * the header lines are located). */
+unsigned plaac_host_threads(void);
+
 /* -B / -F parameter files: 22 lines, first token = number (:2684-2713).
  * warn_line (nullable, >= 22 ints): set to 1 where the optional "# name" column disagrees with the alphabet. */
 plaac_status plaac_read_aa_params(const char *path, double vec[PLAAC_NAA], int *warn_line);

@@ -153,6 +153,18 @@ plaac_status plaac_histogram(plaac_ctx *ctx, const uint8_t *codes, const uint64_
 plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
                          plaac_row *rows, const plaac_tracks *tracks);
 
+/* ---- resident batches: upload once, use many times -------------------------------------------------------
+ * The reference makes one full pass over the input for the background counts and a second one for scoring
+ * (plaac.java:377-384 then :755), and a parameter sweep (BASELINE config 5) re-scores the same proteome under
+ * several (alpha, core length) settings. A resident batch keeps the encoded residues in HBM across those calls. */
+typedef struct plaac_batch plaac_batch;
+plaac_status plaac_batch_upload(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                                plaac_batch **out);
+plaac_status plaac_batch_histogram(plaac_batch *b, int64_t counts[PLAAC_NAA]);
+/* scores with the ctx's CURRENT parameters (plaac_ctx_set_params between calls = one sweep point each) */
+plaac_status plaac_batch_score(plaac_batch *b, plaac_row *rows, const plaac_tracks *tracks);
+void plaac_batch_free(plaac_batch *b);
+
 /* Same, on buffers already resident in device memory (all pointers are device pointers, including
  * the ones inside *tracks; the tracks struct itself lives on the host). `stream` is a hipStream_t
  * (NULL = the ctx's own stream). All work is ordered after earlier work on `stream` and before later work on

@@ -9,11 +9,13 @@
 // the -B file by mistake), histogram bins are 64-bit, records with an empty sequence are skipped with
 // a note on stderr instead of crashing, -h (GraphViz export) is not implemented, the -d column notes
 // and the usage text are worded independently. All scoring runs on the GPU; there is no CPU path.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "plaac_host.h"
@@ -29,6 +31,20 @@ struct Options {
 };
 
 void put(const std::string &s) { std::fwrite(s.data(), 1, s.size(), stdout); }
+
+// PLAAC_TIMING=1: wall-clock of the host stages on stderr (never on stdout: the tables stay byte-identical)
+struct StageTimer {
+    bool on = std::getenv("PLAAC_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what, double units = 0, const char *unit = "") {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        const double s = std::chrono::duration<double>(t1 - t0).count();
+        if (units > 0) std::fprintf(stderr, "plaac-timing: %-28s %9.3f ms  %.3g %s/s\n", what, s * 1e3, units / s, unit);
+        else std::fprintf(stderr, "plaac-timing: %-28s %9.3f ms\n", what, s * 1e3);
+        t0 = t1;
+    }
+} g_timer;
 
 void usage() {
     put("------------------------------------------------------------\n"
@@ -102,7 +118,8 @@ bool die(plaac_ctx *ctx, const char *what, plaac_status st) {
 }
 
 // counts of a FASTA on the device (computeaafreq :1655-1666)
-bool count_background(plaac_ctx *ctx, const std::string &path, double out[PLAAC_NAA], plaac_fasta **keep) {
+bool count_background(plaac_ctx *ctx, const std::string &path, double out[PLAAC_NAA], plaac_fasta **keep,
+                      plaac_batch **keep_batch) {
     for (int i = 0; i < PLAAC_NAA; ++i) out[i] = 0.0;
     plaac_fasta *f = nullptr;
     plaac_status st = plaac_fasta_read(path.c_str(), &f);
@@ -111,15 +128,26 @@ bool count_background(plaac_ctx *ctx, const std::string &path, double out[PLAAC_
         return true;
     }
     if (st != PLAAC_OK) return die(nullptr, "reading FASTA", st);
+    g_timer.lap("read+encode FASTA", (double)f->nres, "residues");
     int64_t counts[PLAAC_NAA];
-    st = plaac_histogram(ctx, f->codes, f->offsets, f->nrec, counts);
+    plaac_batch *b = nullptr; // upload once: the scoring pass reuses the resident residues
+    st = plaac_batch_upload(ctx, f->codes, f->offsets, f->nrec, &b);
+    g_timer.lap("upload batch (H2D)", (double)f->nres, "residues");
+    if (st == PLAAC_OK) st = plaac_batch_histogram(b, counts);
+    g_timer.lap("background histogram (GPU)", (double)f->nres, "residues");
     if (st != PLAAC_OK) {
+        plaac_batch_free(b);
         plaac_fasta_free(f);
-        return die(ctx, "plaac_histogram", st);
+        return die(ctx, "plaac_batch_histogram", st);
     }
     for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (double)counts[i];
-    if (keep) *keep = f;
-    else plaac_fasta_free(f);
+    if (keep) {
+        *keep = f;
+        *keep_batch = b;
+    } else {
+        plaac_batch_free(b);
+        plaac_fasta_free(f);
+    }
     return true;
 }
 
@@ -141,34 +169,55 @@ bool read_params_file(const std::string &path, double vec[PLAAC_NAA]) {
 
 const char *rec_name(const plaac_fasta *f, uint32_t i) { return f->names + f->name_off[i]; }
 
-bool score_all(plaac_ctx *ctx, const plaac_fasta *f, const Options &o) {
+bool score_all(plaac_ctx *ctx, const plaac_fasta *f, plaac_batch *batch, const Options &o) {
     if (o.headers) column_notes();
     put(std::string(plaac_summary_header()) + "\n");
     if (f->nrec == 0) return true;
     std::vector<plaac_row> rows(f->nrec);
-    plaac_status st = plaac_score(ctx, f->codes, f->offsets, f->nrec, rows.data(), nullptr);
+    plaac_status st = batch ? plaac_batch_score(batch, rows.data(), nullptr)
+                            : plaac_score(ctx, f->codes, f->offsets, f->nrec, rows.data(), nullptr);
     if (st != PLAAC_OK) return die(ctx, "plaac_score", st);
-    std::vector<char> line;
-    std::string out;
-    for (uint32_t i = 0; i < f->nrec; ++i) {
-        const uint64_t len = f->offsets[i + 1] - f->offsets[i];
-        if (len == 0) {
-            std::fprintf(stderr, "plaac: record '%s' has no sequence, skipped\n", rec_name(f, i));
-            continue;
+    g_timer.lap(batch ? "score resident batch (GPU + D2H)" : "score (H2D + GPU + D2H)", (double)f->nres, "residues");
+    // format in parallel (contiguous row ranges per thread), print in file order
+    const unsigned nt = f->nrec < 2048 ? 1u : plaac_host_threads();
+    std::vector<std::string> part(nt);
+    std::vector<int> bad(nt, 0);
+    auto work = [&](unsigned t) {
+        const uint32_t r0 = (uint32_t)((uint64_t)f->nrec * t / nt), r1 = (uint32_t)((uint64_t)f->nrec * (t + 1) / nt);
+        std::vector<char> line;
+        std::string &out = part[t];
+        for (uint32_t i = r0; i < r1; ++i) {
+            const uint64_t len = f->offsets[i + 1] - f->offsets[i];
+            if (len == 0) {
+                std::fprintf(stderr, "plaac: record '%s' has no sequence, skipped\n", rec_name(f, i));
+                continue;
+            }
+            line.resize(len * 3 + std::strlen(rec_name(f, i)) + 2048);
+            long k = plaac_format_summary_row(&rows[i], rec_name(f, i), f->codes + f->offsets[i], len, o.corelength,
+                                              o.ww2, line.data(), line.size());
+            if (k < 0) {
+                bad[t] = 1;
+                return;
+            }
+            if (k == 0) continue; // nothing left after the stop trim (:762)
+            out.append(line.data(), (size_t)k);
+            out.push_back('\n');
         }
-        line.resize(len * 3 + std::strlen(rec_name(f, i)) + 2048);
-        long k = plaac_format_summary_row(&rows[i], rec_name(f, i), f->codes + f->offsets[i], len, o.corelength, o.ww2,
-                                          line.data(), line.size());
-        if (k < 0) return false;
-        if (k == 0) continue; // nothing left after the stop trim (:762)
-        out.append(line.data(), (size_t)k);
-        out.push_back('\n');
-        if (out.size() > (1u << 22)) {
-            put(out);
-            out.clear();
-        }
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
     }
-    put(out);
+    g_timer.lap("format rows", (double)f->nrec, "rows");
+    for (unsigned t = 0; t < nt; ++t) {
+        if (bad[t]) return false;
+        put(part[t]);
+    }
+    std::fflush(stdout);
+    g_timer.lap("write table");
     return true;
 }
 
@@ -326,7 +375,9 @@ int main(int argc, char **argv) {
     plaac_ctx *ctx = nullptr;
     auto need_ctx = [&]() -> bool {
         if (ctx) return true;
+        g_timer.lap("start-up");
         plaac_status st = plaac_ctx_create(&P, 0, &ctx);
+        g_timer.lap("create GPU context");
         if (st != PLAAC_OK) {
             std::fprintf(stderr, "plaac: no usable MI355X (gfx950) device: %s\n", plaac_last_error(nullptr));
             return false;
@@ -337,13 +388,14 @@ int main(int argc, char **argv) {
     // background counts (:377-384)
     double bgf[PLAAC_NAA] = {0}, fgf[PLAAC_NAA];
     plaac_fasta *input = nullptr;
+    plaac_batch *input_batch = nullptr;
     bool ok = true;
     if (!o.bgfreq.empty()) {
         ok = read_params_file(o.bgfreq, bgf);
     } else if (!o.bgfile.empty()) {
-        ok = need_ctx() && count_background(ctx, o.bgfile, bgf, o.bgfile == o.input ? &input : nullptr);
+        ok = need_ctx() && count_background(ctx, o.bgfile, bgf, o.bgfile == o.input ? &input : nullptr, &input_batch);
     } else if (!o.input.empty()) {
-        ok = need_ctx() && count_background(ctx, o.input, bgf, &input);
+        ok = need_ctx() && count_background(ctx, o.input, bgf, &input, &input_batch);
     }
     if (!ok) return 1;
     const bool have_fg = !o.fgfreq.empty();
@@ -382,7 +434,7 @@ int main(int argc, char **argv) {
             plaac_fasta empty{};
             uint64_t zero = 0;
             empty.offsets = &zero;
-            ok = o.plotlist.empty() ? score_all(ctx, &empty, o) : plot_some(ctx, &empty, o);
+            ok = o.plotlist.empty() ? score_all(ctx, &empty, nullptr, o) : plot_some(ctx, &empty, o);
             plaac_ctx_destroy(ctx);
             return ok ? 0 : 1;
         }
@@ -391,7 +443,8 @@ int main(int argc, char **argv) {
             return 1;
         }
     }
-    ok = o.plotlist.empty() ? score_all(ctx, input, o) : plot_some(ctx, input, o);
+    ok = o.plotlist.empty() ? score_all(ctx, input, input_batch, o) : plot_some(ctx, input, o);
+    plaac_batch_free(input_batch);
     plaac_fasta_free(input);
     plaac_ctx_destroy(ctx);
     return ok ? 0 : 1;

@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -129,14 +131,6 @@ std::string java_double_tostring(double v) {
     return out;
 }
 
-// String.trim(): strip chars <= ' ' at both ends
-std::string java_trim(const std::string &s) {
-    size_t b = 0, e = s.size();
-    while (b < e && (unsigned char)s[b] <= ' ') ++b;
-    while (e > b && (unsigned char)s[e - 1] <= ' ') --e;
-    return s.substr(b, e - b);
-}
-
 // BufferedReader.readLine over an in-memory file: terminators \n, \r, \r\n
 struct LineReader {
     const std::string &buf;
@@ -159,7 +153,16 @@ struct LineReader {
 bool slurp(const char *path, std::string &out) {
     FILE *f = std::fopen(path, "rb");
     if (!f) return false;
-    char chunk[1 << 16];
+    if (std::fseek(f, 0, SEEK_END) == 0) { // regular file: one sized read
+        const long sz = std::ftell(f);
+        std::rewind(f);
+        if (sz > 0) {
+            out.resize((size_t)sz);
+            const size_t got = std::fread(&out[0], 1, (size_t)sz, f);
+            out.resize(got);
+        }
+    }
+    char chunk[1 << 16]; // pipes / growing files: whatever is left
     size_t n;
     while ((n = std::fread(chunk, 1, sizeof chunk, f)) > 0) out.append(chunk, n);
     std::fclose(f);
@@ -188,6 +191,26 @@ long emit(const std::string &s, char *buf, size_t cap) {
 
 double inf2nan(double x) { return std::isinf(x) ? std::nan("") : x; } // (:1008)
 
+// worker threads for parsing / formatting: hardware threads capped by the cgroup CPU quota and PLAAC_THREADS
+unsigned host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        long period = 0;
+        if (std::fscanf(f, "%63s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+            const long cap = std::atol(q) / period;
+            if (cap >= 1 && (unsigned)cap < n) n = (unsigned)cap;
+        }
+        std::fclose(f);
+    }
+    if (const char *e = std::getenv("PLAAC_THREADS")) {
+        const int v = std::atoi(e);
+        if (v >= 1) n = (unsigned)v;
+    }
+    return n > 64 ? 64 : n;
+}
+
 } // namespace
 
 extern "C" {
@@ -197,60 +220,136 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
     *out = nullptr;
     std::string file;
     if (!slurp(path, file)) return PLAAC_ERR_IO;
-    std::vector<uint64_t> offs{0}, noffs{0};
-    std::string names, codes_txt;
-    LineReader rd(file);
-    std::string line, name, seq;
-    bool ondeck = false;
-    for (;;) {
-        if (!ondeck) { // hasmorefastas (:4355-4372): skip to the next header, its name is trimmed
-            bool found = false;
-            while (rd.next(line)) {
-                if (!line.empty() && line[0] == '>') {
-                    name = java_trim(line).substr(1);
-                    found = true;
+    // Record starts = lines beginning with '>' (fastareader :4325-4372: a header ends the previous record
+    // whether that record was still being read or was being skipped after a blank line). Everything between two
+    // starts is one record, so records can be parsed independently; only the trimming of a name depends on how
+    // the PREVIOUS record ended (first record / after a blank line: found by hasmorefastas, trimmed).
+    const char *d = file.data();
+    const size_t nbytes = file.size();
+    std::vector<size_t> starts;
+    {
+        size_t p = 0;
+        bool bol = true;
+        while (p < nbytes) {
+            if (bol && d[p] == '>') starts.push_back(p);
+            const char *q = (const char *)memchr(d + p, '\n', nbytes - p);
+            const char *r = (const char *)memchr(d + p, '\r', q ? (size_t)(q - (d + p)) : nbytes - p);
+            const char *e = r ? r : q; // first line terminator
+            if (!e) break;
+            p = (size_t)(e - d) + 1;
+            if (*e == '\r' && p < nbytes && d[p] == '\n') ++p;
+            bol = true;
+        }
+    }
+    const size_t nrec = starts.size();
+    struct Rec {
+        size_t name_b = 0, name_e = 0; // header text after '>' (untrimmed)
+        size_t seq_len = 0;
+        bool blank_end = false;
+    };
+    std::vector<Rec> recs(nrec);
+    // pass 1 (parallel): header extent, sequence length, how the record ended
+    auto parse_range = [&](size_t r0, size_t r1, uint8_t *codes_out, const uint64_t *offs) {
+        std::string line;
+        for (size_t i = r0; i < r1; ++i) {
+            const size_t rb = starts[i], re = i + 1 < nrec ? starts[i + 1] : nbytes;
+            size_t p = rb;
+            auto next_line = [&](size_t &lb, size_t &le) -> bool { // BufferedReader.readLine on [p, re)
+                if (p >= re) return false;
+                size_t e = p;
+                while (e < re && d[e] != '\n' && d[e] != '\r') ++e;
+                lb = p;
+                le = e;
+                if (e < re) {
+                    if (d[e] == '\r' && e + 1 < nbytes && d[e + 1] == '\n') ++e;
+                    ++e;
+                }
+                p = e;
+                return true;
+            };
+            size_t lb, le;
+            next_line(lb, le); // the header line
+            Rec &R = recs[i];
+            if (!codes_out) {
+                R.name_b = lb + 1;
+                R.name_e = le;
+            }
+            size_t len = 0;
+            bool blank = false;
+            while (next_line(lb, le)) {
+                if (le == lb) { // blank line: the rest of the record is skipped
+                    blank = true;
                     break;
                 }
+                if (codes_out) plaac_encode(d + lb, le - lb, codes_out + offs[i] + len);
+                len += le - lb;
             }
-            if (!found) break;
-        }
-        // nextfasta (:4325-4348)
-        seq.clear();
-        std::string nextname;
-        ondeck = false;
-        while (rd.next(line)) {
-            if (line.empty()) break; // blank line ends the record; the remainder is skipped
-            if (line[0] == '>') {
-                ondeck = true;
-                nextname = line.substr(1); // not trimmed
-                break;
+            if (!codes_out) {
+                R.seq_len = len;
+                R.blank_end = blank;
             }
-            seq += line;
         }
-        names += name;
-        names.push_back('\0');
-        noffs.push_back(names.size());
-        codes_txt += seq;
-        offs.push_back(codes_txt.size());
-        if (ondeck) name = nextname;
-    }
+    };
+    const unsigned nthreads = host_threads();
+    auto run_parallel = [&](uint8_t *codes_out, const uint64_t *offs) {
+        if (nrec < 4096 || nthreads <= 1) {
+            parse_range(0, nrec, codes_out, offs);
+            return;
+        }
+        std::vector<std::thread> pool;
+        // split by bytes, not by record count, so threads get equal work
+        size_t r0 = 0;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            const size_t target = nbytes / nthreads * (t + 1);
+            size_t r1 = t + 1 == nthreads ? nrec
+                                          : (size_t)(std::lower_bound(starts.begin(), starts.end(), target) - starts.begin());
+            if (r1 < r0) r1 = r0;
+            pool.emplace_back(parse_range, r0, r1, codes_out, offs);
+            r0 = r1;
+        }
+        for (auto &th : pool) th.join();
+    };
+    run_parallel(nullptr, nullptr);
+
     plaac_fasta *f = (plaac_fasta *)std::calloc(1, sizeof(plaac_fasta));
     if (!f) return PLAAC_ERR_NOMEM;
-    f->nrec = (uint32_t)(offs.size() - 1);
-    f->nres = codes_txt.size();
-    f->codes = (uint8_t *)std::malloc(codes_txt.size() + 64);
-    f->offsets = (uint64_t *)std::malloc(offs.size() * sizeof(uint64_t));
-    f->names = (char *)std::malloc(names.size() + 1);
-    f->name_off = (uint64_t *)std::malloc(noffs.size() * sizeof(uint64_t));
-    if (!f->codes || !f->offsets || !f->names || !f->name_off) {
+    f->nrec = (uint32_t)nrec;
+    f->offsets = (uint64_t *)std::malloc((nrec + 1) * sizeof(uint64_t));
+    f->name_off = (uint64_t *)std::malloc((nrec + 1) * sizeof(uint64_t));
+    if (!f->offsets || !f->name_off) {
         plaac_fasta_free(f);
         return PLAAC_ERR_NOMEM;
     }
-    plaac_encode(codes_txt.data(), codes_txt.size(), f->codes);
-    std::memcpy(f->offsets, offs.data(), offs.size() * sizeof(uint64_t));
-    std::memcpy(f->names, names.data(), names.size());
-    f->names[names.size()] = '\0';
-    std::memcpy(f->name_off, noffs.data(), noffs.size() * sizeof(uint64_t));
+    // names: first record and records that follow a blank-line-terminated one are trimmed (:4362), others not
+    std::vector<std::pair<size_t, size_t>> nm(nrec);
+    uint64_t off = 0, noff = 0;
+    for (size_t i = 0; i < nrec; ++i) {
+        size_t b = recs[i].name_b, e = recs[i].name_e;
+        if (i == 0 || recs[i - 1].blank_end) { // hasmorefastas: line.trim().substring(1)
+            while (e > b && (unsigned char)d[e - 1] <= ' ') --e;
+            // leading blanks cannot precede '>' (the line starts with it); blanks after '>' stay
+        }
+        nm[i] = {b, e};
+        f->offsets[i] = off;
+        f->name_off[i] = noff;
+        off += recs[i].seq_len;
+        noff += (e - b) + 1;
+    }
+    f->offsets[nrec] = off;
+    f->name_off[nrec] = noff;
+    f->nres = off;
+    f->codes = (uint8_t *)std::malloc(off + 64);
+    f->names = (char *)std::malloc(noff + 1);
+    if (!f->codes || !f->names) {
+        plaac_fasta_free(f);
+        return PLAAC_ERR_NOMEM;
+    }
+    for (size_t i = 0; i < nrec; ++i) {
+        std::memcpy(f->names + f->name_off[i], d + nm[i].first, nm[i].second - nm[i].first);
+        f->names[f->name_off[i + 1] - 1] = '\0';
+    }
+    f->names[noff] = '\0';
+    run_parallel(f->codes, f->offsets); // pass 2 (parallel): encode straight into the final buffer
     *out = f;
     return PLAAC_OK;
 }
@@ -293,6 +392,8 @@ plaac_status plaac_read_aa_params(const char *path, double vec[PLAAC_NAA], int *
     }
     return PLAAC_OK;
 }
+
+unsigned plaac_host_threads(void) { return host_threads(); }
 
 int plaac_format_fixed(double v, int decimals, char *buf, size_t cap) {
     return (int)emit(fixed_string(v, decimals), buf, cap);

@@ -1901,18 +1901,19 @@ plaac_status plaac_histogram(plaac_ctx *ctx, const uint8_t *codes, const uint64_
     return PLAAC_OK;
 }
 
-plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
-                         plaac_row *rows, const plaac_tracks *tracks) {
-    if (!ctx) return PLAAC_ERR_ARG;
-    if (nprot == 0) return PLAAC_OK;
-    if (!rows) return fail(ctx, PLAAC_ERR_ARG, "null rows");
-    PL_HIP(ctx, hipSetDevice(ctx->device));
-    uint64_t total = 0;
-    plaac_status rc = stage_in(ctx, codes, offsets, nprot, &total);
-    if (rc != PLAAC_OK) return rc;
+// score device-resident codes/offsets and bring rows (+ tracks) back to host buffers
+static plaac_status score_resident_to_host(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
+                                           uint32_t nprot, uint64_t total, plaac_row *rows,
+                                           const plaac_tracks *tracks) {
+    plaac_status rc;
     if ((rc = grow(ctx, ctx->d_rows, ctx->cap_rows, (size_t)nprot)) != PLAAC_OK) return rc;
     plaac_tracks dt{};
     if (tracks) {
+        double *hd[10] = {tracks->charge, tracks->hydro,      tracks->fi,     tracks->plaacllr, tracks->papa,
+                          tracks->fix2,   tracks->plaacllrx2, tracks->papax2, tracks->post0,    tracks->post1};
+        for (double *q : hd)
+            if (!q) return fail(ctx, PLAAC_ERR_ARG, "tracks struct has a null array");
+        if (!tracks->vit || !tracks->map) return fail(ctx, PLAAC_ERR_ARG, "tracks struct has a null array");
         const size_t need = (size_t)total + 8;
         if (need > ctx->cap_trk || !ctx->d_trk8) {
             if (ctx->d_trk8) PL_HIP(ctx, hipFree(ctx->d_trk8));
@@ -1938,12 +1939,11 @@ plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *o
         dt.papax2 = b + 7 * s;
         dt.post0 = b + 8 * s;
         dt.post1 = b + 9 * s;
-        // entries of trimmed stops are "left untouched": start from the caller's bytes
+        // entries of trimmed stops are unspecified: make them deterministic (0 / NaN)
         PL_HIP(ctx, hipMemsetAsync(ctx->d_trk8, 0, 2 * s, ctx->stream));
         PL_HIP(ctx, hipMemsetAsync(ctx->d_trk64, 0xff, 10 * s * sizeof(double), ctx->stream));
     }
-    rc = plaac_score_device(ctx, ctx->d_codes, ctx->d_offsets, nprot, total, ctx->d_rows, tracks ? &dt : nullptr,
-                            ctx->stream);
+    rc = plaac_score_device(ctx, d_codes, d_offsets, nprot, total, ctx->d_rows, tracks ? &dt : nullptr, ctx->stream);
     if (rc != PLAAC_OK) return rc;
     PL_HIP(ctx, hipMemcpyAsync(rows, ctx->d_rows, sizeof(plaac_row) * (size_t)nprot, hipMemcpyDeviceToHost, ctx->stream));
     if (tracks && total) {
@@ -1955,13 +1955,83 @@ plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *o
                           tracks->fix2,   tracks->plaacllrx2, tracks->papax2, tracks->post0,    tracks->post1};
         double *dd[10] = {dt.charge, dt.hydro, dt.fi, dt.plaacllr, dt.papa, dt.fix2, dt.plaacllrx2, dt.papax2, dt.post0,
                           dt.post1};
-        for (int i = 0; i < 10; ++i) {
-            if (!hd[i]) return fail(ctx, PLAAC_ERR_ARG, "tracks struct has a null array");
+        for (int i = 0; i < 10; ++i)
             PL_HIP(ctx, hipMemcpyAsync(hd[i], dd[i], nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        }
     }
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PLAAC_OK;
+}
+
+plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                         plaac_row *rows, const plaac_tracks *tracks) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (nprot == 0) return PLAAC_OK;
+    if (!rows) return fail(ctx, PLAAC_ERR_ARG, "null rows");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t total = 0;
+    plaac_status rc = stage_in(ctx, codes, offsets, nprot, &total);
+    if (rc != PLAAC_OK) return rc;
+    return score_resident_to_host(ctx, ctx->d_codes, ctx->d_offsets, nprot, total, rows, tracks);
+}
+
+struct plaac_batch {
+    plaac_ctx *ctx;
+    uint8_t *d_codes;
+    uint64_t *d_offsets;
+    uint32_t nprot;
+    uint64_t total;
+};
+
+plaac_status plaac_batch_upload(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                                plaac_batch **out) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (!out) return fail(ctx, PLAAC_ERR_ARG, "null out");
+    *out = nullptr;
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t total = 0;
+    // stage through the ctx buffers' validation, then hand the device copies over to the batch
+    plaac_status rc = stage_in(ctx, codes, offsets, nprot, &total);
+    if (rc != PLAAC_OK) return rc;
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    plaac_batch *b = new (std::nothrow) plaac_batch{ctx, ctx->d_codes, ctx->d_offsets, nprot, total};
+    if (!b) return fail(ctx, PLAAC_ERR_NOMEM, "out of host memory");
+    ctx->d_codes = nullptr; // ownership moves to the batch; the ctx allocates fresh staging buffers on demand
+    ctx->d_offsets = nullptr;
+    ctx->cap_codes = ctx->cap_offs = 0;
+    *out = b;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_batch_histogram(plaac_batch *b, int64_t counts[PLAAC_NAA]) {
+    if (!b || !b->ctx) return PLAAC_ERR_ARG;
+    plaac_ctx *ctx = b->ctx;
+    if (!counts) return fail(ctx, PLAAC_ERR_ARG, "null counts");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    plaac_status rc = plaac_histogram_device(ctx, b->d_codes, b->d_offsets, b->nprot, (int64_t *)ctx->d_counts, ctx->stream);
+    if (rc != PLAAC_OK) return rc;
+    PL_HIP(ctx, hipMemcpyAsync(counts, ctx->d_counts, sizeof(int64_t) * NAA, hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PLAAC_OK;
+}
+
+plaac_status plaac_batch_score(plaac_batch *b, plaac_row *rows, const plaac_tracks *tracks) {
+    if (!b || !b->ctx) return PLAAC_ERR_ARG;
+    plaac_ctx *ctx = b->ctx;
+    if (b->nprot == 0) return PLAAC_OK;
+    if (!rows) return fail(ctx, PLAAC_ERR_ARG, "null rows");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    return score_resident_to_host(ctx, b->d_codes, b->d_offsets, b->nprot, b->total, rows, tracks);
+}
+
+void plaac_batch_free(plaac_batch *b) {
+    if (!b) return;
+    if (b->ctx) {
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+    }
+    if (b->d_codes) (void)hipFree(b->d_codes);
+    if (b->d_offsets) (void)hipFree(b->d_offsets);
+    delete b;
 }
 
 } // extern "C"

@@ -17,6 +17,7 @@ HOST_EXPORTS = (
     "plaac_fasta_read", "plaac_fasta_free", "plaac_read_aa_params", "plaac_format_fixed",
     "plaac_format_double_tostring", "plaac_format_summary_row", "plaac_summary_header", "plaac_tracks_header",
     "plaac_format_track_rows", "plaac_track_rows_bound", "plaac_format_param_block", "plaac_format_aa_params",
+    "plaac_host_threads",
 )
 
 _ready = False

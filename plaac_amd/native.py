@@ -67,7 +67,8 @@ EXPORTS = (
     "plaac_abi_version", "plaac_sizeof_params", "plaac_sizeof_row", "plaac_builtin_tables", "plaac_params_init",
     "plaac_encode", "plaac_ctx_create", "plaac_ctx_set_params", "plaac_ctx_destroy", "plaac_last_error",
     "plaac_histogram", "plaac_score", "plaac_score_device", "plaac_histogram_device", "plaac_ctx_sync",
-    "plaac_last_timings", "plaac_timings_mean",
+    "plaac_last_timings", "plaac_timings_mean", "plaac_batch_upload", "plaac_batch_histogram", "plaac_batch_score",
+    "plaac_batch_free",
 )
 
 _lib = None
@@ -117,6 +118,11 @@ def load():
     L.plaac_ctx_sync.argtypes = [C.c_void_p]
     L.plaac_last_timings.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_timings_mean.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.plaac_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.plaac_batch_histogram.argtypes = [C.c_void_p, C.c_void_p]
+    L.plaac_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.plaac_batch_free.argtypes = [C.c_void_p]
+    L.plaac_batch_free.restype = None
     _lib = L
     return L
 
@@ -221,6 +227,10 @@ class Context:
                                         tptr))
         return (rows, tr) if tracks else rows
 
+    # ---- resident batch: upload once, histogram / score (under several parameter sets) many times ----
+    def upload(self, codes, offsets):
+        return Batch(self, codes, offsets)
+
     # ---- device-resident entry points: raw device pointers (e.g. torch tensors' data_ptr()) ----
     def score_device(self, d_codes, d_offsets, nprot, total, d_rows, d_tracks=None, stream=None):
         T = None
@@ -244,3 +254,54 @@ class Context:
         self._check(self._L.plaac_timings_mean(self._h, int(ncalls), C.addressof(ms)))
         return {"total": ms[0], "plan": ms[1], "vit": ms[2], "fwd": ms[3], "win": ms[4], "tracks": ms[5],
                 "pack": ms[6]}
+
+
+class Batch:
+    """plaac_batch: encoded residues resident in HBM (one upload for the background pass, the scoring pass
+    and every point of a parameter sweep)."""
+
+    def __init__(self, ctx, codes, offsets):
+        self.ctx = ctx
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.nprot = len(offsets) - 1
+        self.total = int(offsets[-1]) if self.nprot > 0 else 0
+        self._h = C.c_void_p()
+        ctx._check(ctx._L.plaac_batch_upload(ctx._h, codes.ctypes.data, offsets.ctypes.data, self.nprot,
+                                             C.byref(self._h)))
+
+    def histogram(self):
+        counts = np.zeros(NAA, dtype=np.int64)
+        self.ctx._check(self.ctx._L.plaac_batch_histogram(self._h, counts.ctypes.data))
+        return counts
+
+    def score(self, tracks=False):
+        rows = np.zeros(self.nprot, dtype=ROW_DTYPE)
+        tr, tptr, T = None, None, None
+        if tracks:
+            tr = alloc_tracks(self.total)
+            T = Tracks(**{k: tr[k].ctypes.data for k in TRACK_U8 + TRACK_F64})
+            tptr = C.addressof(T)
+        self.ctx._check(self.ctx._L.plaac_batch_score(self._h, rows.ctypes.data, tptr))
+        return (rows, tr) if tracks else rows
+
+    def sweep(self, param_sets):
+        """score the resident batch under each plaac_params of `param_sets`; returns a list of row arrays"""
+        out = []
+        for P in param_sets:
+            self.ctx.set_params(P)
+            out.append(self.score())
+        return out
+
+    def close(self):
+        if self._h:
+            self.ctx._L.plaac_batch_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -249,3 +249,27 @@ def test_context_reuse_with_growing_and_shrinking_batches(native, oracle, ctx):
     for nprot, seed in ((7, 1), (3000, 2), (65, 3), (9000, 4), (1, 5), (640, 6)):
         codes, offs = synth.make_batch(4, nprot=nprot, seed=seed)
         assert_rows_equal(ctx.score(codes, offs), oracle.score_batch(Po, codes, offs, nthreads=8), "n=%d" % nprot)
+
+
+def test_resident_batch_histogram_score_and_sweep(native, oracle, ctx):
+    """upload once; background pass, scoring pass and a BASELINE config-5 style alpha x core-length sweep reuse
+    the resident residues. Every sweep point must equal an independent oracle run."""
+    from plaac_amd import synth
+    codes, offs = synth.make_batch(4, nprot=700, seed=31, stop_fraction=0.1)
+    ctx.set_params(native.make_params())
+    with ctx.upload(codes, offs) as batch:
+        counts = batch.histogram()
+        assert np.array_equal(counts, oracle.histogram(codes, offs))
+        bg = counts.astype(np.float64)
+        points = [(a, c) for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)]
+        got = batch.sweep([native.make_params(alpha=a, corelength=c, bgcounts=bg) for a, c in points])
+        for (a, c), rows in zip(points, got):
+            want = oracle.score_batch(oracle.build_params(alpha=a, corelength=c, bgcounts=bg), codes, offs, nthreads=8)
+            assert_rows_equal(rows, want, "alpha=%s c=%d" % (a, c))
+        # the context still works for ordinary calls after handing its staging buffers to the batch
+        ctx.set_params(native.make_params())
+        assert_rows_equal(ctx.score(codes, offs), oracle.score_batch(oracle.build_params(), codes, offs, nthreads=8))
+        rows, tr = batch.score(tracks=True)
+        want, wtr = oracle.score_batch(oracle.build_params(), codes, offs, tracks=True, nthreads=8)
+        assert_rows_equal(rows, want)
+        assert_tracks_equal(tr, wtr, codes, offs)

@@ -178,3 +178,62 @@ def test_param_block_text(io, native):
                                                      "## plaac_llr", "## papa_lods"]
     assert lines[4].startswith("## bg_input: {X=0.00000;A=0.00870;")  # X and * zeroed, rest normalised
     assert lines[8] == "#" * 87
+
+
+def _py_fastareader(data):
+    """straight Python restatement of fastareader (:4302-4375) for cross-checking the parallel C++ reader"""
+    import re as _re
+    lines = _re.split(b"\r\n|\n|\r", data)
+    if lines and lines[-1] == b"":
+        lines.pop()
+    recs, i, ondeck, name = [], 0, False, None
+    jtrim = lambda b: b.strip(bytes(range(0, 33)))
+    while True:
+        if not ondeck:
+            found = False
+            while i < len(lines):
+                ln = lines[i]
+                i += 1
+                if len(ln) > 0 and ln[:1] == b">":
+                    name = jtrim(ln)[1:]
+                    found = True
+                    break
+            if not found:
+                break
+        seq, ondeck, nextname = [], False, None
+        while i < len(lines):
+            ln = lines[i]
+            i += 1
+            if len(ln) == 0:
+                break
+            if ln[:1] == b">":
+                ondeck, nextname = True, ln[1:]
+                break
+            seq.append(ln)
+        recs.append((name, b"".join(seq)))
+        if ondeck:
+            name = nextname
+    return recs
+
+
+def test_parallel_fasta_reader_matches_serial_semantics(io, native, tmp_path, monkeypatch):
+    rng = np.random.default_rng(12)
+    aas = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYacdXB* -", dtype=np.uint8)
+    out = [b"leading junk\n"]
+    for r in range(7000):
+        out.append(b">rec%d some text%s" % (r, b"  " if r % 7 == 0 else b"") + (b"\r\n" if r % 5 == 0 else b"\n"))
+        for _ in range(int(rng.integers(0, 4))):
+            out.append(bytes(rng.choice(aas, int(rng.integers(1, 70)))) + (b"\r\n" if r % 11 == 0 else b"\n"))
+        if r % 13 == 0:
+            out.append(b"\nskipped tail\nmore skipped\n")  # blank line: rest of the record is ignored
+    data = b"".join(out)[:-1]  # no final newline
+    p = tmp_path / "big.fa"
+    p.write_bytes(data)
+    want = _py_fastareader(data)
+    for nthreads in ("1", "5"):
+        monkeypatch.setenv("PLAAC_THREADS", nthreads)
+        names, codes, offs = io.read_fasta(p)
+        assert len(names) == len(want) == 7000
+        assert names == [n for n, _ in want]
+        got = [bytes(codes[int(offs[i]):int(offs[i + 1])]) for i in range(len(names))]
+        assert got == [bytes(native.encode(s)) for _, s in want]
