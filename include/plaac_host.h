@@ -71,6 +71,9 @@ size_t plaac_track_rows_bound(uint32_t n, size_t id_len, size_t name_len);
 
 /* "## parameters at run-time" block (:503-514), newline-terminated. Returns the length or -1. */
 long plaac_format_param_block(const plaac_params *p, char *buf, size_t cap);
+/* GraphViz description of the two-state HMM with its emission tables: hmm.dottify(file, true), the -h flag
+ * (:4209-4287, :520-522). Returns the length or -1. */
+long plaac_format_hmm_dot(const plaac_params *p, char *buf, size_t cap);
 /* the 22 lines "%.6f # %s" of print_aa_params (:2665-2669). Returns the length or -1. */
 long plaac_format_aa_params(const double vec[PLAAC_NAA], char *buf, size_t cap);
 

@@ -7,7 +7,7 @@
 //
 // Deliberate divergences from the reference: -F reads the -F file (the reference reads
 // the -B file by mistake), histogram bins are 64-bit, records with an empty sequence are skipped with
-// a note on stderr instead of crashing, -h (GraphViz export) is not implemented, the -d column notes
+// a note on stderr instead of crashing, the -d column notes
 // and the usage text are worded independently. All scoring runs on the GPU; there is no CPU path.
 #include <chrono>
 #include <cstdio>
@@ -63,7 +63,7 @@ void usage() {
         "  -d               print a description of the output columns\n"
         "  -s               do not print the run-time parameter block\n"
         "  -p list.txt|all  per-residue table for the listed sequence names (or all) instead of the summary\n"
-        "  -h file          (GraphViz export of the HMM; not implemented in this engine)\n");
+        "  -h file          write the HMM (transitions + emission tables) in GraphViz dot format to file\n");
 }
 
 void column_notes() {
@@ -420,7 +420,17 @@ int main(int argc, char **argv) {
         plaac_format_param_block(&P, text, sizeof text);
         put(text);
     }
-    if (!o.dotfile.empty()) std::fprintf(stderr, "plaac: -h (GraphViz export) is not implemented, ignored\n");
+    if (!o.dotfile.empty()) { // hmm1.dottify(hmmdotfile, true) (:520-522)
+        std::vector<char> dot(16384);
+        const long k = plaac_format_hmm_dot(&P, dot.data(), dot.size());
+        FILE *fp = k >= 0 ? std::fopen(o.dotfile.c_str(), "wb") : nullptr;
+        if (fp) {
+            std::fwrite(dot.data(), 1, (size_t)k, fp);
+            std::fclose(fp);
+        } else {
+            put("## problem writing to dotfile\n");
+        }
+    }
 
     if (!need_ctx()) return 1;
     if (plaac_ctx_set_params(ctx, &P) != PLAAC_OK) {

@@ -539,6 +539,62 @@ long plaac_format_param_block(const plaac_params *p, char *buf, size_t cap) {
     return emit(s, buf, cap);
 }
 
+// hmm.dottify(filename, true) (:4209-4287) for the two-state model of prionhmm1 (:968-981): the same nodes,
+// edges, labels and attributes, so `dot -Tpng` draws the same picture.
+long plaac_format_hmm_dot(const plaac_params *p, char *buf, size_t cap) {
+    if (!p || !buf) return -1;
+    const double trans[2][2] = {{99.9 / 100, 0.1 / 100}, {2.0 / 100, 98.0 / 100}};
+    const double init[2] = {0.9524, 0.0476};
+    const char *names[2] = {"background", "PrD-like"};
+    double eprob[2][PLAAC_NAA]; // emat = normalize(bg), normalize(fg) (:974-975)
+    for (int st = 0; st < 2; ++st) {
+        const double *src = st == 0 ? p->bg : p->fg;
+        double sum = 0;
+        for (int k = 0; k < PLAAC_NAA; ++k) sum = sum + src[k];
+        sum = 1.0 * sum;
+        if (sum < 0.000000000001) sum = 1;
+        for (int k = 0; k < PLAAC_NAA; ++k) eprob[st][k] = src[k] / sum;
+    }
+    std::string s = "Digraph G {\n"
+                    "edge [fontname=Courier, fontsize=8, labelfontname=Courier,labelfontsize=8];\n"
+                    " node [fontname=Courier, fontsize=10]\n"
+                    " start [label=start, shape=circle, height=0.25, style=filled, color=grey, rank=source];\n";
+    auto node = [](int i) { return "n" + std::to_string(i); };
+    for (int i = 0; i < 2; ++i) {
+        s += "  " + node(i) + " [label=\"" + names[i] + "\", shape=circle, height=1.2];\n";
+        s += "  start -> " + node(i) + " [label=\"" + fixed_string(init[i], 3) + "\", color=gray];\n";
+    }
+    for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j) {
+            if (!(trans[i][j] > 0)) continue;
+            const std::string lab = fixed_string(trans[i][j], 3);
+            if (i == j) { // an invisible inner self-edge makes the visible outer one a little bigger
+                const std::string port = (i % 2 == 0) ? ":w" : ":e";
+                const std::string ends = "  " + node(i) + port + " -> " + node(j) + port;
+                s += ends + " [label=\"\", color=gray, style=invis];\n";
+                s += ends + " [label=\"" + lab + "\", color=gray];\n";
+            } else {
+                const std::string ends = "  " + node(i) + " -> " + node(j);
+                if (i < j) s += ends + " [label=\"spacerlabel\", color=gray, constraint=false, style=invis];\n";
+                s += ends + " [label=\"" + lab + "\", color=gray, constraint=false];\n";
+            }
+        }
+    }
+    for (int i = 0; i < 2; ++i) { // emission records, X and * left out
+        s += "rec" + std::to_string(i) + " [shape=record, label=\"{ <fs> AA";
+        for (int k = 1; k < PLAAC_NAA - 1; ++k) {
+            s += '|';
+            s += kAlphabet[k];
+        }
+        s += "}|{ <f" + std::to_string(i) + "> prob";
+        for (int k = 1; k < PLAAC_NAA - 1; ++k) s += "|" + fixed_string(eprob[i][k], 4);
+        s += "}\"];\n";
+    }
+    for (int i = 0; i < 2; ++i) s += "  " + node(i) + " -> rec" + std::to_string(i) + " [style=dashed];\n";
+    s += "}\n";
+    return emit(s, buf, cap);
+}
+
 long plaac_format_aa_params(const double vec[PLAAC_NAA], char *buf, size_t cap) {
     if (!vec || !buf) return -1;
     std::string s;

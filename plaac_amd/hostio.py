@@ -17,7 +17,7 @@ HOST_EXPORTS = (
     "plaac_fasta_read", "plaac_fasta_free", "plaac_read_aa_params", "plaac_format_fixed",
     "plaac_format_double_tostring", "plaac_format_summary_row", "plaac_summary_header", "plaac_tracks_header",
     "plaac_format_track_rows", "plaac_track_rows_bound", "plaac_format_param_block", "plaac_format_aa_params",
-    "plaac_host_threads",
+    "plaac_host_threads", "plaac_format_hmm_dot",
 )
 
 _ready = False
@@ -47,6 +47,8 @@ def _lib():
         L.plaac_format_param_block.restype = C.c_long
         L.plaac_format_aa_params.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.plaac_format_aa_params.restype = C.c_long
+        L.plaac_format_hmm_dot.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.plaac_format_hmm_dot.restype = C.c_long
         _ready = True
     return L
 
@@ -132,4 +134,10 @@ def format_aa_params(vec):
     vec = np.ascontiguousarray(vec, dtype=np.float64)
     buf = C.create_string_buffer(2048)
     k = _lib().plaac_format_aa_params(vec.ctypes.data, buf, 2048)
+    return buf.raw[:k].decode()
+
+
+def format_hmm_dot(P):
+    buf = C.create_string_buffer(16384)
+    k = _lib().plaac_format_hmm_dot(C.addressof(P), buf, 16384)
     return buf.raw[:k].decode()

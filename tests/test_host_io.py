@@ -237,3 +237,22 @@ def test_parallel_fasta_reader_matches_serial_semantics(io, native, tmp_path, mo
         assert names == [n for n, _ in want]
         got = [bytes(codes[int(offs[i]):int(offs[i + 1])]) for i in range(len(names))]
         assert got == [bytes(native.encode(s)) for _, s in want]
+
+
+def test_hmm_dot_export(io, native):
+    """-h: the GraphViz text of hmm.dottify(file, true) for prionhmm1 (plaac.java:4209-4287)"""
+    P = native.make_params()
+    lines = io.format_hmm_dot(P).split("\n")
+    assert lines[0] == "Digraph G {" and lines[-2] == "}" and lines[-1] == ""
+    assert '  n0 [label="background", shape=circle, height=1.2];' in lines
+    assert '  n1 [label="PrD-like", shape=circle, height=1.2];' in lines
+    assert '  start -> n0 [label="0.952", color=gray];' in lines and '  start -> n1 [label="0.048", color=gray];' in lines
+    assert '  n0:w -> n0:w [label="0.999", color=gray];' in lines and '  n1:e -> n1:e [label="0.980", color=gray];' in lines
+    assert '  n0 -> n1 [label="0.001", color=gray, constraint=false];' in lines
+    assert '  n1 -> n0 [label="0.020", color=gray, constraint=false];' in lines
+    assert '  n0 -> n1 [label="spacerlabel", color=gray, constraint=false, style=invis];' in lines
+    rec1 = [l for l in lines if l.startswith("rec1 ")][0]
+    assert rec1.startswith('rec1 [shape=record, label="{ <fs> AA|A|C|D|E|') and "|Y}|{ <f1> prob|" in rec1
+    probs = rec1.split("prob|")[1].split("}")[0].split("|")
+    assert len(probs) == 20 and probs[11] == io.format_fixed(P.fg[12] / sum(P.fg), 4)  # N is the 12th code
+    assert lines[-4:-2] == ["  n0 -> rec0 [style=dashed];", "  n1 -> rec1 [style=dashed];"]
