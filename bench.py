@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4))
     ap.add_argument("--nprot", type=int, default=0, help="sequences per GPU (default: config 4 -> 1,250,000)")
     ap.add_argument("--tracks", action="store_true", help="per-residue track mode (82 B/residue written)")
+    ap.add_argument("--sweep", action="store_true", help="BASELINE config 5: a step = the 9-point sweep "
+                    "alpha in {0,0.5,1} x core length in {30,60,90} over the resident shard (value counts every "
+                    "residue once per point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' + --one-device lets two ranks share one GPU for a plumbing check")
@@ -98,12 +101,25 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.synchronize(dev)
 
+    sweep_params = None
+    if args.sweep:
+        cnt = torch.zeros(22, dtype=torch.int64, device=dev)
+        ctx.histogram_device(codes.data_ptr(), offsets.data_ptr(), nprot, cnt.data_ptr())
+        ctx.sync()
+        counts = pdist.allreduce_counts(cnt.cpu().numpy(), device=dev if world > 1 else None)  # exchange (i)
+        sweep_params = [native.make_params(alpha=a, corelength=c, bgcounts=counts.astype(np.float64))
+                        for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)]
+    npoints = len(sweep_params) if sweep_params else 1
+
     def step():
         with torch.cuda.stream(stream):
-            ctx.score_device(codes.data_ptr(), offsets.data_ptr(), nprot, total, rows.data_ptr(), d_tracks,
-                             stream=stream.cuda_stream)
-            if world > 1:  # final gather of per-protein summary rows, ordered after the kernels
-                dist.gather(rows, gather_list, dst=0)
+            for k in range(npoints):
+                if sweep_params:
+                    ctx.set_params(sweep_params[k])
+                ctx.score_device(codes.data_ptr(), offsets.data_ptr(), nprot, total, rows.data_ptr(), d_tracks,
+                                 stream=stream.cuda_stream)
+                if world > 1:  # final gather of per-protein summary rows, ordered after the kernels
+                    dist.gather(rows, gather_list, dst=0)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -210,16 +226,17 @@ def main():
         }
 
     out = {
-        "metric": "residues/sec", "value": round(job_res * args.steps / dt, 1), "unit": "residues/s",
+        "metric": "residues/sec", "value": round(job_res * npoints * args.steps / dt, 1), "unit": "residues/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "proteins_per_sec": round(job_prot * args.steps / dt, 1),
+        "proteins_per_sec": round(job_prot * npoints * args.steps / dt, 1),
         "config": {
             "workload": {2: "cfg2 yeast-shaped proteome", 3: "cfg3 human-shaped proteome",
                          4: "cfg4 UniRef50-shaped, 10M sequences over 8 GPUs = 1.25M sequences per GPU"}[
                 args.config],
-            "mode": "tracks" if args.tracks else "summary", "sequences_per_gpu": nprot,
+            "mode": ("tracks" if args.tracks else "summary") + (" x 9-point alpha/core sweep (cfg5)" if args.sweep
+                                                                  else ""), "sequences_per_gpu": nprot,
             "residues_per_gpu": total, "sequences_total": job_prot, "residues_total": job_res,
             "params": "c=60 ww=41 alpha=1.0 fg=prd_freq_scer_28", "sharding": "by sequence, %d rank(s)" % world,
             "exchange": ("%s gather of 160 B rows to rank 0" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
