@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--sweep", action="store_true", help="BASELINE config 5: a step = the 9-point sweep "
                     "alpha in {0,0.5,1} x core length in {30,60,90} over the resident shard (value counts every "
                     "residue once per point)")
+    ap.add_argument("--naive-sweep", action="store_true", help="with --sweep: nine full passes instead of the "
+                    "sweep-aware scheduler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' + --one-device lets two ranks share one GPU for a plumbing check")
@@ -111,8 +113,17 @@ def main():
                         for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)]
     npoints = len(sweep_params) if sweep_params else 1
 
+    sweep_rows = [torch.zeros_like(rows) for _ in range(npoints)] if sweep_params else None
+
     def step():
         with torch.cuda.stream(stream):
+            if sweep_params and not args.naive_sweep:  # one planned pass, shared per-alpha work
+                ctx.score_sweep_device(codes.data_ptr(), offsets.data_ptr(), nprot, total, sweep_params,
+                                       [r.data_ptr() for r in sweep_rows], stream=stream.cuda_stream)
+                if world > 1:
+                    for r in sweep_rows:
+                        dist.gather(r, gather_list, dst=0)
+                return
             for k in range(npoints):
                 if sweep_params:
                     ctx.set_params(sweep_params[k])

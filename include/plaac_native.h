@@ -176,6 +176,16 @@ void plaac_batch_free(plaac_batch *b);
 plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,
                                 uint64_t total_residues, plaac_row *d_rows, const plaac_tracks *d_tracks,
                                 void *stream);
+/* Parameter sweep over one resident batch (BASELINE config 5: alpha x core length): npoints parameter sets,
+ * one device row array per point. Points that differ only in the core length share everything that does not
+ * depend on it (sort, packed copy, forward pass, FoldIndex/PAPA tracks, Viterbi + traceback); only the two
+ * prefix-sum window searches run per core length. Each d_rows[i] is bit-identical to what plaac_score_device
+ * produces for points[i] alone. The ctx's own parameters are not changed. */
+plaac_status plaac_score_sweep_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
+                                      uint32_t nprot, uint64_t total_residues, const plaac_params *points,
+                                      uint32_t npoints, plaac_row *const *d_rows, void *stream);
+/* host-buffer form on a resident batch: rows[i] = host array of nprot rows for points[i] */
+plaac_status plaac_batch_sweep(plaac_batch *b, const plaac_params *points, uint32_t npoints, plaac_row *const *rows);
 plaac_status plaac_histogram_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
                                     uint32_t nprot, int64_t *d_counts, void *stream);
 plaac_status plaac_ctx_sync(plaac_ctx *ctx);

@@ -34,6 +34,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "plaac_native.h"
 
@@ -377,38 +378,52 @@ __device__ __forceinline__ uint32_t traceback_block(uint32_t &state, int &cur, i
     return vw;
 }
 
-struct CoreState {
-    double mL, mT, best;
-    int bstart;
+// Parameter sweeps (BASELINE config 5): the Viterbi parse depends on the background mix alpha but not on the core
+// length, so ONE pass of sweeps 1-2 serves up to MAXC core lengths; sweep 3 then carries one trailing chain
+// and one best-window record per core length. NC = 1 is the ordinary single-parameter call.
+constexpr int MAXC = 4;
+struct SweepTargets {
+    uint32_t c[MAXC];     // core lengths
+    plaac_row *rows[MAXC]; // one row array per core length
 };
 
-// STEADY: the whole block has t >= c, i.e. both prefix-sum chains run and every step closes a window
-template <bool GUARD, bool STEADY>
-__device__ __forceinline__ void core_block(CoreState &S, const double *__restrict__ s_row, const uint4 cur,
-                                           const uint4 tcur, uint32_t wl, uint32_t tv, uint32_t t0, uint32_t n,
-                                           uint32_t c, double big_neg) {
+template <int NC>
+struct CoreState {
+    double mL;
+    double mT[NC], best[NC];
+    int bstart[NC];
+};
+
+// STEADY: the whole block has t >= c for every core length, i.e. all chains run and every step closes a window
+template <bool GUARD, bool STEADY, int NC>
+__device__ __forceinline__ void core_block(CoreState<NC> &S, const double *__restrict__ s_row, const uint4 cur,
+                                           const uint4 (&tcur)[NC], uint32_t wl, const uint32_t (&tv)[NC], uint32_t t0,
+                                           uint32_t n, const uint32_t (&c)[NC], double big_neg) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t t = t0 + (uint32_t)j;
         if (!GUARD || t < n) {
             const double lv = s_row[block_code(cur, j) * R_W + R_LLR];
             S.mL = S.mL + (((wl >> j) & 1u) ? lv : big_neg); // psum[i+1] = psum[i] + maa3[i]
-            if (STEADY || t >= c) {                           // same chain, c steps later
-                const double lo = s_row[block_code(tcur, j) * R_W + R_LLR];
-                S.mT = S.mT + (((tv >> j) & 1u) ? lo : big_neg);
-            }
-            if (STEADY || t + 1 >= c) {
-                const bool first = !STEADY && t + 1 == c;
-                const double d = first ? S.mL : S.mL - S.mT;
-                const bool upd = first || d > S.best; // strict >: the first window wins ties
-                S.best = upd ? d : S.best;
-                S.bstart = upd ? (int)(t + 1 - c) : S.bstart;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (STEADY || t >= c[k]) { // same chain, c steps later
+                    const double lo = s_row[block_code(tcur[k], j) * R_W + R_LLR];
+                    S.mT[k] = S.mT[k] + (((tv[k] >> j) & 1u) ? lo : big_neg);
+                }
+                if (STEADY || t + 1 >= c[k]) {
+                    const bool first = !STEADY && t + 1 == c[k];
+                    const double d = first ? S.mL : S.mL - S.mT[k];
+                    const bool upd = first || d > S.best[k]; // strict >: the first window wins ties
+                    S.best[k] = upd ? d : S.best[k];
+                    S.bstart[k] = upd ? (int)(t + 1 - c[k]) : S.bstart[k];
+                }
             }
         }
     }
 }
 
-template <bool TRACKS>
+template <bool TRACKS, int NC>
 __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
                                                     const uint32_t *__restrict__ grow, uint32_t *__restrict__ bits,
-                                                    plaac_row *__restrict__ rows, TrackPtrs tr) {
+                                                    SweepTargets tg, TrackPtrs tr) {
     __shared__ double s_row[ROWS * R_W];
     load_rows(s_row, T);
     __syncthreads();
@@ -424,10 +439,13 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     const uint32_t n = J.n;
     set_wave_priority(n);
     if (blockIdx.x * KA_THREADS + threadIdx.x >= nprot) return;
-    plaac_row *row = rows + J.p;
     if (n == 0) { // skipped record (:762): zero the fields this kernel owns
-        row->core_score = row->prd_score = row->hmm_vit = 0.0;
-        row->vit_maxrun = row->core_start = row->core_end = row->prd_start = row->prd_end = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            plaac_row *row = tg.rows[k] + J.p;
+            row->core_score = row->prd_score = row->hmm_vit = 0.0;
+            row->vit_maxrun = row->core_start = row->core_end = row->prd_start = row->prd_end = 0;
+        }
         return;
     }
     const uint8_t *__restrict__ x = codes + J.off;
@@ -439,7 +457,9 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     const double lt00 = T->lt[0][0], lt01 = T->lt[0][1], lt10 = T->lt[1][0], lt11 = T->lt[1][1];
     const double lf0 = T->lf[0], lf1 = T->lf[1];
     const double h0lt = T->h0_lt00;
-    const uint32_t c = (uint32_t)T->corelength;
+    uint32_t c[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) c[k] = tg.c[k];
 
     // ---------------- sweep 1: t = 0 .. n-1 ----------------
     VitState V;
@@ -464,7 +484,11 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     // end of Viterbi (:3102-3109)
     const double vend0 = V.s0 + lf0, vend1 = V.s1 + lf1;
     uint32_t state = vend1 > vend0 ? 1u : 0u;
-    row->hmm_vit = (state ? vend1 : vend0) - (V.h0 + T->h0_lf0);
+    {
+        const double hv = (state ? vend1 : vend0) - (V.h0 + T->h0_lf0);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) tg.rows[k][J.p].hmm_vit = hv;
+    }
 
     // ---------------- sweep 2: traceback t = n-1 .. 0 (:3111-3113), longest run ----------------
     {
@@ -479,63 +503,92 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
                                                 : traceback_block<true, TRACKS>(state, cur, maxrun, word, t0, n, vit_out);
             PL.set_word(wi, vw); // this word now holds vit[16*wi .. 16*wi+15]
         }
-        row->vit_maxrun = maxrun;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) tg.rows[k][J.p].vit_maxrun = maxrun;
     }
 
-    // ---------------- sweep 3: masked core window (:818-833) ----------------
-    CoreState C{0.0, 0.0, -INFINITY, -1};
+    // ---------------- sweep 3: masked core window(s) (:818-833) ----------------
+    CoreState<NC> C;
+    C.mL = 0.0;
+    uint32_t cmax = 0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        C.mT[k] = 0.0;
+        C.best[k] = -INFINITY;
+        C.bstart[k] = -1;
+        cmax = c[k] > cmax ? c[k] : cmax;
+    }
     const double big_neg = T->big_neg;
     {
-        // lead stream: residues + path bits of block t0; trailing stream: the same, c steps later, i.e. the
-        // 16 positions s .. s+15 with s = t0 - c. Both are fetched one block ahead.
-        uint4 nxt = PL.chunk(0), tnxt = make_uint4(0u, 0u, 0u, 0u);
-        uint32_t wlnext = PL.word(0), plo = 0u, phi = 0u;
-        auto prefetch_trail = [&](int s) { // block starting at position s (>= -15) of this protein
-            tnxt = PL.window(s);
+        // lead stream: residues + path bits of block t0; trailing stream k: the same, c[k] steps later, i.e. the
+        // 16 positions s .. s+15 with s = t0 - c[k]. All are fetched one block ahead.
+        uint4 nxt = PL.chunk(0), tnxt[NC];
+        uint32_t wlnext = PL.word(0), plo[NC], phi[NC];
+        auto prefetch_trail = [&](int k, int s) { // block starting at position s (>= -15) of this protein
+            tnxt[k] = PL.window(s);
             const uint32_t w0 = s >= 0 ? (uint32_t)s >> 4 : 0u;
-            plo = PL.word(w0);
-            phi = (s >= 0 && w0 + 1u < nw) ? PL.word(w0 + 1u) : 0u;
+            plo[k] = PL.word(w0);
+            phi[k] = (s >= 0 && w0 + 1u < nw) ? PL.word(w0 + 1u) : 0u;
         };
-        if (15 >= (int)c) prefetch_trail(-(int)c);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            tnxt[k] = make_uint4(0u, 0u, 0u, 0u);
+            plo[k] = phi[k] = 0u;
+            if (15 >= (int)c[k]) prefetch_trail(k, -(int)c[k]);
+        }
         for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
-            const uint4 cur = nxt, tcur = tnxt;
+            const uint4 cur = nxt;
+            uint4 tcur[NC];
+            uint32_t tv[NC];
             const uint32_t wl = wlnext;
-            const int s = (int)t0 - (int)c;
-            const uint32_t tv = s >= 0 ? ((plo | (phi << 16)) >> (s & 15)) : (s > -16 ? (plo << (-s)) : 0u);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                tcur[k] = tnxt[k];
+                const int s = (int)t0 - (int)c[k];
+                tv[k] = s >= 0 ? ((plo[k] | (phi[k] << 16)) >> (s & 15)) : (s > -16 ? (plo[k] << (-s)) : 0u);
+            }
             if (t0 + 16u < n) {
                 nxt = PL.chunk((t0 >> 4) + 1u);
                 wlnext = PL.word((t0 >> 4) + 1u);
-                if (s + 31 >= 0) prefetch_trail(s + 16);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const int s = (int)t0 - (int)c[k];
+                    if (s + 31 >= 0) prefetch_trail(k, s + 16);
+                }
             }
             const bool full = t0 + 16u <= n;
-            if (t0 >= c) { // wave-uniform
-                if (full) core_block<false, true>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
-                else core_block<true, true>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
+            if (t0 >= cmax) { // wave-uniform
+                if (full) core_block<false, true, NC>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
+                else core_block<true, true, NC>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
             } else {
-                core_block<true, false>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
+                core_block<true, false, NC>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
             }
         }
     }
-    if (C.best > big_neg / 2) { // :861 — a core exists; expand it to the whole Viterbi run (:863-866)
-        auto bit = [&](int q) { return (PL.word((uint32_t)q >> 4) >> (q & 15)) & 1u; };
-        int a = C.bstart, z = C.bstart + (int)c - 1;
-        while (a > 0 && bit(a - 1)) --a;
-        while (z + 1 < (int)n && bit(z + 1)) ++z;
-        double prd = 0.0; // PRDscore: left-to-right sum over the run (:870-872)
-        for (int k = a; k <= z; ++k) prd = prd + s_row[ld_code(x, (uint32_t)k) * R_W + R_LLR];
-        row->core_score = C.best;
-        row->core_start = C.bstart;
-        row->core_end = C.bstart + (int)c - 1;
-        row->prd_score = prd;
-        row->prd_start = a;
-        row->prd_end = z;
-    } else { // :873-880
-        row->core_score = __builtin_nan("");
-        row->core_start = -1;
-        row->core_end = -2;
-        row->prd_score = 0.0;
-        row->prd_start = -1;
-        row->prd_end = -2;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        plaac_row *row = tg.rows[k] + J.p;
+        if (C.best[k] > big_neg / 2) { // :861 — a core exists; expand it to the whole Viterbi run (:863-866)
+            auto bit = [&](int q) { return (PL.word((uint32_t)q >> 4) >> (q & 15)) & 1u; };
+            int a = C.bstart[k], z = C.bstart[k] + (int)c[k] - 1;
+            while (a > 0 && bit(a - 1)) --a;
+            while (z + 1 < (int)n && bit(z + 1)) ++z;
+            double prd = 0.0; // PRDscore: left-to-right sum over the run (:870-872)
+            for (int q = a; q <= z; ++q) prd = prd + s_row[ld_code(x, (uint32_t)q) * R_W + R_LLR];
+            row->core_score = C.best[k];
+            row->core_start = C.bstart[k];
+            row->core_end = C.bstart[k] + (int)c[k] - 1;
+            row->prd_score = prd;
+            row->prd_start = a;
+            row->prd_end = z;
+        } else { // :873-880
+            row->core_score = __builtin_nan("");
+            row->core_start = -1;
+            row->core_end = -2;
+            row->prd_score = 0.0;
+            row->prd_start = -1;
+            row->prd_end = -2;
+        }
     }
 }
 
@@ -657,18 +710,21 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
 
 // ---- role W: MW (:767-771) and LLR (:782-783) windows over prefix sums (hss2 :1206-1257 with
 //      min == max), mean hydropathy / charge / FoldIndex (:4877-4885) ----
+template <int NC>
 struct WinState {
-    double hydsum, psL, psT, llrbest;
-    int chg, cntL, cntT, mwbest, mwstart, llrstart;
+    double hydsum, psL;
+    double psT[NC], llrbest[NC];
+    int chg, cntL, cntT, mwbest, mwstart;
+    int llrstart[NC];
 };
 
 __device__ __forceinline__ int is_nq(uint32_t c) { return (c == 12u || c == 14u) ? 1 : 0; }
 
-// STEADY: the whole block has t >= max(c, 80): both trailing streams run and every step closes both windows
-template <bool GUARD, bool STEADY>
-__device__ __forceinline__ void win_block(WinState &S, const double *__restrict__ s_row, const uint4 cur,
-                                          const uint4 ccur, const uint4 mcur, uint32_t t0, uint32_t n, uint32_t c,
-                                          uint32_t mw) {
+// STEADY: the whole block has t >= max(c, 80): all trailing streams run and every step closes every window
+template <bool GUARD, bool STEADY, int NC>
+__device__ __forceinline__ void win_block(WinState<NC> &S, const double *__restrict__ s_row, const uint4 cur,
+                                          const uint4 (&ccur)[NC], const uint4 mcur, uint32_t t0, uint32_t n,
+                                          const uint32_t (&c)[NC], uint32_t mw) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t t = t0 + (uint32_t)j;
@@ -690,27 +746,31 @@ __device__ __forceinline__ void win_block(WinState &S, const double *__restrict_
                 S.mwbest = upd ? d : S.mwbest;
                 S.mwstart = upd ? (int)(t + 1 - mw) : S.mwstart;
             }
-            // psum[i+1] = psum[i] + llr[x_i]; the trailing prefix sum is the same chain c steps later
+            // psum[i+1] = psum[i] + llr[x_i]; each trailing prefix sum is the same chain c steps later
             S.psL = S.psL + r[R_LLR];
-            if (STEADY || t >= c) S.psT = S.psT + s_row[block_code(ccur, j) * R_W + R_LLR];
-            if (STEADY || t + 1 >= c) {
-                const bool first = !STEADY && t + 1 == c;
-                const double d = first ? S.psL : S.psL - S.psT;
-                const bool upd = first || d > S.llrbest;
-                S.llrbest = upd ? d : S.llrbest;
-                S.llrstart = upd ? (int)(t + 1 - c) : S.llrstart;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (STEADY || t >= c[k]) S.psT[k] = S.psT[k] + s_row[block_code(ccur[k], j) * R_W + R_LLR];
+                if (STEADY || t + 1 >= c[k]) {
+                    const bool first = !STEADY && t + 1 == c[k];
+                    const double d = first ? S.psL : S.psL - S.psT[k];
+                    const bool upd = first || d > S.llrbest[k];
+                    S.llrbest[k] = upd ? d : S.llrbest[k];
+                    S.llrstart[k] = upd ? (int)(t + 1 - c[k]) : S.llrstart[k];
+                }
             }
         }
     }
 }
 
+template <int NC>
 __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
                                                     const uint32_t *__restrict__ order, uint32_t nprot,
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
-                                                    const uint32_t *__restrict__ grow, plaac_row *__restrict__ rows) {
+                                                    const uint32_t *__restrict__ grow, SweepTargets tg) {
     __shared__ double s_row[ROWS * R_W];
     load_rows(s_row, T);
     __syncthreads();
@@ -718,50 +778,99 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
     const uint32_t n = J.n;
     set_wave_priority(n);
     if (blockIdx.x * KA_THREADS + threadIdx.x >= nprot) return;
-    plaac_row *row = rows + J.p;
     if (n == 0) {
-        row->llr_score = row->fi_meanhydro = row->fi_meancharge = row->fi_meancombo = 0.0;
-        row->mw_score = row->mw_start = row->mw_end = row->llr_start = row->llr_end = 0;
-        row->prot_len = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            plaac_row *row = tg.rows[k] + J.p;
+            row->llr_score = row->fi_meanhydro = row->fi_meancharge = row->fi_meancombo = 0.0;
+            row->mw_score = row->mw_start = row->mw_end = row->llr_start = row->llr_end = 0;
+            row->prot_len = 0;
+        }
         return;
     }
     const PackedLane PL = packed_lane(packed, nullptr, grow);
-    const uint32_t c = (uint32_t)T->corelength;
+    uint32_t c[NC];
+    uint32_t steady_from = 80u;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        c[k] = tg.c[k];
+        steady_from = c[k] > steady_from ? c[k] : steady_from;
+    }
     const uint32_t mw = n < 80u ? n : 80u; // :769-770 (a protein shorter than 80 has a single window)
-    const uint32_t steady_from = c > 80u ? c : 80u;
 
-    WinState W{0.0, 0.0, 0.0, -INFINITY, 0, 0, 0, 0, 0, -1};
-    // three phase-locked streams: residues at t, at t - c (LLR window) and at t - 80 (MW window)
-    uint4 nxt = PL.chunk(0), cnxt = make_uint4(0u, 0u, 0u, 0u), mnxt = cnxt;
-    if (15 >= (int)c) cnxt = PL.window(-(int)c);
+    WinState<NC> W;
+    W.hydsum = W.psL = 0.0;
+    W.chg = W.cntL = W.cntT = W.mwbest = W.mwstart = 0;
+    // phase-locked streams: residues at t, at t - c[k] (LLR windows) and at t - 80 (MW window)
+    uint4 nxt = PL.chunk(0), cnxt[NC], mnxt = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        W.psT[k] = 0.0;
+        W.llrbest[k] = -INFINITY;
+        W.llrstart[k] = -1;
+        cnxt[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (15 >= (int)c[k]) cnxt[k] = PL.window(-(int)c[k]);
+    }
     for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
-        const uint4 cur = nxt, ccur = cnxt, mcur = mnxt;
+        const uint4 cur = nxt, mcur = mnxt;
+        uint4 ccur[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) ccur[k] = cnxt[k];
         if (t0 + 16u < n) {
             nxt = PL.chunk((t0 >> 4) + 1u);
-            const int sc = (int)t0 + 16 - (int)c, sm = (int)t0 + 16 - 80;
-            if (sc + 15 >= 0) cnxt = PL.window(sc);
+            const int sm = (int)t0 + 16 - 80;
             if (sm + 15 >= 0) mnxt = PL.window(sm);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int sc = (int)t0 + 16 - (int)c[k];
+                if (sc + 15 >= 0) cnxt[k] = PL.window(sc);
+            }
         }
         const bool full = t0 + 16u <= n;
         if (t0 >= steady_from) { // wave-uniform
-            if (full) win_block<false, true>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
-            else win_block<true, true>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
+            if (full) win_block<false, true, NC>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
+            else win_block<true, true, NC>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
         } else {
-            win_block<true, false>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
+            win_block<true, false, NC>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
         }
     }
-    row->prot_len = (int32_t)n;
-    row->mw_score = W.mwbest;
-    row->mw_start = W.mwstart;
-    row->mw_end = W.mwstart + (int)mw - 1;
-    row->llr_score = W.llrbest;
-    row->llr_start = W.llrstart;
-    row->llr_end = W.llrstart < 0 ? -2 : W.llrstart + (int)c - 1;
     const double meanhydro = (1.0 * W.hydsum) / (double)(int)n;
     const double meancharge = (1.0 * (double)W.chg) / (double)(int)n;
-    row->fi_meanhydro = meanhydro;
-    row->fi_meancharge = meancharge;
-    row->fi_meancombo = (T->cc[2] + T->cc[1] * fabs(meancharge)) + T->cc[0] * meanhydro; // :4885
+    const double meanfi = (T->cc[2] + T->cc[1] * fabs(meancharge)) + T->cc[0] * meanhydro; // :4885
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        plaac_row *row = tg.rows[k] + J.p;
+        row->prot_len = (int32_t)n;
+        row->mw_score = W.mwbest;
+        row->mw_start = W.mwstart;
+        row->mw_end = W.mwstart + (int)mw - 1;
+        row->llr_score = W.llrbest[k];
+        row->llr_start = W.llrstart[k];
+        row->llr_end = W.llrstart[k] < 0 ? -2 : W.llrstart[k] + (int)c[k] - 1;
+        row->fi_meanhydro = meanhydro;
+        row->fi_meancharge = meancharge;
+        row->fi_meancombo = meanfi;
+    }
+}
+
+// copies the fields that do not depend on the core length (k_fwd's and K-B's) from the first row array of a
+// sweep group to the other core lengths' row arrays
+__global__ void k_replicate(const plaac_row *__restrict__ src, SweepTargets tg, int ndst, uint32_t nprot) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprot) return;
+    const plaac_row r = src[p];
+    for (int k = 1; k <= ndst; ++k) {
+        plaac_row *d = tg.rows[k] + p;
+        d->hmm_all = r.hmm_all;
+        d->papa_combo = r.papa_combo;
+        d->papa_prop = r.papa_prop;
+        d->papa_fi = r.papa_fi;
+        d->papa_llr = r.papa_llr;
+        d->papa_llr2 = r.papa_llr2;
+        d->fi_numaa = r.fi_numaa;
+        d->fi_maxrun = r.fi_maxrun;
+        d->papa_cen = r.papa_cen;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1466,7 +1575,11 @@ struct plaac_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevTables *d_tab = nullptr;
+    DevTables *d_tab = nullptr;   // tables of ctx->params
+    DevTables *d_tabs = nullptr;  // tables of the groups of a sweep
+    size_t cap_tabs = 0;
+    std::vector<hipEvent_t> gev;  // per-group "forward pass done" events of a sweep
+    hipEvent_t jev[3] = {nullptr, nullptr, nullptr}; // join events of the three side streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
     uint32_t *d_neff = nullptr, *d_order = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
@@ -1628,6 +1741,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         for (auto &a : ctx->aux)
             if ((e = hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest)) != hipSuccess)
                 return bail("hipStreamCreateWithPriority", e);
+        for (auto &je : ctx->jev)
+            if ((e = hipEventCreateWithFlags(&je, hipEventDisableTiming)) != hipSuccess)
+                return bail("hipEventCreate", e);
         const char *ser = std::getenv("PLAAC_SERIAL_STREAMS");
         ctx->serial = ser && ser[0] == '1';
         const char *gen = std::getenv("PLAAC_GENERIC_TRACKS");
@@ -1689,6 +1805,11 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
             (void)hipStreamSynchronize(a);
             (void)hipStreamDestroy(a);
         }
+    for (hipEvent_t e : ctx->gev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->jev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->d_tabs) (void)hipFree(ctx->d_tabs);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1700,13 +1821,22 @@ plaac_status plaac_ctx_sync(plaac_ctx *ctx) {
     return PLAAC_OK;
 }
 
-plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,
-                                uint64_t total_residues, plaac_row *d_rows, const plaac_tracks *d_tracks,
-                                void *stream_) {
-    if (!ctx) return PLAAC_ERR_ARG;
-    if (nprot == 0) return PLAAC_OK;
-    if (!d_offsets || !d_rows || (!d_codes && total_residues)) return fail(ctx, PLAAC_ERR_ARG, "null device buffer");
+// One planned pass over a resident batch for `npoints` parameter sets (npoints == 1: the ordinary call).
+// Points whose tables differ only in the core length form a group: the plan, the packed copy, the forward pass,
+// the window tracks and Viterbi + traceback run once per group; only the two prefix-sum window searches run per
+// core length (inside the same kernels, up to MAXC at a time).
+static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,
+                                 uint64_t total_residues, const plaac_params *points, uint32_t npoints,
+                                 plaac_row *const *d_rows, const plaac_tracks *d_tracks, void *stream_) {
+    if (nprot == 0 || npoints == 0) return PLAAC_OK;
+    if (!d_offsets || !d_rows || !points || (!d_codes && total_residues))
+        return fail(ctx, PLAAC_ERR_ARG, "null device buffer");
     if ((uintptr_t)d_codes & 15u) return fail(ctx, PLAAC_ERR_ARG, "d_codes must be 16-byte aligned");
+    if (d_tracks && npoints != 1) return fail(ctx, PLAAC_ERR_ARG, "tracks are not available in sweeps");
+    for (uint32_t i = 0; i < npoints; ++i) {
+        if (!d_rows[i]) return fail(ctx, PLAAC_ERR_ARG, "null row array");
+        if (const char *why = check_params(points[i])) return fail(ctx, PLAAC_ERR_ARG, why);
+    }
     TrackPtrs tp{};
     if (d_tracks) {
         tp = TrackPtrs{d_tracks->vit,   d_tracks->map,  d_tracks->charge,     d_tracks->hydro,
@@ -1720,6 +1850,27 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     PL_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
 
+    // ---- group the points: same tables up to the core length
+    struct Group {
+        uint32_t first;
+        std::vector<uint32_t> members;
+    };
+    std::vector<Group> groups;
+    for (uint32_t i = 0; i < npoints; ++i) {
+        bool placed = false;
+        for (Group &g : groups) {
+            plaac_params a = points[g.first], b = points[i];
+            a.corelength = b.corelength = 0;
+            if (std::memcmp(&a, &b, sizeof a) == 0) {
+                g.members.push_back(i);
+                placed = true;
+                break;
+            }
+        }
+        if (!placed) groups.push_back(Group{i, {i}});
+    }
+    const size_t ng = groups.size();
+
     plaac_status rc;
     if ((rc = grow(ctx, ctx->d_neff, ctx->cap_prot, (size_t)nprot)) != PLAAC_OK) return rc;
     if ((rc = grow(ctx, ctx->d_order, ctx->cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
@@ -1727,39 +1878,56 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 1)) != PLAAC_OK) return rc;
     if (d_tracks)
         if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, (size_t)(2 * total_residues + 2))) != PLAAC_OK) return rc;
-
-    const int wmax = std::max(ctx->params.ww1 / 2, std::max(ctx->params.ww2 / 2, ctx->params.ww3 / 2));
+    // device tables: slot 0 keeps the ctx parameters (single-point calls), sweep groups use slots 1..ng
+    const DevTables *gtab0 = ctx->d_tab;
+    if (!(npoints == 1 && std::memcmp(&points[0], &ctx->params, sizeof(plaac_params)) == 0)) {
+        if ((rc = grow(ctx, ctx->d_tabs, ctx->cap_tabs, ng)) != PLAAC_OK) return rc;
+        std::vector<DevTables> host(ng);
+        for (size_t g = 0; g < ng; ++g) fill_tables(points[groups[g].first], host[g]);
+        PL_HIP(ctx, hipMemcpyAsync(ctx->d_tabs, host.data(), sizeof(DevTables) * ng, hipMemcpyHostToDevice, st));
+        PL_HIP(ctx, hipStreamSynchronize(st)); // `host` is a temporary
+        gtab0 = ctx->d_tabs;
+    }
+    while (ctx->gev.size() < ng) {
+        hipEvent_t e = nullptr;
+        PL_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->gev.push_back(e);
+    }
 
     hipEvent_t *evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
     enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10, E_PACK = 11 };
     hipStream_t sv = ctx->serial ? st : ctx->aux[0], sf = ctx->serial ? st : ctx->aux[1],
                 sw = ctx->serial ? st : ctx->aux[2];
-    const bool fast20 = ctx->params.ww1 / 2 == TW && ctx->params.ww2 / 2 == TW && ctx->params.ww3 / 2 == TW &&
-                        !ctx->generic_tracks;
-    auto launch_tracks = [&]() -> plaac_status { // K-B: needs only the order, not the packed copy
-        PL_HIP(ctx, hipEventRecord(evs[E_TRK], st));
+
+    auto launch_tracks = [&](size_t g) -> plaac_status { // K-B: needs only the order, not the packed copy
+        const plaac_params &P = points[groups[g].first];
+        const DevTables *tab = gtab0 + g;
+        plaac_row *rows = d_rows[groups[g].first];
+        const int wmax = std::max(P.ww1 / 2, std::max(P.ww2 / 2, P.ww3 / 2));
+        const bool fast20 = P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && !ctx->generic_tracks;
+        if (g == 0) PL_HIP(ctx, hipEventRecord(evs[E_TRK], st));
 #define LAUNCH_KB(RING)                                                                                            \
     do {                                                                                                           \
         if (d_tracks)                                                                                              \
             hipLaunchKernelGGL((k_tracks<RING, true>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,           \
-                               ctx->d_neff, ctx->d_order, nprot, ctx->d_tab, d_rows, tp);                          \
+                               ctx->d_neff, ctx->d_order, nprot, tab, rows, tp);                                   \
         else                                                                                                       \
             hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,          \
-                               ctx->d_neff, ctx->d_order, nprot, ctx->d_tab, d_rows, tp);                          \
+                               ctx->d_neff, ctx->d_order, nprot, tab, rows, tp);                                   \
     } while (0)
         if (fast20) {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
             if (d_tracks)
                 hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
+                                   ctx->d_order, nprot, total_residues, tab, rows, tp);
             else
                 hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, ctx->d_tab, d_rows, tp);
+                                   ctx->d_order, nprot, total_residues, tab, rows, tp);
         } else if (wmax <= 32) LAUNCH_KB(128);
         else if (wmax <= 96) LAUNCH_KB(256);
         else LAUNCH_KB(1024);
 #undef LAUNCH_KB
-        PL_HIP(ctx, hipEventRecord(evs[E_TRK + 1], st));
+        if (g == 0) PL_HIP(ctx, hipEventRecord(evs[E_TRK + 1], st));
         return PLAAC_OK;
     };
 
@@ -1774,7 +1942,7 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     // so the long serial chains (which set the wall time) overlap each other and the throughput-bound window
     // kernel. K-B starts right away on the caller's stream; the packing of the K-A input runs beside it.
     if (!ctx->serial) {
-        if ((rc = launch_tracks()) != PLAAC_OK) return rc;
+        if ((rc = launch_tracks(0)) != PLAAC_OK) return rc;
         PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PLAN], 0));
     }
     // group rows of the interleaved copy; their total is the one value the host needs back (buffer sizes)
@@ -1793,36 +1961,111 @@ plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const ui
     if (!ctx->serial)
         for (hipStream_t a : {sf, sw}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
     const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
-    PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
-    if (d_tracks)
-        hipLaunchKernelGGL(k_vit<true>, dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, ctx->d_tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, d_rows, tp);
-    else
-        hipLaunchKernelGGL(k_vit<false>, dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, ctx->d_tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, d_rows, tp);
-    PL_HIP(ctx, hipEventRecord(evs[E_VIT + 1], sv));
-    PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
-    if (d_tracks)
-        hipLaunchKernelGGL(k_fwd<true>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, ctx->d_tab, ctx->d_packed, ctx->d_grow, d_rows, tp, ctx->d_fwd);
-    else
-        hipLaunchKernelGGL(k_fwd<false>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order, nprot, ctx->d_tab, ctx->d_packed, ctx->d_grow, d_rows, tp,
-                           (double *)nullptr);
-    PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
-    PL_HIP(ctx, hipEventRecord(evs[E_WIN], sw));
-    hipLaunchKernelGGL(k_win, dim3(ab), dim3(KA_THREADS), 0, sw, d_codes, d_offsets, ctx->d_neff, ctx->d_order, nprot,
-                       ctx->d_tab, ctx->d_packed, ctx->d_grow, d_rows);
-    PL_HIP(ctx, hipEventRecord(evs[E_WIN + 1], sw));
-    if (ctx->serial) {
-        if ((rc = launch_tracks()) != PLAAC_OK) return rc;
-    } else {
-        for (int done : {E_VIT + 1, E_FWD + 1, E_WIN + 1}) PL_HIP(ctx, hipStreamWaitEvent(st, evs[done], 0));
+
+    for (size_t g = 0; g < ng; ++g) {
+        const Group &G = groups[g];
+        const DevTables *tab = gtab0 + g;
+        plaac_row *rows0 = d_rows[G.first];
+        const bool timed = g == 0;
+        // K-B of this group (group 0 was launched before the host round trip; serialised mode launches it last)
+        if (g > 0 && !ctx->serial) {
+            if ((rc = launch_tracks(g)) != PLAAC_OK) return rc;
+        }
+        // forward pass: once per group
+        if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
+        if (d_tracks)
+            hipLaunchKernelGGL(k_fwd<true>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
+                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, tp, ctx->d_fwd);
+        else
+            hipLaunchKernelGGL(k_fwd<false>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
+                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, tp, (double *)nullptr);
+        if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
+        // Viterbi / windows: up to MAXC core lengths per launch
+        for (size_t m0 = 0; m0 < G.members.size(); m0 += MAXC) {
+            const int nc = (int)std::min<size_t>(MAXC, G.members.size() - m0);
+            SweepTargets tg{};
+            for (int k = 0; k < MAXC; ++k) {
+                const uint32_t idx = G.members[m0 + (size_t)std::min(k, nc - 1)];
+                tg.c[k] = (uint32_t)points[idx].corelength;
+                tg.rows[k] = d_rows[idx];
+            }
+            const bool t0 = timed && m0 == 0;
+            if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
+#define LAUNCH_VIT(NC)                                                                                             \
+    do {                                                                                                           \
+        if (d_tracks)                                                                                              \
+            hipLaunchKernelGGL((k_vit<true, NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,           \
+                               ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, tg, \
+                               tp);                                                                                \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_vit<false, NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,          \
+                               ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, tg, \
+                               tp);                                                                                \
+    } while (0)
+            switch (nc) {
+            case 1: LAUNCH_VIT(1); break;
+            case 2: LAUNCH_VIT(2); break;
+            case 3: LAUNCH_VIT(3); break;
+            default: LAUNCH_VIT(4); break;
+            }
+#undef LAUNCH_VIT
+            if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT + 1], sv));
+            if (t0) PL_HIP(ctx, hipEventRecord(evs[E_WIN], sw));
+#define LAUNCH_WIN(NC)                                                                                             \
+    hipLaunchKernelGGL((k_win<NC>), dim3(ab), dim3(KA_THREADS), 0, sw, d_codes, d_offsets, ctx->d_neff, ctx->d_order, \
+                       nprot, tab, ctx->d_packed, ctx->d_grow, tg)
+            switch (nc) {
+            case 1: LAUNCH_WIN(1); break;
+            case 2: LAUNCH_WIN(2); break;
+            case 3: LAUNCH_WIN(3); break;
+            default: LAUNCH_WIN(4); break;
+            }
+#undef LAUNCH_WIN
+            if (t0) PL_HIP(ctx, hipEventRecord(evs[E_WIN + 1], sw));
+        }
+        if (ctx->serial) {
+            if ((rc = launch_tracks(g)) != PLAAC_OK) return rc;
+        }
+        // fields that do not depend on the core length: copy from the group's first row array to the others
+        if (G.members.size() > 1) {
+            if (!ctx->serial) {
+                PL_HIP(ctx, hipEventRecord(ctx->gev[g], sf));
+                PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gev[g], 0));
+            }
+            for (size_t m0 = 1; m0 < G.members.size(); m0 += MAXC - 1) {
+                const int nd = (int)std::min<size_t>(MAXC - 1, G.members.size() - m0);
+                SweepTargets tg{};
+                for (int k = 1; k <= nd; ++k) tg.rows[k] = d_rows[G.members[m0 + (size_t)k - 1]];
+                hipLaunchKernelGGL(k_replicate, dim3(pb), dim3(256), 0, st, rows0, tg, nd, nprot);
+            }
+        }
+    }
+    if (!ctx->serial) {
+        // join: everything enqueued on the side streams so far
+        PL_HIP(ctx, hipEventRecord(ctx->jev[0], sv));
+        PL_HIP(ctx, hipEventRecord(ctx->jev[1], sf));
+        PL_HIP(ctx, hipEventRecord(ctx->jev[2], sw));
+        for (hipEvent_t e : ctx->jev) PL_HIP(ctx, hipStreamWaitEvent(st, e, 0));
     }
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->ncalls++;
     return PLAAC_OK;
+}
+
+plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,
+                                uint64_t total_residues, plaac_row *d_rows, const plaac_tracks *d_tracks,
+                                void *stream_) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    plaac_row *rows1[1] = {d_rows};
+    return score_points(ctx, d_codes, d_offsets, nprot, total_residues, &ctx->params, 1, rows1, d_tracks, stream_);
+}
+
+plaac_status plaac_score_sweep_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
+                                      uint32_t nprot, uint64_t total_residues, const plaac_params *points,
+                                      uint32_t npoints, plaac_row *const *d_rows, void *stream_) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    return score_points(ctx, d_codes, d_offsets, nprot, total_residues, points, npoints, d_rows, nullptr, stream_);
 }
 
 plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
@@ -2021,6 +2264,29 @@ plaac_status plaac_batch_score(plaac_batch *b, plaac_row *rows, const plaac_trac
     if (!rows) return fail(ctx, PLAAC_ERR_ARG, "null rows");
     PL_HIP(ctx, hipSetDevice(ctx->device));
     return score_resident_to_host(ctx, b->d_codes, b->d_offsets, b->nprot, b->total, rows, tracks);
+}
+
+plaac_status plaac_batch_sweep(plaac_batch *b, const plaac_params *points, uint32_t npoints, plaac_row *const *rows) {
+    if (!b || !b->ctx) return PLAAC_ERR_ARG;
+    plaac_ctx *ctx = b->ctx;
+    if (b->nprot == 0 || npoints == 0) return PLAAC_OK;
+    if (!points || !rows) return fail(ctx, PLAAC_ERR_ARG, "null argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    plaac_status rc;
+    if ((rc = grow(ctx, ctx->d_rows, ctx->cap_rows, (size_t)b->nprot * npoints)) != PLAAC_OK) return rc;
+    std::vector<plaac_row *> drows(npoints);
+    for (uint32_t i = 0; i < npoints; ++i) {
+        if (!rows[i]) return fail(ctx, PLAAC_ERR_ARG, "null row array");
+        drows[i] = ctx->d_rows + (size_t)i * b->nprot;
+    }
+    rc = score_points(ctx, b->d_codes, b->d_offsets, b->nprot, b->total, points, npoints, drows.data(), nullptr,
+                      ctx->stream);
+    if (rc != PLAAC_OK) return rc;
+    for (uint32_t i = 0; i < npoints; ++i)
+        PL_HIP(ctx, hipMemcpyAsync(rows[i], drows[i], sizeof(plaac_row) * (size_t)b->nprot, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PLAAC_OK;
 }
 
 void plaac_batch_free(plaac_batch *b) {

@@ -68,7 +68,7 @@ EXPORTS = (
     "plaac_encode", "plaac_ctx_create", "plaac_ctx_set_params", "plaac_ctx_destroy", "plaac_last_error",
     "plaac_histogram", "plaac_score", "plaac_score_device", "plaac_histogram_device", "plaac_ctx_sync",
     "plaac_last_timings", "plaac_timings_mean", "plaac_batch_upload", "plaac_batch_histogram", "plaac_batch_score",
-    "plaac_batch_free",
+    "plaac_batch_free", "plaac_batch_sweep", "plaac_score_sweep_device",
 )
 
 _lib = None
@@ -123,6 +123,9 @@ def load():
     L.plaac_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.plaac_batch_free.argtypes = [C.c_void_p]
     L.plaac_batch_free.restype = None
+    L.plaac_batch_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.plaac_score_sweep_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
+                                           C.c_uint32, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -240,6 +243,15 @@ class Context:
                                                int(d_rows), None if T is None else C.addressof(T),
                                                None if stream is None else int(stream)))
 
+    def score_sweep_device(self, d_codes, d_offsets, nprot, total, param_sets, d_rows_list, stream=None):
+        """plaac_score_sweep_device: one planned pass for several parameter sets, one device row array each"""
+        param_sets = list(param_sets)
+        pts = (Params * len(param_sets))(*param_sets)
+        ptrs = (C.c_void_p * len(d_rows_list))(*[int(x) for x in d_rows_list])
+        self._check(self._L.plaac_score_sweep_device(self._h, int(d_codes), int(d_offsets), int(nprot), int(total),
+                                                     C.addressof(pts), len(param_sets), C.addressof(ptrs),
+                                                     None if stream is None else int(stream)))
+
     def histogram_device(self, d_codes, d_offsets, nprot, d_counts, stream=None):
         self._check(self._L.plaac_histogram_device(self._h, int(d_codes), int(d_offsets), int(nprot), int(d_counts),
                                                    None if stream is None else int(stream)))
@@ -285,13 +297,22 @@ class Batch:
         self.ctx._check(self.ctx._L.plaac_batch_score(self._h, rows.ctypes.data, tptr))
         return (rows, tr) if tracks else rows
 
-    def sweep(self, param_sets):
-        """score the resident batch under each plaac_params of `param_sets`; returns a list of row arrays"""
-        out = []
-        for P in param_sets:
-            self.ctx.set_params(P)
-            out.append(self.score())
-        return out
+    def sweep(self, param_sets, naive=False):
+        """score the resident batch under each plaac_params of `param_sets`; returns a list of row arrays.
+        Default: plaac_batch_sweep (points differing only in the core length share the passes that do not
+        depend on it). naive=True: one full pass per point (ctx.set_params + score)."""
+        param_sets = list(param_sets)
+        if naive:
+            out = []
+            for P in param_sets:
+                self.ctx.set_params(P)
+                out.append(self.score())
+            return out
+        pts = (Params * len(param_sets))(*param_sets)
+        rows = [np.zeros(self.nprot, dtype=ROW_DTYPE) for _ in param_sets]
+        ptrs = (C.c_void_p * len(rows))(*[r.ctypes.data for r in rows])
+        self.ctx._check(self.ctx._L.plaac_batch_sweep(self._h, C.addressof(pts), len(param_sets), C.addressof(ptrs)))
+        return rows
 
     def close(self):
         if self._h:

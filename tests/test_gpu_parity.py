@@ -262,10 +262,19 @@ def test_resident_batch_histogram_score_and_sweep(native, oracle, ctx):
         assert np.array_equal(counts, oracle.histogram(codes, offs))
         bg = counts.astype(np.float64)
         points = [(a, c) for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)]
-        got = batch.sweep([native.make_params(alpha=a, corelength=c, bgcounts=bg) for a, c in points])
-        for (a, c), rows in zip(points, got):
+        psets = [native.make_params(alpha=a, corelength=c, bgcounts=bg) for a, c in points]
+        got = batch.sweep(psets)                # grouped: shared passes per alpha
+        naive = batch.sweep(psets, naive=True)  # one full pass per point
+        for (a, c), rows, rows_naive in zip(points, got, naive):
             want = oracle.score_batch(oracle.build_params(alpha=a, corelength=c, bgcounts=bg), codes, offs, nthreads=8)
             assert_rows_equal(rows, want, "alpha=%s c=%d" % (a, c))
+            assert rows.tobytes() == rows_naive.tobytes()
+        # more core lengths than one launch carries (MAXC = 4), unsorted, with a duplicate and one > every protein
+        cs = [60, 15, 90, 33, 60, 7, 100000, 45]
+        got = batch.sweep([native.make_params(alpha=0.25, corelength=c, bgcounts=bg) for c in cs])
+        for c, rows in zip(cs, got):
+            want = oracle.score_batch(oracle.build_params(alpha=0.25, corelength=c, bgcounts=bg), codes, offs, nthreads=8)
+            assert_rows_equal(rows, want, "c=%d" % c)
         # the context still works for ordinary calls after handing its staging buffers to the batch
         ctx.set_params(native.make_params())
         assert_rows_equal(ctx.score(codes, offs), oracle.score_batch(oracle.build_params(), codes, offs, nthreads=8))
