@@ -360,9 +360,9 @@ __device__ __forceinline__ uint32_t vit_block(VitState &S, const double *__restr
     return tbw;
 }
 
-template <bool GUARD, bool TRACKS>
+template <bool GUARD>
 __device__ __forceinline__ uint32_t traceback_block(uint32_t &state, int &cur, int &maxrun, uint32_t word,
-                                                    uint32_t t0, uint32_t n, uint8_t *__restrict__ vit_out) {
+                                                    uint32_t t0, uint32_t n) {
     uint32_t vw = 0;
 #pragma unroll
     for (int j = 15; j >= 0; --j) {
@@ -371,7 +371,6 @@ __device__ __forceinline__ uint32_t traceback_block(uint32_t &state, int &cur, i
             vw |= state << j;
             cur = state ? cur + 1 : 0;
             maxrun = cur > maxrun ? cur : maxrun;
-            if (TRACKS) vit_out[t0 + (uint32_t)j] = (uint8_t)state;
             state = (word >> (2 * j + (int)state)) & 1u; // tb[vit[t]][t] = vit[t-1]
         }
     }
@@ -423,7 +422,7 @@ __device__ __forceinline__ void core_block(CoreState<NC> &S, const double *__res
     }
 }
 
-template <bool TRACKS, int NC>
+template <int NC>
 __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
@@ -431,7 +430,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
                                                     const uint32_t *__restrict__ grow, uint32_t *__restrict__ bits,
-                                                    SweepTargets tg, TrackPtrs tr) {
+                                                    SweepTargets tg) {
     __shared__ double s_row[ROWS * R_W];
     load_rows(s_row, T);
     __syncthreads();
@@ -494,13 +493,12 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     {
         int cur = 0, maxrun = 0;
         uint32_t wnext = PL.word(nw - 1u); // traceback words are prefetched one block ahead
-        uint8_t *vit_out = TRACKS ? tr.vit + J.off : nullptr;
         for (uint32_t wi = nw; wi-- > 0u;) {
             const uint32_t word = wnext;
             if (wi > 0u) wnext = PL.word(wi - 1u);
             const uint32_t t0 = wi << 4;
-            const uint32_t vw = (t0 + 16u <= n) ? traceback_block<false, TRACKS>(state, cur, maxrun, word, t0, n, vit_out)
-                                                : traceback_block<true, TRACKS>(state, cur, maxrun, word, t0, n, vit_out);
+            const uint32_t vw = (t0 + 16u <= n) ? traceback_block<false>(state, cur, maxrun, word, t0, n)
+                                                : traceback_block<true>(state, cur, maxrun, word, t0, n);
             PL.set_word(wi, vw); // this word now holds vit[16*wi .. 16*wi+15]
         }
 #pragma unroll
@@ -602,7 +600,7 @@ template <bool GUARD, bool TRACKS>
 __device__ __forceinline__ void fwd_block(FwdState &S, const double *__restrict__ s_row,
                                           const double *__restrict__ s_lut, const uint4 cur, uint32_t t0, uint32_t n,
                                           double lt00, double lt01, double lt10, double lt11, double h0lt, int jfirst,
-                                          double *__restrict__ fwd_out) {
+                                          double2 *__restrict__ fw) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         if (j < jfirst) continue;
@@ -615,10 +613,29 @@ __device__ __forceinline__ void fwd_block(FwdState &S, const double *__restrict_
             S.a0 = f0 + e0;
             S.a1 = f1 + e1;
             S.h0 = (h0lt + S.h0) + eh;
-            if (TRACKS) {
-                fwd_out[2 * (t0 + (uint32_t)j)] = S.a0;
-                fwd_out[2 * (t0 + (uint32_t)j) + 1] = S.a1;
-            }
+            if (TRACKS) fw[(size_t)(t0 + (uint32_t)j) * 64u] = make_double2(S.a0, S.a1);
+        }
+    }
+}
+
+// backward recurrence (:3377-3391) over one block, t = t0+15 .. t0: replaces the stored forward pair a[.][t] by
+// a[.][t] + b[.][t] (what the posterior needs, :3403) and steps b to t-1 with the emission of residue t
+template <bool GUARD>
+__device__ __forceinline__ void bwd_block(double &b0, double &b1, const double *__restrict__ s_row,
+                                          const double *__restrict__ s_lut, const uint4 cur, uint32_t t0, uint32_t n,
+                                          double lt00, double lt01, double lt10, double lt11,
+                                          double2 *__restrict__ fw) {
+#pragma unroll
+    for (int j = 15; j >= 0; --j) {
+        const uint32_t t = t0 + (uint32_t)j;
+        if (!GUARD || t < n) {
+            const double2 a = fw[(size_t)t * 64u];
+            fw[(size_t)t * 64u] = make_double2(a.x + b0, a.y + b1);
+            const double *__restrict__ r = s_row + block_code(cur, j) * R_W;
+            const double u0 = (lt00 + b0) + r[R_LE0], u1 = (lt01 + b1) + r[R_LE1];
+            const double w0 = (lt10 + b0) + r[R_LE0], w1 = (lt11 + b1) + r[R_LE1];
+            b0 = lse_lut(s_lut, u0, u1); // (for t = 0 this steps to "t = -1"; that value is never used)
+            b1 = lse_lut(s_lut, w0, w1);
         }
     }
 }
@@ -631,7 +648,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
                                                     const uint32_t *__restrict__ grow, plaac_row *__restrict__ rows,
-                                                    TrackPtrs tr, double *__restrict__ fwd) {
+                                                    double2 *__restrict__ fwd, double *__restrict__ lpseq_out) {
     __shared__ double s_lut[LUTLEN + 1];
     __shared__ double s_row[ROWS * R_W];
     for (int i = threadIdx.x; i < LUTLEN; i += KA_THREADS) s_lut[i] = T->loglut[i];
@@ -641,19 +658,21 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
     const LaneJob J = lane_job(offsets, neff, order, nprot);
     const uint32_t n = J.n;
     set_wave_priority(n);
-    if (blockIdx.x * KA_THREADS + threadIdx.x >= nprot) return;
+    const uint32_t gid = blockIdx.x * KA_THREADS + threadIdx.x;
+    if (gid >= nprot) return;
     plaac_row *row = rows + J.p;
     if (n == 0) {
         row->hmm_all = 0.0;
+        if (TRACKS) lpseq_out[gid] = 0.0;
         return;
     }
-    const uint8_t *__restrict__ x = codes + J.off;
-    (void)x;
+    (void)codes;
     const PackedLane PL = packed_lane(packed, nullptr, grow);
     const double lt00 = T->lt[0][0], lt01 = T->lt[0][1], lt10 = T->lt[1][0], lt11 = T->lt[1][1];
     const double lf0 = T->lf[0], lf1 = T->lf[1];
     const double h0lt = T->h0_lt00;
-    double *fwd_out = TRACKS ? fwd + 2 * J.off : nullptr;
+    // track mode: forward pairs in the same group-interleaved row numbering as the residues (16 steps per row)
+    double2 *fw = TRACKS ? fwd + ((size_t)grow[gid >> 6] * 16u) * 64u + (gid & 63u) : nullptr;
 
     FwdState F;
     {
@@ -663,47 +682,96 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
             F.a0 = T->li[0] + r[R_LE0];
             F.a1 = T->li[1] + r[R_LE1];
             F.h0 = T->h0_li0 + r[R_LE0H];
-            if (TRACKS) {
-                fwd_out[0] = F.a0;
-                fwd_out[1] = F.a1;
-            }
+            if (TRACKS) fw[0] = make_double2(F.a0, F.a1);
         }
         for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
             const uint4 cur = nxt;
             if (t0 + 16u < n) nxt = PL.chunk((t0 >> 4) + 1u);
-            if (t0 == 0u) fwd_block<true, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 1, fwd_out);
+            if (t0 == 0u) fwd_block<true, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 1, fw);
             else if (t0 + 16u <= n)
-                fwd_block<false, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0, fwd_out);
-            else fwd_block<true, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0, fwd_out);
+                fwd_block<false, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0, fw);
+            else fwd_block<true, TRACKS>(F, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0, fw);
         }
     }
     const double lmarg1 = lse_lut(s_lut, F.a0 + lf0, F.a1 + lf1); // (:3369-3375)
     row->hmm_all = lmarg1 - (F.h0 + T->h0_lf0);
 
     if (TRACKS) {
-        // lpseq needs b[.][0]: one full backward sweep first, then a second one that emits posteriors
-        double q0 = lf0, q1 = lf1;
-        for (uint32_t t = n - 1; t >= 1; --t) {
-            const double *__restrict__ r = s_row + ld_code(x, t) * R_W;
-            const double u0 = (lt00 + q0) + r[R_LE0], u1 = (lt01 + q1) + r[R_LE1];
-            const double w0 = (lt10 + q0) + r[R_LE0], w1 = (lt11 + q1) + r[R_LE1];
-            q0 = lse_lut(s_lut, u0, u1);
-            q1 = lse_lut(s_lut, w0, w1);
-        }
-        const double lpseq = lse_lut(s_lut, fwd_out[0] + q0, fwd_out[1] + q1);
+        // backward sweep; the posteriors themselves (exp, :3403) are position-parallel work: k_post
         double b0 = lf0, b1 = lf1;
-        for (uint32_t t = n - 1;; --t) {
-            const double fa0 = fwd_out[2 * t], fa1 = fwd_out[2 * t + 1];
-            const double pp0 = exp((fa0 + b0) - lpseq), pp1 = exp((fa1 + b1) - lpseq);
-            tr.post0[J.off + t] = pp0;
-            tr.post1[J.off + t] = pp1;
-            tr.map[J.off + t] = pp1 > pp0 ? 1 : 0; // MAP ties -> 0 (:4039)
-            if (t == 0) break;
-            const double *__restrict__ r = s_row + ld_code(x, t) * R_W;
-            const double u0 = (lt00 + b0) + r[R_LE0], u1 = (lt01 + b1) + r[R_LE1];
-            const double w0 = (lt10 + b0) + r[R_LE0], w1 = (lt11 + b1) + r[R_LE1];
-            b0 = lse_lut(s_lut, u0, u1);
-            b1 = lse_lut(s_lut, w0, w1);
+        const uint32_t nw = (n + 15u) >> 4;
+        uint4 nxt = PL.chunk(nw - 1u);
+        for (uint32_t wi = nw; wi-- > 0u;) {
+            const uint4 cur = nxt;
+            if (wi > 0u) nxt = PL.chunk(wi - 1u);
+            const uint32_t t0 = wi << 4;
+            if (t0 + 16u <= n) bwd_block<false>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, fw);
+            else bwd_block<true>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, fw);
+        }
+        const double2 ab = fw[0]; // a[.][0] + b[.][0]
+        lpseq_out[gid] = lse_lut(s_lut, ab.x, ab.y); // lpseq (:3393-3396)
+    }
+}
+
+// ---- posteriors / MAP / Viterbi bytes of track mode (:3403, :4037-4041): position-parallel ----
+// One wave per (wave-group, 32-step tile): reads the interleaved a+b pairs coalesced, takes the exp, transposes
+// through LDS and writes each protein's 32 consecutive values as one contiguous run.
+constexpr int PT = 32; // steps per tile
+__global__ __launch_bounds__(64) void k_post(const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ neff,
+                                              const uint32_t *__restrict__ order, uint32_t nprot,
+                                              const uint32_t *__restrict__ grow, const double2 *__restrict__ fwd,
+                                              const double *__restrict__ lpseq, const uint32_t *__restrict__ bits,
+                                              TrackPtrs tr) {
+    __shared__ double s0[PT][65], s1[PT][65];
+    __shared__ uint8_t sb[PT][64]; // bit 0 = Viterbi state, bit 1 = MAP state
+    __shared__ uint32_t sh_n[64];
+    __shared__ uint64_t sh_off[64];
+    const uint32_t g = blockIdx.x >> 2, sub = blockIdx.x & 3u;
+    const int lane = threadIdx.x;
+    const uint32_t gid = g * 64u + (uint32_t)lane;
+    uint32_t n = 0;
+    uint64_t off = 0;
+    double lp = 0.0;
+    if (gid < nprot) {
+        const uint32_t p = order[gid];
+        n = neff[p];
+        off = offsets[p];
+        lp = lpseq[gid];
+    }
+    sh_n[lane] = n;
+    sh_off[lane] = off;
+    const uint32_t nmax = __shfl(n, 0); // descending order: lane 0 is the longest of the group
+    const size_t rbase = (size_t)grow[g];
+    const double2 *__restrict__ fw = fwd + rbase * 16u * 64u + (size_t)lane;
+    const uint32_t *__restrict__ wb = bits + rbase * 64u + (size_t)lane;
+    const int half = lane >> 5, tt2 = lane & 31;
+    for (uint32_t t0 = sub * PT; t0 < nmax; t0 += 4u * PT) {
+        __syncthreads();
+        uint32_t w = 0;
+#pragma unroll 4
+        for (int tt = 0; tt < PT; ++tt) {
+            const uint32_t t = t0 + (uint32_t)tt;
+            if ((t & 15u) == 0u && t < n) w = wb[(size_t)(t >> 4) * 64u];
+            if (t < n) {
+                const double2 ab = fw[(size_t)t * 64u];
+                const double pp0 = exp(ab.x - lp), pp1 = exp(ab.y - lp); // exp((a+b) - lpseq)
+                s0[tt][lane] = pp0;
+                s1[tt][lane] = pp1;
+                sb[tt][lane] = (uint8_t)(((w >> (t & 15u)) & 1u) | (pp1 > pp0 ? 2u : 0u)); // MAP ties -> 0 (:4039)
+            }
+        }
+        __syncthreads();
+        for (int lp2 = 0; lp2 < 32; ++lp2) {
+            const int L = 2 * lp2 + half;
+            const uint32_t t = t0 + (uint32_t)tt2;
+            if (t < sh_n[L]) {
+                const uint64_t o = sh_off[L] + t;
+                tr.post0[o] = s0[tt2][L];
+                tr.post1[o] = s1[tt2][L];
+                const uint8_t bb = sb[tt2][L];
+                tr.vit[o] = bb & 1u;
+                tr.map[o] = bb >> 1;
+            }
         }
     }
 }
@@ -1584,9 +1652,10 @@ struct plaac_ctx {
     // plan / scratch buffers (grown on demand)
     uint32_t *d_neff = nullptr, *d_order = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
     uint4 *d_packed = nullptr;
-    double *d_fwd = nullptr;
+    double2 *d_fwd = nullptr; // track mode: forward / a+b pairs, group-interleaved
+    double *d_lpseq = nullptr;
     uint32_t *h_pin = nullptr; // pinned word for the one device->host readback of a call (total packed rows)
-    size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_grow = 0, cap_packed = 0;
+    size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_lpseq = 0, cap_grow = 0, cap_packed = 0;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
     uint64_t *d_offsets = nullptr;
@@ -1792,6 +1861,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_lpseq) (void)hipFree(ctx->d_lpseq);
     void *bufs[] = {ctx->d_tab,  ctx->d_neff,    ctx->d_order, ctx->d_hist, ctx->d_bits,  ctx->d_fwd,   ctx->d_codes,
                     ctx->d_offsets, ctx->d_rows, ctx->d_trk8,  ctx->d_trk64, ctx->d_counts, ctx->d_grow, ctx->d_packed};
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -1877,7 +1947,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const uint32_t ngroups = (nprot + 63u) / 64u;
     if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 1)) != PLAAC_OK) return rc;
     if (d_tracks)
-        if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, (size_t)(2 * total_residues + 2))) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_lpseq, ctx->cap_lpseq, (size_t)nprot)) != PLAAC_OK) return rc;
     // device tables: slot 0 keeps the ctx parameters (single-point calls), sweep groups use slots 1..ng
     const DevTables *gtab0 = ctx->d_tab;
     if (!(npoints == 1 && std::memcmp(&points[0], &ctx->params, sizeof(plaac_params)) == 0)) {
@@ -1955,6 +2025,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const size_t total_rows = ctx->h_pin[0];
     if ((rc = grow(ctx, ctx->d_packed, ctx->cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
     if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
+    if (d_tracks)
+        if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
     hipLaunchKernelGGL(k_pack, dim3((nprot + 255u) / 256u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
@@ -1975,10 +2047,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
         if (d_tracks)
             hipLaunchKernelGGL(k_fwd<true>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, tp, ctx->d_fwd);
+                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, ctx->d_fwd, ctx->d_lpseq);
         else
             hipLaunchKernelGGL(k_fwd<false>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, tp, (double *)nullptr);
+                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, (double2 *)nullptr,
+                               (double *)nullptr);
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
         // Viterbi / windows: up to MAXC core lengths per launch
         for (size_t m0 = 0; m0 < G.members.size(); m0 += MAXC) {
@@ -1992,16 +2065,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             const bool t0 = timed && m0 == 0;
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
 #define LAUNCH_VIT(NC)                                                                                             \
-    do {                                                                                                           \
-        if (d_tracks)                                                                                              \
-            hipLaunchKernelGGL((k_vit<true, NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,           \
-                               ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, tg, \
-                               tp);                                                                                \
-        else                                                                                                       \
-            hipLaunchKernelGGL((k_vit<false, NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,          \
-                               ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, tg, \
-                               tp);                                                                                \
-    } while (0)
+    hipLaunchKernelGGL((k_vit<NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff, ctx->d_order, \
+                       nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, tg)
             switch (nc) {
             case 1: LAUNCH_VIT(1); break;
             case 2: LAUNCH_VIT(2); break;
@@ -2047,6 +2112,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[2], sw));
         for (hipEvent_t e : ctx->jev) PL_HIP(ctx, hipStreamWaitEvent(st, e, 0));
     }
+    if (d_tracks) // posteriors, MAP and Viterbi bytes: needs the backward sweep (k_fwd) and the path bits (k_vit)
+        hipLaunchKernelGGL(k_post, dim3(ngroups * 4u), dim3(64), 0, st, d_offsets, ctx->d_neff, ctx->d_order, nprot,
+                           ctx->d_grow, ctx->d_fwd, ctx->d_lpseq, ctx->d_bits, tp);
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->ncalls++;
