@@ -190,9 +190,17 @@ __global__ void k_group_rows(const uint32_t *__restrict__ neff, const uint32_t *
                              uint32_t ngroups, uint32_t *__restrict__ grow) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ngroups) return;
-    const uint32_t n0 = neff[order[64u * g]]; // descending order: lane 0 is the longest
+    // Lane 0 is the longest of its group, EXCEPT inside the last length bin (lengths >= LEN_BINS-1 are not
+    // ordered among themselves): take the maximum of the group when its first member is that long.
+    uint32_t n0 = neff[order[64u * g]];
+    if (n0 >= (uint32_t)(LEN_BINS - 1)) {
+        const uint32_t e = 64u * g + 64u < nprot ? 64u * g + 64u : nprot;
+        for (uint32_t i = 64u * g + 1u; i < e; ++i) {
+            const uint32_t v = neff[order[i]];
+            n0 = v > n0 ? v : n0;
+        }
+    }
     grow[g] = (n0 + 15u) >> 4;
-    (void)nprot;
 }
 
 // single block: in-place exclusive scan of a[0..n), total written to a[n]
@@ -740,7 +748,11 @@ __global__ __launch_bounds__(64) void k_post(const uint64_t *__restrict__ offset
     }
     sh_n[lane] = n;
     sh_off[lane] = off;
-    const uint32_t nmax = __shfl(n, 0); // descending order: lane 0 is the longest of the group
+    uint32_t nmax = n; // longest of the group (lane 0, except inside the unsorted last length bin)
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(nmax, d);
+        nmax = o > nmax ? o : nmax;
+    }
     const size_t rbase = (size_t)grow[g];
     const double2 *__restrict__ fw = fwd + rbase * 16u * 64u + (size_t)lane;
     const uint32_t *__restrict__ wb = bits + rbase * 64u + (size_t)lane;

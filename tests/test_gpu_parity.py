@@ -282,3 +282,13 @@ def test_resident_batch_histogram_score_and_sweep(native, oracle, ctx):
         want, wtr = oracle.score_batch(oracle.build_params(), codes, offs, tracks=True, nthreads=8)
         assert_rows_equal(rows, want)
         assert_tracks_equal(tr, wtr, codes, offs)
+
+
+def test_proteins_beyond_the_last_length_bin(native, oracle, ctx):
+    """lengths >= 65535 share one (unsorted) length bin of the planner: group row counts must use the true max"""
+    from plaac_amd import synth
+    P = native.make_params()
+    rng = np.random.default_rng(77)
+    lens = np.array([100, 65535, 70001, 65534, 66000, 12, 65600, 300], dtype=np.int64)
+    codes, offs = synth.residues(lens, np.array(P.fg), np.array(P.bg), rng)
+    check_batch(native, oracle, ctx, codes, offs, what="beyond-bins")
