@@ -73,17 +73,39 @@ struct TrackPtrs {
 // ------------------------------------------------------------------------------------------------
 // planning kernels: effective lengths, descending-length counting sort
 // ------------------------------------------------------------------------------------------------
-__global__ void k_plan_lengths(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets, uint32_t nprot,
-                               uint32_t *__restrict__ neff, uint32_t *__restrict__ hist) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nprot) return;
-    uint64_t b = offsets[p], e = offsets[p + 1];
-    uint64_t len = e > b ? e - b : 0;
-    if (len > 0 && codes[e - 1] == 21) --len; // one trailing stop is dropped before scoring (:758)
-    if (len > 0x7fffffffu) len = 0x7fffffffu;
-    neff[p] = (uint32_t)len;
-    uint32_t bin = len < (uint64_t)(LEN_BINS - 1) ? (uint32_t)len : (uint32_t)(LEN_BINS - 1);
-    atomicAdd(&hist[bin], 1u);
+// Both counting-sort passes privatise the popular bins (lengths < PLAN_LDS_BINS) in LDS: one global atomic
+// per touched bin per block instead of one per protein (the length histogram is very peaked).
+constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_ITEMS = 8;          // proteins per thread
+constexpr int PLAN_LDS_BINS = 8192;
+
+__device__ __forceinline__ uint32_t plan_bin(uint32_t len) {
+    return len < (uint32_t)(LEN_BINS - 1) ? len : (uint32_t)(LEN_BINS - 1);
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_plan_lengths(const uint8_t *__restrict__ codes,
+                                                               const uint64_t *__restrict__ offsets, uint32_t nprot,
+                                                               uint32_t *__restrict__ neff,
+                                                               uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[PLAN_LDS_BINS];
+    for (int i = threadIdx.x; i < PLAN_LDS_BINS; i += PLAN_THREADS) h[i] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (PLAN_THREADS * PLAN_ITEMS);
+    for (int k = 0; k < PLAN_ITEMS; ++k) {
+        const uint32_t p = base + (uint32_t)k * PLAN_THREADS + threadIdx.x;
+        if (p >= nprot) break;
+        const uint64_t b = offsets[p], e = offsets[p + 1];
+        uint64_t len = e > b ? e - b : 0;
+        if (len > 0 && codes[e - 1] == 21) --len; // one trailing stop is dropped before scoring (:758)
+        if (len > 0x7fffffffu) len = 0x7fffffffu;
+        neff[p] = (uint32_t)len;
+        const uint32_t bin = plan_bin((uint32_t)len);
+        if (bin < (uint32_t)PLAN_LDS_BINS) atomicAdd(&h[bin], 1u);
+        else atomicAdd(&hist[bin], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PLAN_LDS_BINS; i += PLAN_THREADS)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
 // single block: cursor[b] = number of proteins in bins > b (descending order start positions)
@@ -111,14 +133,35 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *__restrict__ hist)
     }
 }
 
-__global__ void k_plan_scatter(const uint32_t *__restrict__ neff, uint32_t nprot, uint32_t *__restrict__ cursor,
-                               uint32_t *__restrict__ order) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nprot) return;
-    uint32_t len = neff[p];
-    uint32_t bin = len < (uint32_t)(LEN_BINS - 1) ? len : (uint32_t)(LEN_BINS - 1);
-    uint32_t pos = atomicAdd(&cursor[bin], 1u);
-    order[pos] = p;
+__global__ __launch_bounds__(PLAN_THREADS) void k_plan_scatter(const uint32_t *__restrict__ neff, uint32_t nprot,
+                                                               uint32_t *__restrict__ cursor,
+                                                               uint32_t *__restrict__ order) {
+    __shared__ uint32_t cnt[PLAN_LDS_BINS]; // per-bin count of this block, then running rank
+    __shared__ uint32_t start[PLAN_LDS_BINS];
+    for (int i = threadIdx.x; i < PLAN_LDS_BINS; i += PLAN_THREADS) cnt[i] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (PLAN_THREADS * PLAN_ITEMS);
+    uint32_t bins[PLAN_ITEMS];
+    for (int k = 0; k < PLAN_ITEMS; ++k) {
+        const uint32_t p = base + (uint32_t)k * PLAN_THREADS + threadIdx.x;
+        bins[k] = p < nprot ? plan_bin(neff[p]) : 0xffffffffu;
+        if (bins[k] < (uint32_t)PLAN_LDS_BINS) atomicAdd(&cnt[bins[k]], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PLAN_LDS_BINS; i += PLAN_THREADS) { // reserve this block's slots of every bin
+        const uint32_t c = cnt[i];
+        start[i] = c ? atomicAdd(&cursor[i], c) : 0u;
+        cnt[i] = 0u;
+    }
+    __syncthreads();
+    for (int k = 0; k < PLAN_ITEMS; ++k) {
+        const uint32_t p = base + (uint32_t)k * PLAN_THREADS + threadIdx.x;
+        if (p >= nprot) break;
+        const uint32_t bin = bins[k];
+        const uint32_t pos = bin < (uint32_t)PLAN_LDS_BINS ? start[bin] + atomicAdd(&cnt[bin], 1u)
+                                                           : atomicAdd(&cursor[bin], 1u);
+        order[pos] = p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2016,9 +2059,12 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     PL_HIP(ctx, hipEventRecord(evs[E_START], st));
     PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * LEN_BINS, st));
     const unsigned pb = (nprot + 255u) / 256u;
-    hipLaunchKernelGGL(k_plan_lengths, dim3(pb), dim3(256), 0, st, d_codes, d_offsets, nprot, ctx->d_neff, ctx->d_hist);
+    const unsigned plb = (nprot + PLAN_THREADS * PLAN_ITEMS - 1) / (PLAN_THREADS * PLAN_ITEMS);
+    hipLaunchKernelGGL(k_plan_lengths, dim3(plb), dim3(PLAN_THREADS), 0, st, d_codes, d_offsets, nprot, ctx->d_neff,
+                       ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ctx->d_hist);
-    hipLaunchKernelGGL(k_plan_scatter, dim3(pb), dim3(256), 0, st, ctx->d_neff, nprot, ctx->d_hist, ctx->d_order);
+    hipLaunchKernelGGL(k_plan_scatter, dim3(plb), dim3(PLAN_THREADS), 0, st, ctx->d_neff, nprot, ctx->d_hist,
+                       ctx->d_order);
     PL_HIP(ctx, hipEventRecord(evs[E_PLAN], st));
     // The three K-A roles and K-B are independent given the plan: fork the K-A side onto high-priority streams
     // so the long serial chains (which set the wall time) overlap each other and the throughput-bound window
