@@ -1248,11 +1248,13 @@ __global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes
 
 // ------------------------------------------------------------------------------------------------
 // K-B fast path: all three half-windows equal 20 (the default ww = 41, also ww = 40).
-// FOUR consecutive positions per lane (256 positions per iteration): the 44 values under the union of the
-// four windows are read once and feed all four fixed-order 41-term sums (0.27 LDS values per add instead
-// of 1), which makes the loop fp64-VALU-bound instead of LDS-bound. Values live in LDS split by position
-// mod 4 so that lane l reads [base + l + g] with an immediate offset g (conflict-free, no address
-// arithmetic); the first 12 slots of every sub-ring are mirrored behind it so base + g never wraps.
+// B consecutive positions per lane (64*B positions per iteration), B chosen PER PROTEIN from {2, 3, 4} so
+// that the last, partly empty iteration wastes as few position slots as possible (UniRef-shaped lengths:
+// 65 % -> 80 % of the slots carry a residue). The 40+B values under the union of a lane's B windows are
+// read once and feed all B fixed-order 41-term sums (B = 4: 0.27 LDS values per add instead of 1), which
+// makes the loop fp64-VALU-bound instead of LDS-bound. Values live in LDS split by position mod B so that
+// lane l reads [base + l + g] with an immediate offset g (conflict-free, no address arithmetic); the head
+// of every sub-ring is mirrored behind it so base + g never wraps.
 // Charge sums are exact integers -> prefix counts (wave scan) instead of 41 adds. The weights of the
 // second smoothing depend only on the position, so weight*value is formed once per position. The four
 // (three) quotients of a position share their denominator: one reciprocal refinement, then a 3-instruction
@@ -1262,13 +1264,24 @@ __global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes
 // long and short ones) and prefetches the next protein's metadata, so the dependent
 // order->length->offset->residues load chain is off the path.
 // ------------------------------------------------------------------------------------------------
-constexpr int TW = 20;             // half window
-constexpr int TB = 4;              // positions per lane
-constexpr int TC = 64 * TB;        // 256 positions per iteration
-constexpr int TRB = 76;            // sub-ring entries per class (>= (TC + 2*TW) / TB = 74)
-constexpr int TMIR = 12;           // mirrored head (max read offset is 10)
-constexpr int TSUB = TRB + TMIR;   // 88
+constexpr int TW = 20;        // half window
+constexpr int RING_DOUBLES = 352; // doubles per ring (all sub-rings of one track), enough for every B below
 enum { RG_H = 0, RG_L = 1, RG_P = 2, RG_WF = 3, RG_WL = 4, RG_WP = 5, RG_N = 6 };
+
+// geometry of the B-positions-per-lane variant
+template <int B>
+struct KbGeom {
+    static constexpr int C = 64 * B;                       // positions per iteration
+    static constexpr int LAG1 = ((TW + B - 1) / B) * B;    // first-level lag: multiple of B, >= 20
+    static constexpr int LAG2 = ((LAG1 + TW + B - 1) / B) * B; // second-level lag: multiple of B, >= LAG1 + 20
+    static constexpr int C0 = ((-TW) % B + B) % B;          // class of the first window position (i0 - 20)
+    static constexpr int GMAX = (2 * TW + B - 1 + C0) / B;  // largest slot offset a window read uses
+    static constexpr int LIVE = (C + LAG2 - LAG1 + TW > C + LAG1 + TW ? C + LAG2 - LAG1 + TW : C + LAG1 + TW);
+    static constexpr int RB = (LIVE + B - 1) / B + 1;       // sub-ring entries per class
+    static constexpr int MIR = GMAX + 1;                    // mirrored head
+    static constexpr int SUB = RB + MIR;
+    static_assert(B * SUB <= RING_DOUBLES, "ring too small");
+};
 
 __device__ __forceinline__ uint32_t load4(const uint8_t *p, const uint8_t *lo, const uint8_t *end) {
     if (p >= lo && p + 4 <= end) {
@@ -1291,6 +1304,15 @@ __device__ __forceinline__ int window_weight_side(int i, int w) {
     return (2 * w + 1) * w - ((m * (m + 1)) >> 1);
 }
 
+// lane broadcast through SGPRs (v_readlane), no LDS round trip; `lane` must be a compile-time constant
+__device__ __forceinline__ int bcast_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+    const long long u = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffll), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // Correctly rounded a/d for several numerators sharing one small positive integer-valued denominator.
 struct SharedDiv {
     double d, y;
@@ -1308,49 +1330,365 @@ struct SharedDiv {
     }
 };
 
-// The four 41-term sums of positions I .. I+3 (I = 0 mod 4) for THREE tracks at once (rings A, A+1, A+2),
-// each in increasing position order: s[track][b] over I+b-20 .. I+b+20. base = slot of position I-20 in the
-// class-0 sub-ring; value e of the union (e = 0..43) is class e&3, slot base + (e>>2).
-__device__ __forceinline__ void window_quads3(const double (*R)[TB][TSUB], int A, int base, double (&s)[3][4]) {
-    double acc[3][4];
+// The B 41-term sums of positions I .. I+B-1 (I = 0 mod B) for THREE tracks at once (rings A, A+1, A+2),
+// each in increasing position order: s[track][b] over I+b-20 .. I+b+20. Value e of the union (e = 0 .. 40+B-1,
+// position I-20+e) is class (e + C0) % B, slot base + (e + C0) / B, where base = slot of position I-20-C0.
+template <int B>
+__device__ __forceinline__ void window_sums3(const double *__restrict__ R, int A, int base, double (&s)[3][B]) {
+    using G = KbGeom<B>;
+    constexpr int NE = 2 * TW + B; // values in the union
+    // value index e lies in window b  <=>  b <= e <= b + 40. `e` is always a compile-time constant after
+    // unrolling (class and slot offset become immediates); `shift` moves the slot by whole body iterations.
+    auto val = [&](int a, int e, int shift = 0) -> double {
+        const int ec = e + G::C0;
+        return R[(A + a) * RING_DOUBLES + (ec % B) * G::SUB + base + ec / B + shift];
+    };
+    double acc[3][B];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double v0 = R[A + a][0][base], v1 = R[A + a][1][base], v2 = R[A + a][2][base], v3 = R[A + a][3][base];
-        // e = 0..3: window b starts at e = b
-        acc[a][0] = ((0.0 + v0) + v1) + v2;
-        acc[a][0] = acc[a][0] + v3;
-        acc[a][1] = (0.0 + v1) + v2;
-        acc[a][1] = acc[a][1] + v3;
-        acc[a][2] = (0.0 + v2) + v3;
-        acc[a][3] = 0.0 + v3;
-    }
-#pragma unroll 3
-    for (int g = 1; g <= 9; ++g) { // e = 4g .. 4g+3 lies in all four windows
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[a][b] = 0.0;
+    // head: e = 0 .. B-2 (not yet in every window)
+#pragma unroll
+    for (int e = 0; e < B - 1; ++e)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double v0 = R[A + a][0][base + g], v1 = R[A + a][1][base + g], v2 = R[A + a][2][base + g],
-                         v3 = R[A + a][3][base + g];
+            const double v = val(a, e);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                acc[a][b] = acc[a][b] + v0;
-                acc[a][b] = acc[a][b] + v1;
-                acc[a][b] = acc[a][b] + v2;
-                acc[a][b] = acc[a][b] + v3;
-            }
+            for (int b = 0; b < B; ++b)
+                if (b <= e) acc[a][b] = acc[a][b] + v;
+        }
+    // body: e = B-1 .. 40 lies in all B windows; partially unrolled on purpose (a fully unrolled body lets the
+    // scheduler hoist every LDS read and spill)
+    constexpr int NBODY = 2 * TW + 1 - (B - 1); // 42 - B values
+    constexpr int STEP = B == 3 ? 3 : 4;
+    static_assert(STEP % B == 0, "a body iteration must advance every class by whole slots");
+#pragma unroll 2
+    for (int it = 0; it < NBODY / STEP; ++it) {
+        const int shift = it * (STEP / B);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double v[STEP];
+#pragma unroll
+            for (int u = 0; u < STEP; ++u) v[u] = val(a, (B - 1) + u, shift);
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int u = 0; u < STEP; ++u) acc[a][b] = acc[a][b] + v[u];
         }
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { // e = 40..43: window b ends at e = 40 + b
-        const double v0 = R[A + a][0][base + 10], v1 = R[A + a][1][base + 10], v2 = R[A + a][2][base + 10],
-                     v3 = R[A + a][3][base + 10];
-        s[a][0] = acc[a][0] + v0;
-        s[a][1] = (acc[a][1] + v0) + v1;
-        s[a][2] = ((acc[a][2] + v0) + v1) + v2;
-        s[a][3] = (((acc[a][3] + v0) + v1) + v2) + v3;
-    }
+    for (int e = (B - 1) + (NBODY / STEP) * STEP; e <= 2 * TW; ++e) // body remainder
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v = val(a, e);
+#pragma unroll
+            for (int b = 0; b < B; ++b) acc[a][b] = acc[a][b] + v;
+        }
+    // tail: e = 41 .. 40+B-1 (already past the first windows)
+#pragma unroll
+    for (int e = 2 * TW + 1; e < NE; ++e)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v = val(a, e);
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+                if (e <= b + 2 * TW) acc[a][b] = acc[a][b] + v;
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < B; ++b) s[a][b] = acc[a][b];
 }
 
 constexpr int KB_PROTEINS_PER_BLOCK = 16; // blocks retire regularly, so the K-A kernels' blocks keep getting slots
+
+struct KbShared {
+    double t_hyd[ROWS], t_llr[ROWS], t_lod[ROWS];
+    int t_chg[ROWS];
+    // rings: mapped inputs hydro/llr/papa (0.0 outside [0,n)), then weight * first-level FoldIndex/llr/papa
+    double ring[RG_N * RING_DOUBLES];
+    int pre[512]; // pre[q & 511] = charge sum of positions < q
+};
+
+struct KbConst {
+    const uint8_t *codes, *cend;
+    int ww1, ww2;
+    bool adjust;
+    double cc0, cc1, cc2;
+};
+
+// one protein with B positions per lane
+template <int B, bool TRACKS>
+__device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, const uint8_t *__restrict__ x,
+                                                 uint64_t off, int n, plaac_row *__restrict__ row, TrackPtrs tr) {
+    using G = KbGeom<B>;
+    const int lane = threadIdx.x;
+    double *__restrict__ ring = S.ring;
+    int *__restrict__ pre = S.pre;
+    for (int i = lane; i < RG_N * RING_DOUBLES; i += 64) ring[i] = 0.0;
+    for (int i = lane; i < 512; i += 64) pre[i] = 0;
+
+    const int we = n - 1 < TW ? n - 1 : TW; // w = ww/2 clamped to n-1 (:2588-2589)
+    int halfw = (K.ww1 - 1) / 2;            // FoldIndex run scan domain (:5010-5013)
+    if (halfw > n / 2) halfw = n / 2;
+    const int dlo = halfw, dhi = n - halfw - 1;
+    const int plo = (K.ww2 - 1) / 2, phi = n - (K.ww2 - 1) / 2; // PAPA centres k in [plo, phi) (:4942)
+    const double cc0 = K.cc0, cc1 = K.cc1, cc2 = K.cc2;
+
+    double pbest = -INFINITY, pfi = 0.0, pll2 = 0.0;
+    int pcen = -1;
+    int numaa = 0, maxlen = 0, carry = 0;   // numaa / maxlen: per-lane partials, reduced at the end
+    int last_zero = INT_MIN, last_flag = 0; // wave-uniform carries of the FoldIndex run scan
+    __syncthreads();
+
+    const int nchunks = (n + G::LAG2 + G::C - 1) / G::C;
+    // ring slot of entry number e (= position / B): e mod RB; per iteration the entry numbers advance by 64
+    auto wrap = [](int s) { return s >= G::RB ? s - G::RB : s; };
+    auto neg_slot = [](int e) { return ((e % G::RB) + G::RB) % G::RB; };
+    int slot_in = 0;                                             // entry 64k            (stage 0 writes)
+    int slot_l1 = neg_slot(-(G::LAG1 + TW + G::C0) / B);         // entry of position 64Bk - LAG1 - 20 - C0
+    int slot_w1 = neg_slot(-G::LAG1 / B);                        // entry of position 64Bk - LAG1 (stage 1 writes)
+    int slot_l2 = neg_slot(-(G::LAG2 + TW + G::C0) / B);         // entry of position 64Bk - LAG2 - 20 - C0
+    for (int k = 0; k < nchunks; ++k) {
+        // ---- stage 0: residues -> mapped inputs at q0 = 64Bk + B*lane .. q0 + B-1
+        {
+            const int q0 = G::C * k + B * lane;
+            double vh[B], vl[B], vp[B];
+            int ch[B];
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                vh[j] = vl[j] = vp[j] = 0.0;
+                ch[j] = 0;
+            }
+            if (q0 < n) {
+                uint32_t cb[B + 2]; // residues q0-2 .. q0+B-1
+                const uint32_t wa = load4(x + q0 - 2, K.codes, K.cend);
+                cb[0] = q0 >= 2 ? (wa & 0xffu) : 255u;
+                cb[1] = q0 >= 1 ? ((wa >> 8) & 0xffu) : 255u;
+                cb[2] = (wa >> 16) & 0xffu;
+                cb[3] = wa >> 24;
+                if (B > 2) {
+                    const uint32_t wb = load4(x + q0 + 2, K.codes, K.cend);
+#pragma unroll
+                    for (int m = 4; m < B + 2; ++m) cb[m] = (wb >> (8 * (m - 4))) & 0xffu;
+                }
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    const bool in = q0 + j < n;
+                    const uint32_t c = cb[2 + j] < 22u ? cb[2 + j] : 22u;
+                    // only the first P of PP / PxP scores (:2653-2654); absolute neighbours p-1, p-2
+                    const bool dup = K.adjust && c == 13u && (cb[1 + j] == 13u || cb[j] == 13u);
+                    vh[j] = in ? S.t_hyd[c] : 0.0;
+                    vl[j] = in ? S.t_llr[c] : 0.0;
+                    ch[j] = in ? S.t_chg[c] : 0;
+                    vp[j] = (in && !dup) ? S.t_lod[c] : 0.0;
+                }
+            }
+            const int idx = wrap(slot_in + lane);
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                ring[RG_H * RING_DOUBLES + j * G::SUB + idx] = vh[j];
+                ring[RG_L * RING_DOUBLES + j * G::SUB + idx] = vl[j];
+                ring[RG_P * RING_DOUBLES + j * G::SUB + idx] = vp[j];
+            }
+            if (idx < G::MIR) { // mirrored head: one branch for all copies
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    ring[RG_H * RING_DOUBLES + j * G::SUB + idx + G::RB] = vh[j];
+                    ring[RG_L * RING_DOUBLES + j * G::SUB + idx + G::RB] = vl[j];
+                    ring[RG_P * RING_DOUBLES + j * G::SUB + idx + G::RB] = vp[j];
+                }
+            }
+            // charge prefix counts: inclusive wave scan of the per-lane sums
+            int lsum = 0;
+#pragma unroll
+            for (int j = 0; j < B; ++j) lsum += ch[j];
+            int s = lsum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(s, d);
+                if (lane >= d) s += o;
+            }
+            int run = carry + s - lsum;
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                run += ch[j];
+                pre[(q0 + j + 1) & 511] = run;
+            }
+            carry += bcast_lane(s, 63);
+        }
+        __syncthreads();
+        // ---- stage 1: first-level tracks at i0 = 64Bk + B*lane - LAG1 .. i0 + B-1
+        {
+            const int i0 = G::C * k + B * lane - G::LAG1;
+            double sums[3][B];
+            window_sums3<B>(ring, RG_H, wrap(slot_l1 + lane), sums);
+            double wfi[B], wll[B], wpa[B];
+            int zpos[B]; // position if FoldIndex >= 0 there (or outside the scan domain), else "none"
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int i = i0 + j;
+                const bool live = i >= 0 && i < n;
+                const int lo = imax(i - TW, 0), hi = imin(i + TW, n - 1);
+                const SharedDiv div(live ? (double)(hi - lo + 1) : 1.0);
+                const int csum = pre[(hi + 1) & 511] - pre[lo & 511];
+                const double hydro = div(sums[0][j]);
+                const double charge = div((double)csum);
+                const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
+                const double llr1 = div(sums[1][j]);
+                const double papa = div(sums[2][j]);
+                const double wt = (double)(1 + imin(i, we) + imin(n - i - 1, we));
+                wfi[j] = live ? wt * fi : 0.0;
+                wll[j] = live ? wt * llr1 : 0.0;
+                wpa[j] = live ? wt * papa : 0.0;
+                const bool neg = live && (fi < 0.0) && i >= dlo && i <= dhi;
+                zpos[j] = neg ? INT_MIN : i;
+                if (TRACKS && live) {
+                    tr.charge[off + i] = charge;
+                    tr.hydro[off + i] = hydro;
+                    tr.fi[off + i] = fi;
+                    tr.plaacllr[off + i] = llr1;
+                    tr.papa[off + i] = papa;
+                }
+            }
+            const int idx = wrap(slot_w1 + lane);
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                ring[RG_WF * RING_DOUBLES + j * G::SUB + idx] = wfi[j];
+                ring[RG_WL * RING_DOUBLES + j * G::SUB + idx] = wll[j];
+                ring[RG_WP * RING_DOUBLES + j * G::SUB + idx] = wpa[j];
+            }
+            if (idx < G::MIR) {
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    ring[RG_WF * RING_DOUBLES + j * G::SUB + idx + G::RB] = wfi[j];
+                    ring[RG_WL * RING_DOUBLES + j * G::SUB + idx + G::RB] = wll[j];
+                    ring[RG_WP * RING_DOUBLES + j * G::SUB + idx + G::RB] = wpa[j];
+                }
+            }
+            // FoldIndex<0 runs (:5020-5058), position-parallel: a run is accounted where it ENDS, i.e. at a
+            // position q without the flag whose predecessor has it; its start is one past the last unflagged
+            // position before q (running max of unflagged positions: in-lane, wave max-scan, carry).
+            {
+                int lanemax = zpos[0];
+#pragma unroll
+                for (int j = 1; j < B; ++j) lanemax = imax(lanemax, zpos[j]);
+                int sc = lanemax;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(sc, d);
+                    if (lane >= d) sc = imax(sc, o);
+                }
+                int before = __shfl_up(sc, 1); // last unflagged position before this lane's first position
+                if (lane == 0) before = INT_MIN;
+                before = imax(before, last_zero);
+                int prevflag = __shfl_up(zpos[B - 1] == INT_MIN ? 1 : 0, 1);
+                if (lane == 0) prevflag = last_flag;
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    const bool flagged = zpos[j] == INT_MIN;
+                    // a run [before+1, q-1] just ended here iff this position is unflagged and its predecessor was
+                    int rs = before + 1, re = i0 + j - 1;
+                    rs = rs == dlo ? 0 : rs;
+                    re = re == dhi ? n - 1 : re;
+                    const int len = re - rs + 1;
+                    const int cnt = (!flagged && prevflag != 0 && len >= 5) ? len : 0;
+                    numaa += cnt;
+                    maxlen = imax(maxlen, cnt);
+                    before = imax(before, zpos[j]);
+                    prevflag = flagged ? 1 : 0;
+                }
+                last_zero = imax(last_zero, bcast_lane(sc, 63));
+                last_flag = bcast_lane(prevflag, 63);
+            }
+        }
+        __syncthreads();
+        // ---- stage 2: weighted second smoothing at i0 = 64Bk + B*lane - LAG2 .. i0 + B-1, PAPA arg-max
+        {
+            const int i0 = G::C * k + B * lane - G::LAG2;
+            double sums[3][B];
+            window_sums3<B>(ring, RG_WF, wrap(slot_l2 + lane), sums);
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int i = i0 + j;
+                const bool valid = i >= we && i <= n - we - 1; // implies 0 <= i < n
+                const int den = (2 * we + 1) + window_weight_side(i, we) + window_weight_side(n - 1 - i, we);
+                const SharedDiv div(valid ? (double)den : 1.0);
+                const double fix2 = valid ? div(sums[0][j]) : __builtin_nan("");
+                const double llx2 = valid ? div(sums[1][j]) : __builtin_nan("");
+                const double pax2 = valid ? div(sums[2][j]) : __builtin_nan("");
+                if (TRACKS && i >= 0 && i < n) {
+                    tr.fix2[off + i] = fix2;
+                    tr.plaacllrx2[off + i] = llx2;
+                    tr.papax2[off + i] = pax2;
+                }
+                // papamode 1 (:4942-4948): NaNs fail both comparisons
+                const bool upd = i >= plo && i < phi && (pax2 > pbest) && (fix2 < 0.0);
+                pbest = upd ? pax2 : pbest;
+                pcen = upd ? i : pcen;
+                pfi = upd ? fix2 : pfi;
+                pll2 = upd ? llx2 : pll2;
+            }
+        }
+        slot_in = wrap(slot_in + 64);
+        slot_l1 = wrap(slot_l1 + 64);
+        slot_w1 = wrap(slot_w1 + 64);
+        slot_l2 = wrap(slot_l2 + 64);
+    }
+    // wave arg-max: largest papax2, smallest centre among equals (first max of the serial loop)
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double ob = __shfl_xor(pbest, d);
+        const int oc = __shfl_xor(pcen, d);
+        const double ofi = __shfl_xor(pfi, d), oll2 = __shfl_xor(pll2, d);
+        const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
+        if (take) {
+            pbest = ob;
+            pcen = oc;
+            pfi = ofi;
+            pll2 = oll2;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { // FoldIndex run statistics: sum / max over lanes
+        numaa += __shfl_xor(numaa, d);
+        maxlen = imax(maxlen, __shfl_xor(maxlen, d));
+    }
+    // PAPAllr = first-level PLAAC-LLR at the centre, recomputed: lanes fetch the 41 taps in parallel,
+    // the fixed-order sum runs over lane broadcasts (out-of-range taps add +0.0)
+    double papallr = __builtin_nan("");
+    if (pcen >= 0) {
+        const int q = pcen - TW + lane;
+        const double v = (lane <= 2 * TW && q >= 0 && q < n) ? S.t_llr[ld_code(x, (uint32_t)q)] : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j <= 2 * TW; ++j) s = s + bcast_lane(v, j);
+        const int lo = imax(pcen - TW, 0), hi = imin(pcen + TW, n - 1);
+        papallr = s / (double)(hi - lo + 1);
+    }
+    if (lane == 0) {
+        row->fi_numaa = numaa;
+        row->fi_maxrun = maxlen;
+        row->papa_cen = pcen;
+        if (pcen >= 0) {
+            row->papa_combo = pbest;
+            row->papa_prop = pbest;
+            row->papa_fi = pfi;
+            row->papa_llr = papallr;
+            row->papa_llr2 = pll2;
+        } else {
+            row->papa_combo = -INFINITY;
+            row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
+        }
+    }
+}
+
+// positions-per-lane variant that wastes the fewest slots for a protein of n residues: iterations x
+// (per-iteration cost ~ B + fixed part)
+__device__ __forceinline__ int kb_choose_b(int n) {
+    auto cost = [n](int b, int lag2) { return ((n + lag2 + 64 * b - 1) / (64 * b)) * (10 * b + 7); };
+    const int c2 = cost(2, KbGeom<2>::LAG2), c3 = cost(3, KbGeom<3>::LAG2), c4 = cost(4, KbGeom<4>::LAG2);
+    return (c4 <= c3 && c4 <= c2) ? 4 : (c3 <= c2 ? 3 : 2);
+}
 
 template <bool TRACKS>
 __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ codes,
@@ -1359,24 +1697,24 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
                                                  const uint32_t *__restrict__ order, uint32_t nprot, uint64_t total,
                                                  const DevTables *__restrict__ T, plaac_row *__restrict__ rows,
                                                  TrackPtrs tr) {
-    __shared__ double t_hyd[ROWS], t_llr[ROWS], t_lod[ROWS];
-    __shared__ int t_chg[ROWS];
-    // rings: mapped inputs hydro/llr/papa (0.0 outside [0,n)), then weight * first-level FoldIndex/llr/papa
-    __shared__ double ring[RG_N][TB][TSUB];
-    __shared__ int pre[512]; // pre[q & 511] = charge sum of positions < q
-
+    __shared__ KbShared S;
     const int lane = threadIdx.x;
     if (lane < ROWS) {
         const int k = lane == NAA ? 0 : lane;
-        t_hyd[lane] = T->hyd[k];
-        t_llr[lane] = T->llr[k];
-        t_lod[lane] = T->lod[k];
-        t_chg[lane] = T->chg[k];
+        S.t_hyd[lane] = T->hyd[k];
+        S.t_llr[lane] = T->llr[k];
+        S.t_lod[lane] = T->lod[k];
+        S.t_chg[lane] = T->chg[k];
     }
-    const uint8_t *cend = codes + total;
-    const int ww1 = T->ww1, ww2 = T->ww2;
-    const bool adjust = T->adjustprolines != 0;
-    const double cc0 = T->cc[0], cc1 = T->cc[1], cc2 = T->cc[2];
+    KbConst K;
+    K.codes = codes;
+    K.cend = codes + total;
+    K.ww1 = T->ww1;
+    K.ww2 = T->ww2;
+    K.adjust = T->adjustprolines != 0;
+    K.cc0 = T->cc[0];
+    K.cc1 = T->cc[1];
+    K.cc2 = T->cc[2];
 
     // metadata of the first protein of this block; the next one is prefetched while the current is scored
     uint32_t b = blockIdx.x;
@@ -1394,8 +1732,7 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
         const int n = (int)n_cur;
         const uint64_t off = off_cur;
         // prefetch: metadata of the next protein, id of the one after
-        const bool has_next = b + gridDim.x < nprot;
-        if (has_next) {
+        if (b + gridDim.x < nprot) {
             p_cur = p_nxt;
             n_cur = neff[p_nxt];
             off_cur = offsets[p_nxt];
@@ -1410,246 +1747,11 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
             continue;
         }
         __syncthreads(); // the previous protein is done with the rings
-        for (int i = lane; i < RG_N * TB * TSUB; i += 64) (&ring[0][0][0])[i] = 0.0;
-        for (int i = lane; i < 512; i += 64) pre[i] = 0;
-
         const uint8_t *__restrict__ x = codes + off;
-        const int we = n - 1 < TW ? n - 1 : TW; // w = ww/2 clamped to n-1 (:2588-2589)
-        int halfw = (ww1 - 1) / 2;              // FoldIndex run scan domain (:5010-5013)
-        if (halfw > n / 2) halfw = n / 2;
-        const int dlo = halfw, dhi = n - halfw - 1;
-        const int plo = (ww2 - 1) / 2, phi = n - (ww2 - 1) / 2; // PAPA centres k in [plo, phi) (:4942)
-
-        double pbest = -INFINITY, pfi = 0.0, pll2 = 0.0;
-        int pcen = -1;
-        int numaa = 0, maxlen = 0, carry = 0;      // numaa / maxlen: per-lane partials, reduced at the end
-        int last_zero = INT_MIN, last_flag = 0;     // wave-uniform carries of the FoldIndex run scan
-        __syncthreads();
-
-        const int nchunks = (n + 2 * TW + TC - 1) / TC;
-        // ring slot of entry number e (= position >> 2): (e mod TRB); per iteration the entry numbers advance by 64
-        int slot_in = 0;                      // slot of entry 64k (stage 0 writes entries 64k + lane)
-        int slot_l1 = TRB - 10;               // slot of entry 64k - 10 (stage 1 reads from position 256k - 40)
-        int slot_w1 = TRB - 5;                // slot of entry 64k - 5  (stage 1 writes position 256k - 20)
-        int slot_l2 = TRB - 15;               // slot of entry 64k - 15 (stage 2 reads from position 256k - 60)
-        auto wrap = [](int s) { return s >= TRB ? s - TRB : s; };
-        for (int k = 0; k < nchunks; ++k) {
-            // ---- stage 0: residues -> mapped inputs at q0 = 256k + 4*lane .. q0 + 3
-            {
-                const int q0 = TC * k + 4 * lane;
-                double vh[4] = {0.0, 0.0, 0.0, 0.0}, vl[4] = {0.0, 0.0, 0.0, 0.0}, vp[4] = {0.0, 0.0, 0.0, 0.0};
-                int ch[4] = {0, 0, 0, 0};
-                if (q0 < n) {
-                    const uint32_t w = load4(x + q0, codes, cend);         // residues q0 .. q0+3
-                    const uint32_t wm = load4(x + q0 - 2, codes, cend);    // residues q0-2, q0-1 (low bytes)
-                    uint32_t cb[6];
-                    cb[0] = q0 >= 2 ? (wm & 0xffu) : 255u;
-                    cb[1] = q0 >= 1 ? ((wm >> 8) & 0xffu) : 255u;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) cb[2 + j] = (w >> (8 * j)) & 0xffu;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (q0 + j < n) {
-                            const uint32_t c = cb[2 + j] < 22u ? cb[2 + j] : 22u;
-                            vh[j] = t_hyd[c];
-                            vl[j] = t_llr[c];
-                            ch[j] = t_chg[c];
-                            // only the first P of PP / PxP scores (:2653-2654); absolute neighbours p-1, p-2
-                            const bool dup = adjust && c == 13u && (cb[1 + j] == 13u || cb[j] == 13u);
-                            vp[j] = dup ? 0.0 : t_lod[c];
-                        }
-                    }
-                }
-                const int idx = wrap(slot_in + lane);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ring[RG_H][j][idx] = vh[j];
-                    ring[RG_L][j][idx] = vl[j];
-                    ring[RG_P][j][idx] = vp[j];
-                }
-                if (idx < TMIR) { // mirrored head: one branch for all twelve copies
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ring[RG_H][j][idx + TRB] = vh[j];
-                        ring[RG_L][j][idx + TRB] = vl[j];
-                        ring[RG_P][j][idx + TRB] = vp[j];
-                    }
-                }
-                // charge prefix counts: inclusive wave scan of the per-lane sums
-                int s = (ch[0] + ch[1]) + (ch[2] + ch[3]);
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int o = __shfl_up(s, d);
-                    if (lane >= d) s += o;
-                }
-                const int before = carry + s - ((ch[0] + ch[1]) + (ch[2] + ch[3]));
-                pre[(q0 + 1) & 511] = before + ch[0];
-                pre[(q0 + 2) & 511] = before + ch[0] + ch[1];
-                pre[(q0 + 3) & 511] = before + ch[0] + ch[1] + ch[2];
-                pre[(q0 + 4) & 511] = carry + s;
-                carry += __shfl(s, 63);
-            }
-            __syncthreads();
-            // ---- stage 1: first-level tracks at i0 = 256k + 4*lane - 20 .. i0 + 3
-            {
-                const int i0 = TC * k + 4 * lane - TW;
-                double sums[3][4];
-                window_quads3(ring, RG_H, wrap(slot_l1 + lane), sums);
-                double wfi[4], wll[4], wpa[4];
-                int zpos[4]; // position if FoldIndex >= 0 there (or outside the scan domain), else "none"
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = i0 + j;
-                    const bool live = i >= 0 && i < n;
-                    const int lo = imax(i - TW, 0), hi = imin(i + TW, n - 1);
-                    const SharedDiv div(live ? (double)(hi - lo + 1) : 1.0);
-                    const int csum = pre[(hi + 1) & 511] - pre[lo & 511];
-                    const double hydro = div(sums[0][j]);
-                    const double charge = div((double)csum);
-                    const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
-                    const double llr1 = div(sums[1][j]);
-                    const double papa = div(sums[2][j]);
-                    const double wt = (double)(1 + imin(i, we) + imin(n - i - 1, we));
-                    wfi[j] = live ? wt * fi : 0.0;
-                    wll[j] = live ? wt * llr1 : 0.0;
-                    wpa[j] = live ? wt * papa : 0.0;
-                    const bool neg = live && (fi < 0.0) && i >= dlo && i <= dhi;
-                    zpos[j] = neg ? INT_MIN : i;
-                    if (TRACKS && live) {
-                        tr.charge[off + i] = charge;
-                        tr.hydro[off + i] = hydro;
-                        tr.fi[off + i] = fi;
-                        tr.plaacllr[off + i] = llr1;
-                        tr.papa[off + i] = papa;
-                    }
-                }
-                const int idx = wrap(slot_w1 + lane);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ring[RG_WF][j][idx] = wfi[j];
-                    ring[RG_WL][j][idx] = wll[j];
-                    ring[RG_WP][j][idx] = wpa[j];
-                }
-                if (idx < TMIR) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ring[RG_WF][j][idx + TRB] = wfi[j];
-                        ring[RG_WL][j][idx + TRB] = wll[j];
-                        ring[RG_WP][j][idx + TRB] = wpa[j];
-                    }
-                }
-                // FoldIndex<0 runs (:5020-5058), position-parallel: a run is accounted where it ENDS, i.e. at a
-                // position q without the flag whose predecessor has it; its start is one past the last unflagged
-                // position before q (running max of unflagged positions: in-lane, wave max-scan, carry).
-                {
-                    const int lanemax = imax(imax(zpos[0], zpos[1]), imax(zpos[2], zpos[3]));
-                    int sc = lanemax;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const int o = __shfl_up(sc, d);
-                        if (lane >= d) sc = imax(sc, o);
-                    }
-                    int before = __shfl_up(sc, 1); // last unflagged position before this lane's first position
-                    if (lane == 0) before = INT_MIN;
-                    before = imax(before, last_zero);
-                    int prevflag = __shfl_up(zpos[3] == INT_MIN ? 1 : 0, 1);
-                    if (lane == 0) prevflag = last_flag;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool flagged = zpos[j] == INT_MIN;
-                        if (!flagged && prevflag) { // a run [before+1, q-1] just ended
-                            int rs = before + 1, re = i0 + j - 1;
-                            if (rs == dlo) rs = 0;
-                            if (re == dhi) re = n - 1;
-                            const int len = re - rs + 1;
-                            if (len >= 5) {
-                                numaa += len;
-                                maxlen = imax(maxlen, len);
-                            }
-                        }
-                        before = imax(before, zpos[j]);
-                        prevflag = flagged ? 1 : 0;
-                    }
-                    last_zero = imax(last_zero, __shfl(sc, 63));
-                    last_flag = __shfl(prevflag, 63);
-                }
-            }
-            __syncthreads();
-            // ---- stage 2: weighted second smoothing at i0 = 256k + 4*lane - 40 .. i0 + 3, PAPA arg-max
-            {
-                const int i0 = TC * k + 4 * lane - 2 * TW;
-                double sums[3][4];
-                window_quads3(ring, RG_WF, wrap(slot_l2 + lane), sums);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = i0 + j;
-                    const bool valid = i >= we && i <= n - we - 1; // implies 0 <= i < n
-                    const int den = (2 * we + 1) + window_weight_side(i, we) + window_weight_side(n - 1 - i, we);
-                    const SharedDiv div(valid ? (double)den : 1.0);
-                    const double fix2 = valid ? div(sums[0][j]) : __builtin_nan("");
-                    const double llx2 = valid ? div(sums[1][j]) : __builtin_nan("");
-                    const double pax2 = valid ? div(sums[2][j]) : __builtin_nan("");
-                    if (TRACKS && i >= 0 && i < n) {
-                        tr.fix2[off + i] = fix2;
-                        tr.plaacllrx2[off + i] = llx2;
-                        tr.papax2[off + i] = pax2;
-                    }
-                    // papamode 1 (:4942-4948): NaNs fail both comparisons
-                    const bool upd = i >= plo && i < phi && (pax2 > pbest) && (fix2 < 0.0);
-                    pbest = upd ? pax2 : pbest;
-                    pcen = upd ? i : pcen;
-                    pfi = upd ? fix2 : pfi;
-                    pll2 = upd ? llx2 : pll2;
-                }
-            }
-            slot_in = wrap(slot_in + 64);
-            slot_l1 = wrap(slot_l1 + 64);
-            slot_w1 = wrap(slot_w1 + 64);
-            slot_l2 = wrap(slot_l2 + 64);
-        }
-        // wave arg-max: largest papax2, smallest centre among equals (first max of the serial loop)
-        for (int d = 32; d >= 1; d >>= 1) {
-            const double ob = __shfl_xor(pbest, d);
-            const int oc = __shfl_xor(pcen, d);
-            const double ofi = __shfl_xor(pfi, d), oll2 = __shfl_xor(pll2, d);
-            const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
-            if (take) {
-                pbest = ob;
-                pcen = oc;
-                pfi = ofi;
-                pll2 = oll2;
-            }
-        }
-        for (int d = 32; d >= 1; d >>= 1) { // FoldIndex run statistics: sum / max over lanes
-            numaa += __shfl_xor(numaa, d);
-            maxlen = imax(maxlen, __shfl_xor(maxlen, d));
-        }
-        // PAPAllr = first-level PLAAC-LLR at the centre, recomputed: lanes fetch the 41 taps in parallel,
-        // the fixed-order sum runs over lane broadcasts (out-of-range taps add +0.0)
-        double papallr = __builtin_nan("");
-        if (pcen >= 0) {
-            const int q = pcen - TW + lane;
-            const double v = (lane <= 2 * TW && q >= 0 && q < n) ? t_llr[ld_code(x, (uint32_t)q)] : 0.0;
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j <= 2 * TW; ++j) s = s + __shfl(v, j);
-            const int lo = imax(pcen - TW, 0), hi = imin(pcen + TW, n - 1);
-            papallr = s / (double)(hi - lo + 1);
-        }
-        if (lane == 0) {
-            row->fi_numaa = numaa;
-            row->fi_maxrun = maxlen;
-            row->papa_cen = pcen;
-            if (pcen >= 0) {
-                row->papa_combo = pbest;
-                row->papa_prop = pbest;
-                row->papa_fi = pfi;
-                row->papa_llr = papallr;
-                row->papa_llr2 = pll2;
-            } else {
-                row->papa_combo = -INFINITY;
-                row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
-            }
+        switch (kb_choose_b(n)) { // wave-uniform
+        case 2: tracks20_protein<2, TRACKS>(S, K, x, off, n, row, tr); break;
+        case 3: tracks20_protein<3, TRACKS>(S, K, x, off, n, row, tr); break;
+        default: tracks20_protein<4, TRACKS>(S, K, x, off, n, row, tr); break;
         }
     }
 }
