@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes
 // ------------------------------------------------------------------------------------------------
 constexpr int TW = 20;        // half window
 constexpr int RING_DOUBLES = 352; // doubles per ring (all sub-rings of one track), enough for every B below
-enum { RG_H = 0, RG_L = 1, RG_P = 2, RG_WF = 3, RG_WL = 4, RG_WP = 5, RG_N = 6 };
+enum { RG_WF = 0, RG_WL = 1, RG_WP = 2 };
 
 // geometry of the B-positions-per-lane variant
 template <int B>
@@ -1330,18 +1330,19 @@ struct SharedDiv {
     }
 };
 
-// The B 41-term sums of positions I .. I+B-1 (I = 0 mod B) for THREE tracks at once (rings A, A+1, A+2),
-// each in increasing position order: s[track][b] over I+b-20 .. I+b+20. Value e of the union (e = 0 .. 40+B-1,
-// position I-20+e) is class (e + C0) % B, slot base + (e + C0) / B, where base = slot of position I-20-C0.
-template <int B>
-__device__ __forceinline__ void window_sums3(const double *__restrict__ R, int A, int base, double (&s)[3][B]) {
+// The B 41-term sums of positions I .. I+B-1 (I = 0 mod B) for THREE tracks at once, each in increasing position
+// order: s[track][b] over I+b-20 .. I+b+20. Value e of the union (e = 0 .. 40+B-1, position I-20+e) is class
+// (e + C0) % B, slot base + (e + C0) / B, where base = slot of position I-20-C0. `src.get(v, cls, slot)` delivers
+// the three tracks' values of one position (from the weighted rings, or from the residue-code ring + tables).
+template <int B, class Src>
+__device__ __forceinline__ void window_sums3(const Src &src, int base, double (&s)[3][B]) {
     using G = KbGeom<B>;
     constexpr int NE = 2 * TW + B; // values in the union
     // value index e lies in window b  <=>  b <= e <= b + 40. `e` is always a compile-time constant after
     // unrolling (class and slot offset become immediates); `shift` moves the slot by whole body iterations.
-    auto val = [&](int a, int e, int shift = 0) -> double {
+    auto val = [&](double (&v)[3], int e, int shift = 0) {
         const int ec = e + G::C0;
-        return R[(A + a) * RING_DOUBLES + (ec % B) * G::SUB + base + ec / B + shift];
+        src.get(v, ec % B, base + ec / B + shift);
     };
     double acc[3][B];
 #pragma unroll
@@ -1350,14 +1351,15 @@ __device__ __forceinline__ void window_sums3(const double *__restrict__ R, int A
         for (int b = 0; b < B; ++b) acc[a][b] = 0.0;
     // head: e = 0 .. B-2 (not yet in every window)
 #pragma unroll
-    for (int e = 0; e < B - 1; ++e)
+    for (int e = 0; e < B - 1; ++e) {
+        double v[3];
+        val(v, e);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double v = val(a, e);
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < B; ++b)
-                if (b <= e) acc[a][b] = acc[a][b] + v;
-        }
+                if (b <= e) acc[a][b] = acc[a][b] + v[a];
+    }
     // body: e = B-1 .. 40 lies in all B windows; partially unrolled on purpose (a fully unrolled body lets the
     // scheduler hoist every LDS read and spill)
     constexpr int NBODY = 2 * TW + 1 - (B - 1); // 42 - B values
@@ -1366,35 +1368,36 @@ __device__ __forceinline__ void window_sums3(const double *__restrict__ R, int A
 #pragma unroll 2
     for (int it = 0; it < NBODY / STEP; ++it) {
         const int shift = it * (STEP / B);
+        double v[STEP][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            double v[STEP];
+        for (int u = 0; u < STEP; ++u) val(v[u], (B - 1) + u, shift);
 #pragma unroll
-            for (int u = 0; u < STEP; ++u) v[u] = val(a, (B - 1) + u, shift);
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < B; ++b)
 #pragma unroll
-                for (int u = 0; u < STEP; ++u) acc[a][b] = acc[a][b] + v[u];
-        }
+                for (int u = 0; u < STEP; ++u) acc[a][b] = acc[a][b] + v[u][a];
     }
 #pragma unroll
-    for (int e = (B - 1) + (NBODY / STEP) * STEP; e <= 2 * TW; ++e) // body remainder
+    for (int e = (B - 1) + (NBODY / STEP) * STEP; e <= 2 * TW; ++e) { // body remainder
+        double v[3];
+        val(v, e);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double v = val(a, e);
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < B; ++b) acc[a][b] = acc[a][b] + v;
-        }
+            for (int b = 0; b < B; ++b) acc[a][b] = acc[a][b] + v[a];
+    }
     // tail: e = 41 .. 40+B-1 (already past the first windows)
 #pragma unroll
-    for (int e = 2 * TW + 1; e < NE; ++e)
+    for (int e = 2 * TW + 1; e < NE; ++e) {
+        double v[3];
+        val(v, e);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double v = val(a, e);
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < B; ++b)
-                if (e <= b + 2 * TW) acc[a][b] = acc[a][b] + v;
-        }
+                if (e <= b + 2 * TW) acc[a][b] = acc[a][b] + v[a];
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1403,12 +1406,37 @@ __device__ __forceinline__ void window_sums3(const double *__restrict__ R, int A
 
 constexpr int KB_PROTEINS_PER_BLOCK = 16; // blocks retire regularly, so the K-A kernels' blocks keep getting slots
 
+// residue codes as the first-level windows see them: 0..21 real, 22 = any other byte (scored as X),
+// 23 = a proline that PAPA skips (second P of PP / PxP: hydropathy and LLR of P, log-odds 0), 24 = no residue
+// (outside the protein: every table holds +0.0, which leaves the fixed-order sums unchanged)
+constexpr int KC_DUP = 23, KC_NONE = 24, KC_ROWS = 25;
 struct KbShared {
-    double t_hyd[ROWS], t_llr[ROWS], t_lod[ROWS];
-    int t_chg[ROWS];
-    // rings: mapped inputs hydro/llr/papa (0.0 outside [0,n)), then weight * first-level FoldIndex/llr/papa
-    double ring[RG_N * RING_DOUBLES];
-    int pre[512]; // pre[q & 511] = charge sum of positions < q
+    double t_hyd[KC_ROWS], t_llr[KC_ROWS], t_lod[KC_ROWS];
+    int t_chg[KC_ROWS];
+    uint8_t cring[RING_DOUBLES + 32];    // residue-code ring (same class/slot geometry as the value rings)
+    double ring[3 * RING_DOUBLES];        // weight * first-level FoldIndex / llr / papa
+    int pre[512];                         // pre[q & 511] = charge sum of positions < q
+};
+
+// value sources of window_sums3
+template <int B>
+struct SrcCodes { // first level: residue code -> three table values
+    const KbShared &S;
+    __device__ __forceinline__ void get(double (&v)[3], int cls, int slot) const {
+        const uint32_t c = S.cring[cls * KbGeom<B>::SUB + slot];
+        v[0] = S.t_hyd[c];
+        v[1] = S.t_llr[c];
+        v[2] = S.t_lod[c];
+    }
+};
+template <int B>
+struct SrcRings { // second level: the three weighted rings
+    const double *__restrict__ R;
+    __device__ __forceinline__ void get(double (&v)[3], int cls, int slot) const {
+        v[0] = R[0 * RING_DOUBLES + cls * KbGeom<B>::SUB + slot];
+        v[1] = R[1 * RING_DOUBLES + cls * KbGeom<B>::SUB + slot];
+        v[2] = R[2 * RING_DOUBLES + cls * KbGeom<B>::SUB + slot];
+    }
 };
 
 struct KbConst {
@@ -1426,7 +1454,8 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
     const int lane = threadIdx.x;
     double *__restrict__ ring = S.ring;
     int *__restrict__ pre = S.pre;
-    for (int i = lane; i < RG_N * RING_DOUBLES; i += 64) ring[i] = 0.0;
+    for (int i = lane; i < 3 * RING_DOUBLES; i += 64) ring[i] = 0.0;
+    for (int i = lane; i < RING_DOUBLES + 32; i += 64) S.cring[i] = (uint8_t)KC_NONE;
     for (int i = lane; i < 512; i += 64) pre[i] = 0;
 
     const int we = n - 1 < TW ? n - 1 : TW; // w = ww/2 clamped to n-1 (:2588-2589)
@@ -1454,11 +1483,11 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
         // ---- stage 0: residues -> mapped inputs at q0 = 64Bk + B*lane .. q0 + B-1
         {
             const int q0 = G::C * k + B * lane;
-            double vh[B], vl[B], vp[B];
+            uint32_t kc[B]; // window codes of the lane's B positions
             int ch[B];
 #pragma unroll
             for (int j = 0; j < B; ++j) {
-                vh[j] = vl[j] = vp[j] = 0.0;
+                kc[j] = (uint32_t)KC_NONE;
                 ch[j] = 0;
             }
             if (q0 < n) {
@@ -1479,26 +1508,16 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
                     const uint32_t c = cb[2 + j] < 22u ? cb[2 + j] : 22u;
                     // only the first P of PP / PxP scores (:2653-2654); absolute neighbours p-1, p-2
                     const bool dup = K.adjust && c == 13u && (cb[1 + j] == 13u || cb[j] == 13u);
-                    vh[j] = in ? S.t_hyd[c] : 0.0;
-                    vl[j] = in ? S.t_llr[c] : 0.0;
+                    kc[j] = in ? (dup ? (uint32_t)KC_DUP : c) : (uint32_t)KC_NONE;
                     ch[j] = in ? S.t_chg[c] : 0;
-                    vp[j] = (in && !dup) ? S.t_lod[c] : 0.0;
                 }
             }
             const int idx = wrap(slot_in + lane);
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
-                ring[RG_H * RING_DOUBLES + j * G::SUB + idx] = vh[j];
-                ring[RG_L * RING_DOUBLES + j * G::SUB + idx] = vl[j];
-                ring[RG_P * RING_DOUBLES + j * G::SUB + idx] = vp[j];
-            }
-            if (idx < G::MIR) { // mirrored head: one branch for all copies
+            for (int j = 0; j < B; ++j) S.cring[j * G::SUB + idx] = (uint8_t)kc[j];
+            if (idx < G::MIR) { // mirrored head
 #pragma unroll
-                for (int j = 0; j < B; ++j) {
-                    ring[RG_H * RING_DOUBLES + j * G::SUB + idx + G::RB] = vh[j];
-                    ring[RG_L * RING_DOUBLES + j * G::SUB + idx + G::RB] = vl[j];
-                    ring[RG_P * RING_DOUBLES + j * G::SUB + idx + G::RB] = vp[j];
-                }
+                for (int j = 0; j < B; ++j) S.cring[j * G::SUB + idx + G::RB] = (uint8_t)kc[j];
             }
             // charge prefix counts: inclusive wave scan of the per-lane sums
             int lsum = 0;
@@ -1523,7 +1542,7 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
         {
             const int i0 = G::C * k + B * lane - G::LAG1;
             double sums[3][B];
-            window_sums3<B>(ring, RG_H, wrap(slot_l1 + lane), sums);
+            window_sums3<B>(SrcCodes<B>{S}, wrap(slot_l1 + lane), sums);
             double wfi[B], wll[B], wpa[B];
             int zpos[B]; // position if FoldIndex >= 0 there (or outside the scan domain), else "none"
 #pragma unroll
@@ -1608,7 +1627,7 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
         {
             const int i0 = G::C * k + B * lane - G::LAG2;
             double sums[3][B];
-            window_sums3<B>(ring, RG_WF, wrap(slot_l2 + lane), sums);
+            window_sums3<B>(SrcRings<B>{ring}, wrap(slot_l2 + lane), sums);
 #pragma unroll
             for (int j = 0; j < B; ++j) {
                 const int i = i0 + j;
@@ -1699,12 +1718,13 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
                                                  TrackPtrs tr) {
     __shared__ KbShared S;
     const int lane = threadIdx.x;
-    if (lane < ROWS) {
-        const int k = lane == NAA ? 0 : lane;
-        S.t_hyd[lane] = T->hyd[k];
-        S.t_llr[lane] = T->llr[k];
-        S.t_lod[lane] = T->lod[k];
-        S.t_chg[lane] = T->chg[k];
+    if (lane < KC_ROWS) {
+        const int k = lane < NAA ? lane : (lane == KC_DUP ? 13 : 0); // 22 -> X, 23 -> P
+        const bool none = lane == KC_NONE;
+        S.t_hyd[lane] = none ? 0.0 : T->hyd[k];
+        S.t_llr[lane] = none ? 0.0 : T->llr[k];
+        S.t_lod[lane] = (none || lane == KC_DUP) ? 0.0 : T->lod[k];
+        S.t_chg[lane] = none ? 0 : T->chg[k];
     }
     KbConst K;
     K.codes = codes;
