@@ -190,7 +190,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             tj = json.load(fh)
         if tj.get("workload") == [args.config, nprot, bool(args.tracks)]:
-            traffic = tj["bytes_per_launch"].get(dom)
+            traffic = tj["bytes_per_launch"].get(dom, tj["bytes_per_launch"].get(dom + "20"))
     except (OSError, ValueError, KeyError):
         pass
     path_ms = ktimes["total"]
