@@ -45,6 +45,33 @@ def usable_cores():
     return n
 
 
+def time_reference_jar(codes, offsets, nseq):
+    """`java -jar $PLAAC_REF_JAR -i sample.fa` (second of two runs), or the reason it was skipped"""
+    import shutil
+    import subprocess
+    import tempfile
+    jar, java = os.environ.get("PLAAC_REF_JAR"), shutil.which("java")
+    if not jar or not java or not os.path.exists(jar):
+        return "skipped: no JVM on PATH" if not java else "skipped: PLAAC_REF_JAR not set"
+    from plaac_amd import native
+    off = offsets[:nseq + 1].cpu().numpy()
+    text = native.decode(codes[:int(off[-1])].cpu().numpy())
+    with tempfile.NamedTemporaryFile("w", suffix=".fa", delete=False) as fh:
+        for i in range(nseq):
+            fh.write(">s%d\n%s\n" % (i, text[int(off[i]):int(off[i + 1])]))
+        path = fh.name
+    try:
+        dt = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            subprocess.run([java, "-jar", jar, "-i", path], stdout=subprocess.DEVNULL, check=True, timeout=600)
+            dt = time.perf_counter() - t0
+        return {"value": round(int(off[-1]) / dt, 1), "unit": "residues/s", "cores": 1, "kind": "reference",
+                "sample": "first %d sequences, parse+score+format, second of two runs" % nseq}
+    finally:
+        os.unlink(path)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +183,23 @@ def main():
     else:
         job_res, job_prot = total, nprot
 
+    # achievable HBM copy rate on this box (SURVEY 8d M3 asks for it next to the nominal 8 TB/s): 1 GiB
+    # device-to-device copy = 2 GiB of traffic, outside the timed region
+    copy_gbps = None
+    if rank == 0:
+        a_ = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        b_ = torch.empty_like(a_)
+        b_.copy_(a_)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b_.copy_(a_)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbps = round(5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a_, b_
+
     if args.calibrate:
         cnt = torch.zeros(22, dtype=torch.int64, device=dev)
         ctx.histogram_device(codes.data_ptr(), offsets.data_ptr(), nprot, cnt.data_ptr(), stream=stream.cuda_stream)
@@ -196,7 +240,7 @@ def main():
     path_ms = ktimes["total"]
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "measured_copy_GBps": copy_gbps,
         "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
         "kernels_overlap": "k_vit, k_fwd, k_win, k_tracks run concurrently on 4 HIP streams; total = first launch -> join",
         "path_achieved_GBps": round(path_bytes / (path_ms * 1e-3) / 1e9, 3),
@@ -235,6 +279,11 @@ def main():
             "value_1core": round(int(off_h[n_1]) / dt1, 1),
             "gpu_rows_match_oracle": bool(got.tobytes() == want.tobytes()),
         }
+
+    # when the operator supplies the real reference (a JVM on PATH and
+    # PLAAC_REF_JAR=/path/plaac.jar) time it too, single-threaded as it is, on a small sample
+    if cpu is not None:
+        cpu["reference_jar"] = time_reference_jar(codes, offsets, min(nprot, 8000))
 
     out = {
         "metric": "residues/sec", "value": round(job_res * npoints * args.steps / dt, 1), "unit": "residues/s",

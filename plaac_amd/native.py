@@ -156,6 +156,11 @@ def encode(seq):
     return out
 
 
+def decode(codes):
+    """codes 0..21 -> residue letters (plaac.java:26 alphabet order)"""
+    return np.frombuffer(b"XACDEFGHIKLMNPQRSTVWY*", dtype=np.uint8)[np.asarray(codes, dtype=np.uint8)].tobytes().decode("ascii")
+
+
 def pack(seqs):
     """records (str/bytes, untrimmed) -> (codes u8[total], offsets u64[n+1])"""
     enc = [encode(s) for s in seqs]
