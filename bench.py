@@ -213,6 +213,8 @@ def main():
     # ---- rank 0: kernel times (HIP events on each kernel's launch stream, mean over the timed steps) ----
     ktimes = ctx.last_timings(min(args.steps, 32))
     kern = {"k_vit": ktimes["vit"], "k_fwd": ktimes["fwd"], "k_win": ktimes["win"], "k_tracks": ktimes["tracks"]}
+    if args.tracks:
+        kern["k_bwd"] = ktimes["bwd"]
     dom = max(kern, key=kern.get)
     dom_ms = kern[dom]
     tb = native.TRACK_BYTES_PER_RESIDUE if args.tracks else 0
@@ -221,7 +223,8 @@ def main():
     # [+ its per-residue track outputs in track mode]
     kbytes = {
         "k_vit": total * (1 + (1 if args.tracks else 0)) + nprot * (16 + 44),
-        "k_fwd": total * (1 + (17 if args.tracks else 0)) + nprot * (16 + 8),
+        "k_fwd": total * (1 + (16 if args.tracks else 0)) + nprot * (16 + 8),  # track mode: a-pairs to scratch
+        "k_bwd": total * (1 + 16) + nprot * 16,
         "k_win": total + nprot * (16 + 56),
         "k_tracks": total * (1 + (64 if args.tracks else 0)) + nprot * (16 + 52),
     }

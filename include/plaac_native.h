@@ -192,9 +192,10 @@ plaac_status plaac_ctx_sync(plaac_ctx *ctx);
 
 /* Device time in ms (HIP events recorded on the stream each kernel is launched on) of the most recent
  * scored batch: [0] whole call (first launch -> all kernels done), [1] plan (length sort),
- * [2] k_vit (Viterbi / traceback / core), [3] k_fwd (forward [+ backward, posteriors]),
+ * [2] k_vit (Viterbi / traceback / core), [3] k_fwd (forward recurrence),
  * [4] k_win (MW / LLR windows, means), [5] k_tracks (FoldIndex / PAPA window tracks),
- * [6] group-interleaved packing of the residues for [2..4] (incl. the host round trip for its size), [7] reserved.
+ * [6] group-interleaved packing of the residues for [2..4] (incl. the host round trip for its size),
+ * [7] k_bwd (backward recurrence; track mode only, else 0).
  * The four scoring kernels run concurrently on separate streams (PLAAC_SERIAL_STREAMS=1 in the
  * environment at ctx creation serialises them for profiling), so [2..5] overlap and do not add up to [0].
  * Blocks until the batch has completed. */

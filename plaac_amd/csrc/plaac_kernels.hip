@@ -669,19 +669,18 @@ __device__ __forceinline__ void fwd_block(FwdState &S, const double *__restrict_
     }
 }
 
-// backward recurrence (:3377-3391) over one block, t = t0+15 .. t0: replaces the stored forward pair a[.][t] by
-// a[.][t] + b[.][t] (what the posterior needs, :3403) and steps b to t-1 with the emission of residue t
+// backward recurrence (:3377-3391) over one block, t = t0+15 .. t0: stores b[.][t] next to the forward pair
+// (the posterior needs a[.][t] + b[.][t], :3403) and steps b to t-1 with the emission of residue t
 template <bool GUARD>
 __device__ __forceinline__ void bwd_block(double &b0, double &b1, const double *__restrict__ s_row,
                                           const double *__restrict__ s_lut, const uint4 cur, uint32_t t0, uint32_t n,
                                           double lt00, double lt01, double lt10, double lt11,
-                                          double2 *__restrict__ fw) {
+                                          double2 *__restrict__ bw) {
 #pragma unroll
     for (int j = 15; j >= 0; --j) {
         const uint32_t t = t0 + (uint32_t)j;
         if (!GUARD || t < n) {
-            const double2 a = fw[(size_t)t * 64u];
-            fw[(size_t)t * 64u] = make_double2(a.x + b0, a.y + b1);
+            bw[(size_t)t * 64u] = make_double2(b0, b1);
             const double *__restrict__ r = s_row + block_code(cur, j) * R_W;
             const double u0 = (lt00 + b0) + r[R_LE0], u1 = (lt01 + b1) + r[R_LE1];
             const double w0 = (lt10 + b0) + r[R_LE0], w1 = (lt11 + b1) + r[R_LE1];
@@ -699,7 +698,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
                                                     const uint32_t *__restrict__ grow, plaac_row *__restrict__ rows,
-                                                    double2 *__restrict__ fwd, double *__restrict__ lpseq_out) {
+                                                    double2 *__restrict__ fwd) {
     __shared__ double s_lut[LUTLEN + 1];
     __shared__ double s_row[ROWS * R_W];
     for (int i = threadIdx.x; i < LUTLEN; i += KA_THREADS) s_lut[i] = T->loglut[i];
@@ -714,7 +713,6 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
     plaac_row *row = rows + J.p;
     if (n == 0) {
         row->hmm_all = 0.0;
-        if (TRACKS) lpseq_out[gid] = 0.0;
         return;
     }
     (void)codes;
@@ -747,38 +745,71 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
     const double lmarg1 = lse_lut(s_lut, F.a0 + lf0, F.a1 + lf1); // (:3369-3375)
     row->hmm_all = lmarg1 - (F.h0 + T->h0_lf0);
 
-    if (TRACKS) {
-        // backward sweep; the posteriors themselves (exp, :3403) are position-parallel work: k_post
-        double b0 = lf0, b1 = lf1;
-        const uint32_t nw = (n + 15u) >> 4;
-        uint4 nxt = PL.chunk(nw - 1u);
-        for (uint32_t wi = nw; wi-- > 0u;) {
-            const uint4 cur = nxt;
-            if (wi > 0u) nxt = PL.chunk(wi - 1u);
-            const uint32_t t0 = wi << 4;
-            if (t0 + 16u <= n) bwd_block<false>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, fw);
-            else bwd_block<true>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, fw);
-        }
-        const double2 ab = fw[0]; // a[.][0] + b[.][0]
-        lpseq_out[gid] = lse_lut(s_lut, ab.x, ab.y); // lpseq (:3393-3396)
+}
+
+// ---- role B (track mode): backward recurrence (:3377-3391). It does not depend on the forward values, so it is
+//      its own chain on its own stream, concurrent with k_fwd; k_post combines the two. ----
+__global__ __launch_bounds__(KA_THREADS) void k_bwd(const uint64_t *__restrict__ offsets,
+                                                    const uint32_t *__restrict__ neff,
+                                                    const uint32_t *__restrict__ order, uint32_t nprot,
+                                                    const DevTables *__restrict__ T,
+                                                    const uint4 *__restrict__ packed,
+                                                    const uint32_t *__restrict__ grow, double2 *__restrict__ bwd) {
+    __shared__ double s_lut[LUTLEN + 1];
+    __shared__ double s_row[ROWS * R_W];
+    for (int i = threadIdx.x; i < LUTLEN; i += KA_THREADS) s_lut[i] = T->loglut[i];
+    if (threadIdx.x == 0) s_lut[LUTLEN] = 0.0;
+    load_rows(s_row, T);
+    __syncthreads();
+    const LaneJob J = lane_job(offsets, neff, order, nprot);
+    const uint32_t n = J.n;
+    set_wave_priority(n);
+    const uint32_t gid = blockIdx.x * KA_THREADS + threadIdx.x;
+    if (gid >= nprot || n == 0) return;
+    const PackedLane PL = packed_lane(packed, nullptr, grow);
+    const double lt00 = T->lt[0][0], lt01 = T->lt[0][1], lt10 = T->lt[1][0], lt11 = T->lt[1][1];
+    double2 *bw = bwd + ((size_t)grow[gid >> 6] * 16u) * 64u + (gid & 63u);
+    double b0 = T->lf[0], b1 = T->lf[1]; // b[.][n-1] = lfprob (:3378)
+    const uint32_t nw = (n + 15u) >> 4;
+    uint4 nxt = PL.chunk(nw - 1u);
+    for (uint32_t wi = nw; wi-- > 0u;) {
+        const uint4 cur = nxt;
+        if (wi > 0u) nxt = PL.chunk(wi - 1u);
+        const uint32_t t0 = wi << 4;
+        if (t0 + 16u <= n) bwd_block<false>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, bw);
+        else bwd_block<true>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, bw);
     }
 }
 
-// ---- posteriors / MAP / Viterbi bytes of track mode (:3403, :4037-4041): position-parallel ----
-// One wave per (wave-group, 32-step tile): reads the interleaved a+b pairs coalesced, takes the exp, transposes
-// through LDS and writes each protein's 32 consecutive values as one contiguous run.
-constexpr int PT = 32; // steps per tile
+// ---- posteriors / MAP / Viterbi bytes of track mode (:3393-3405, :4037-4041): position-parallel ----
+// One wave per packed row (= 16 steps of the 64 proteins of one wave-group): finds its group in the row prefix
+// sums, reads the interleaved forward and backward pairs coalesced (1 KiB per step and array), takes the exp,
+// transposes through LDS and writes each protein's 16 consecutive values as one contiguous 128-byte run.
+constexpr int PT = 16; // steps per tile = one packed row
 __global__ __launch_bounds__(64) void k_post(const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ neff,
-                                              const uint32_t *__restrict__ order, uint32_t nprot,
-                                              const uint32_t *__restrict__ grow, const double2 *__restrict__ fwd,
-                                              const double *__restrict__ lpseq, const uint32_t *__restrict__ bits,
-                                              TrackPtrs tr) {
+                                              const uint32_t *__restrict__ order, uint32_t nprot, uint32_t ngroups,
+                                              const uint32_t *__restrict__ grow, const DevTables *__restrict__ T,
+                                              const double2 *__restrict__ fwd, const double2 *__restrict__ bwd,
+                                              const uint32_t *__restrict__ bits, TrackPtrs tr) {
     __shared__ double s0[PT][65], s1[PT][65];
     __shared__ uint8_t sb[PT][64]; // bit 0 = Viterbi state, bit 1 = MAP state
     __shared__ uint32_t sh_n[64];
     __shared__ uint64_t sh_off[64];
-    const uint32_t g = blockIdx.x >> 2, sub = blockIdx.x & 3u;
+    const uint32_t r = blockIdx.x; // packed row
     const int lane = threadIdx.x;
+    // group of this row: the largest g with grow[g] <= r (64-ary search, wave-uniform; empty groups repeat a value)
+    uint32_t lo = 0, hi = ngroups;
+    while (hi - lo > 1u) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint32_t idx = lo + ((uint32_t)lane + 1u) * step;
+        const bool le = idx < hi && grow[idx] <= r;
+        const uint32_t k = (uint32_t)__popcll(__ballot(le));
+        lo += k * step;
+        hi = lo + step < hi ? lo + step : hi;
+    }
+    const uint32_t g = lo;
+    const size_t rbase = (size_t)grow[g];
+    const uint32_t t0 = (r - (uint32_t)rbase) * 16u;
     const uint32_t gid = g * 64u + (uint32_t)lane;
     uint32_t n = 0;
     uint64_t off = 0;
@@ -787,46 +818,39 @@ __global__ __launch_bounds__(64) void k_post(const uint64_t *__restrict__ offset
         const uint32_t p = order[gid];
         n = neff[p];
         off = offsets[p];
-        lp = lpseq[gid];
+        if (n) { // lpseq (:3393-3396) from a[.][0] + b[.][0]
+            const double2 a = fwd[rbase * 16u * 64u + (size_t)lane], b = bwd[rbase * 16u * 64u + (size_t)lane];
+            lp = lse_lut(T->loglut, a.x + b.x, a.y + b.y);
+        }
     }
     sh_n[lane] = n;
     sh_off[lane] = off;
-    uint32_t nmax = n; // longest of the group (lane 0, except inside the unsorted last length bin)
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = __shfl_xor(nmax, d);
-        nmax = o > nmax ? o : nmax;
-    }
-    const size_t rbase = (size_t)grow[g];
-    const double2 *__restrict__ fw = fwd + rbase * 16u * 64u + (size_t)lane;
-    const uint32_t *__restrict__ wb = bits + rbase * 64u + (size_t)lane;
-    const int half = lane >> 5, tt2 = lane & 31;
-    for (uint32_t t0 = sub * PT; t0 < nmax; t0 += 4u * PT) {
-        __syncthreads();
-        uint32_t w = 0;
+    const double2 *__restrict__ fw = fwd + (size_t)r * 16u * 64u + (size_t)lane;
+    const double2 *__restrict__ bw = bwd + (size_t)r * 16u * 64u + (size_t)lane;
+    const uint32_t w = t0 < n ? bits[(size_t)r * 64u + (size_t)lane] : 0u;
 #pragma unroll 4
-        for (int tt = 0; tt < PT; ++tt) {
-            const uint32_t t = t0 + (uint32_t)tt;
-            if ((t & 15u) == 0u && t < n) w = wb[(size_t)(t >> 4) * 64u];
-            if (t < n) {
-                const double2 ab = fw[(size_t)t * 64u];
-                const double pp0 = exp(ab.x - lp), pp1 = exp(ab.y - lp); // exp((a+b) - lpseq)
-                s0[tt][lane] = pp0;
-                s1[tt][lane] = pp1;
-                sb[tt][lane] = (uint8_t)(((w >> (t & 15u)) & 1u) | (pp1 > pp0 ? 2u : 0u)); // MAP ties -> 0 (:4039)
-            }
+    for (int tt = 0; tt < PT; ++tt) {
+        if (t0 + (uint32_t)tt < n) {
+            const double2 a = fw[(size_t)tt * 64u], b = bw[(size_t)tt * 64u];
+            const double pp0 = exp((a.x + b.x) - lp), pp1 = exp((a.y + b.y) - lp); // (:3403)
+            s0[tt][lane] = pp0;
+            s1[tt][lane] = pp1;
+            sb[tt][lane] = (uint8_t)(((w >> tt) & 1u) | (pp1 > pp0 ? 2u : 0u)); // MAP ties -> 0 (:4039)
         }
-        __syncthreads();
-        for (int lp2 = 0; lp2 < 32; ++lp2) {
-            const int L = 2 * lp2 + half;
-            const uint32_t t = t0 + (uint32_t)tt2;
-            if (t < sh_n[L]) {
-                const uint64_t o = sh_off[L] + t;
-                tr.post0[o] = s0[tt2][L];
-                tr.post1[o] = s1[tt2][L];
-                const uint8_t bb = sb[tt2][L];
-                tr.vit[o] = bb & 1u;
-                tr.map[o] = bb >> 1;
-            }
+    }
+    __syncthreads();
+    const int sub = lane >> 4, tt2 = lane & 15;
+    const uint32_t t = t0 + (uint32_t)tt2;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int L = 4 * it + sub;
+        if (t < sh_n[L]) {
+            const uint64_t o = sh_off[L] + t;
+            tr.post0[o] = s0[tt2][L];
+            tr.post1[o] = s1[tt2][L];
+            const uint8_t bb = sb[tt2][L];
+            tr.vit[o] = bb & 1u;
+            tr.map[o] = bb >> 1;
         }
     }
 }
@@ -1824,15 +1848,14 @@ struct plaac_ctx {
     DevTables *d_tabs = nullptr;  // tables of the groups of a sweep
     size_t cap_tabs = 0;
     std::vector<hipEvent_t> gev;  // per-group "forward pass done" events of a sweep
-    hipEvent_t jev[3] = {nullptr, nullptr, nullptr}; // join events of the three side streams
+    hipEvent_t jev[4] = {nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
     uint32_t *d_neff = nullptr, *d_order = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
     uint4 *d_packed = nullptr;
-    double2 *d_fwd = nullptr; // track mode: forward / a+b pairs, group-interleaved
-    double *d_lpseq = nullptr;
+    double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
     uint32_t *h_pin = nullptr; // pinned word for the one device->host readback of a call (total packed rows)
-    size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_lpseq = 0, cap_grow = 0, cap_packed = 0;
+    size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_bwd = 0, cap_grow = 0, cap_packed = 0;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
     uint64_t *d_offsets = nullptr;
@@ -1842,10 +1865,10 @@ struct plaac_ctx {
     unsigned long long *d_counts = nullptr;
     size_t cap_codes = 0, cap_offs = 0, cap_rows = 0, cap_trk = 0;
     static constexpr int EV_SETS = 32; // timings of the last 32 scored batches
-    static constexpr int EV_PER = 13;  // start, planned, {begin,end} x {vit,fwd,win,tracks}, joined, {begin,end} pack
+    static constexpr int EV_PER = 15;  // start, planned, {begin,end} x {vit,fwd,win,tracks}, joined, {begin,end} x {pack,bwd}
     hipEvent_t ev[EV_SETS][EV_PER] = {};
     uint64_t ncalls = 0;
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // high-priority side streams of the three K-A roles
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; // high-priority side streams of the K-A roles
     bool serial = false;                              // PLAAC_SERIAL_STREAMS=1: everything on one stream
     bool generic_tracks = false;                      // PLAAC_GENERIC_TRACKS=1: never use the ww=41 fast path
     std::string err;
@@ -2038,7 +2061,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->d_lpseq) (void)hipFree(ctx->d_lpseq);
+    if (ctx->d_bwd) (void)hipFree(ctx->d_bwd);
     void *bufs[] = {ctx->d_tab,  ctx->d_neff,    ctx->d_order, ctx->d_hist, ctx->d_bits,  ctx->d_fwd,   ctx->d_codes,
                     ctx->d_offsets, ctx->d_rows, ctx->d_trk8,  ctx->d_trk64, ctx->d_counts, ctx->d_grow, ctx->d_packed};
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -2123,8 +2146,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if ((rc = grow(ctx, ctx->d_order, ctx->cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
     const uint32_t ngroups = (nprot + 63u) / 64u;
     if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 1)) != PLAAC_OK) return rc;
-    if (d_tracks)
-        if ((rc = grow(ctx, ctx->d_lpseq, ctx->cap_lpseq, (size_t)nprot)) != PLAAC_OK) return rc;
     // device tables: slot 0 keeps the ctx parameters (single-point calls), sweep groups use slots 1..ng
     const DevTables *gtab0 = ctx->d_tab;
     if (!(npoints == 1 && std::memcmp(&points[0], &ctx->params, sizeof(plaac_params)) == 0)) {
@@ -2142,9 +2163,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     }
 
     hipEvent_t *evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
-    enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10, E_PACK = 11 };
+    enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10, E_PACK = 11, E_BWD = 13 };
     hipStream_t sv = ctx->serial ? st : ctx->aux[0], sf = ctx->serial ? st : ctx->aux[1],
-                sw = ctx->serial ? st : ctx->aux[2];
+                sw = ctx->serial ? st : ctx->aux[2], sb = ctx->serial ? st : ctx->aux[3];
 
     auto launch_tracks = [&](size_t g) -> plaac_status { // K-B: needs only the order, not the packed copy
         const plaac_params &P = points[groups[g].first];
@@ -2205,14 +2226,22 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const size_t total_rows = ctx->h_pin[0];
     if ((rc = grow(ctx, ctx->d_packed, ctx->cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
     if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
-    if (d_tracks)
+    if (d_tracks) {
         if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_bwd, ctx->cap_bwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
+    }
     hipLaunchKernelGGL(k_pack, dim3((nprot + 255u) / 256u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
     if (!ctx->serial)
-        for (hipStream_t a : {sf, sw}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
+        for (hipStream_t a : {sf, sw, sb}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
     const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
+    // track mode: the backward recurrence is a chain of its own, beside the forward one
+    PL_HIP(ctx, hipEventRecord(evs[E_BWD], sb));
+    if (d_tracks)
+        hipLaunchKernelGGL(k_bwd, dim3(ab), dim3(KA_THREADS), 0, sb, d_offsets, ctx->d_neff, ctx->d_order, nprot, gtab0,
+                           ctx->d_packed, ctx->d_grow, ctx->d_bwd);
+    PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
 
     for (size_t g = 0; g < ng; ++g) {
         const Group &G = groups[g];
@@ -2227,11 +2256,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
         if (d_tracks)
             hipLaunchKernelGGL(k_fwd<true>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, ctx->d_fwd, ctx->d_lpseq);
+                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, ctx->d_fwd);
         else
             hipLaunchKernelGGL(k_fwd<false>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, (double2 *)nullptr,
-                               (double *)nullptr);
+                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, (double2 *)nullptr);
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
         // Viterbi / windows: up to MAXC core lengths per launch
         for (size_t m0 = 0; m0 < G.members.size(); m0 += MAXC) {
@@ -2290,11 +2318,12 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[0], sv));
         PL_HIP(ctx, hipEventRecord(ctx->jev[1], sf));
         PL_HIP(ctx, hipEventRecord(ctx->jev[2], sw));
+        PL_HIP(ctx, hipEventRecord(ctx->jev[3], sb));
         for (hipEvent_t e : ctx->jev) PL_HIP(ctx, hipStreamWaitEvent(st, e, 0));
     }
-    if (d_tracks) // posteriors, MAP and Viterbi bytes: needs the backward sweep (k_fwd) and the path bits (k_vit)
-        hipLaunchKernelGGL(k_post, dim3(ngroups * 4u), dim3(64), 0, st, d_offsets, ctx->d_neff, ctx->d_order, nprot,
-                           ctx->d_grow, ctx->d_fwd, ctx->d_lpseq, ctx->d_bits, tp);
+    if (d_tracks && total_rows) // posteriors, MAP, Viterbi bytes: needs k_fwd, k_bwd and the path bits (k_vit)
+        hipLaunchKernelGGL(k_post, dim3((unsigned)total_rows), dim3(64), 0, st, d_offsets, ctx->d_neff, ctx->d_order,
+                           nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp);
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->ncalls++;
@@ -2324,11 +2353,11 @@ plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
     if (ncalls > ctx->ncalls) ncalls = (uint32_t)ctx->ncalls;
     PL_HIP(ctx, hipSetDevice(ctx->device));
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    static const int pairs[7][2] = {{0, 10}, {0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {11, 12}};
+    static const int pairs[8][2] = {{0, 10}, {0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {11, 12}, {13, 14}};
     for (uint32_t k = 0; k < ncalls; ++k) {
         hipEvent_t *evs = ctx->ev[(ctx->ncalls - 1 - k) % plaac_ctx::EV_SETS];
         PL_HIP(ctx, hipEventSynchronize(evs[10]));
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < 8; ++i) {
             float t = 0.f;
             PL_HIP(ctx, hipEventElapsedTime(&t, evs[pairs[i][0]], evs[pairs[i][1]]));
             acc[i] += t;

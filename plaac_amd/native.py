@@ -270,7 +270,7 @@ class Context:
         ms = (C.c_float * 8)()
         self._check(self._L.plaac_timings_mean(self._h, int(ncalls), C.addressof(ms)))
         return {"total": ms[0], "plan": ms[1], "vit": ms[2], "fwd": ms[3], "win": ms[4], "tracks": ms[5],
-                "pack": ms[6]}
+                "pack": ms[6], "bwd": ms[7]}
 
 
 class Batch:
