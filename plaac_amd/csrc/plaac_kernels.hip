@@ -1300,7 +1300,9 @@ struct KbGeom {
     static constexpr int LAG2 = ((LAG1 + TW + B - 1) / B) * B; // second-level lag: multiple of B, >= LAG1 + 20
     static constexpr int C0 = ((-TW) % B + B) % B;          // class of the first window position (i0 - 20)
     static constexpr int GMAX = (2 * TW + B - 1 + C0) / B;  // largest slot offset a window read uses
-    static constexpr int LIVE = (C + LAG2 - LAG1 + TW > C + LAG1 + TW ? C + LAG2 - LAG1 + TW : C + LAG1 + TW);
+    static constexpr int LIVE_LAG = (C + LAG2 - LAG1 + TW > C + LAG1 + TW ? C + LAG2 - LAG1 + TW : C + LAG1 + TW);
+    static constexpr int LIVE_NOLAG = C + 2 * TW + C0 + B;  // single-iteration variant: positions -20-C0 .. C+20+B-1
+    static constexpr int LIVE = LIVE_LAG > LIVE_NOLAG ? LIVE_LAG : LIVE_NOLAG;
     static constexpr int RB = (LIVE + B - 1) / B + 1;       // sub-ring entries per class
     static constexpr int MIR = GMAX + 1;                    // mirrored head
     static constexpr int SUB = RB + MIR;
@@ -1352,6 +1354,8 @@ struct SharedDiv {
         const double r = __builtin_fma(-d, q0, a);
         return __builtin_fma(r, y, q0);
     }
+    // every later quotient becomes NaN unless ok (one select instead of one per quotient)
+    __device__ __forceinline__ void poison_unless(bool ok) { y = ok ? y : __builtin_nan(""); }
 };
 
 // The B 41-term sums of positions I .. I+B-1 (I = 0 mod B) for THREE tracks at once, each in increasing position
@@ -1470,11 +1474,14 @@ struct KbConst {
     double cc0, cc1, cc2;
 };
 
-// one protein with B positions per lane
+// one protein with B positions per lane. `nolag` (n < 64*B): the whole protein fits one iteration, so the three
+// stages run back to back over the same positions instead of as a lagged pipeline (no fill/drain iteration).
 template <int B, bool TRACKS>
 __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, const uint8_t *__restrict__ x,
-                                                 uint64_t off, int n, plaac_row *__restrict__ row, TrackPtrs tr) {
+                                                 uint64_t off, int n, bool nolag, plaac_row *__restrict__ row,
+                                                 TrackPtrs tr) {
     using G = KbGeom<B>;
+    const int lag1 = nolag ? 0 : G::LAG1, lag2 = nolag ? 0 : G::LAG2;
     const int lane = threadIdx.x;
     double *__restrict__ ring = S.ring;
     int *__restrict__ pre = S.pre;
@@ -1492,17 +1499,18 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
     double pbest = -INFINITY, pfi = 0.0, pll2 = 0.0;
     int pcen = -1;
     int numaa = 0, maxlen = 0, carry = 0;   // numaa / maxlen: per-lane partials, reduced at the end
-    int last_zero = INT_MIN, last_flag = 0; // wave-uniform carries of the FoldIndex run scan
+    int last_zero = -1, last_flag = 0;      // wave-uniform carries of the FoldIndex run scan (position -1 is
+                                            // unflagged: a run can start at 0 at the earliest)
     __syncthreads();
 
-    const int nchunks = (n + G::LAG2 + G::C - 1) / G::C;
+    const int nchunks = (n + lag2 + G::C - 1) / G::C;
     // ring slot of entry number e (= position / B): e mod RB; per iteration the entry numbers advance by 64
     auto wrap = [](int s) { return s >= G::RB ? s - G::RB : s; };
     auto neg_slot = [](int e) { return ((e % G::RB) + G::RB) % G::RB; };
     int slot_in = 0;                                             // entry 64k            (stage 0 writes)
-    int slot_l1 = neg_slot(-(G::LAG1 + TW + G::C0) / B);         // entry of position 64Bk - LAG1 - 20 - C0
-    int slot_w1 = neg_slot(-G::LAG1 / B);                        // entry of position 64Bk - LAG1 (stage 1 writes)
-    int slot_l2 = neg_slot(-(G::LAG2 + TW + G::C0) / B);         // entry of position 64Bk - LAG2 - 20 - C0
+    int slot_l1 = neg_slot(-(lag1 + TW + G::C0) / B);            // entry of position 64Bk - LAG1 - 20 - C0
+    int slot_w1 = neg_slot(-lag1 / B);                           // entry of position 64Bk - LAG1 (stage 1 writes)
+    int slot_l2 = neg_slot(-(lag2 + TW + G::C0) / B);            // entry of position 64Bk - LAG2 - 20 - C0
     for (int k = 0; k < nchunks; ++k) {
         // ---- stage 0: residues -> mapped inputs at q0 = 64Bk + B*lane .. q0 + B-1
         {
@@ -1564,7 +1572,7 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
         __syncthreads();
         // ---- stage 1: first-level tracks at i0 = 64Bk + B*lane - LAG1 .. i0 + B-1
         {
-            const int i0 = G::C * k + B * lane - G::LAG1;
+            const int i0 = G::C * k + B * lane - lag1;
             double sums[3][B];
             window_sums3<B>(SrcCodes<B>{S}, wrap(slot_l1 + lane), sums);
             double wfi[B], wll[B], wpa[B];
@@ -1581,10 +1589,11 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
                 const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
                 const double llr1 = div(sums[1][j]);
                 const double papa = div(sums[2][j]);
-                const double wt = (double)(1 + imin(i, we) + imin(n - i - 1, we));
-                wfi[j] = live ? wt * fi : 0.0;
-                wll[j] = live ? wt * llr1 : 0.0;
-                wpa[j] = live ? wt * papa : 0.0;
+                // weight 0 outside the protein: +-0.0 in the ring leaves every fixed-order sum unchanged
+                const double wt = (double)(live ? 1 + imin(i, we) + imin(n - i - 1, we) : 0);
+                wfi[j] = wt * fi;
+                wll[j] = wt * llr1;
+                wpa[j] = wt * papa;
                 const bool neg = live && (fi < 0.0) && i >= dlo && i <= dhi;
                 zpos[j] = neg ? INT_MIN : i;
                 if (TRACKS && live) {
@@ -1649,7 +1658,7 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
         __syncthreads();
         // ---- stage 2: weighted second smoothing at i0 = 64Bk + B*lane - LAG2 .. i0 + B-1, PAPA arg-max
         {
-            const int i0 = G::C * k + B * lane - G::LAG2;
+            const int i0 = G::C * k + B * lane - lag2;
             double sums[3][B];
             window_sums3<B>(SrcRings<B>{ring}, wrap(slot_l2 + lane), sums);
 #pragma unroll
@@ -1657,10 +1666,9 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
                 const int i = i0 + j;
                 const bool valid = i >= we && i <= n - we - 1; // implies 0 <= i < n
                 const int den = (2 * we + 1) + window_weight_side(i, we) + window_weight_side(n - 1 - i, we);
-                const SharedDiv div(valid ? (double)den : 1.0);
-                const double fix2 = valid ? div(sums[0][j]) : __builtin_nan("");
-                const double llx2 = valid ? div(sums[1][j]) : __builtin_nan("");
-                const double pax2 = valid ? div(sums[2][j]) : __builtin_nan("");
+                SharedDiv div(valid ? (double)den : 1.0);
+                div.poison_unless(valid); // NaN outside [w, n-w-1] (:2597-2600)
+                const double fix2 = div(sums[0][j]), llx2 = div(sums[1][j]), pax2 = div(sums[2][j]);
                 if (TRACKS && i >= 0 && i < n) {
                     tr.fix2[off + i] = fix2;
                     tr.plaacllrx2[off + i] = llx2;
@@ -1726,9 +1734,11 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
 }
 
 // positions-per-lane variant that wastes the fewest slots for a protein of n residues: iterations x
-// (per-iteration cost ~ B + fixed part)
+// (per-iteration cost ~ B + fixed part). A protein shorter than one iteration needs no pipeline lag.
 __device__ __forceinline__ int kb_choose_b(int n) {
-    auto cost = [n](int b, int lag2) { return ((n + lag2 + 64 * b - 1) / (64 * b)) * (10 * b + 7); };
+    auto cost = [n](int b, int lag2) {
+        return n < 64 * b ? 10 * b + 7 : ((n + lag2 + 64 * b - 1) / (64 * b)) * (10 * b + 7);
+    };
     const int c2 = cost(2, KbGeom<2>::LAG2), c3 = cost(3, KbGeom<3>::LAG2), c4 = cost(4, KbGeom<4>::LAG2);
     return (c4 <= c3 && c4 <= c2) ? 4 : (c3 <= c2 ? 3 : 2);
 }
@@ -1792,10 +1802,12 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
         }
         __syncthreads(); // the previous protein is done with the rings
         const uint8_t *__restrict__ x = codes + off;
-        switch (kb_choose_b(n)) { // wave-uniform
-        case 2: tracks20_protein<2, TRACKS>(S, K, x, off, n, row, tr); break;
-        case 3: tracks20_protein<3, TRACKS>(S, K, x, off, n, row, tr); break;
-        default: tracks20_protein<4, TRACKS>(S, K, x, off, n, row, tr); break;
+        const int bsel = kb_choose_b(n); // wave-uniform
+        const bool nolag = n < 64 * bsel;
+        switch (bsel) {
+        case 2: tracks20_protein<2, TRACKS>(S, K, x, off, n, nolag, row, tr); break;
+        case 3: tracks20_protein<3, TRACKS>(S, K, x, off, n, nolag, row, tr); break;
+        default: tracks20_protein<4, TRACKS>(S, K, x, off, n, nolag, row, tr); break;
         }
     }
 }
