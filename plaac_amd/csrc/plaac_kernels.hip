@@ -1432,6 +1432,14 @@ __device__ __forceinline__ void window_sums3(const Src &src, int base, double (&
         for (int b = 0; b < B; ++b) s[a][b] = acc[a][b];
 }
 
+// K-B blocks are ONE wave: a wave's LDS operations complete in program order, so stage hand-overs through LDS
+// need no s_barrier and no counter drain, only a point the compiler does not move LDS accesses across
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int KB_PROTEINS_PER_BLOCK = 16; // blocks retire regularly, so the K-A kernels' blocks keep getting slots
 
 // residue codes as the first-level windows see them: 0..21 real, 22 = any other byte (scored as X),
@@ -1501,7 +1509,7 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
     int numaa = 0, maxlen = 0, carry = 0;   // numaa / maxlen: per-lane partials, reduced at the end
     int last_zero = -1, last_flag = 0;      // wave-uniform carries of the FoldIndex run scan (position -1 is
                                             // unflagged: a run can start at 0 at the earliest)
-    __syncthreads();
+    wave_sync();
 
     const int nchunks = (n + lag2 + G::C - 1) / G::C;
     // ring slot of entry number e (= position / B): e mod RB; per iteration the entry numbers advance by 64
@@ -1569,7 +1577,7 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
             }
             carry += bcast_lane(s, 63);
         }
-        __syncthreads();
+        wave_sync();
         // ---- stage 1: first-level tracks at i0 = 64Bk + B*lane - LAG1 .. i0 + B-1
         {
             const int i0 = G::C * k + B * lane - lag1;
@@ -1655,7 +1663,7 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
                 last_flag = bcast_lane(prevflag, 63);
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- stage 2: weighted second smoothing at i0 = 64Bk + B*lane - LAG2 .. i0 + B-1, PAPA arg-max
         {
             const int i0 = G::C * k + B * lane - lag2;
@@ -1800,7 +1808,7 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
             }
             continue;
         }
-        __syncthreads(); // the previous protein is done with the rings
+        wave_sync(); // the previous protein is done with the rings
         const uint8_t *__restrict__ x = codes + off;
         const int bsel = kb_choose_b(n); // wave-uniform
         const bool nolag = n < 64 * bsel;
