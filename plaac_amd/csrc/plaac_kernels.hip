@@ -1446,12 +1446,19 @@ constexpr int KB_PROTEINS_PER_BLOCK = 16; // blocks retire regularly, so the K-A
 // 23 = a proline that PAPA skips (second P of PP / PxP: hydropathy and LLR of P, log-odds 0), 24 = no residue
 // (outside the protein: every table holds +0.0, which leaves the fixed-order sums unchanged)
 constexpr int KC_DUP = 23, KC_NONE = 24, KC_ROWS = 25;
+typedef double kb_d2 __attribute__((ext_vector_type(2)));
+// Window-code tables, 16-byte rows: (hyd, llr) is ONE aligned 16-byte LDS read, lod sits at the same row offset of
+// a second table. 16-byte rows put 16 different codes on 16 different bank quads (only codes c and c+16 collide).
+constexpr uint32_t KB_ROW_BYTES = 16;
 struct KbShared {
-    double t_hyd[KC_ROWS], t_llr[KC_ROWS], t_lod[KC_ROWS];
+    alignas(16) kb_d2 t_hl[KC_ROWS];  // (hydropathy, llr)
+    alignas(16) kb_d2 t_lod[KC_ROWS]; // (PAPA log-odds, unused)
+    alignas(16) double ring[3 * RING_DOUBLES]; // weight * first-level FoldIndex / llr / papa
+    int pre[512];                              // pre[q & 511] = charge sum of positions < q
     int t_chg[KC_ROWS];
-    uint8_t cring[RING_DOUBLES + 32];    // residue-code ring (same class/slot geometry as the value rings)
-    double ring[3 * RING_DOUBLES];        // weight * first-level FoldIndex / llr / papa
-    int pre[512];                         // pre[q & 511] = charge sum of positions < q
+    // window-code ring (same class/slot geometry as the value rings); an entry is the code's BYTE OFFSET into t_hl,
+    // so a lookup is one 16-bit read and two table reads without any address arithmetic
+    uint16_t cring[RING_DOUBLES + 32];
 };
 
 // value sources of window_sums3
@@ -1459,10 +1466,12 @@ template <int B>
 struct SrcCodes { // first level: residue code -> three table values
     const KbShared &S;
     __device__ __forceinline__ void get(double (&v)[3], int cls, int slot) const {
-        const uint32_t c = S.cring[cls * KbGeom<B>::SUB + slot];
-        v[0] = S.t_hyd[c];
-        v[1] = S.t_llr[c];
-        v[2] = S.t_lod[c];
+        const uint32_t o = S.cring[cls * KbGeom<B>::SUB + slot];
+        const kb_d2 hl = *reinterpret_cast<const kb_d2 *>(
+            __builtin_assume_aligned(reinterpret_cast<const char *>(S.t_hl) + o, 16));
+        v[0] = hl.x;
+        v[1] = hl.y;
+        v[2] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(S.t_lod) + o);
     }
 };
 template <int B>
@@ -1494,7 +1503,7 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
     double *__restrict__ ring = S.ring;
     int *__restrict__ pre = S.pre;
     for (int i = lane; i < 3 * RING_DOUBLES; i += 64) ring[i] = 0.0;
-    for (int i = lane; i < RING_DOUBLES + 32; i += 64) S.cring[i] = (uint8_t)KC_NONE;
+    for (int i = lane; i < RING_DOUBLES + 32; i += 64) S.cring[i] = (uint16_t)(KC_NONE * KB_ROW_BYTES);
     for (int i = lane; i < 512; i += 64) pre[i] = 0;
 
     const int we = n - 1 < TW ? n - 1 : TW; // w = ww/2 clamped to n-1 (:2588-2589)
@@ -1554,10 +1563,11 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
             }
             const int idx = wrap(slot_in + lane);
 #pragma unroll
-            for (int j = 0; j < B; ++j) S.cring[j * G::SUB + idx] = (uint8_t)kc[j];
+            for (int j = 0; j < B; ++j) S.cring[j * G::SUB + idx] = (uint16_t)(kc[j] * KB_ROW_BYTES);
             if (idx < G::MIR) { // mirrored head
 #pragma unroll
-                for (int j = 0; j < B; ++j) S.cring[j * G::SUB + idx + G::RB] = (uint8_t)kc[j];
+                for (int j = 0; j < B; ++j)
+                    S.cring[j * G::SUB + idx + G::RB] = (uint16_t)(kc[j] * KB_ROW_BYTES);
             }
             // charge prefix counts: inclusive wave scan of the per-lane sums
             int lsum = 0;
@@ -1676,18 +1686,20 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
                 const int den = (2 * we + 1) + window_weight_side(i, we) + window_weight_side(n - 1 - i, we);
                 SharedDiv div(valid ? (double)den : 1.0);
                 div.poison_unless(valid); // NaN outside [w, n-w-1] (:2597-2600)
-                const double fix2 = div(sums[0][j]), llx2 = div(sums[1][j]), pax2 = div(sums[2][j]);
+                const double pax2 = div(sums[2][j]);
                 if (TRACKS && i >= 0 && i < n) {
-                    tr.fix2[off + i] = fix2;
-                    tr.plaacllrx2[off + i] = llx2;
+                    tr.fix2[off + i] = div(sums[0][j]);
+                    tr.plaacllrx2[off + i] = div(sums[1][j]);
                     tr.papax2[off + i] = pax2;
                 }
-                // papamode 1 (:4942-4948): NaNs fail both comparisons
-                const bool upd = i >= plo && i < phi && (pax2 > pbest) && (fix2 < 0.0);
+                // papamode 1 (:4942-4948): NaNs fail the comparison. fix2 < 0 <=> its numerator < 0 (the positive
+                // denominator is at most 1681, a quotient cannot underflow to zero); the two other quotients of the
+                // winning position are formed once, after the scan, from the kept numerators.
+                const bool upd = i >= plo && i < phi && (pax2 > pbest) && (sums[0][j] < 0.0);
                 pbest = upd ? pax2 : pbest;
                 pcen = upd ? i : pcen;
-                pfi = upd ? fix2 : pfi;
-                pll2 = upd ? llx2 : pll2;
+                pfi = upd ? sums[0][j] : pfi;
+                pll2 = upd ? sums[1][j] : pll2;
             }
         }
         slot_in = wrap(slot_in + 64);
@@ -1695,32 +1707,41 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
         slot_w1 = wrap(slot_w1 + 64);
         slot_l2 = wrap(slot_l2 + 64);
     }
-    // wave arg-max: largest papax2, smallest centre among equals (first max of the serial loop)
-    for (int d = 32; d >= 1; d >>= 1) {
-        const double ob = __shfl_xor(pbest, d);
-        const int oc = __shfl_xor(pcen, d);
-        const double ofi = __shfl_xor(pfi, d), oll2 = __shfl_xor(pll2, d);
-        const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
-        if (take) {
-            pbest = ob;
-            pcen = oc;
-            pfi = ofi;
-            pll2 = oll2;
+    // wave arg-max: largest papax2, smallest centre among equals (first max of the serial loop); the lane that
+    // owns the winning centre then hands over the numerators it kept
+    {
+        const int mine = pcen;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ob = __shfl_xor(pbest, d);
+            const int oc = __shfl_xor(pcen, d);
+            const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
+            pbest = take ? ob : pbest;
+            pcen = take ? oc : pcen;
+        }
+        if (pcen >= 0) { // wave-uniform
+            const int src = __builtin_ctzll(__ballot(mine == pcen));
+            const double s0 = bcast_lane(pfi, src), s1 = bcast_lane(pll2, src);
+            const int den = (2 * we + 1) + window_weight_side(pcen, we) + window_weight_side(n - 1 - pcen, we);
+            const SharedDiv div((double)den);
+            pfi = div(s0);
+            pll2 = div(s1);
         }
     }
     for (int d = 32; d >= 1; d >>= 1) { // FoldIndex run statistics: sum / max over lanes
         numaa += __shfl_xor(numaa, d);
         maxlen = imax(maxlen, __shfl_xor(maxlen, d));
     }
-    // PAPAllr = first-level PLAAC-LLR at the centre, recomputed: lanes fetch the 41 taps in parallel,
-    // the fixed-order sum runs over lane broadcasts (out-of-range taps add +0.0)
+    // PAPAllr = first-level PLAAC-LLR at the centre, recomputed: lanes fetch the 41 taps in parallel and park them
+    // in LDS (the rings are free now), the fixed-order sum reads them back as broadcasts (out-of-range taps add +0.0)
     double papallr = __builtin_nan("");
     if (pcen >= 0) {
         const int q = pcen - TW + lane;
-        const double v = (lane <= 2 * TW && q >= 0 && q < n) ? S.t_llr[ld_code(x, (uint32_t)q)] : 0.0;
+        wave_sync();
+        ring[lane] = (lane <= 2 * TW && q >= 0 && q < n) ? S.t_hl[ld_code(x, (uint32_t)q)].y : 0.0;
+        wave_sync();
         double s = 0.0;
 #pragma unroll
-        for (int j = 0; j <= 2 * TW; ++j) s = s + bcast_lane(v, j);
+        for (int j = 0; j <= 2 * TW; ++j) s = s + ring[j];
         const int lo = imax(pcen - TW, 0), hi = imin(pcen + TW, n - 1);
         papallr = s / (double)(hi - lo + 1);
     }
@@ -1763,9 +1784,10 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
     if (lane < KC_ROWS) {
         const int k = lane < NAA ? lane : (lane == KC_DUP ? 13 : 0); // 22 -> X, 23 -> P
         const bool none = lane == KC_NONE;
-        S.t_hyd[lane] = none ? 0.0 : T->hyd[k];
-        S.t_llr[lane] = none ? 0.0 : T->llr[k];
-        S.t_lod[lane] = (none || lane == KC_DUP) ? 0.0 : T->lod[k];
+        S.t_hl[lane].x = none ? 0.0 : T->hyd[k];
+        S.t_hl[lane].y = none ? 0.0 : T->llr[k];
+        S.t_lod[lane].x = (none || lane == KC_DUP) ? 0.0 : T->lod[k];
+        S.t_lod[lane].y = 0.0;
         S.t_chg[lane] = none ? 0 : T->chg[k];
     }
     KbConst K;

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplaac_native.so")
+# PLAAC_NATIVE_LIB: another build of the same library (tools/kb_probe.sh uses the cost-breakdown build)
+LIB_PATH = os.environ.get("PLAAC_NATIVE_LIB") or os.path.join(_HERE, "libplaac_native.so")
 
 NAA = 22
 LUTLEN = 4001
