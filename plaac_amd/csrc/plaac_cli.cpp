@@ -14,9 +14,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #include "plaac_host.h"
 #include "plaac_native.h"
@@ -118,7 +121,8 @@ bool die(plaac_ctx *ctx, const char *what, plaac_status st) {
 }
 
 // counts of a FASTA on the device (computeaafreq :1655-1666)
-bool count_background(plaac_ctx *ctx, const std::string &path, double out[PLAAC_NAA], plaac_fasta **keep,
+template <class GetCtx>
+bool count_background(GetCtx &&get_ctx, const std::string &path, double out[PLAAC_NAA], plaac_fasta **keep,
                       plaac_batch **keep_batch) {
     for (int i = 0; i < PLAAC_NAA; ++i) out[i] = 0.0;
     plaac_fasta *f = nullptr;
@@ -129,6 +133,11 @@ bool count_background(plaac_ctx *ctx, const std::string &path, double out[PLAAC_
     }
     if (st != PLAAC_OK) return die(nullptr, "reading FASTA", st);
     g_timer.lap("read+encode FASTA", (double)f->nres, "residues");
+    plaac_ctx *ctx = get_ctx();
+    if (!ctx) {
+        plaac_fasta_free(f);
+        return false;
+    }
     int64_t counts[PLAAC_NAA];
     plaac_batch *b = nullptr; // upload once: the scoring pass reuses the resident residues
     st = plaac_batch_upload(ctx, f->codes, f->offsets, f->nrec, &b);
@@ -173,9 +182,10 @@ bool score_all(plaac_ctx *ctx, const plaac_fasta *f, plaac_batch *batch, const O
     if (o.headers) column_notes();
     put(std::string(plaac_summary_header()) + "\n");
     if (f->nrec == 0) return true;
-    std::vector<plaac_row> rows(f->nrec);
-    plaac_status st = batch ? plaac_batch_score(batch, rows.data(), nullptr)
-                            : plaac_score(ctx, f->codes, f->offsets, f->nrec, rows.data(), nullptr);
+    // not value-initialised: the library overwrites every row, and its copy threads fault the pages in in parallel
+    std::unique_ptr<plaac_row[]> rows(new plaac_row[f->nrec]);
+    plaac_status st = batch ? plaac_batch_score(batch, rows.get(), nullptr)
+                            : plaac_score(ctx, f->codes, f->offsets, f->nrec, rows.get(), nullptr);
     if (st != PLAAC_OK) return die(ctx, "plaac_score", st);
     g_timer.lap(batch ? "score resident batch (GPU + D2H)" : "score (H2D + GPU + D2H)", (double)f->nres, "residues");
     // format in parallel (contiguous row ranges per thread), print in file order
@@ -336,6 +346,7 @@ bool plot_some(plaac_ctx *ctx, const plaac_fasta *f, const Options &o) {
 } // namespace
 
 int main(int argc, char **argv) {
+    g_timer.lap("process start-up (dynamic loading)");
     Options o;
     std::vector<std::string> a(argv + 1, argv + argc);
     // the reference's hand-rolled loop (:337-353): value flags consume the next token; a value flag in
@@ -372,19 +383,45 @@ int main(int argc, char **argv) {
 
     plaac_params P;
     plaac_params_init(&P, nullptr, nullptr, 1.0, o.corelength, o.ww1, o.ww2, o.ww3, 1);
+    // The GPU context (HIP start-up, a few hundred ms) is created on a second thread while this one reads and
+    // encodes the FASTA; need_ctx() joins it the first time a device call is due.
     plaac_ctx *ctx = nullptr;
+    std::string ctx_err;
+    plaac_status ctx_st = PLAAC_OK;
+    std::thread ctx_thread;
+    bool ctx_started = false, ctx_joined = false;
+    if (!o.input.empty() || !o.bgfile.empty()) {
+        ctx_started = true;
+        ctx_thread = std::thread([&] {
+            ctx_st = plaac_ctx_create(&P, 0, &ctx);
+            if (ctx_st != PLAAC_OK) ctx_err = plaac_last_error(nullptr); // thread-local message: copy it here
+        });
+    }
     auto need_ctx = [&]() -> bool {
-        if (ctx) return true;
-        g_timer.lap("start-up");
-        plaac_status st = plaac_ctx_create(&P, 0, &ctx);
-        g_timer.lap("create GPU context");
-        if (st != PLAAC_OK) {
-            std::fprintf(stderr, "plaac: no usable MI355X (gfx950) device: %s\n", plaac_last_error(nullptr));
+        if (!ctx_started) {
+            ctx_started = ctx_joined = true;
+            ctx_st = plaac_ctx_create(&P, 0, &ctx);
+            if (ctx_st != PLAAC_OK) ctx_err = plaac_last_error(nullptr);
+        } else if (!ctx_joined) {
+            ctx_thread.join();
+            ctx_joined = true;
+            g_timer.lap("wait for GPU context");
+        }
+        if (ctx_st != PLAAC_OK) {
+            std::fprintf(stderr, "plaac: no usable MI355X (gfx950) device: %s\n", ctx_err.c_str());
             return false;
         }
         return true;
     };
+    struct Joiner { // never leave main with the thread still joinable
+        std::thread &t;
+        bool &joined;
+        ~Joiner() {
+            if (t.joinable() && !joined) t.join();
+        }
+    } joiner{ctx_thread, ctx_joined};
 
+    auto get_ctx = [&]() -> plaac_ctx * { return need_ctx() ? ctx : nullptr; };
     // background counts (:377-384)
     double bgf[PLAAC_NAA] = {0}, fgf[PLAAC_NAA];
     plaac_fasta *input = nullptr;
@@ -393,9 +430,9 @@ int main(int argc, char **argv) {
     if (!o.bgfreq.empty()) {
         ok = read_params_file(o.bgfreq, bgf);
     } else if (!o.bgfile.empty()) {
-        ok = need_ctx() && count_background(ctx, o.bgfile, bgf, o.bgfile == o.input ? &input : nullptr, &input_batch);
+        ok = count_background(get_ctx, o.bgfile, bgf, o.bgfile == o.input ? &input : nullptr, &input_batch);
     } else if (!o.input.empty()) {
-        ok = need_ctx() && count_background(ctx, o.input, bgf, &input, &input_batch);
+        ok = count_background(get_ctx, o.input, bgf, &input, &input_batch);
     }
     if (!ok) return 1;
     const bool have_fg = !o.fgfreq.empty();
@@ -454,8 +491,15 @@ int main(int argc, char **argv) {
         }
     }
     ok = o.plotlist.empty() ? score_all(ctx, input, input_batch, o) : plot_some(ctx, input, o);
+    // The output is complete and flushed. Leaving through _exit skips unmapping hundreds of MB of host and device
+    // buffers and the HIP runtime's own shutdown, which the operating system does faster (PLAAC_TEARDOWN=1 keeps
+    // the orderly path, e.g. under leak checkers).
+    std::fflush(stdout);
+    std::fflush(stderr);
+    if (!std::getenv("PLAAC_TEARDOWN")) ::_exit(ok ? 0 : 1);
     plaac_batch_free(input_batch);
     plaac_fasta_free(input);
     plaac_ctx_destroy(ctx);
+    g_timer.lap("teardown");
     return ok ? 0 : 1;
 }

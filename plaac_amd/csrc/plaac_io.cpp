@@ -18,6 +18,11 @@
 #include <algorithm>
 #include <string>
 #include <thread>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -169,6 +174,39 @@ bool slurp(const char *path, std::string &out) {
     return true;
 }
 
+// read-only view of a whole file: mmap for regular files (no copy; the parser's threads fault the pages in in
+// parallel), a buffered read for pipes and the like
+struct FileView {
+    const char *data = nullptr;
+    size_t size = 0;
+    void *map = nullptr;
+    std::string buf;
+    bool open(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                ::madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                map = m;
+                data = (const char *)m;
+                size = (size_t)st.st_size;
+                ::close(fd);
+                return true;
+            }
+        }
+        ::close(fd);
+        if (!slurp(path, buf)) return false;
+        data = buf.data();
+        size = buf.size();
+        return true;
+    }
+    ~FileView() {
+        if (map) ::munmap(map, size);
+    }
+};
+
 // submatrix(int[], r1, r2) clamps (:1445-1456)
 void clamp_range(int m, int &r1, int &r2) {
     if (r1 < 0) r1 = 0;
@@ -218,28 +256,44 @@ extern "C" {
 plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
     if (!path || !out) return PLAAC_ERR_ARG;
     *out = nullptr;
-    std::string file;
-    if (!slurp(path, file)) return PLAAC_ERR_IO;
+    FileView file;
+    if (!file.open(path)) return PLAAC_ERR_IO;
     // Record starts = lines beginning with '>' (fastareader :4325-4372: a header ends the previous record
     // whether that record was still being read or was being skipped after a blank line). Everything between two
     // starts is one record, so records can be parsed independently; only the trimming of a name depends on how
     // the PREVIOUS record ended (first record / after a blank line: found by hasmorefastas, trimmed).
-    const char *d = file.data();
-    const size_t nbytes = file.size();
+    const char *d = file.data;
+    const size_t nbytes = file.size;
+    const unsigned nthreads = host_threads();
+    // a '>' starts a line iff it is the first byte or follows a line terminator (\n, \r or \r\n): found per byte
+    // range in parallel, concatenated in order
     std::vector<size_t> starts;
     {
-        size_t p = 0;
-        bool bol = true;
-        while (p < nbytes) {
-            if (bol && d[p] == '>') starts.push_back(p);
-            const char *q = (const char *)memchr(d + p, '\n', nbytes - p);
-            const char *r = (const char *)memchr(d + p, '\r', q ? (size_t)(q - (d + p)) : nbytes - p);
-            const char *e = r ? r : q; // first line terminator
-            if (!e) break;
-            p = (size_t)(e - d) + 1;
-            if (*e == '\r' && p < nbytes && d[p] == '\n') ++p;
-            bol = true;
+        const unsigned nt = nbytes < (8u << 20) ? 1u : nthreads;
+        std::vector<std::vector<size_t>> part(nt);
+        auto scan = [&](unsigned t) {
+            size_t p = nbytes / nt * t;
+            const size_t e = t + 1 == nt ? nbytes : nbytes / nt * (t + 1);
+            std::vector<size_t> &out = part[t];
+            while (p < e) {
+                const char *q = (const char *)memchr(d + p, '>', e - p);
+                if (!q) break;
+                p = (size_t)(q - d);
+                if (p == 0 || d[p - 1] == '\n' || d[p - 1] == '\r') out.push_back(p);
+                ++p;
+            }
+        };
+        if (nt == 1) {
+            scan(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t) pool.emplace_back(scan, t);
+            for (auto &th : pool) th.join();
         }
+        size_t total = 0;
+        for (auto &v : part) total += v.size();
+        starts.reserve(total);
+        for (auto &v : part) starts.insert(starts.end(), v.begin(), v.end());
     }
     const size_t nrec = starts.size();
     struct Rec {
@@ -248,6 +302,9 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
         bool blank_end = false;
     };
     std::vector<Rec> recs(nrec);
+    std::vector<std::pair<size_t, size_t>> nm(nrec); // name extents after trimming
+    char *names_out = nullptr;
+    const uint64_t *name_off = nullptr;
     // pass 1 (parallel): header extent, sequence length, how the record ended
     auto parse_range = [&](size_t r0, size_t r1, uint8_t *codes_out, const uint64_t *offs) {
         std::string line;
@@ -273,6 +330,9 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
             if (!codes_out) {
                 R.name_b = lb + 1;
                 R.name_e = le;
+            } else { // pass 2: the (possibly trimmed) name goes to its final place
+                std::memcpy(names_out + name_off[i], d + nm[i].first, nm[i].second - nm[i].first);
+                names_out[name_off[i + 1] - 1] = '\0';
             }
             size_t len = 0;
             bool blank = false;
@@ -290,7 +350,6 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
             }
         }
     };
-    const unsigned nthreads = host_threads();
     auto run_parallel = [&](uint8_t *codes_out, const uint64_t *offs) {
         if (nrec < 4096 || nthreads <= 1) {
             parse_range(0, nrec, codes_out, offs);
@@ -321,7 +380,6 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
         return PLAAC_ERR_NOMEM;
     }
     // names: first record and records that follow a blank-line-terminated one are trimmed (:4362), others not
-    std::vector<std::pair<size_t, size_t>> nm(nrec);
     uint64_t off = 0, noff = 0;
     for (size_t i = 0; i < nrec; ++i) {
         size_t b = recs[i].name_b, e = recs[i].name_e;
@@ -344,12 +402,10 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
         plaac_fasta_free(f);
         return PLAAC_ERR_NOMEM;
     }
-    for (size_t i = 0; i < nrec; ++i) {
-        std::memcpy(f->names + f->name_off[i], d + nm[i].first, nm[i].second - nm[i].first);
-        f->names[f->name_off[i + 1] - 1] = '\0';
-    }
     f->names[noff] = '\0';
-    run_parallel(f->codes, f->offsets); // pass 2 (parallel): encode straight into the final buffer
+    names_out = f->names;
+    name_off = f->name_off;
+    run_parallel(f->codes, f->offsets); // pass 2 (parallel): encode and copy names straight into the final buffers
     *out = f;
     return PLAAC_OK;
 }

@@ -34,6 +34,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "plaac_native.h"
@@ -1845,6 +1846,22 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
 // ------------------------------------------------------------------------------------------------
 // histogram over valid records (:1698-1706, :1732-1739); one wave per record, grid-stride
 // ------------------------------------------------------------------------------------------------
+// residue codes of a host upload must be 0..21 (they index 22-row tables): one flag for the whole buffer
+__global__ __launch_bounds__(256) void k_validate(const uint8_t *__restrict__ codes, uint64_t total,
+                                                   uint32_t *__restrict__ flag) {
+    const uint64_t nvec = total >> 4;
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x * 256u) {
+        const uint4 v = reinterpret_cast<const uint4 *>(codes)[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) // any byte > 21 <=> (byte + 106) has bit 7 set, or the byte itself has
+            bad |= (((w[k] & 0x7f7f7f7fu) + 0x6a6a6a6au) | w[k]) & 0x80808080u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (total & 15u)) bad |= codes[(nvec << 4) + threadIdx.x] > 21u;
+    if (bad) atomicOr(flag, 1u);
+}
+
 __global__ __launch_bounds__(256) void k_hist(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets,
                                               uint32_t nprot, unsigned long long *__restrict__ counts) {
     __shared__ unsigned int s_cnt[4][NAA + 2];
@@ -1896,7 +1913,12 @@ struct plaac_ctx {
     uint32_t *d_neff = nullptr, *d_order = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
     uint4 *d_packed = nullptr;
     double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
-    uint32_t *h_pin = nullptr; // pinned word for the one device->host readback of a call (total packed rows)
+    uint32_t *h_pin = nullptr; // pinned words: [0] total packed rows of a call, [1] upload validation flag
+    // pinned staging for the host-buffer entry points (pageable memcpy runs at a tenth of the link rate)
+    static constexpr size_t STAGE_BYTES = 16u << 20;
+    uint8_t *h_stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    uint32_t *d_flag = nullptr;
     size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_bwd = 0, cap_grow = 0, cap_packed = 0;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
@@ -2107,6 +2129,11 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     void *bufs[] = {ctx->d_tab,  ctx->d_neff,    ctx->d_order, ctx->d_hist, ctx->d_bits,  ctx->d_fwd,   ctx->d_codes,
                     ctx->d_offsets, ctx->d_rows, ctx->d_trk8,  ctx->d_trk64, ctx->d_counts, ctx->d_grow, ctx->d_packed};
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
+        if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
+    }
+    if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &set : ctx->ev)
@@ -2428,6 +2455,83 @@ plaac_status plaac_histogram_device(plaac_ctx *ctx, const uint8_t *d_codes, cons
     return PLAAC_OK;
 }
 
+static unsigned copy_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("PLAAC_THREADS")) n = (unsigned)std::max(1, std::atoi(e));
+    return std::max(1u, std::min(n, 4u));
+}
+
+static void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+    const unsigned nt = bytes < (4u << 20) ? 1u : copy_threads();
+    if (nt == 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t b = bytes * t / nt, e = bytes * (t + 1) / nt;
+        pool.emplace_back([=] { std::memcpy((char *)dst + b, (const char *)src + b, e - b); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+static plaac_status ensure_stage(plaac_ctx *ctx) {
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->h_stage[i]) PL_HIP(ctx, hipHostMalloc((void **)&ctx->h_stage[i], plaac_ctx::STAGE_BYTES, hipHostMallocDefault));
+        if (!ctx->stage_ev[i]) PL_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+    }
+    return PLAAC_OK;
+}
+
+// host (pageable) -> device through two pinned buffers: the copy into pinned memory of chunk k+1 overlaps the
+// DMA of chunk k. Small copies go directly.
+static plaac_status copy_in(plaac_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (bytes < (1u << 20)) {
+        PL_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return PLAAC_OK;
+    }
+    plaac_status rc = ensure_stage(ctx);
+    if (rc != PLAAC_OK) return rc;
+    size_t done = 0;
+    for (int k = 0; done < bytes; ++k) {
+        const int b = k & 1;
+        const size_t n = std::min(plaac_ctx::STAGE_BYTES, bytes - done);
+        if (k >= 2) PL_HIP(ctx, hipEventSynchronize(ctx->stage_ev[b])); // DMA out of this buffer has finished
+        parallel_memcpy(ctx->h_stage[b], (const char *)src + done, n);
+        PL_HIP(ctx, hipMemcpyAsync((char *)dst + done, ctx->h_stage[b], n, hipMemcpyHostToDevice, st));
+        PL_HIP(ctx, hipEventRecord(ctx->stage_ev[b], st));
+        done += n;
+    }
+    PL_HIP(ctx, hipStreamSynchronize(st)); // the staging buffers are free again when this returns
+    return PLAAC_OK;
+}
+
+// device -> host (pageable), same scheme; returns with the data in place
+static plaac_status copy_out(plaac_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (bytes < (1u << 20)) {
+        PL_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+        PL_HIP(ctx, hipStreamSynchronize(st));
+        return PLAAC_OK;
+    }
+    plaac_status rc = ensure_stage(ctx);
+    if (rc != PLAAC_OK) return rc;
+    const size_t nchunks = (bytes + plaac_ctx::STAGE_BYTES - 1) / plaac_ctx::STAGE_BYTES;
+    auto issue = [&](size_t k) -> plaac_status {
+        const size_t o = k * plaac_ctx::STAGE_BYTES, n = std::min(plaac_ctx::STAGE_BYTES, bytes - o);
+        PL_HIP(ctx, hipMemcpyAsync(ctx->h_stage[k & 1], (const char *)src + o, n, hipMemcpyDeviceToHost, st));
+        PL_HIP(ctx, hipEventRecord(ctx->stage_ev[k & 1], st));
+        return PLAAC_OK;
+    };
+    if ((rc = issue(0)) != PLAAC_OK) return rc;
+    for (size_t k = 0; k < nchunks; ++k) {
+        if (k + 1 < nchunks && (rc = issue(k + 1)) != PLAAC_OK) return rc; // other buffer: drained in iteration k-1
+        PL_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k & 1]));
+        const size_t o = k * plaac_ctx::STAGE_BYTES, n = std::min(plaac_ctx::STAGE_BYTES, bytes - o);
+        parallel_memcpy((char *)dst + o, ctx->h_stage[k & 1], n);
+    }
+    return PLAAC_OK;
+}
+
 static plaac_status stage_in(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
                              uint64_t *total_out) {
     if (!offsets) return fail(ctx, PLAAC_ERR_ARG, "null offsets");
@@ -2436,14 +2540,22 @@ static plaac_status stage_in(plaac_ctx *ctx, const uint8_t *codes, const uint64_
         if (offsets[p + 1] < offsets[p]) return fail(ctx, PLAAC_ERR_ARG, "offsets must be non-decreasing");
     const uint64_t total = offsets[nprot];
     if (total && !codes) return fail(ctx, PLAAC_ERR_ARG, "null codes");
-    for (uint64_t i = 0; i < total; ++i)
-        if (codes[i] > 21) return fail(ctx, PLAAC_ERR_ARG, "residue code > 21");
     plaac_status rc;
     if ((rc = grow(ctx, ctx->d_codes, ctx->cap_codes, (size_t)total + 64)) != PLAAC_OK) return rc;
     if ((rc = grow(ctx, ctx->d_offsets, ctx->cap_offs, (size_t)nprot + 1)) != PLAAC_OK) return rc;
-    if (total) PL_HIP(ctx, hipMemcpyAsync(ctx->d_codes, codes, total, hipMemcpyHostToDevice, ctx->stream));
-    PL_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, sizeof(uint64_t) * ((size_t)nprot + 1), hipMemcpyHostToDevice,
-                               ctx->stream));
+    if (total && (rc = copy_in(ctx, ctx->d_codes, codes, total, ctx->stream)) != PLAAC_OK) return rc;
+    if ((rc = copy_in(ctx, ctx->d_offsets, offsets, sizeof(uint64_t) * ((size_t)nprot + 1), ctx->stream)) != PLAAC_OK)
+        return rc;
+    // codes must be 0..21 (they index the kernels' tables): checked on the device, the upload is there anyway
+    if (total) {
+        if (!ctx->d_flag) PL_HIP(ctx, hipMalloc((void **)&ctx->d_flag, sizeof(uint32_t)));
+        PL_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(uint32_t), ctx->stream));
+        const unsigned vb = (unsigned)std::min<uint64_t>(((total >> 4) + 255u) / 256u + 1u, 2048u);
+        hipLaunchKernelGGL(k_validate, dim3(vb), dim3(256), 0, ctx->stream, ctx->d_codes, total, ctx->d_flag);
+        PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 1, ctx->d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_pin[1]) return fail(ctx, PLAAC_ERR_ARG, "residue code > 21");
+    }
     *total_out = total;
     return PLAAC_OK;
 }
@@ -2507,18 +2619,19 @@ static plaac_status score_resident_to_host(plaac_ctx *ctx, const uint8_t *d_code
     }
     rc = plaac_score_device(ctx, d_codes, d_offsets, nprot, total, ctx->d_rows, tracks ? &dt : nullptr, ctx->stream);
     if (rc != PLAAC_OK) return rc;
-    PL_HIP(ctx, hipMemcpyAsync(rows, ctx->d_rows, sizeof(plaac_row) * (size_t)nprot, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = copy_out(ctx, rows, ctx->d_rows, sizeof(plaac_row) * (size_t)nprot, ctx->stream)) != PLAAC_OK) return rc;
     if (tracks && total) {
         const size_t nb = (size_t)total;
         uint8_t *h8[2] = {tracks->vit, tracks->map};
         uint8_t *d8[2] = {dt.vit, dt.map};
-        for (int i = 0; i < 2; ++i) PL_HIP(ctx, hipMemcpyAsync(h8[i], d8[i], nb, hipMemcpyDeviceToHost, ctx->stream));
+        for (int i = 0; i < 2; ++i)
+            if ((rc = copy_out(ctx, h8[i], d8[i], nb, ctx->stream)) != PLAAC_OK) return rc;
         double *hd[10] = {tracks->charge, tracks->hydro,      tracks->fi,     tracks->plaacllr, tracks->papa,
                           tracks->fix2,   tracks->plaacllrx2, tracks->papax2, tracks->post0,    tracks->post1};
         double *dd[10] = {dt.charge, dt.hydro, dt.fi, dt.plaacllr, dt.papa, dt.fix2, dt.plaacllrx2, dt.papax2, dt.post0,
                           dt.post1};
         for (int i = 0; i < 10; ++i)
-            PL_HIP(ctx, hipMemcpyAsync(hd[i], dd[i], nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            if ((rc = copy_out(ctx, hd[i], dd[i], nb * sizeof(double), ctx->stream)) != PLAAC_OK) return rc;
     }
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PLAAC_OK;
