@@ -1340,6 +1340,10 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+__device__ __forceinline__ double bcast_lane_dyn(double v, int lane) { // `lane` wave-uniform, not constant
+    return bcast_lane(v, __builtin_amdgcn_readfirstlane(lane));
+}
+
 // Correctly rounded a/d for several numerators sharing one small positive integer-valued denominator.
 struct SharedDiv {
     double d, y;
@@ -1773,6 +1777,86 @@ __device__ __forceinline__ int kb_choose_b(int n) {
     return (c4 <= c3 && c4 <= c2) ? 4 : (c3 <= c2 ? 3 : 2);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Sweeps: the window tracks depend on the background mix alpha only through the llr table, and the summary row
+// keeps just two llr-derived values, both AT the PAPA centre (which itself does not depend on alpha). For every
+// further alpha of a sweep K-B therefore shrinks to this kernel: one wave per protein takes the centre from the
+// row the full kernel wrote for the first alpha, recomputes PAPAllr (first-level window, :4891-4897) and PAPAllr2
+// (weighted second smoothing of the 2w+1 first-level values around it, :4903-4905) with this group's llr table -
+// the same fixed-order sums, ~1/10 of the work - and copies the alpha-independent fields.
+// ------------------------------------------------------------------------------------------------
+constexpr int LLRAT_MAXW = 31; // 2w+1 first-level windows, one per lane
+__global__ __launch_bounds__(256) void k_llr_at_centre(const uint8_t *__restrict__ codes,
+                                                        const uint64_t *__restrict__ offsets,
+                                                        const uint32_t *__restrict__ neff, uint32_t nprot,
+                                                        const DevTables *__restrict__ T,
+                                                        const plaac_row *__restrict__ src, plaac_row *__restrict__ dst) {
+    __shared__ double s_llr[NAA];
+    __shared__ uint8_t s_code[4][4 * LLRAT_MAXW + 4];
+    __shared__ double s_val[4][64];
+    if (threadIdx.x < NAA) s_llr[threadIdx.x] = T->llr[threadIdx.x];
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t p = blockIdx.x * 4u + (uint32_t)wv;
+    if (p >= nprot) return;
+    const int n = (int)neff[p];
+    const plaac_row *r = src + p;
+    plaac_row *o = dst + p;
+    const int c = r->papa_cen;
+    double llr1c = __builtin_nan(""), llx2 = __builtin_nan("");
+    if (n > 0 && c >= 0) { // wave-uniform
+        const int w = T->ww3 / 2;
+        const int we = n - 1 < w ? n - 1 : w; // (:2588-2589)
+        const uint8_t *x = codes + offsets[p];
+        // residues c-2we .. c+2we (positions outside the protein: X, never used because of the range checks)
+        for (int k = lane; k <= 4 * we; k += 64) {
+            const int q = c - 2 * we + k;
+            s_code[wv][k] = (q >= 0 && q < n) ? (uint8_t)ld_code(x, (uint32_t)q) : (uint8_t)0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double v = 0.0, l1 = 0.0;
+        if (lane <= 2 * we) { // first-level window of position i = c - we + lane (inside the protein: c is a valid centre)
+            const int i = c - we + lane;
+            double sum = 0.0;
+            for (int t = 0; t <= 2 * we; ++t) { // increasing position; taps outside the protein are skipped
+                const int q = i - we + t;
+                if (q >= 0 && q < n) sum = sum + s_llr[s_code[wv][lane + t]];
+            }
+            const int lo = imax(i - we, 0), hi = imin(i + we, n - 1);
+            l1 = sum / (double)(hi - lo + 1);
+            v = (double)(1 + imin(i, we) + imin(n - i - 1, we)) * l1;
+        }
+        s_val[wv][lane] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double s2 = 0.0;
+        for (int t = 0; t <= 2 * we; ++t) s2 = s2 + s_val[wv][t];
+        const int den = (2 * we + 1) + window_weight_side(c, we) + window_weight_side(n - 1 - c, we);
+        // the centre comes from the PAPA window (ww2); for the llr window (ww3) it may lie in the NaN margin (:2597-2600)
+        llx2 = (c >= we && c <= n - we - 1) ? s2 / (double)den : __builtin_nan("");
+        llr1c = bcast_lane_dyn(l1, we);
+    }
+    if (lane == 0) {
+        o->papa_combo = r->papa_combo;
+        o->papa_prop = r->papa_prop;
+        o->papa_fi = r->papa_fi;
+        o->fi_numaa = r->fi_numaa;
+        o->fi_maxrun = r->fi_maxrun;
+        o->papa_cen = c;
+        if (n > 0 && c >= 0) {
+            o->papa_llr = llr1c;
+            o->papa_llr2 = llx2;
+        } else { // no centre (NaN) or skipped record (0.0): the same values for every alpha
+            o->papa_llr = r->papa_llr;
+            o->papa_llr2 = r->papa_llr2;
+        }
+    }
+}
+
 template <bool TRACKS>
 __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ codes,
                                                  const uint64_t *__restrict__ offsets,
@@ -1907,6 +1991,8 @@ struct plaac_ctx {
     DevTables *d_tabs = nullptr;  // tables of the groups of a sweep
     size_t cap_tabs = 0;
     std::vector<hipEvent_t> gev;  // per-group "forward pass done" events of a sweep
+    std::vector<hipStream_t> gstreams; // side streams of the 2nd, 3rd ... group of a sweep (three each)
+    std::vector<hipEvent_t> gjev;      // their join events
     hipEvent_t jev[4] = {nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
@@ -2146,6 +2232,13 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         }
     for (hipEvent_t e : ctx->gev)
         if (e) (void)hipEventDestroy(e);
+    for (hipStream_t a : ctx->gstreams)
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
+    for (hipEvent_t e : ctx->gjev)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->jev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->d_tabs) (void)hipFree(ctx->d_tabs);
@@ -2230,13 +2323,50 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->gev.push_back(e);
     }
+    // The groups of a sweep are independent of each other: every group gets its own three side streams (and its
+    // own traceback-bit buffer), so that the long serial chains of all groups advance together instead of one
+    // group's tail after the other's.
+    while (!ctx->serial && ctx->gstreams.size() < 3 * (ng - 1)) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        hipStream_t a = nullptr;
+        PL_HIP(ctx, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest));
+        ctx->gstreams.push_back(a);
+        hipEvent_t e = nullptr;
+        PL_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->gjev.push_back(e);
+    }
 
     hipEvent_t *evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
     enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10, E_PACK = 11, E_BWD = 13 };
     hipStream_t sv = ctx->serial ? st : ctx->aux[0], sf = ctx->serial ? st : ctx->aux[1],
                 sw = ctx->serial ? st : ctx->aux[2], sb = ctx->serial ? st : ctx->aux[3];
 
+    // K-B base of a group: an earlier group whose window tracks differ only through the llr table (another alpha of
+    // a sweep); such a group needs PAPAllr / PAPAllr2 at the known PAPA centre only (k_llr_at_centre)
+    auto kb_base = [&](size_t g) -> long {
+        const plaac_params &P = points[groups[g].first];
+        if (P.ww3 / 2 > LLRAT_MAXW) return -1;
+        for (size_t h = 0; h < g; ++h) {
+            const plaac_params &Q = points[groups[h].first];
+            if (P.ww1 == Q.ww1 && P.ww2 == Q.ww2 && P.ww3 == Q.ww3 && P.adjustprolines == Q.adjustprolines &&
+                std::memcmp(P.cc, Q.cc, sizeof P.cc) == 0 && std::memcmp(P.hydro2, Q.hydro2, sizeof P.hydro2) == 0 &&
+                std::memcmp(P.charge, Q.charge, sizeof P.charge) == 0 &&
+                std::memcmp(P.lodpapa, Q.lodpapa, sizeof P.lodpapa) == 0)
+                return (long)h;
+        }
+        return -1;
+    };
     auto launch_tracks = [&](size_t g) -> plaac_status { // K-B: needs only the order, not the packed copy
+        if (!d_tracks) {
+            const long base = kb_base(g);
+            if (base >= 0) {
+                hipLaunchKernelGGL(k_llr_at_centre, dim3((nprot + 3u) / 4u), dim3(256), 0, st, d_codes, d_offsets,
+                                   ctx->d_neff, nprot, gtab0 + g, d_rows[groups[(size_t)base].first],
+                                   d_rows[groups[g].first]);
+                return PLAAC_OK;
+            }
+        }
         const plaac_params &P = points[groups[g].first];
         const DevTables *tab = gtab0 + g;
         plaac_row *rows = d_rows[groups[g].first];
@@ -2294,7 +2424,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     PL_HIP(ctx, hipStreamSynchronize(sv));
     const size_t total_rows = ctx->h_pin[0];
     if ((rc = grow(ctx, ctx->d_packed, ctx->cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
-    if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
+    const size_t bits_stride = total_rows * 64u + 64u; // one traceback-bit buffer per group
+    if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, bits_stride * ng)) != PLAAC_OK) return rc;
     if (d_tracks) {
         if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_bwd, ctx->cap_bwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
@@ -2302,8 +2433,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     hipLaunchKernelGGL(k_pack, dim3((nprot + 255u) / 256u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
-    if (!ctx->serial)
+    if (!ctx->serial) {
         for (hipStream_t a : {sf, sw, sb}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
+        for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(ctx->gstreams[k], evs[E_PACK + 1], 0));
+    }
     const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
     // track mode: the backward recurrence is a chain of its own, beside the forward one
     PL_HIP(ctx, hipEventRecord(evs[E_BWD], sb));
@@ -2312,11 +2445,20 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                            ctx->d_packed, ctx->d_grow, ctx->d_bwd);
     PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
 
+    const hipStream_t sv0 = sv, sf0 = sf, sw0 = sw;
     for (size_t g = 0; g < ng; ++g) {
         const Group &G = groups[g];
         const DevTables *tab = gtab0 + g;
         plaac_row *rows0 = d_rows[G.first];
         const bool timed = g == 0;
+        // streams of this group
+        hipStream_t sv = sv0, sf = sf0, sw = sw0;
+        if (g > 0 && !ctx->serial) {
+            sv = ctx->gstreams[3 * (g - 1)];
+            sf = ctx->gstreams[3 * (g - 1) + 1];
+            sw = ctx->gstreams[3 * (g - 1) + 2];
+        }
+        uint32_t *gbits = ctx->d_bits + bits_stride * g;
         // K-B of this group (group 0 was launched before the host round trip; serialised mode launches it last)
         if (g > 0 && !ctx->serial) {
             if ((rc = launch_tracks(g)) != PLAAC_OK) return rc;
@@ -2343,7 +2485,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
 #define LAUNCH_VIT(NC)                                                                                             \
     hipLaunchKernelGGL((k_vit<NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff, ctx->d_order, \
-                       nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_bits, tg)
+                       nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg)
             switch (nc) {
             case 1: LAUNCH_VIT(1); break;
             case 2: LAUNCH_VIT(2); break;
@@ -2389,6 +2531,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[2], sw));
         PL_HIP(ctx, hipEventRecord(ctx->jev[3], sb));
         for (hipEvent_t e : ctx->jev) PL_HIP(ctx, hipStreamWaitEvent(st, e, 0));
+        for (size_t k = 0; k < 3 * (ng - 1); ++k) {
+            PL_HIP(ctx, hipEventRecord(ctx->gjev[k], ctx->gstreams[k]));
+            PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
+        }
     }
     if (d_tracks && total_rows) // posteriors, MAP, Viterbi bytes: needs k_fwd, k_bwd and the path bits (k_vit)
         hipLaunchKernelGGL(k_post, dim3((unsigned)total_rows), dim3(64), 0, st, d_offsets, ctx->d_neff, ctx->d_order,
