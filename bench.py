@@ -125,6 +125,13 @@ def main():
     gather_list = None
     if world > 1 and rank == 0:
         gather_list = [torch.empty_like(rows) for _ in range(world)]
+    # N > 1: the row gather of step k (rank 0 <- every rank, RCCL) runs on its own stream and overlaps the kernels
+    # of step k+1, which write the other of two row buffers; everything is drained inside the timed region
+    rows_pp = [rows, torch.zeros_like(rows)] if world > 1 else [rows]
+    comm = torch.cuda.Stream(dev) if world > 1 else None
+    scored = [torch.cuda.Event() for _ in rows_pp]
+    gathered = [torch.cuda.Event() for _ in rows_pp]
+    step_no = [0]
     # a real (non-null) HIP stream: the kernels are launched on it, the HIP events that time them are
     # recorded on it, and RCCL orders the row gather after it
     stream = torch.cuda.Stream(dev)
@@ -154,10 +161,18 @@ def main():
             for k in range(npoints):
                 if sweep_params:
                     ctx.set_params(sweep_params[k])
-                ctx.score_device(codes.data_ptr(), offsets.data_ptr(), nprot, total, rows.data_ptr(), d_tracks,
+                b = step_no[0] % len(rows_pp)
+                step_no[0] += 1
+                if world > 1 and step_no[0] > len(rows_pp):
+                    stream.wait_event(gathered[b])  # the gather that last read this buffer has finished
+                ctx.score_device(codes.data_ptr(), offsets.data_ptr(), nprot, total, rows_pp[b].data_ptr(), d_tracks,
                                  stream=stream.cuda_stream)
-                if world > 1:  # final gather of per-protein summary rows, ordered after the kernels
-                    dist.gather(rows, gather_list, dst=0)
+                if world > 1:  # final gather of per-protein summary rows, ordered after this step's kernels
+                    scored[b].record(stream)
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(scored[b])
+                        dist.gather(rows_pp[b], gather_list, dst=0)
+                        gathered[b].record(comm)
 
     def fence():
         torch.cuda.synchronize(dev)
