@@ -136,16 +136,18 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *__restrict__ hist)
 
 __global__ __launch_bounds__(PLAN_THREADS) void k_plan_scatter(const uint32_t *__restrict__ neff, uint32_t nprot,
                                                                uint32_t *__restrict__ cursor,
-                                                               uint32_t *__restrict__ order) {
+                                                               const uint64_t *__restrict__ offsets,
+                                                               uint4 *__restrict__ order) {
     __shared__ uint32_t cnt[PLAN_LDS_BINS]; // per-bin count of this block, then running rank
     __shared__ uint32_t start[PLAN_LDS_BINS];
     for (int i = threadIdx.x; i < PLAN_LDS_BINS; i += PLAN_THREADS) cnt[i] = 0u;
     __syncthreads();
     const uint32_t base = blockIdx.x * (PLAN_THREADS * PLAN_ITEMS);
-    uint32_t bins[PLAN_ITEMS];
+    uint32_t bins[PLAN_ITEMS], lens[PLAN_ITEMS];
     for (int k = 0; k < PLAN_ITEMS; ++k) {
         const uint32_t p = base + (uint32_t)k * PLAN_THREADS + threadIdx.x;
-        bins[k] = p < nprot ? plan_bin(neff[p]) : 0xffffffffu;
+        lens[k] = p < nprot ? neff[p] : 0u;
+        bins[k] = p < nprot ? plan_bin(lens[k]) : 0xffffffffu;
         if (bins[k] < (uint32_t)PLAN_LDS_BINS) atomicAdd(&cnt[bins[k]], 1u);
     }
     __syncthreads();
@@ -161,7 +163,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_scatter(const uint32_t *_
         const uint32_t bin = bins[k];
         const uint32_t pos = bin < (uint32_t)PLAN_LDS_BINS ? start[bin] + atomicAdd(&cnt[bin], 1u)
                                                            : atomicAdd(&cursor[bin], 1u);
-        order[pos] = p;
+        // the sorted plan carries everything the scoring kernels need about a protein, so that they read it
+        // coalesced / sequentially instead of gathering neff[p] and offsets[p] (a 128-byte line per 4-8 bytes)
+        const uint64_t off = offsets[p];
+        order[pos] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), lens[k], p);
     }
 }
 
@@ -230,17 +235,17 @@ __device__ __forceinline__ uint4 load16(const uint8_t *p, const uint8_t *lo, con
 // whole sector through L2, measured 8-20x over-fetch), and every residue crosses HBM once per sweep.
 // The traceback / Viterbi-path bit words use the same row numbering (one 32-bit word per lane per row).
 // rows[g] = ceil(longest length in group / 16); grow[] = exclusive prefix sum (grow[ngroups] = total rows).
-__global__ void k_group_rows(const uint32_t *__restrict__ neff, const uint32_t *__restrict__ order, uint32_t nprot,
+__global__ void k_group_rows(const uint32_t *__restrict__ neff, const uint4 *__restrict__ order, uint32_t nprot,
                              uint32_t ngroups, uint32_t *__restrict__ grow) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ngroups) return;
     // Lane 0 is the longest of its group, EXCEPT inside the last length bin (lengths >= LEN_BINS-1 are not
     // ordered among themselves): take the maximum of the group when its first member is that long.
-    uint32_t n0 = neff[order[64u * g]];
+    uint32_t n0 = order[64u * g].z;
     if (n0 >= (uint32_t)(LEN_BINS - 1)) {
         const uint32_t e = 64u * g + 64u < nprot ? 64u * g + 64u : nprot;
         for (uint32_t i = 64u * g + 1u; i < e; ++i) {
-            const uint32_t v = neff[order[i]];
+            const uint32_t v = order[i].z;
             n0 = v > n0 ? v : n0;
         }
     }
@@ -273,14 +278,14 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uin
 }
 
 __global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets,
-                                              const uint32_t *__restrict__ neff, const uint32_t *__restrict__ order,
+                                              const uint32_t *__restrict__ neff, const uint4 *__restrict__ order,
                                               uint32_t nprot, uint64_t total, const uint32_t *__restrict__ grow,
                                               uint4 *__restrict__ packed) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (gid >= nprot) return;
-    const uint32_t p = order[gid];
-    const uint32_t n = neff[p];
-    const uint8_t *x = codes + offsets[p];
+    const uint4 it = order[gid];
+    const uint32_t n = it.z;
+    const uint8_t *x = codes + (((uint64_t)it.y << 32) | it.x);
     const uint8_t *cend = codes + total;
     uint4 *__restrict__ col = packed + (size_t)grow[gid >> 6] * 64u + (gid & 63u);
     const uint32_t nj = (n + 15u) >> 4;
@@ -363,13 +368,14 @@ struct LaneJob {
 };
 
 __device__ __forceinline__ LaneJob lane_job(const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ neff,
-                                            const uint32_t *__restrict__ order, uint32_t nprot) {
+                                            const uint4 *__restrict__ order, uint32_t nprot) {
     LaneJob j{0u, 0u, 0ull};
     const uint32_t gid = blockIdx.x * KA_THREADS + threadIdx.x;
     if (gid < nprot) {
-        j.p = order[gid];
-        j.n = neff[j.p];
-        j.off = offsets[j.p];
+        const uint4 it = order[gid];
+        j.p = it.w;
+        j.n = it.z;
+        j.off = ((uint64_t)it.y << 32) | it.x;
     }
     return j;
 }
@@ -478,7 +484,7 @@ template <int NC>
 __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
-                                                    const uint32_t *__restrict__ order, uint32_t nprot,
+                                                    const uint4 *__restrict__ order, uint32_t nprot,
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
                                                     const uint32_t *__restrict__ grow, uint32_t *__restrict__ bits,
@@ -695,7 +701,7 @@ template <bool TRACKS>
 __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
-                                                    const uint32_t *__restrict__ order, uint32_t nprot,
+                                                    const uint4 *__restrict__ order, uint32_t nprot,
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
                                                     const uint32_t *__restrict__ grow, plaac_row *__restrict__ rows,
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
 //      its own chain on its own stream, concurrent with k_fwd; k_post combines the two. ----
 __global__ __launch_bounds__(KA_THREADS) void k_bwd(const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
-                                                    const uint32_t *__restrict__ order, uint32_t nprot,
+                                                    const uint4 *__restrict__ order, uint32_t nprot,
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
                                                     const uint32_t *__restrict__ grow, double2 *__restrict__ bwd) {
@@ -788,7 +794,7 @@ __global__ __launch_bounds__(KA_THREADS) void k_bwd(const uint64_t *__restrict__
 // transposes through LDS and writes each protein's 16 consecutive values as one contiguous 128-byte run.
 constexpr int PT = 16; // steps per tile = one packed row
 __global__ __launch_bounds__(64) void k_post(const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ neff,
-                                              const uint32_t *__restrict__ order, uint32_t nprot, uint32_t ngroups,
+                                              const uint4 *__restrict__ order, uint32_t nprot, uint32_t ngroups,
                                               const uint32_t *__restrict__ grow, const DevTables *__restrict__ T,
                                               const double2 *__restrict__ fwd, const double2 *__restrict__ bwd,
                                               const uint32_t *__restrict__ bits, TrackPtrs tr) {
@@ -816,9 +822,9 @@ __global__ __launch_bounds__(64) void k_post(const uint64_t *__restrict__ offset
     uint64_t off = 0;
     double lp = 0.0;
     if (gid < nprot) {
-        const uint32_t p = order[gid];
-        n = neff[p];
-        off = offsets[p];
+        const uint4 it = order[gid];
+        n = it.z;
+        off = ((uint64_t)it.y << 32) | it.x;
         if (n) { // lpseq (:3393-3396) from a[.][0] + b[.][0]
             const double2 a = fwd[rbase * 16u * 64u + (size_t)lane], b = bwd[rbase * 16u * 64u + (size_t)lane];
             lp = lse_lut(T->loglut, a.x + b.x, a.y + b.y);
@@ -915,7 +921,7 @@ template <int NC>
 __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
-                                                    const uint32_t *__restrict__ order, uint32_t nprot,
+                                                    const uint4 *__restrict__ order, uint32_t nprot,
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
                                                     const uint32_t *__restrict__ grow, SweepTargets tg) {
@@ -1040,7 +1046,7 @@ __device__ __forceinline__ int sum_min_left(int i, int w) {
 template <int RING, bool TRACKS>
 __global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets,
                                                const uint32_t *__restrict__ neff,
-                                               const uint32_t *__restrict__ order, uint32_t nprot,
+                                               const uint4 *__restrict__ order, uint32_t nprot,
                                                const DevTables *__restrict__ T, plaac_row *__restrict__ rows,
                                                TrackPtrs tr) {
     constexpr int M = RING - 1;
@@ -1052,8 +1058,9 @@ __global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes
     __shared__ double r_ll[RING];                            // first-level PLAAC-LLR (for PAPAllr)
 
     const int lane = threadIdx.x;
-    const uint32_t p = order[blockIdx.x];
-    const int n = (int)neff[p];
+    const uint4 it = order[blockIdx.x];
+    const uint32_t p = it.w;
+    const int n = (int)it.z;
     plaac_row *row = rows + p;
     if (n == 0) {
         if (lane == 0) {
@@ -1078,7 +1085,7 @@ __global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes
         w_pa[i] = 0.0;
         r_ll[i] = 0.0;
     }
-    const uint64_t off = offsets[p];
+    const uint64_t off = ((uint64_t)it.y << 32) | it.x;
     const uint8_t *__restrict__ x = codes + off;
     const int ww1 = T->ww1, ww2 = T->ww2, ww3 = T->ww3;
     // w = ww/2 clamped to n-1 (:2588-2589)
@@ -1861,7 +1868,7 @@ template <bool TRACKS>
 __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ codes,
                                                  const uint64_t *__restrict__ offsets,
                                                  const uint32_t *__restrict__ neff,
-                                                 const uint32_t *__restrict__ order, uint32_t nprot, uint64_t total,
+                                                 const uint4 *__restrict__ order, uint32_t nprot, uint64_t total,
                                                  const DevTables *__restrict__ T, plaac_row *__restrict__ rows,
                                                  TrackPtrs tr) {
     __shared__ KbShared S;
@@ -1887,26 +1894,14 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
 
     // metadata of the first protein of this block; the next one is prefetched while the current is scored
     uint32_t b = blockIdx.x;
-    uint32_t p_cur = 0, n_cur = 0, p_nxt = 0;
-    uint64_t off_cur = 0;
-    if (b < nprot) {
-        p_cur = order[b];
-        n_cur = neff[p_cur];
-        off_cur = offsets[p_cur];
-    }
-    if (b + gridDim.x < nprot) p_nxt = order[b + gridDim.x];
+    uint4 it_nxt = make_uint4(0u, 0u, 0u, 0u);
+    if (b < nprot) it_nxt = order[b];
 
     for (; b < nprot; b += gridDim.x) {
-        const uint32_t p = p_cur;
-        const int n = (int)n_cur;
-        const uint64_t off = off_cur;
-        // prefetch: metadata of the next protein, id of the one after
-        if (b + gridDim.x < nprot) {
-            p_cur = p_nxt;
-            n_cur = neff[p_nxt];
-            off_cur = offsets[p_nxt];
-            if (b + 2u * gridDim.x < nprot) p_nxt = order[b + 2u * gridDim.x];
-        }
+        const uint32_t p = it_nxt.w;
+        const int n = (int)it_nxt.z;
+        const uint64_t off = ((uint64_t)it_nxt.y << 32) | it_nxt.x;
+        if (b + gridDim.x < nprot) it_nxt = order[b + gridDim.x]; // prefetch the next protein's plan item
         plaac_row *row = rows + p;
         if (n == 0) {
             if (lane == 0) {
@@ -1996,7 +1991,8 @@ struct plaac_ctx {
     hipEvent_t jev[4] = {nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
-    uint32_t *d_neff = nullptr, *d_order = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
+    uint32_t *d_neff = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
+    uint4 *d_order = nullptr; // the sorted plan: {offset lo, offset hi, effective length, protein index}
     uint4 *d_packed = nullptr;
     double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
     uint32_t *h_pin = nullptr; // pinned words: [0] total packed rows of a call, [1] upload validation flag
@@ -2406,7 +2402,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                        ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ctx->d_hist);
     hipLaunchKernelGGL(k_plan_scatter, dim3(plb), dim3(PLAN_THREADS), 0, st, ctx->d_neff, nprot, ctx->d_hist,
-                       ctx->d_order);
+                       d_offsets, ctx->d_order);
     PL_HIP(ctx, hipEventRecord(evs[E_PLAN], st));
     // The three K-A roles and K-B are independent given the plan: fork the K-A side onto high-priority streams
     // so the long serial chains (which set the wall time) overlap each other and the throughput-bound window
