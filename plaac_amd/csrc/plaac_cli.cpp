@@ -392,8 +392,8 @@ int main(int argc, char **argv) {
     bool ctx_started = false, ctx_joined = false;
     if (!o.input.empty() || !o.bgfile.empty()) {
         ctx_started = true;
-        ctx_thread = std::thread([&] {
-            ctx_st = plaac_ctx_create(&P, 0, &ctx);
+        ctx_thread = std::thread([&, P0 = P] { // its own copy: main re-initialises P once the background is known
+            ctx_st = plaac_ctx_create(&P0, 0, &ctx);
             if (ctx_st != PLAAC_OK) ctx_err = plaac_last_error(nullptr); // thread-local message: copy it here
         });
     }

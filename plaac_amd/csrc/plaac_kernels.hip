@@ -1774,6 +1774,386 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K-B, stream form: the 16 proteins of a block are laid end to end on ONE position axis (segment k starts at a
+// multiple of 4, S[k+1] = S[k] + n_k + gap, gap = 20..23 positions without residues), and the three pipelined
+// stages of tracks20_protein<4> run over that stream instead of over one protein at a time:
+//  * no fill / drain iteration and no partly empty last iteration per protein (UniRef-shaped lengths: 83 % ->
+//    90 % of the position slots carry a residue), and every iteration has 4 positions per lane, the variant with
+//    the fewest LDS reads per add (the per-protein kernel needs 2 or 3 for short proteins);
+//  * rings, prefix counts and code ring are initialised once per block, not once per protein.
+// A gap of >= 20 empty positions (window code "none", ring value 0.0, charge 0) isolates neighbours exactly: every
+// window of a position reaches at most 20 positions beyond its protein. What was wave-uniform per protein (n, the
+// clamped half width, the scan domains) becomes per lane: a lane's 4 positions always lie in one segment. Per-protein
+// results: FoldIndex run statistics go to LDS accumulators (a run is accounted at the position where it ends, which
+// lies in the same segment); the PAPA arg-max keeps one candidate per lane for the lane's current segment and one for
+// its previous segment, and a protein is finalised (wave arg-max over the lanes tagged with it, PAPAllr, row write)
+// in the iteration in which stage 2 passes its last residue - by then no lane has moved on by more than one segment.
+// ------------------------------------------------------------------------------------------------
+constexpr int KS_GAP = TW; // empty positions after every protein (rounded up so that segments start at multiples of 4)
+struct KsShared {
+    KbShared kb;
+    int segS[KB_PROTEINS_PER_BLOCK + 1]; // stream start of every segment; [16] = end of the stream
+    int segN[KB_PROTEINS_PER_BLOCK];
+    uint32_t segP[KB_PROTEINS_PER_BLOCK];
+    uint64_t segOff[KB_PROTEINS_PER_BLOCK];
+    int acc_numaa[KB_PROTEINS_PER_BLOCK], acc_maxlen[KB_PROTEINS_PER_BLOCK];
+    double bc[64];
+};
+
+struct KsCand { // PAPA arg-max candidate of one lane for one segment
+    int tag, cen;
+    double best, s0, s1;
+};
+
+template <bool TRACKS>
+__global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ codes, const uint4 *__restrict__ order,
+                                                  uint32_t nprot, uint64_t total, const DevTables *__restrict__ T,
+                                                  plaac_row *__restrict__ rows, TrackPtrs tr) {
+    constexpr int B = 4;
+    using G = KbGeom<B>;
+    constexpr int NP = KB_PROTEINS_PER_BLOCK;
+    __shared__ KsShared Z;
+    KbShared &S = Z.kb;
+    const int lane = threadIdx.x;
+    double *__restrict__ ring = S.ring;
+    int *__restrict__ pre = S.pre;
+    if (lane < KC_ROWS) {
+        const int k = lane < NAA ? lane : (lane == KC_DUP ? 13 : 0); // 22 -> X, 23 -> P
+        const bool none = lane == KC_NONE;
+        S.t_hl[lane].x = none ? 0.0 : T->hyd[k];
+        S.t_hl[lane].y = none ? 0.0 : T->llr[k];
+        S.t_lod[lane].x = (none || lane == KC_DUP) ? 0.0 : T->lod[k];
+        S.t_lod[lane].y = 0.0;
+        S.t_chg[lane] = none ? 0 : T->chg[k];
+    }
+    for (int i = lane; i < 3 * RING_DOUBLES; i += 64) ring[i] = 0.0;
+    for (int i = lane; i < RING_DOUBLES + 32; i += 64) S.cring[i] = (uint16_t)(KC_NONE * KB_ROW_BYTES);
+    for (int i = lane; i < 512; i += 64) pre[i] = 0;
+    // ---- segment table: protein k of this block is plan item blockIdx.x + k * gridDim.x (every block gets the same
+    //      mix of long and short proteins of the descending-length plan)
+    {
+        uint4 it = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t idx = blockIdx.x + (uint32_t)lane * gridDim.x;
+        const bool have = lane < NP && idx < nprot;
+        if (have) it = order[idx];
+        const int n = have ? (int)it.z : 0;
+        const int span = n > 0 ? ((n + KS_GAP + 3) & ~3) : 0;
+        int incl = span;
+#pragma unroll
+        for (int d = 1; d < NP; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane < NP) {
+            Z.segS[lane] = incl - span;
+            Z.segN[lane] = n;
+            Z.segP[lane] = it.w;
+            Z.segOff[lane] = ((uint64_t)it.y << 32) | it.x;
+            Z.acc_numaa[lane] = 0;
+            Z.acc_maxlen[lane] = 0;
+            if (lane == NP - 1) Z.segS[NP] = incl;
+            if (have && n == 0) { // skipped record (:762): zero the fields this kernel owns
+                plaac_row *row = rows + it.w;
+                row->papa_combo = row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = 0.0;
+                row->fi_numaa = row->fi_maxrun = row->papa_cen = 0;
+            }
+        }
+    }
+    wave_sync();
+    const int stream_end = Z.segS[NP]; // wave-uniform
+    if (stream_end == 0) return;
+    const uint8_t *cend = codes + total;
+    const int ww1 = T->ww1, ww2 = T->ww2;
+    const bool adjust = T->adjustprolines != 0;
+    const double cc0 = T->cc[0], cc1 = T->cc[1], cc2 = T->cc[2];
+    const int plo = (ww2 - 1) / 2;
+
+    // segment of the 4 positions starting at stream position s (s may be negative: segment 0); `cur` = wave-uniform
+    // segment of the iteration's first position, `last` = stream position of the iteration's last lane
+    auto seg_of = [&](int s, int cur, int last) {
+        int k = cur;
+        for (int kk = cur + 1; kk < NP; ++kk) { // wave-uniform trip count: segments that start inside the iteration
+            const int sk = __builtin_amdgcn_readfirstlane(Z.segS[kk]);
+            if (sk > last) break;
+            k = s >= sk ? kk : k;
+        }
+        return k;
+    };
+    auto advance = [&](int cur, int first) { // largest k with segS[k] <= first
+        while (cur + 1 < NP && __builtin_amdgcn_readfirstlane(Z.segS[cur + 1]) <= first) ++cur;
+        return cur;
+    };
+
+    KsCand cur{-1, -1, -INFINITY, 0.0, 0.0}, prv{-1, -1, -INFINITY, 0.0, 0.0};
+    int carry = 0, last_zero = -1, last_flag = 0;
+    int c0 = 0, c1 = 0, c2 = 0, fin = 0; // segment cursors of the three stages; next protein to finalise
+    auto wrap = [](int s) { return s >= G::RB ? s - G::RB : s; };
+    auto neg_slot = [](int e) { return ((e % G::RB) + G::RB) % G::RB; };
+    int slot_in = 0;
+    int slot_l1 = neg_slot(-(G::LAG1 + TW + G::C0) / B);
+    int slot_w1 = neg_slot(-G::LAG1 / B);
+    int slot_l2 = neg_slot(-(G::LAG2 + TW + G::C0) / B);
+    // the last residue sits at most at stream_end - KS_GAP - 1; stage 2 (lag LAG2) has to pass it
+    const int nchunks = (stream_end - KS_GAP + G::LAG2 + G::C - 1) / G::C;
+    for (int c = 0; c < nchunks; ++c) {
+        // ---- stage 0: residues -> window codes, charge prefix counts
+        {
+            const int s = G::C * c + B * lane;
+            c0 = advance(c0, G::C * c);
+            const int k = seg_of(s, c0, G::C * c + G::C - 1);
+            const int n = Z.segN[k], i0 = s - Z.segS[k];
+            uint32_t kc[B];
+            int ch[B];
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                kc[j] = (uint32_t)KC_NONE;
+                ch[j] = 0;
+            }
+            if (i0 < n) {
+                const uint8_t *x = codes + Z.segOff[k];
+                uint32_t cb[B + 2]; // residues i0-2 .. i0+3
+                const uint32_t wa = load4(x + i0 - 2, codes, cend);
+                cb[0] = i0 >= 2 ? (wa & 0xffu) : 255u;
+                cb[1] = i0 >= 1 ? ((wa >> 8) & 0xffu) : 255u;
+                cb[2] = (wa >> 16) & 0xffu;
+                cb[3] = wa >> 24;
+                const uint32_t wb = load4(x + i0 + 2, codes, cend);
+#pragma unroll
+                for (int m = 4; m < B + 2; ++m) cb[m] = (wb >> (8 * (m - 4))) & 0xffu;
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    const bool in = i0 + j < n;
+                    const uint32_t cd = cb[2 + j] < 22u ? cb[2 + j] : 22u;
+                    const bool dup = adjust && cd == 13u && (cb[1 + j] == 13u || cb[j] == 13u); // (:2653-2654)
+                    kc[j] = in ? (dup ? (uint32_t)KC_DUP : cd) : (uint32_t)KC_NONE;
+                    ch[j] = in ? S.t_chg[cd] : 0;
+                }
+            }
+            const int idx = wrap(slot_in + lane);
+#pragma unroll
+            for (int j = 0; j < B; ++j) S.cring[j * G::SUB + idx] = (uint16_t)(kc[j] * KB_ROW_BYTES);
+            if (idx < G::MIR) {
+#pragma unroll
+                for (int j = 0; j < B; ++j) S.cring[j * G::SUB + idx + G::RB] = (uint16_t)(kc[j] * KB_ROW_BYTES);
+            }
+            int lsum = 0;
+#pragma unroll
+            for (int j = 0; j < B; ++j) lsum += ch[j];
+            int sc = lsum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(sc, d);
+                if (lane >= d) sc += o;
+            }
+            int run = carry + sc - lsum;
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                run += ch[j];
+                pre[(s + j + 1) & 511] = run;
+            }
+            carry += bcast_lane(sc, 63);
+        }
+        wave_sync();
+        // ---- stage 1: first-level tracks, LAG1 positions behind
+        {
+            const int s = G::C * c + B * lane - G::LAG1;
+            c1 = advance(c1, G::C * c - G::LAG1);
+            const int k = seg_of(s, c1, G::C * c + G::C - 1 - G::LAG1);
+            const int n = Z.segN[k], sg = Z.segS[k], i0 = s - sg;
+            const int we = n - 1 < TW ? n - 1 : TW; // (:2588-2589)
+            int halfw = (ww1 - 1) / 2;              // (:5010-5013)
+            halfw = halfw > n / 2 ? n / 2 : halfw;
+            const int dlo = halfw, dhi = n - halfw - 1;
+            double sums[3][B];
+            window_sums3<B>(SrcCodes<B>{S}, wrap(slot_l1 + lane), sums);
+            double wfi[B], wll[B], wpa[B];
+            int zpos[B]; // STREAM position if FoldIndex >= 0 there (or outside the scan domain), else "none"
+            uint64_t off = 0;
+            if (TRACKS) off = Z.segOff[k];
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int i = i0 + j;
+                const bool live = i >= 0 && i < n;
+                const int lo = imax(i - TW, 0), hi = imin(i + TW, n - 1);
+                const SharedDiv div(live ? (double)(hi - lo + 1) : 1.0);
+                const int csum = pre[(sg + hi + 1) & 511] - pre[(sg + lo) & 511];
+                const double hydro = div(sums[0][j]);
+                const double charge = div((double)csum);
+                const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
+                const double llr1 = div(sums[1][j]);
+                const double papa = div(sums[2][j]);
+                const double wt = (double)(live ? 1 + imin(i, we) + imin(n - i - 1, we) : 0);
+                wfi[j] = wt * fi;
+                wll[j] = wt * llr1;
+                wpa[j] = wt * papa;
+                const bool neg = live && (fi < 0.0) && i >= dlo && i <= dhi;
+                zpos[j] = neg ? INT_MIN : s + j;
+                if (TRACKS && live) {
+                    tr.charge[off + i] = charge;
+                    tr.hydro[off + i] = hydro;
+                    tr.fi[off + i] = fi;
+                    tr.plaacllr[off + i] = llr1;
+                    tr.papa[off + i] = papa;
+                }
+            }
+            const int idx = wrap(slot_w1 + lane);
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                ring[RG_WF * RING_DOUBLES + j * G::SUB + idx] = wfi[j];
+                ring[RG_WL * RING_DOUBLES + j * G::SUB + idx] = wll[j];
+                ring[RG_WP * RING_DOUBLES + j * G::SUB + idx] = wpa[j];
+            }
+            if (idx < G::MIR) {
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    ring[RG_WF * RING_DOUBLES + j * G::SUB + idx + G::RB] = wfi[j];
+                    ring[RG_WL * RING_DOUBLES + j * G::SUB + idx + G::RB] = wll[j];
+                    ring[RG_WP * RING_DOUBLES + j * G::SUB + idx + G::RB] = wpa[j];
+                }
+            }
+            // FoldIndex<0 runs (:5020-5058) as in tracks20_protein, on stream positions; gap positions are unflagged,
+            // so no run crosses a segment, and a run ends (is accounted) inside its own segment
+            {
+                int lanemax = zpos[0];
+#pragma unroll
+                for (int j = 1; j < B; ++j) lanemax = imax(lanemax, zpos[j]);
+                int sc = lanemax;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(sc, d);
+                    if (lane >= d) sc = imax(sc, o);
+                }
+                int before = __shfl_up(sc, 1);
+                if (lane == 0) before = INT_MIN;
+                before = imax(before, last_zero);
+                int prevflag = __shfl_up(zpos[B - 1] == INT_MIN ? 1 : 0, 1);
+                if (lane == 0) prevflag = last_flag;
+                int numaa = 0, maxlen = 0;
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    const bool flagged = zpos[j] == INT_MIN;
+                    int rs = before + 1 - sg, re = i0 + j - 1; // the run that ends here, in protein coordinates
+                    rs = rs == dlo ? 0 : rs;
+                    re = re == dhi ? n - 1 : re;
+                    const int len = re - rs + 1;
+                    const int cnt = (!flagged && prevflag != 0 && len >= 5) ? len : 0;
+                    numaa += cnt;
+                    maxlen = imax(maxlen, cnt);
+                    before = imax(before, zpos[j]);
+                    prevflag = flagged ? 1 : 0;
+                }
+                if (numaa) {
+                    atomicAdd(&Z.acc_numaa[k], numaa);
+                    atomicMax(&Z.acc_maxlen[k], maxlen);
+                }
+                last_zero = imax(last_zero, bcast_lane(sc, 63));
+                last_flag = bcast_lane(prevflag, 63);
+            }
+        }
+        wave_sync();
+        // ---- stage 2: weighted second smoothing, LAG2 positions behind; PAPA candidates
+        {
+            const int s = G::C * c + B * lane - G::LAG2;
+            c2 = advance(c2, G::C * c - G::LAG2);
+            const int k = seg_of(s, c2, G::C * c + G::C - 1 - G::LAG2);
+            const int n = Z.segN[k], i0 = s - Z.segS[k];
+            const int we = n - 1 < TW ? n - 1 : TW;
+            const int phi = n - plo; // PAPA centres in [plo, phi) (:4942)
+            if (k != cur.tag) { // this lane has moved on to another protein: keep the old candidate one more segment
+                prv = cur;
+                cur = KsCand{k, -1, -INFINITY, 0.0, 0.0};
+            }
+            double sums[3][B];
+            window_sums3<B>(SrcRings<B>{ring}, wrap(slot_l2 + lane), sums);
+            uint64_t off = 0;
+            if (TRACKS) off = Z.segOff[k];
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int i = i0 + j;
+                const bool valid = i >= we && i <= n - we - 1; // implies 0 <= i < n
+                const int den = (2 * we + 1) + window_weight_side(i, we) + window_weight_side(n - 1 - i, we);
+                SharedDiv div(valid ? (double)den : 1.0);
+                div.poison_unless(valid); // NaN outside [w, n-w-1] (:2597-2600)
+                const double pax2 = div(sums[2][j]);
+                if (TRACKS && i >= 0 && i < n) {
+                    tr.fix2[off + i] = div(sums[0][j]);
+                    tr.plaacllrx2[off + i] = div(sums[1][j]);
+                    tr.papax2[off + i] = pax2;
+                }
+                const bool upd = i >= plo && i < phi && (pax2 > cur.best) && (sums[0][j] < 0.0); // (:4942-4948)
+                cur.best = upd ? pax2 : cur.best;
+                cur.cen = upd ? i : cur.cen;
+                cur.s0 = upd ? sums[0][j] : cur.s0;
+                cur.s1 = upd ? sums[1][j] : cur.s1;
+            }
+        }
+        // ---- proteins whose last residue stage 2 has passed in this iteration
+        const int passed = G::C * c + G::C - 1 - G::LAG2;
+        while (fin < NP) { // wave-uniform
+            const int n = __builtin_amdgcn_readfirstlane(Z.segN[fin]);
+            const int sg = __builtin_amdgcn_readfirstlane(Z.segS[fin]);
+            if (n > 0 && sg + n - 1 > passed) break;
+            if (n > 0) {
+                const bool mc = cur.tag == fin, mp = prv.tag == fin;
+                double pbest = mc ? cur.best : (mp ? prv.best : -INFINITY);
+                int pcen = mc ? cur.cen : (mp ? prv.cen : -1);
+                const double ms0 = mc ? cur.s0 : prv.s0, ms1 = mc ? cur.s1 : prv.s1;
+                const int mine = pcen;
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const double ob = __shfl_xor(pbest, d);
+                    const int oc = __shfl_xor(pcen, d);
+                    const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
+                    pbest = take ? ob : pbest;
+                    pcen = take ? oc : pcen;
+                }
+                const int we = n - 1 < TW ? n - 1 : TW;
+                double pfi = 0.0, pll2 = 0.0, papallr = __builtin_nan("");
+                if (pcen >= 0) { // wave-uniform
+                    const int src = __builtin_ctzll(__ballot(mine == pcen));
+                    const double s0 = bcast_lane_dyn(ms0, src), s1 = bcast_lane_dyn(ms1, src);
+                    const int den = (2 * we + 1) + window_weight_side(pcen, we) + window_weight_side(n - 1 - pcen, we);
+                    const SharedDiv div((double)den);
+                    pfi = div(s0);
+                    pll2 = div(s1);
+                    // PAPAllr = first-level PLAAC-LLR at the centre, recomputed (41 taps through LDS broadcasts)
+                    const uint8_t *x = codes + Z.segOff[fin];
+                    const int q = pcen - TW + lane;
+                    wave_sync();
+                    Z.bc[lane] = (lane <= 2 * TW && q >= 0 && q < n) ? S.t_hl[ld_code(x, (uint32_t)q)].y : 0.0;
+                    wave_sync();
+                    double sm = 0.0;
+#pragma unroll
+                    for (int j = 0; j <= 2 * TW; ++j) sm = sm + Z.bc[j];
+                    const int lo = imax(pcen - TW, 0), hi = imin(pcen + TW, n - 1);
+                    papallr = sm / (double)(hi - lo + 1);
+                }
+                if (lane == 0) {
+                    plaac_row *row = rows + Z.segP[fin];
+                    row->fi_numaa = Z.acc_numaa[fin];
+                    row->fi_maxrun = Z.acc_maxlen[fin];
+                    row->papa_cen = pcen;
+                    if (pcen >= 0) {
+                        row->papa_combo = pbest;
+                        row->papa_prop = pbest;
+                        row->papa_fi = pfi;
+                        row->papa_llr = papallr;
+                        row->papa_llr2 = pll2;
+                    } else {
+                        row->papa_combo = -INFINITY;
+                        row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
+                    }
+                }
+            }
+            ++fin;
+        }
+        slot_in = wrap(slot_in + 64);
+        slot_l1 = wrap(slot_l1 + 64);
+        slot_w1 = wrap(slot_w1 + 64);
+        slot_l2 = wrap(slot_l2 + 64);
+    }
+}
+
 // positions-per-lane variant that wastes the fewest slots for a protein of n residues: iterations x
 // (per-iteration cost ~ B + fixed part). A protein shorter than one iteration needs no pipeline lag.
 __device__ __forceinline__ int kb_choose_b(int n) {
@@ -2017,6 +2397,7 @@ struct plaac_ctx {
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; // high-priority side streams of the K-A roles
     bool serial = false;                              // PLAAC_SERIAL_STREAMS=1: everything on one stream
     bool generic_tracks = false;                      // PLAAC_GENERIC_TRACKS=1: never use the ww=41 fast path
+    bool per_protein_tracks = false;                  // PLAAC_KB_PER_PROTEIN=1: ww=41 fast path, one protein at a time
     std::string err;
 };
 
@@ -2163,6 +2544,8 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         ctx->serial = ser && ser[0] == '1';
         const char *gen = std::getenv("PLAAC_GENERIC_TRACKS");
         ctx->generic_tracks = gen && gen[0] == '1';
+        const char *ppt = std::getenv("PLAAC_KB_PER_PROTEIN");
+        ctx->per_protein_tracks = ppt && ppt[0] == '1';
     }
     for (auto &set : ctx->ev)
         for (auto &ev : set)
@@ -2378,7 +2761,15 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,          \
                                ctx->d_neff, ctx->d_order, nprot, tab, rows, tp);                                   \
     } while (0)
-        if (fast20) {
+        if (fast20 && !ctx->per_protein_tracks) {
+            const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
+            if (d_tracks)
+                hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                                   total_residues, tab, rows, tp);
+            else
+                hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                                   total_residues, tab, rows, tp);
+        } else if (fast20) {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
             if (d_tracks)
                 hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
