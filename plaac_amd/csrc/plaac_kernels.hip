@@ -1452,7 +1452,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int KB_PROTEINS_PER_BLOCK = 16; // blocks retire regularly, so the K-A kernels' blocks keep getting slots
+constexpr int KB_PROTEINS_PER_BLOCK = 32; // blocks retire regularly, so the K-A kernels' blocks keep getting slots
 
 // residue codes as the first-level windows see them: 0..21 real, 22 = any other byte (scored as X),
 // 23 = a proline that PAPA skips (second P of PP / PxP: hydropathy and LLR of P, log-odds 0), 24 = no residue
