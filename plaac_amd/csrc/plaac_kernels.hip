@@ -409,8 +409,10 @@ __device__ __forceinline__ uint32_t vit_block(VitState &S, const double *__restr
             // (:3087-3100): state 0 stays the arg-max on ties (strict >)
             const double v00 = lt00 + S.s0, v10 = lt10 + S.s1, v01 = lt01 + S.s0, v11 = lt11 + S.s1;
             const bool g0 = v10 > v00, g1 = v11 > v01;
-            S.s0 = (g0 ? v10 : v00) + e0;
-            S.s1 = (g1 ? v11 : v01) + e1;
+            // the larger candidate as a VALUE is the same whichever way a tie is broken: one max instead of a
+            // two-register select; the tie rule lives in the traceback bit only
+            S.s0 = __builtin_fmax(v00, v10) + e0;
+            S.s1 = __builtin_fmax(v01, v11) + e1;
             S.h0 = (h0lt + S.h0) + eh; // hmm0: Viterbi == forward == running sum
             tbw |= ((uint32_t)g0 | ((uint32_t)g1 << 1)) << (2 * j);
         }
@@ -427,9 +429,10 @@ __device__ __forceinline__ uint32_t traceback_block(uint32_t &state, int &cur, i
         if (!GUARD || t0 + (uint32_t)j < n) {
             // here `state` = vit[t]
             vw |= state << j;
-            cur = state ? cur + 1 : 0;
+            cur = (int)((uint32_t)cur * state + state); // state ? cur + 1 : 0
             maxrun = cur > maxrun ? cur : maxrun;
-            state = (word >> (2 * j + (int)state)) & 1u; // tb[vit[t]][t] = vit[t-1]
+            const uint32_t wj = word >> (2 * j);         // off the serial chain
+            state = (wj >> state) & 1u;                  // tb[vit[t]][t] = vit[t-1]
         }
     }
     return vw;
@@ -453,20 +456,19 @@ struct CoreState {
 
 // STEADY: the whole block has t >= c for every core length, i.e. all chains run and every step closes a window
 template <bool GUARD, bool STEADY, int NC>
-__device__ __forceinline__ void core_block(CoreState<NC> &S, const double *__restrict__ s_row, const uint4 cur,
+__device__ __forceinline__ void core_block(CoreState<NC> &S, const double *__restrict__ s_mask, const uint4 cur,
                                            const uint4 (&tcur)[NC], uint32_t wl, const uint32_t (&tv)[NC], uint32_t t0,
-                                           uint32_t n, const uint32_t (&c)[NC], double big_neg) {
+                                           uint32_t n, const uint32_t (&c)[NC]) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t t = t0 + (uint32_t)j;
         if (!GUARD || t < n) {
-            const double lv = s_row[block_code(cur, j) * R_W + R_LLR];
-            S.mL = S.mL + (((wl >> j) & 1u) ? lv : big_neg); // psum[i+1] = psum[i] + maa3[i]
+            // maa3[i] (:818-823) = llr if the path bit is set, else big_neg: one lookup in a two-plane table
+            S.mL = S.mL + s_mask[(((wl >> j) & 1u) << 5) | block_code(cur, j)]; // psum[i+1] = psum[i] + maa3[i]
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 if (STEADY || t >= c[k]) { // same chain, c steps later
-                    const double lo = s_row[block_code(tcur[k], j) * R_W + R_LLR];
-                    S.mT[k] = S.mT[k] + (((tv[k] >> j) & 1u) ? lo : big_neg);
+                    S.mT[k] = S.mT[k] + s_mask[(((tv[k] >> j) & 1u) << 5) | block_code(tcur[k], j)];
                 }
                 if (STEADY || t + 1 >= c[k]) {
                     const bool first = !STEADY && t + 1 == c[k];
@@ -490,7 +492,12 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
                                                     const uint32_t *__restrict__ grow, uint32_t *__restrict__ bits,
                                                     SweepTargets tg) {
     __shared__ double s_row[ROWS * R_W];
+    __shared__ double s_mask[64]; // [0..31]: big_neg (path bit 0), [32..63]: llr by code (path bit 1)
     load_rows(s_row, T);
+    if (threadIdx.x < 64) {
+        const int k = threadIdx.x & 31;
+        s_mask[threadIdx.x] = threadIdx.x < 32 ? T->big_neg : (k < NAA ? T->llr[k] : T->llr[0]);
+    }
     __syncthreads();
     const LaneJob J = lane_job(offsets, neff, order, nprot);
     const uint32_t n = J.n;
@@ -614,10 +621,10 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
             }
             const bool full = t0 + 16u <= n;
             if (t0 >= cmax) { // wave-uniform
-                if (full) core_block<false, true, NC>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
-                else core_block<true, true, NC>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
+                if (full) core_block<false, true, NC>(C, s_mask, cur, tcur, wl, tv, t0, n, c);
+                else core_block<true, true, NC>(C, s_mask, cur, tcur, wl, tv, t0, n, c);
             } else {
-                core_block<true, false, NC>(C, s_row, cur, tcur, wl, tv, t0, n, c, big_neg);
+                core_block<true, false, NC>(C, s_mask, cur, tcur, wl, tv, t0, n, c);
             }
         }
     }
