@@ -237,6 +237,7 @@ __device__ __forceinline__ uint4 load16(const uint8_t *p, const uint8_t *lo, con
 // rows[g] = ceil(longest length in group / 16); grow[] = exclusive prefix sum (grow[ngroups] = total rows).
 __global__ void k_group_rows(const uint32_t *__restrict__ neff, const uint4 *__restrict__ order, uint32_t nprot,
                              uint32_t ngroups, uint32_t *__restrict__ grow) {
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ngroups) return;
     // Lane 0 is the longest of its group, EXCEPT inside the last length bin (lengths >= LEN_BINS-1 are not
@@ -255,6 +256,7 @@ __global__ void k_group_rows(const uint32_t *__restrict__ neff, const uint4 *__r
 // single block: in-place exclusive scan of a[0..n), total written to a[n]
 __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uint32_t n) {
     __shared__ uint32_t part[1024];
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t b = tid * per, e = b + per < n ? b + per : n;
@@ -277,11 +279,16 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uin
     if (tid == 1023u) a[n] = part[1023];
 }
 
+// 16 lanes per protein: a protein's residues are read as contiguous 256-byte pieces (coalesced; one lane per
+// protein reading 16 bytes at a time dragged every 128-byte line through L2 2.5 times), the 16-byte writes of the 64
+// proteins of a group land in the same 1 KiB rows at about the same time and merge in L2.
 __global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ offsets,
                                               const uint32_t *__restrict__ neff, const uint4 *__restrict__ order,
                                               uint32_t nprot, uint64_t total, const uint32_t *__restrict__ grow,
                                               uint4 *__restrict__ packed) {
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    __builtin_amdgcn_s_setprio(3); // on the critical path of the serial chains, beside the window kernel
+    const uint32_t gid = blockIdx.x * 16u + (threadIdx.x >> 4); // 16 proteins per block
+    const uint32_t sub = threadIdx.x & 15u;
     if (gid >= nprot) return;
     const uint4 it = order[gid];
     const uint32_t n = it.z;
@@ -289,16 +296,13 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ codes,
     const uint8_t *cend = codes + total;
     uint4 *__restrict__ col = packed + (size_t)grow[gid >> 6] * 64u + (gid & 63u);
     const uint32_t nj = (n + 15u) >> 4;
-    uint32_t j = 0;
-    for (; j + 4u <= nj; j += 4u) { // four independent 16-byte loads in flight per lane
-        const uint4 v0 = load16(x + 16u * j, codes, cend), v1 = load16(x + 16u * j + 16u, codes, cend),
-                    v2 = load16(x + 16u * j + 32u, codes, cend), v3 = load16(x + 16u * j + 48u, codes, cend);
+    uint32_t j = sub;
+    for (; j + 16u < nj; j += 32u) { // two independent loads in flight per lane
+        const uint4 v0 = load16(x + 16u * j, codes, cend), v1 = load16(x + 16u * j + 256u, codes, cend);
         col[(size_t)j * 64u] = v0;
-        col[(size_t)(j + 1u) * 64u] = v1;
-        col[(size_t)(j + 2u) * 64u] = v2;
-        col[(size_t)(j + 3u) * 64u] = v3;
+        col[(size_t)(j + 16u) * 64u] = v1;
     }
-    for (; j < nj; ++j) col[(size_t)j * 64u] = load16(x + 16u * j, codes, cend);
+    if (j < nj) col[(size_t)j * 64u] = load16(x + 16u * j, codes, cend);
 }
 
 // one lane's view of its group's packed rows
@@ -352,6 +356,14 @@ __device__ __forceinline__ uint32_t block_code(const uint4 &c, int j) {
     const uint32_t w = j < 4 ? c.x : j < 8 ? c.y : j < 12 ? c.z : c.w;
     const uint32_t b = (w >> (8 * (j & 3))) & 0xffu;
     return b < 22u ? b : 22u;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d);
+        v = o > v ? o : v;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
 // issue priority by chain length: the longest chains define the kernel's duration
@@ -557,14 +569,22 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     // ---------------- sweep 2: traceback t = n-1 .. 0 (:3111-3113), longest run ----------------
     {
         int cur = 0, maxrun = 0;
-        uint32_t wnext = PL.word(nw - 1u); // traceback words are prefetched one block ahead
-        for (uint32_t wi = nw; wi-- > 0u;) {
-            const uint32_t word = wnext;
-            if (wi > 0u) wnext = PL.word(wi - 1u);
-            const uint32_t t0 = wi << 4;
-            const uint32_t vw = (t0 + 16u <= n) ? traceback_block<false>(state, cur, maxrun, word, t0, n)
-                                                : traceback_block<true>(state, cur, maxrun, word, t0, n);
-            PL.set_word(wi, vw); // this word now holds vit[16*wi .. 16*wi+15]
+        // Phase-locked like the forward sweeps: all lanes walk the SAME block index down from the group's last block
+        // (a lane joins when the index reaches its own last block), so a word load is one coalesced 256-byte row
+        // instead of 64 lines; words are fetched two blocks ahead (a traceback block is only ~150 instructions).
+        const uint32_t nwmax = wave_max_u32(nw);
+        auto word_at = [&](uint32_t wi) { return wi < nw ? PL.word(wi) : 0u; };
+        uint32_t q0 = word_at(nwmax - 1u), q1 = nwmax > 1u ? word_at(nwmax - 2u) : 0u;
+        for (uint32_t wi = nwmax; wi-- > 0u;) {
+            const uint32_t word = q0;
+            q0 = q1;
+            if (wi >= 2u) q1 = word_at(wi - 2u);
+            if (wi < nw) {
+                const uint32_t t0 = wi << 4;
+                const uint32_t vw = (t0 + 16u <= n) ? traceback_block<false>(state, cur, maxrun, word, t0, n)
+                                                    : traceback_block<true>(state, cur, maxrun, word, t0, n);
+                PL.set_word(wi, vw); // this word now holds vit[16*wi .. 16*wi+15]
+            }
         }
 #pragma unroll
         for (int k = 0; k < NC; ++k) tg.rows[k][J.p].vit_maxrun = maxrun;
@@ -785,13 +805,18 @@ __global__ __launch_bounds__(KA_THREADS) void k_bwd(const uint64_t *__restrict__
     double2 *bw = bwd + ((size_t)grow[gid >> 6] * 16u) * 64u + (gid & 63u);
     double b0 = T->lf[0], b1 = T->lf[1]; // b[.][n-1] = lfprob (:3378)
     const uint32_t nw = (n + 15u) >> 4;
-    uint4 nxt = PL.chunk(nw - 1u);
-    for (uint32_t wi = nw; wi-- > 0u;) {
+    // phase-locked downwards from the group's last block (see k_vit's traceback): coalesced row loads
+    const uint32_t nwmax = wave_max_u32(nw);
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 nxt = nwmax - 1u < nw ? PL.chunk(nwmax - 1u) : zero4;
+    for (uint32_t wi = nwmax; wi-- > 0u;) {
         const uint4 cur = nxt;
-        if (wi > 0u) nxt = PL.chunk(wi - 1u);
-        const uint32_t t0 = wi << 4;
-        if (t0 + 16u <= n) bwd_block<false>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, bw);
-        else bwd_block<true>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, bw);
+        if (wi > 0u) nxt = wi - 1u < nw ? PL.chunk(wi - 1u) : zero4;
+        if (wi < nw) {
+            const uint32_t t0 = wi << 4;
+            if (t0 + 16u <= n) bwd_block<false>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, bw);
+            else bwd_block<true>(b0, b1, s_row, s_lut, cur, t0, n, lt00, lt01, lt10, lt11, bw);
+        }
     }
 }
 
@@ -2824,7 +2849,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_bwd, ctx->cap_bwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
     }
-    hipLaunchKernelGGL(k_pack, dim3((nprot + 255u) / 256u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
+    hipLaunchKernelGGL(k_pack, dim3((nprot + 15u) / 16u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
     if (!ctx->serial) {

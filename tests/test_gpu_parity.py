@@ -292,3 +292,42 @@ def test_proteins_beyond_the_last_length_bin(native, oracle, ctx):
     lens = np.array([100, 65535, 70001, 65534, 66000, 12, 65600, 300], dtype=np.int64)
     codes, offs = synth.residues(lens, np.array(P.fg), np.array(P.bg), rng)
     check_batch(native, oracle, ctx, codes, offs, what="beyond-bins")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,lo,hi,nprot", [(11, 0, 30, 6000), (12, 1, 70, 4000), (13, 35, 300, 3000)])
+def test_many_tiny_proteins_share_one_position_stream(native, oracle, ctx, seed, lo, hi, nprot):
+    """The window kernel lays 32 proteins end to end on one position axis (k_tracks20s): many very short records, empty
+    records and stop-only records in a row, a few long ones between them, several segments per 256-position iteration."""
+    rng = np.random.default_rng(seed)
+    aas = list("ACDEFGHIKLMNPQRSTVWY")
+    lens = rng.integers(lo, hi + 1, nprot)
+    lens[rng.integers(0, nprot, 12)] = rng.integers(900, 2600, 12)
+    # prion-like stretches make cores / PAPA centres exist
+    seqs = []
+    for n in lens:
+        s = rng.choice(aas, int(n))
+        if n >= 40 and rng.random() < 0.5:
+            a = int(rng.integers(0, n - 30))
+            s[a:a + 30] = rng.choice(list("QNSYG"), 30)
+        seqs.append("".join(s) + ("*" if rng.random() < 0.2 else ""))
+    codes, offs = native.pack(seqs)
+    check_batch(native, oracle, ctx, codes, offs, tracks=bool(seed & 1), what="tiny%d" % seed)
+
+
+@pytest.mark.gpu
+def test_stream_and_per_protein_window_kernels_agree(native, oracle):
+    """PLAAC_KB_PER_PROTEIN=1 selects the older one-protein-at-a-time form of the ww=41 window kernel: both forms must
+    give the same bytes (and therefore both equal the oracle, which other tests check for the default form)."""
+    from plaac_amd import synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(4, nprot=20000, fg=np.array(P.fg), bg=np.array(P.bg))
+    rows = {}
+    for flag in ("0", "1"):
+        os.environ["PLAAC_KB_PER_PROTEIN"] = flag
+        try:
+            with native.Context(P) as c:
+                rows[flag] = c.score(codes, offs, tracks=False)
+        finally:
+            os.environ.pop("PLAAC_KB_PER_PROTEIN", None)
+    assert rows["0"].tobytes() == rows["1"].tobytes()
