@@ -428,6 +428,13 @@ __device__ __forceinline__ uint32_t vit_block(VitState &S, const double *__restr
             S.h0 = (h0lt + S.h0) + eh; // hmm0: Viterbi == forward == running sum
             tbw |= ((uint32_t)g0 | ((uint32_t)g1 << 1)) << (2 * j);
         }
+        // Left alone, the scheduler defers all 32 compares (they are off the critical chain) to the end of the block and
+        // keeps their 64 operands alive: 180 VGPRs, so that a wave of this kernel never fits on a SIMD beside three
+        // waves of the window kernel. Pinning the traceback word every four steps brings the kernel to 62 VGPRs.
+        if ((j & 3) == 3) {
+            asm volatile("" : "+v"(tbw));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     return tbw;
 }
