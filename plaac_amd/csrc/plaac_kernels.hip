@@ -2800,7 +2800,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,          \
                                ctx->d_neff, ctx->d_order, nprot, tab, rows, tp);                                   \
     } while (0)
-        if (fast20 && !ctx->per_protein_tracks) {
+        // the stream form keeps 32 proteins on one int32 position axis: fall back to one protein at a time when a
+        // block's stream could not be indexed that way
+        if (fast20 && !ctx->per_protein_tracks && total_residues < 0x70000000ull) {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
             if (d_tracks)
                 hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
