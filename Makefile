@@ -22,11 +22,6 @@ bin/plaac: $(CSRC)/plaac_cli.cpp $(LIB)
 oracle:
 	$(MAKE) -C oracle
 
-# cost-breakdown build of the library (PLAAC_KB_SKIP=<mask>, see plaac_kernels.hip); never shipped
-probe: $(LIBSRC)
-	mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DPLAAC_KB_PROBE -Iinclude -shared -o build/libplaac_native_probe.so $(LIBSRC) -Wl,-rpath,/opt/rocm/lib
-
 asm: $(CSRC)/plaac_kernels.hip
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -Iinclude --cuda-device-only -S -o build/plaac_kernels.s $(CSRC)/plaac_kernels.hip \

@@ -331,3 +331,25 @@ def test_stream_and_per_protein_window_kernels_agree(native, oracle):
         finally:
             os.environ.pop("PLAAC_KB_PER_PROTEIN", None)
     assert rows["0"].tobytes() == rows["1"].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ww", [dict(ww1=31, ww2=21), dict(ww1=41, ww2=41, ww3=21), dict(ww1=41, ww2=21, ww3=61)])
+def test_sweep_over_alpha_with_other_windows(native, oracle, ctx, ww):
+    """The further alphas of a sweep take the PAPA centre from the first alpha's window kernel and recompute only the two
+    llr-derived values there (k_llr_at_centre). With ww3 != ww2 the centre (PAPA window) can lie in the NaN margin of
+    the llr window; with windows other than 41 the generic window kernel supplies the centre."""
+    from plaac_amd import synth
+    codes, offs = synth.make_batch(2, nprot=300, seed=5, stop_fraction=0.1)
+    extra = native.pack(["QNQNQNQNQNYYGGSSQQNN" * k for k in (1, 2, 3, 5)] + ["A", "", "QN"])
+    codes = np.concatenate([codes, extra[0]])
+    offs = np.concatenate([offs, offs[-1] + extra[1][1:]])
+    bg = oracle.histogram(codes, offs).astype(np.float64)
+    with ctx.upload(codes, offs) as batch:
+        points = [(a, c) for a in (1.0, 0.3, 0.0) for c in (20, 60)]
+        got = batch.sweep([native.make_params(alpha=a, corelength=c, bgcounts=bg, **ww) for a, c in points])
+        for (a, c), rows in zip(points, got):
+            want = oracle.score_batch(oracle.build_params(alpha=a, corelength=c, bgcounts=bg, **ww), codes, offs,
+                                      nthreads=8)
+            assert_rows_equal(rows, want, "%s alpha=%s c=%d" % (ww, a, c))
+    ctx.set_params(native.make_params())
