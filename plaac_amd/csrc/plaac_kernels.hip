@@ -13,15 +13,19 @@
 //                   MW and LLR fixed-width windows over prefix sums  hss2 :1206-1257 via :767-783
 //                   masked core window, PRD expansion, PRD score          :816-880
 //                   mean hydropathy / charge / FoldIndex                  :4877-4885
-//                   (track mode) backward, posteriors, MAP path           :3377-3405, :4032-4045
 //                 A serial chain cannot be re-associated (bit-exactness), so the parallelism is
 //                 ACROSS proteins: 64 independent chains per wave, tables + 32 KB loglut in LDS.
-//   k_tracks      "K-B", ONE WAVE PER PROTEIN, position-parallel. The window tracks of disorderreport
-//                 (:4866-5068): hydro/charge/FoldIndex, PLAAC-LLR and PAPA sliding means (fixed-order
-//                 41-term sums per position), their weighted second smoothing, the PAPA arg-max and the
-//                 FoldIndex run statistics. Tiles stream through LDS rings; wave ballots/shuffles for
-//                 the run-length and arg-max reductions.
-//   k_hist        22-bin histogram over valid records (countaas/isvalidprotein :1698-1739).
+//   k_group_rows / k_scan_u32 / k_pack  group-interleaved copy of the residues for the K-A kernels (coalesced rows).
+//   k_bwd / k_post  (track mode) backward recurrence as its own chain; posteriors, MAP and path bytes per packed row.
+//   k_tracks*     "K-B", position-parallel. The window tracks of disorderreport (:4866-5068): hydro/charge/
+//                 FoldIndex, PLAAC-LLR and PAPA sliding means (fixed-order 41-term sums per position), their
+//                 weighted second smoothing, the PAPA arg-max and the FoldIndex run statistics, as three
+//                 pipelined stages over LDS rings with wave scans / shuffles for the reductions.
+//                   k_tracks20s   ww = 41/40 (default): ONE WAVE PER 32 PROTEINS laid end to end on one position axis
+//                   k_tracks20    same windows, one wave per protein (PLAAC_KB_PER_PROTEIN=1; very large batches)
+//                   k_tracks<R>   any other window size, one wave per protein
+//   k_llr_at_centre  sweeps: the two llr-dependent K-B outputs at the known PAPA centre, for the 2nd, 3rd ... alpha.
+//   k_hist / k_validate  22-bin histogram over valid records (countaas/isvalidprotein :1698-1739); code range check.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
