@@ -258,17 +258,19 @@ __global__ void k_group_rows(const uint32_t *__restrict__ neff, const uint4 *__r
 }
 
 // single block: in-place exclusive scan of a[0..n), total written to a[n]
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uint32_t n) {
-    __shared__ uint32_t part[1024];
+// (256 threads: a 1024-thread block needs 4 waves per SIMD at once and can wait milliseconds for room beside the window
+// kernel)
+__global__ __launch_bounds__(256) void k_scan_u32(uint32_t *__restrict__ a, uint32_t n) {
+    __shared__ uint32_t part[256];
     __builtin_amdgcn_s_setprio(3);
     const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t per = (n + 255u) / 256u;
     const uint32_t b = tid * per, e = b + per < n ? b + per : n;
     uint32_t s = 0;
     for (uint32_t i = b; i < e; ++i) s += a[i];
     part[tid] = s;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
         const uint32_t v = tid >= d ? part[tid - d] : 0u;
         __syncthreads();
         part[tid] += v;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uin
         a[i] = run;
         run += c;
     }
-    if (tid == 1023u) a[n] = part[1023];
+    if (tid == 255u) a[n] = part[255];
 }
 
 // 16 lanes per protein: a protein's residues are read as contiguous 256-byte pieces (coalesced; one lane per
@@ -957,6 +959,11 @@ __device__ __forceinline__ void win_block(WinState<NC> &S, const double *__restr
                 }
             }
         }
+        if ((j & 3) == 3) { // keeps the integer side work of four steps from piling up at the block's end (80 VGPRs
+                            // instead of 86: the wave then fits beside three window-kernel waves of 144)
+            asm volatile("" : "+v"(S.mwbest), "+v"(S.chg));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -1394,6 +1401,8 @@ __device__ __forceinline__ double bcast_lane_dyn(double v, int lane) { // `lane`
     return bcast_lane(v, __builtin_amdgcn_readfirstlane(lane));
 }
 
+constexpr int TW_CONST = 20; // = TW (declared below): half window of the fast path
+
 // Correctly rounded a/d for several numerators sharing one small positive integer-valued denominator.
 struct SharedDiv {
     double d, y;
@@ -1409,9 +1418,38 @@ struct SharedDiv {
         const double r = __builtin_fma(-d, q0, a);
         return __builtin_fma(r, y, q0);
     }
+    __device__ __forceinline__ SharedDiv(double den, double recip) : d(den), y(recip) {} // from a KbDivTab entry
     // every later quotient becomes NaN unless ok (one select instead of one per quotient)
     __device__ __forceinline__ void poison_unless(bool ok) { y = ok ? y : __builtin_nan(""); }
 };
+
+// The denominators of the two window levels at half width 20 take few values: the refined reciprocals that
+// SharedDiv's constructor computes (1 transcendental + 4 fma, after up to 13 integer operations for the
+// second-level denominator) are tabulated once per context by the same instructions and fetched with one load.
+//   first[c]          c = 1 .. 41 residues under the window (0: unused)
+//   second[ml*41+mr]  ml = max(0, 40 - i), mr = max(0, 40 - (n-1-i)): den = 41 + (820 - ml(ml+1)/2) + (820 - mr(mr+1)/2)
+//   second[41*41]     = (1, NaN): positions where the second smoothing is undefined
+//   second[41*41+1]   = (1, 1): the single position of a one-residue protein (w = 0)
+struct KbDivTab {
+    double2 first[2 * TW_CONST + 2];
+    double2 second[(2 * TW_CONST + 1) * (2 * TW_CONST + 1) + 2];
+};
+__global__ void k_build_divtab(KbDivTab *t) {
+    constexpr int W = TW_CONST, M = 2 * W + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M + 1) {
+        const SharedDiv dv((double)(i > 0 ? i : 1));
+        t->first[i] = make_double2(dv.d, dv.y);
+    }
+    if (i < M * M) {
+        const int ml = i / M, mr = i % M;
+        const int den = M + (M * W - ((ml * (ml + 1)) >> 1)) + (M * W - ((mr * (mr + 1)) >> 1));
+        const SharedDiv dv((double)den);
+        t->second[i] = make_double2(dv.d, dv.y);
+    }
+    if (i == M * M) t->second[i] = make_double2(1.0, __builtin_nan(""));
+    if (i == M * M + 1) t->second[i] = make_double2(1.0, SharedDiv(1.0).y); // n = 1: the value itself
+}
 
 // The B 41-term sums of positions I .. I+B-1 (I = 0 mod B) for THREE tracks at once, each in increasing position
 // order: s[track][b] over I+b-20 .. I+b+20. Value e of the union (e = 0 .. 40+B-1, position I-20+e) is class
@@ -1852,7 +1890,9 @@ struct KsCand { // PAPA arg-max candidate of one lane for one segment
 template <bool TRACKS>
 __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ codes, const uint4 *__restrict__ order,
                                                   uint32_t nprot, uint64_t total, const DevTables *__restrict__ T,
-                                                  plaac_row *__restrict__ rows, TrackPtrs tr) {
+                                                  const KbDivTab *__restrict__ DT, plaac_row *__restrict__ rows,
+                                                  TrackPtrs tr) {
+    static_assert(TW_CONST == TW, "KbDivTab is built for the fast path's half window");
     constexpr int B = 4;
     using G = KbGeom<B>;
     constexpr int NP = KB_PROTEINS_PER_BLOCK;
@@ -2019,7 +2059,13 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
                 const int i = i0 + j;
                 const bool live = i >= 0 && i < n;
                 const int lo = imax(i - TW, 0), hi = imin(i + TW, n - 1);
-                const SharedDiv div(live ? (double)(hi - lo + 1) : 1.0);
+                // The reciprocal is FETCHED AFTER the window sums (the empty asm ties the index to a sum): fetched
+                // before them, the four table entries stay live across the sums and cost the registers that let a
+                // fourth wave of another kernel share the SIMD.
+                int c1 = live ? hi - lo + 1 : 1;
+                asm volatile("" : "+v"(c1) : "v"(sums[0][j]));
+                const double2 e1 = DT->first[c1];
+                const SharedDiv div(e1.x, e1.y);
                 const int csum = pre[(sg + hi + 1) & 511] - pre[(sg + lo) & 511];
                 const double hydro = div(sums[0][j]);
                 const double charge = div((double)csum);
@@ -2114,10 +2160,15 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
 #pragma unroll
             for (int j = 0; j < B; ++j) {
                 const int i = i0 + j;
-                const bool valid = i >= we && i <= n - we - 1; // implies 0 <= i < n
-                const int den = (2 * we + 1) + window_weight_side(i, we) + window_weight_side(n - 1 - i, we);
-                SharedDiv div(valid ? (double)den : 1.0);
-                div.poison_unless(valid); // NaN outside [w, n-w-1] (:2597-2600)
+                const bool valid = i >= we && i <= n - we - 1; // implies 0 <= i < n; NaN elsewhere (:2597-2600)
+                // a protein of at most 20 residues (w clamped to n-1 < 20) has a valid position only for n = 1: i = 0,
+                // w = 0, denominator 1 - the table's last entry
+                const int ml = imax(0, 2 * TW - i), mr = imax(0, 2 * TW - (n - 1 - i));
+                int c2 = valid ? (we == TW ? ml * (2 * TW + 1) + mr : (2 * TW + 1) * (2 * TW + 1) + 1)
+                               : (2 * TW + 1) * (2 * TW + 1);
+                asm volatile("" : "+v"(c2) : "v"(sums[2][j])); // fetch after the sums, see stage 1
+                const double2 e2 = DT->second[c2];
+                const SharedDiv div(e2.x, e2.y);
                 const double pax2 = div(sums[2][j]);
                 if (TRACKS && i >= 0 && i < n) {
                     tr.fix2[off + i] = div(sums[0][j]);
@@ -2424,6 +2475,7 @@ struct plaac_ctx {
     uint8_t *h_stage[2] = {nullptr, nullptr};
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     uint32_t *d_flag = nullptr;
+    KbDivTab *d_divtab = nullptr; // reciprocal tables of the window kernel
     size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_bwd = 0, cap_grow = 0, cap_packed = 0;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
@@ -2600,6 +2652,10 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         return bail("hipMalloc(counts)", e);
     if ((e = hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_divtab, sizeof(KbDivTab))) != hipSuccess) return bail("hipMalloc(divtab)", e);
+    hipLaunchKernelGGL(k_build_divtab, dim3(((2 * TW + 1) * (2 * TW + 1) + 256) / 256), dim3(256), 0, ctx->stream,
+                       ctx->d_divtab);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail("k_build_divtab", e);
     plaac_status st = plaac_ctx_set_params(ctx, params);
     if (st != PLAAC_OK) {
         g_create_err = ctx->err;
@@ -2642,6 +2698,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+    if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &set : ctx->ev)
@@ -2810,10 +2867,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
             if (d_tracks)
                 hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
-                                   total_residues, tab, rows, tp);
+                                   total_residues, tab, ctx->d_divtab, rows, tp);
             else
                 hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
-                                   total_residues, tab, rows, tp);
+                                   total_residues, tab, ctx->d_divtab, rows, tp);
         } else if (fast20) {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
             if (d_tracks)
@@ -2851,7 +2908,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     PL_HIP(ctx, hipEventRecord(evs[E_PACK], sv));
     hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, sv, ctx->d_neff, ctx->d_order, nprot,
                        ngroups, ctx->d_grow);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, sv, ctx->d_grow, ngroups);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, sv, ctx->d_grow, ngroups);
     PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_grow + ngroups, sizeof(uint32_t), hipMemcpyDeviceToHost, sv));
     PL_HIP(ctx, hipStreamSynchronize(sv));
     const size_t total_rows = ctx->h_pin[0];
