@@ -1871,6 +1871,32 @@ __device__ __forceinline__ void tracks20_protein(KbShared &S, const KbConst &K, 
 // its previous segment, and a protein is finalised (wave arg-max over the lanes tagged with it, PAPAllr, row write)
 // in the iteration in which stage 2 passes its last residue - by then no lane has moved on by more than one segment.
 // ------------------------------------------------------------------------------------------------
+// Wave-wide inclusive scans and a one-lane shift in DPP form (GFX9 row_shr / row_bcast / wave_shr modifiers): six
+// data-parallel moves instead of six ds_bpermute round trips through the LDS crossbar with their address arithmetic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_move(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_scan_add(int s) {
+    s += dpp_move<0x111, 0xf>(0, s); // row_shr:1
+    s += dpp_move<0x112, 0xf>(0, s); // row_shr:2
+    s += dpp_move<0x114, 0xf>(0, s); // row_shr:4
+    s += dpp_move<0x118, 0xf>(0, s); // row_shr:8  -> inclusive within each row of 16
+    s += dpp_move<0x142, 0xa>(0, s); // row_bcast:15 into rows 1 and 3
+    s += dpp_move<0x143, 0xc>(0, s); // row_bcast:31 into rows 2 and 3
+    return s;
+}
+__device__ __forceinline__ int wave_scan_max(int s) {
+    s = imax(s, dpp_move<0x111, 0xf>(INT_MIN, s));
+    s = imax(s, dpp_move<0x112, 0xf>(INT_MIN, s));
+    s = imax(s, dpp_move<0x114, 0xf>(INT_MIN, s));
+    s = imax(s, dpp_move<0x118, 0xf>(INT_MIN, s));
+    s = imax(s, dpp_move<0x142, 0xa>(INT_MIN, s));
+    s = imax(s, dpp_move<0x143, 0xc>(INT_MIN, s));
+    return s;
+}
+__device__ __forceinline__ int wave_shr1(int fill, int v) { return dpp_move<0x138, 0xf>(fill, v); } // lane l <- lane l-1
+
 constexpr int KS_GAP = TW; // empty positions after every protein (rounded up so that segments start at multiples of 4)
 struct KsShared {
     KbShared kb;
@@ -2023,12 +2049,7 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
             int lsum = 0;
 #pragma unroll
             for (int j = 0; j < B; ++j) lsum += ch[j];
-            int sc = lsum;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(sc, d);
-                if (lane >= d) sc += o;
-            }
+            const int sc = wave_scan_add(lsum);
             int run = carry + sc - lsum;
 #pragma unroll
             for (int j = 0; j < B; ++j) {
@@ -2107,17 +2128,10 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
                 int lanemax = zpos[0];
 #pragma unroll
                 for (int j = 1; j < B; ++j) lanemax = imax(lanemax, zpos[j]);
-                int sc = lanemax;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int o = __shfl_up(sc, d);
-                    if (lane >= d) sc = imax(sc, o);
-                }
-                int before = __shfl_up(sc, 1);
-                if (lane == 0) before = INT_MIN;
-                before = imax(before, last_zero);
-                int prevflag = __shfl_up(zpos[B - 1] == INT_MIN ? 1 : 0, 1);
-                if (lane == 0) prevflag = last_flag;
+                const int sc = wave_scan_max(lanemax);
+                const int before0 = imax(wave_shr1(INT_MIN, sc), last_zero);
+                int before = before0;
+                int prevflag = wave_shr1(last_flag, zpos[B - 1] == INT_MIN ? 1 : 0);
                 int numaa = 0, maxlen = 0;
 #pragma unroll
                 for (int j = 0; j < B; ++j) {
