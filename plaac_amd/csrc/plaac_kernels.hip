@@ -1896,6 +1896,34 @@ __device__ __forceinline__ int wave_scan_max(int s) {
     return s;
 }
 __device__ __forceinline__ int wave_shr1(int fill, int v) { return dpp_move<0x138, 0xf>(fill, v); } // lane l <- lane l-1
+// wave-wide maximum of a double / minimum of an int, returned wave-uniform (lane 63 of the scan)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double old, double v) {
+    const long long o = __builtin_bit_cast(long long, old), u = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)dpp_move<CTRL, ROW_MASK>((int)(unsigned)(o & 0xffffffffll), (int)(unsigned)(u & 0xffffffffll));
+    const unsigned hi = (unsigned)dpp_move<CTRL, ROW_MASK>((int)(unsigned)((unsigned long long)o >> 32),
+                                                            (int)(unsigned)((unsigned long long)u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_max_f64(double s) { // values are never NaN here
+    const double ninf = -INFINITY;
+    s = __builtin_fmax(s, dpp_move_f64<0x111, 0xf>(ninf, s));
+    s = __builtin_fmax(s, dpp_move_f64<0x112, 0xf>(ninf, s));
+    s = __builtin_fmax(s, dpp_move_f64<0x114, 0xf>(ninf, s));
+    s = __builtin_fmax(s, dpp_move_f64<0x118, 0xf>(ninf, s));
+    s = __builtin_fmax(s, dpp_move_f64<0x142, 0xa>(ninf, s));
+    s = __builtin_fmax(s, dpp_move_f64<0x143, 0xc>(ninf, s));
+    return bcast_lane(s, 63);
+}
+__device__ __forceinline__ int wave_min_i32(int s) {
+    s = imin(s, dpp_move<0x111, 0xf>(INT_MAX, s));
+    s = imin(s, dpp_move<0x112, 0xf>(INT_MAX, s));
+    s = imin(s, dpp_move<0x114, 0xf>(INT_MAX, s));
+    s = imin(s, dpp_move<0x118, 0xf>(INT_MAX, s));
+    s = imin(s, dpp_move<0x142, 0xa>(INT_MAX, s));
+    s = imin(s, dpp_move<0x143, 0xc>(INT_MAX, s));
+    return bcast_lane(s, 63);
+}
 
 constexpr int KS_GAP = TW; // empty positions after every protein (rounded up so that segments start at multiples of 4)
 struct KsShared {
@@ -2204,17 +2232,14 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
             if (n > 0 && sg + n - 1 > passed) break;
             if (n > 0) {
                 const bool mc = cur.tag == fin, mp = prv.tag == fin;
-                double pbest = mc ? cur.best : (mp ? prv.best : -INFINITY);
-                int pcen = mc ? cur.cen : (mp ? prv.cen : -1);
+                const double mbest = mc ? cur.best : (mp ? prv.best : -INFINITY);
+                const int mine = mc ? cur.cen : (mp ? prv.cen : -1);
                 const double ms0 = mc ? cur.s0 : prv.s0, ms1 = mc ? cur.s1 : prv.s1;
-                const int mine = pcen;
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const double ob = __shfl_xor(pbest, d);
-                    const int oc = __shfl_xor(pcen, d);
-                    const bool take = (oc >= 0) && (pcen < 0 || ob > pbest || (ob == pbest && oc < pcen));
-                    pbest = take ? ob : pbest;
-                    pcen = take ? oc : pcen;
-                }
+                // wave arg-max: the largest papax2 among the lanes that hold a candidate, then the smallest centre
+                // among the lanes that hold that value (first maximum of the serial loop)
+                const double pbest = wave_max_f64(mine >= 0 ? mbest : -INFINITY);
+                const int cmin = wave_min_i32((mine >= 0 && mbest == pbest) ? mine : INT_MAX);
+                const int pcen = cmin == INT_MAX ? -1 : cmin;
                 const int we = n - 1 < TW ? n - 1 : TW;
                 double pfi = 0.0, pll2 = 0.0, papallr = __builtin_nan("");
                 if (pcen >= 0) { // wave-uniform
