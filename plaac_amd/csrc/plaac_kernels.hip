@@ -201,7 +201,9 @@ __device__ __forceinline__ double lse_lut(const double *__restrict__ lut, double
     const double x = 100.0 * (inrange ? c : 0.0);
     const double dexf = floor(x);
     const int dex = (int)dexf;
-    const double r = hi + ((x - dexf) * lut[dex + 1] + ((dexf + 1.0) - x) * lut[dex]);
+    // (dex + 1 - 100c) of the reference: x - floor(x) is exact, so 1 - (x - dexf) is the same real number rounded once
+    const double fr = x - dexf;
+    const double r = hi + (fr * lut[dex + 1] + (1.0 - fr) * lut[dex]);
     return inrange ? r : hi;
 }
 
