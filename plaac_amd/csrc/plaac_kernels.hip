@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(64) void k_tracks(const uint8_t *__restrict__ codes
 // order->length->offset->residues load chain is off the path.
 // ------------------------------------------------------------------------------------------------
 constexpr int TW = 20;        // half window
-constexpr int RING_DOUBLES = 352; // doubles per ring (all sub-rings of one track), enough for every B below
+constexpr int RING_DOUBLES = 348; // doubles per ring (all sub-rings of one track), enough for every B below
 enum { RG_WF = 0, RG_WL = 1, RG_WP = 2 };
 
 // geometry of the B-positions-per-lane variant
@@ -1541,6 +1541,7 @@ constexpr int KB_PROTEINS_PER_BLOCK = 32; // blocks retire regularly, so the K-A
 // 23 = a proline that PAPA skips (second P of PP / PxP: hydropathy and LLR of P, log-odds 0), 24 = no residue
 // (outside the protein: every table holds +0.0, which leaves the fixed-order sums unchanged)
 constexpr int KC_DUP = 23, KC_NONE = 24, KC_ROWS = 25;
+constexpr int PRE_MIRROR = 48; // >= 2 * TW + 1 + 3
 typedef double kb_d2 __attribute__((ext_vector_type(2)));
 // Window-code tables, 16-byte rows: (hyd, llr) is ONE aligned 16-byte LDS read, lod sits at the same row offset of
 // a second table. 16-byte rows put 16 different codes on 16 different bank quads (only codes c and c+16 collide).
@@ -1549,7 +1550,9 @@ struct KbShared {
     alignas(16) kb_d2 t_hl[KC_ROWS];  // (hydropathy, llr)
     alignas(16) kb_d2 t_lod[KC_ROWS]; // (PAPA log-odds, unused)
     alignas(16) double ring[3 * RING_DOUBLES]; // weight * first-level FoldIndex / llr / papa
-    int pre[512];                              // pre[q & 511] = charge sum of positions < q
+    // pre[q & 511] = charge sum of positions < q; the first PRE_MIRROR entries are repeated behind the end so that the
+    // stream form can read pre[base + constant] without wrapping every index
+    int pre[512 + PRE_MIRROR];
     int t_chg[KC_ROWS];
     // window-code ring (same class/slot geometry as the value rings); an entry is the code's BYTE OFFSET into t_hl,
     // so a lookup is one 16-bit read and two table reads without any address arithmetic
@@ -1935,7 +1938,7 @@ struct KsShared {
     uint32_t segP[KB_PROTEINS_PER_BLOCK];
     uint64_t segOff[KB_PROTEINS_PER_BLOCK];
     int acc_numaa[KB_PROTEINS_PER_BLOCK], acc_maxlen[KB_PROTEINS_PER_BLOCK];
-    double bc[64];
+    double bc[48]; // the 41 taps of the PAPAllr recompute
 };
 
 struct KsCand { // PAPA arg-max candidate of one lane for one segment
@@ -1968,7 +1971,7 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
     }
     for (int i = lane; i < 3 * RING_DOUBLES; i += 64) ring[i] = 0.0;
     for (int i = lane; i < RING_DOUBLES + 32; i += 64) S.cring[i] = (uint16_t)(KC_NONE * KB_ROW_BYTES);
-    for (int i = lane; i < 512; i += 64) pre[i] = 0;
+    for (int i = lane; i < 512 + PRE_MIRROR; i += 64) pre[i] = 0;
     // ---- segment table: protein k of this block is plan item blockIdx.x + k * gridDim.x (every block gets the same
     //      mix of long and short proteins of the descending-length plan)
     {
@@ -2084,7 +2087,9 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
 #pragma unroll
             for (int j = 0; j < B; ++j) {
                 run += ch[j];
-                pre[(s + j + 1) & 511] = run;
+                const int pi = (s + j + 1) & 511;
+                pre[pi] = run;
+                if (pi < PRE_MIRROR) pre[512 + pi] = run;
             }
             carry += bcast_lane(sc, 63);
         }
@@ -2103,6 +2108,9 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
             window_sums3<B>(SrcCodes<B>{S}, wrap(slot_l1 + lane), sums);
             double wfi[B], wll[B], wpa[B];
             int zpos[B]; // STREAM position if FoldIndex >= 0 there (or outside the scan domain), else "none"
+            // charge sum of a window = difference of two prefix counts, 41 positions apart on the stream: positions
+            // outside the protein are empty for at least 20 positions on either side, so no clamping is needed
+            const int *__restrict__ pw = pre + ((s - TW) & 511);
             uint64_t off = 0;
             if (TRACKS) off = Z.segOff[k];
 #pragma unroll
@@ -2117,7 +2125,7 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
                 asm volatile("" : "+v"(c1) : "v"(sums[0][j]));
                 const double2 e1 = DT->first[c1];
                 const SharedDiv div(e1.x, e1.y);
-                const int csum = pre[(sg + hi + 1) & 511] - pre[(sg + lo) & 511];
+                const int csum = pw[j + 2 * TW + 1] - pw[j];
                 const double hydro = div(sums[0][j]);
                 const double charge = div((double)csum);
                 const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
@@ -2255,7 +2263,7 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
                     const uint8_t *x = codes + Z.segOff[fin];
                     const int q = pcen - TW + lane;
                     wave_sync();
-                    Z.bc[lane] = (lane <= 2 * TW && q >= 0 && q < n) ? S.t_hl[ld_code(x, (uint32_t)q)].y : 0.0;
+                    if (lane <= 2 * TW) Z.bc[lane] = (q >= 0 && q < n) ? S.t_hl[ld_code(x, (uint32_t)q)].y : 0.0;
                     wave_sync();
                     double sm = 0.0;
 #pragma unroll
