@@ -353,3 +353,33 @@ def test_sweep_over_alpha_with_other_windows(native, oracle, ctx, ww):
                                       nthreads=8)
             assert_rows_equal(rows, want, "%s alpha=%s c=%d" % (ww, a, c))
     ctx.set_params(native.make_params())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key,fasta,kw", [
+    ("classic4_default", "four_classic_prions.fasta", {}),
+    ("classic4_c40_alpha0", "four_classic_prions.fasta",
+     dict(corelength=40, alpha=0.0, bgcounts=np.arange(22, dtype=np.float64) + 5.0)),
+    ("kat28_fg04", "kat28.fasta", "fg04"),
+])
+def test_hip_path_reproduces_the_committed_rows(native, ctx, key, fasta, kw):
+    """HIP path through the C ABI against tests/golden/oracle_rows.json (committed oracle output, floats as bit
+    patterns): the golden-fixture leg of the parity tests, independent of an oracle build on the GPU box."""
+    import json
+    from conftest import read_fasta_simple
+    if kw == "fg04":
+        kw = dict(fg=np.loadtxt(os.path.join(GOLDEN, "prd_freq_scer_04.txt"), usecols=0))
+    recs = read_fasta_simple(os.path.join(GOLDEN, fasta))
+    codes, offs = native.pack([s for _, s in recs])
+    ctx.set_params(native.make_params(**kw))
+    rows = ctx.score(codes, offs)
+    with open(os.path.join(GOLDEN, "oracle_rows.json")) as f:
+        want = json.load(f)[key]
+    for r, w in zip(rows, want):
+        for fld in rows.dtype.names:
+            if rows.dtype[fld].kind == "f":
+                g, x = float(r[fld]), (float("nan") if w[fld] == "nan" else float.fromhex(w[fld]))
+                assert (g != g and x != x) or g.hex() == x.hex(), "%s %s %s: %r vs %r" % (key, w["name"], fld, g, x)
+            else:
+                assert int(r[fld]) == w[fld], "%s %s %s" % (key, w["name"], fld)
+    ctx.set_params(native.make_params())

@@ -206,3 +206,42 @@ def test_output_invariants_on_synthetic_proteome(oracle):
                                (wt[k - w:k + w + 1] * fi[k - w:k + w + 1]).sum() / wt[k - w:k + w + 1].sum(),
                                rtol=1e-12)
     assert np.all(np.isnan(tr["fix2"][int(offs[i]):int(offs[i]) + w]))
+
+
+def _fixture_rows(key):
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_rows.json")) as f:
+        return json.load(f)[key]
+
+
+def _same_row(got, want, what):
+    for f in got.dtype.names:
+        if got.dtype[f].kind == "f":
+            w = float.fromhex(want[f]) if want[f] != "nan" else float("nan")
+            g = float(got[f])
+            assert (g != g and w != w) or g.hex() == w.hex(), "%s %s: %r vs %r" % (what, f, g, w)
+        else:
+            assert int(got[f]) == want[f], "%s %s" % (what, f)
+
+
+@pytest.mark.parametrize("key,fasta,kw", [
+    ("classic4_default", "four_classic_prions.fasta", {}),
+    ("classic4_c40_alpha0", "four_classic_prions.fasta",
+     dict(corelength=40, alpha=0.0, bgcounts=np.arange(22, dtype=np.float64) + 5.0)),
+    ("kat28_fg04", "kat28.fasta", "fg04"),
+])
+def test_oracle_reproduces_its_committed_rows(oracle, key, fasta, kw):
+    """Regression anchor of the oracle itself (tests/golden/oracle_rows.json, generator beside it): every field of
+    every row, floats bit for bit. Guards the checker against accidental edits; it is not reference output."""
+    from conftest import GOLDEN, read_fasta_simple
+    if kw == "fg04":
+        kw = dict(fg=np.loadtxt(os.path.join(GOLDEN, "prd_freq_scer_04.txt"), usecols=0))
+    recs = read_fasta_simple(os.path.join(GOLDEN, fasta))
+    enc = [oracle.encode(s) for _, s in recs]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    rows = oracle.score_batch(oracle.build_params(**kw), np.concatenate(enc), offs, nthreads=2)
+    want = _fixture_rows(key)
+    assert [w["name"] for w in want] == [n for n, _ in recs]
+    for r, w in zip(rows, want):
+        _same_row(r, w, key + " " + w["name"])
