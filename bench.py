@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — PLAAC scoring hot path on MI355X: residues/s with roofline and CPU baseline.
+"""bench.py — PLAAC scoring hot path on MI355X: residues/s with roofline, CPU baseline and end-to-end leg.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--nprot P] [--config 2|3|4] [--tracks]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--nprot P] [--shard] [--tracks] [--sweep]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (BASELINE.json configs[3], the one `metric` is quoted on): UniRef50-shaped synthetic proteome,
-10 M sequences sharded over 8 GPUs = 1.25 M sequences (~0.36 G residues) PER GPU, default parameters.
-Scaling is weak: every rank scores its own 1.25 M-sequence shard, then the 160-byte summary rows are
-gathered to rank 0 over RCCL (the only exchange of the path). A step = one pass of the whole hot path
-(plan + recurrence kernel + window-track kernel + row gather) over the resident shard.
+10 M sequences (~2.85 G residues), default parameters. It fits one GPU, so N = 1 scores ALL of it; at N > 1
+every rank scores its own 10 M-sequence proteome (weak scaling: per-GPU work fixed; `--shard` instead splits
+the one 10 M-sequence proteome over the ranks = BASELINE's "sharded 8 x MI355X", 1.25 M sequences per GPU at
+N = 8). The 160-byte summary rows are gathered to rank 0 over RCCL (the only exchange of the path).
+A step = one pass of the whole hot path (plan + pack + recurrence kernels + window-track kernel [+ row
+gather]) over the resident proteome (reference loop replaced: cli/src/plaac.java:755-948).
 Inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,6 +28,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec 8 TB/s (6.3 TB/s achievable)
 FP64_VALU_PEAK_GOPS = 39300.0  # 78.6 TFLOP/s vector fp64 counts FMA as 2; this path may not fuse -> 39.3 T op/s
 ALGO_OPS_PER_RESIDUE = 470     # non-fusable fp64 ops per residue (summary mode)
+SYNTH_CHUNK = 1_250_000        # the synthetic proteome is generated in HBM in pieces of this many sequences
+CFG_NPROT = {2: 5880, 3: 20600, 4: 10_000_000}
 
 
 def usable_cores():
@@ -45,40 +50,94 @@ def usable_cores():
     return n
 
 
-def time_reference_jar(codes, offsets, nseq):
+def time_reference_jar(fasta_path, nres):
     """`java -jar $PLAAC_REF_JAR -i sample.fa` (second of two runs), or the reason it was skipped"""
     import shutil
-    import subprocess
-    import tempfile
     jar, java = os.environ.get("PLAAC_REF_JAR"), shutil.which("java")
     if not jar or not java or not os.path.exists(jar):
         return "skipped: no JVM on PATH" if not java else "skipped: PLAAC_REF_JAR not set"
-    from plaac_amd import native
-    off = offsets[:nseq + 1].cpu().numpy()
-    text = native.decode(codes[:int(off[-1])].cpu().numpy())
-    with tempfile.NamedTemporaryFile("w", suffix=".fa", delete=False) as fh:
-        for i in range(nseq):
-            fh.write(">s%d\n%s\n" % (i, text[int(off[i]):int(off[i + 1])]))
-        path = fh.name
+    dt = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        subprocess.run([java, "-jar", jar, "-i", fasta_path], stdout=subprocess.DEVNULL, check=True, timeout=900)
+        dt = time.perf_counter() - t0
+    return {"value": round(nres / dt, 1), "unit": "residues/s", "cores": 1, "kind": "reference",
+            "sample": "%s, parse+score+format, second of two runs" % os.path.basename(fasta_path)}
+
+
+def write_fasta(torch, codes, offsets, nseq, path):
+    """FASTA text of the first nseq records of the resident batch, assembled in HBM (10-byte header
+    '>s%07d\\n', one sequence line per record) and written with one tofile(). Returns (bytes, residues)."""
+    dev = codes.device
+    off = offsets[:nseq + 1]
+    nres = int(off[-1].item())
+    lens = off[1:] - off[:-1]
+    letters = torch.tensor(list(b"XACDEFGHIKLMNPQRSTVWY*"), dtype=torch.uint8, device=dev)
+    out = torch.full((nres + 11 * nseq,), 10, dtype=torch.uint8, device=dev)  # '\n' everywhere first
+    rec = torch.repeat_interleave(torch.arange(nseq, device=dev, dtype=torch.int64), lens)
+    dst = torch.arange(nres, device=dev, dtype=torch.int64) + 11 * rec + 10
+    out[dst] = letters[codes[:nres].long()]
+    del rec, dst
+    hdr0 = off[:-1] + 11 * torch.arange(nseq, device=dev, dtype=torch.int64)
+    out[hdr0] = ord(">")
+    out[hdr0 + 1] = ord("s")
+    idx = torch.arange(nseq, device=dev, dtype=torch.int64)
+    for d in range(7):
+        out[hdr0 + 2 + d] = (48 + (idx // 10 ** (6 - d)) % 10).to(torch.uint8)
+    out.cpu().numpy().tofile(path)
+    return int(out.numel()), nres
+
+
+def run_e2e(torch, codes, offsets, nseq, keep_fasta=False):
+    """FASTA bytes in -> TSV bytes out through bin/plaac (the C++ host above the C ABI), wall clock around the
+    whole process (HIP start-up, parse, upload, kernels, download, formatting, write)."""
+    exe = os.path.join(ROOT, "bin", "plaac")
+    if not os.path.exists(exe):
+        return {"skipped": "bin/plaac not built"}
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    fa, tsv = os.path.join(tmp, "plaac_bench_%d.fa" % os.getpid()), os.path.join(tmp, "plaac_bench_%d.tsv" % os.getpid())
     try:
-        dt = None
+        t0 = time.perf_counter()
+        fbytes, nres = write_fasta(torch, codes, offsets, nseq, fa)
+        t_write = time.perf_counter() - t0
+        best, runs = None, []
         for _ in range(2):
             t0 = time.perf_counter()
-            subprocess.run([java, "-jar", jar, "-i", path], stdout=subprocess.DEVNULL, check=True, timeout=600)
+            with open(tsv, "wb") as fh:
+                r = subprocess.run([exe, "-i", fa], stdout=fh, stderr=subprocess.PIPE, timeout=1800)
             dt = time.perf_counter() - t0
-        return {"value": round(int(off[-1]) / dt, 1), "unit": "residues/s", "cores": 1, "kind": "reference",
-                "sample": "first %d sequences, parse+score+format, second of two runs" % nseq}
+            if r.returncode != 0:
+                return {"error": "bin/plaac exit %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
+            runs.append(round(dt, 4))
+            best = dt if best is None or dt < best else best
+        obytes = os.path.getsize(tsv)
+        with open(tsv, "rb") as fh:
+            nl = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
+        out = {"value": round(nres / best, 1), "unit": "residues/s", "proteins_per_sec": round(nseq / best, 1),
+               "wall_s": runs, "sequences": nseq, "residues": nres, "fasta_bytes": fbytes, "tsv_bytes": obytes,
+               "tsv_lines": nl, "fasta_write_s": round(t_write, 3),
+               "what": "bin/plaac -i <FASTA> > <TSV>, whole process incl. HIP start-up, best of two runs, 1 GPU"}
+        if keep_fasta:
+            out["_fasta"] = fa
+        return out
     finally:
-        os.unlink(path)
+        for p in ((tsv,) if keep_fasta else (fa, tsv)):
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4))
-    ap.add_argument("--nprot", type=int, default=0, help="sequences per GPU (default: config 4 -> 1,250,000)")
+    ap.add_argument("--nprot", type=int, default=0, help="sequences per GPU (default: the whole config: cfg4 = "
+                    "10,000,000; track mode 1,250,000 because 82 B/residue of tracks for 10 M do not fit)")
+    ap.add_argument("--shard", action="store_true", help="split ONE proteome of the config's size over the ranks "
+                    "(strong scaling; cfg4 at N = 8 is BASELINE's 1.25 M sequences per GPU) instead of one per rank")
     ap.add_argument("--tracks", action="store_true", help="per-residue track mode (82 B/residue written)")
     ap.add_argument("--sweep", action="store_true", help="BASELINE config 5: a step = the 9-point sweep "
                     "alpha in {0,0.5,1} x core length in {30,60,90} over the resident shard (value counts every "
@@ -86,6 +145,9 @@ def main():
     ap.add_argument("--naive-sweep", action="store_true", help="with --sweep: nine full passes instead of the "
                     "sweep-aware scheduler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the FASTA-in -> TSV-out leg through bin/plaac")
+    ap.add_argument("--e2e-nprot", type=int, default=2_000_000, help="sequences of the resident proteome written "
+                    "as FASTA for the end-to-end leg")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' + --one-device lets two ranks share one GPU for a plumbing check")
     ap.add_argument("--one-device", action="store_true", help="TEST ONLY: every rank uses cuda:0")
@@ -108,13 +170,29 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    nprot = args.nprot or {2: 5880, 3: 20600, 4: 1_250_000}[args.config]
-    P = native.make_params()  # defaults: c=60, ww=41, alpha=1, fg28
+    nprot = args.nprot
+    if not nprot:
+        nprot = CFG_NPROT[args.config]
+        if args.tracks and args.config == 4:
+            nprot = 1_250_000
+        if args.shard:
+            nprot = (nprot + world - 1) // world
+    two_pass = args.config == 3 and not args.sweep  # cfg3: -a 0.5, background from the scored input
+    alpha = 0.5 if args.config == 3 else 1.0
+    P = native.make_params()  # defaults: c=60, ww=41, alpha=1, fg28 (cfg3 replaces it inside every step)
     ctx = native.Context(P, device=local_rank)
 
-    # ---- synthetic shard, generated in HBM (seed differs per rank) -------------------------------
-    codes, offsets = synth.make_batch_torch(args.config, nprot, np.array(P.fg), np.array(P.bg), dev,
-                                            seed=synth.SEED0 + args.config + 1000 * rank)
+    # ---- synthetic proteome, generated in HBM piece by piece (seed differs per rank and piece) ---------------
+    pieces, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=dev)], 0
+    for ci, start in enumerate(range(0, nprot, SYNTH_CHUNK)):
+        c_, o_ = synth.make_batch_torch(args.config, min(SYNTH_CHUNK, nprot - start), np.array(P.fg), np.array(P.bg),
+                                        dev, seed=synth.SEED0 + args.config + 1000 * rank + 100000 * ci)
+        pieces.append(c_)
+        offs.append(o_[1:] + base)
+        base += int(o_[-1].item())
+    codes = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
+    offsets = torch.cat(offs)
+    del pieces, offs
     total = int(offsets[-1].item())
     rows = torch.zeros(nprot * native.ROW_BYTES, dtype=torch.uint8, device=dev)
     d_tracks = None
@@ -137,12 +215,20 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.synchronize(dev)
 
+    cnt = torch.zeros(22, dtype=torch.int64, device=dev)
+
+    def background_counts():
+        """pass 1 of the reference (plaac.java:377-384): histogram of the input, summed over the ranks"""
+        ctx.histogram_device(codes.data_ptr(), offsets.data_ptr(), nprot, cnt.data_ptr(), stream=stream.cuda_stream)
+        if world > 1:
+            with torch.cuda.stream(stream):
+                dist.all_reduce(cnt, op=dist.ReduceOp.SUM)  # exchange (i): 22 x int64
+        stream.synchronize()
+        return cnt.cpu().numpy()
+
     sweep_params = None
     if args.sweep:
-        cnt = torch.zeros(22, dtype=torch.int64, device=dev)
-        ctx.histogram_device(codes.data_ptr(), offsets.data_ptr(), nprot, cnt.data_ptr())
-        ctx.sync()
-        counts = pdist.allreduce_counts(cnt.cpu().numpy(), device=dev if world > 1 else None)  # exchange (i)
+        counts = background_counts()
         sweep_params = [native.make_params(alpha=a, corelength=c, bgcounts=counts.astype(np.float64))
                         for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)]
     npoints = len(sweep_params) if sweep_params else 1
@@ -158,6 +244,8 @@ def main():
                     for r in sweep_rows:
                         dist.gather(r, gather_list, dst=0)
                 return
+            if two_pass:  # cfg3: background pass, table setup (plaac.java:444-500) and upload are part of the step
+                ctx.set_params(native.make_params(alpha=alpha, bgcounts=background_counts().astype(np.float64)))
             for k in range(npoints):
                 if sweep_params:
                     ctx.set_params(sweep_params[k])
@@ -167,6 +255,8 @@ def main():
                     stream.wait_event(gathered[b])  # the gather that last read this buffer has finished
                 ctx.score_device(codes.data_ptr(), offsets.data_ptr(), nprot, total, rows_pp[b].data_ptr(), d_tracks,
                                  stream=stream.cuda_stream)
+                if sweep_params:
+                    sweep_rows[k].copy_(rows_pp[b], non_blocking=True)
                 if world > 1:  # final gather of per-protein summary rows, ordered after this step's kernels
                     scored[b].record(stream)
                     with torch.cuda.stream(comm):
@@ -216,7 +306,6 @@ def main():
         del a_, b_
 
     if args.calibrate:
-        cnt = torch.zeros(22, dtype=torch.int64, device=dev)
         ctx.histogram_device(codes.data_ptr(), offsets.data_ptr(), nprot, cnt.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
     if rank != 0:
@@ -226,107 +315,156 @@ def main():
         return
 
     # ---- rank 0: kernel times (HIP events on each kernel's launch stream, mean over the timed steps) ----
-    ktimes = ctx.last_timings(min(args.steps, 32))
+    ktimes = ctx.last_timings(min(args.steps * (npoints if args.naive_sweep else 1), 32))
     kern = {"k_vit": ktimes["vit"], "k_fwd": ktimes["fwd"], "k_win": ktimes["win"], "k_tracks": ktimes["tracks"]}
     if args.tracks:
         kern["k_bwd"] = ktimes["bwd"]
     dom = max(kern, key=kern.get)
     dom_ms = kern[dom]
     tb = native.TRACK_BYTES_PER_RESIDUE if args.tracks else 0
-    # algorithmic bytes of ONE launch of each kernel (DESIGN.md "Algorithmic bytes"): codes R (1 B/residue)
-    # + per protein 16 B of plan (8 offset + 4 length + 4 order) + the bytes of the 160 B row the kernel owns
-    # [+ its per-residue track outputs in track mode]
-    kbytes = {
-        "k_vit": total * (1 + (1 if args.tracks else 0)) + nprot * (16 + 44),
-        "k_fwd": total * (1 + (16 if args.tracks else 0)) + nprot * (16 + 8),  # track mode: a-pairs to scratch
-        "k_bwd": total * (1 + 16) + nprot * 16,
-        "k_win": total + nprot * (16 + 56),
-        "k_tracks": total * (1 + (64 if args.tracks else 0)) + nprot * (16 + 52),
-    }
-    path_bytes = total * (1 + tb) + nprot * 168
-    achieved = kbytes[dom] / (dom_ms * 1e-3) / 1e9
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; tools/pmc.sh
-    # collects FETCH_SIZE / WRITE_SIZE for this same workload and leaves the per-launch byte counts here
-    traffic = None
+    # ALGORITHMIC bytes of one pass: 1 B/residue code read + 8 B offset + 160 B row per protein
+    # [+ 82 B/residue of tracks] [+ 1 B/residue for the background pass of cfg3]; `achieved` divides them by the
+    # average launch duration of the longest kernel (the four scoring kernels overlap, see kernels_overlap)
+    path_bytes = total * (1 + tb + (1 if two_pass else 0)) + nprot * 168
+    achieved = path_bytes / (dom_ms * 1e-3) / 1e9
+    # HBM traffic and executed instruction counts: PMC counters cannot be read from inside this process;
+    # tools/pmc.sh collects them for this same workload and leaves the per-launch figures under profiles/
+    traffic, traffic_all, exec_ops = None, None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             tj = json.load(fh)
         if tj.get("workload") == [args.config, nprot, bool(args.tracks)]:
-            traffic = tj["bytes_per_launch"].get(dom, tj["bytes_per_launch"].get(dom + "20"))
+            per = tj["bytes_per_launch"]
+            names = [k for k in per if k.startswith(dom)]  # k_tracks -> k_tracks20s / k_tracks20 / k_tracks
+            traffic = max(per[k] for k in names) if names else None
+            traffic_all = tj.get("bytes_per_step")
+            exec_ops = tj.get("fp64_ops_per_residue_executed")
     except (OSError, ValueError, KeyError):
         pass
     path_ms = ktimes["total"]
+    algo_gops = ALGO_OPS_PER_RESIDUE * total / (path_ms * 1e-3) / 1e9
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "measured_copy_GBps": copy_gbps,
+        "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_all_kernels": traffic_all,
+        "algorithmic_bytes": path_bytes, "measured_copy_GBps": copy_gbps,
         "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
         "kernels_overlap": "k_vit, k_fwd, k_win, k_tracks run concurrently on 4 HIP streams; total = first launch -> join",
         "path_achieved_GBps": round(path_bytes / (path_ms * 1e-3) / 1e9, 3),
         "note": "fp64-VALU-bound path (SURVEY 8d M3): secondary roof below",
         "valu_fp64": {
-            "achieved_Gops": round(ALGO_OPS_PER_RESIDUE * total / (path_ms * 1e-3) / 1e9, 1),
+            "algorithmic": {"ops_per_residue": ALGO_OPS_PER_RESIDUE, "achieved_Gops": round(algo_gops, 1),
+                            "frac": round(algo_gops / FP64_VALU_PEAK_GOPS, 4)},
+            "executed_pmc": None if not exec_ops else {
+                "ops_per_residue": exec_ops, "achieved_Gops": round(algo_gops * exec_ops / ALGO_OPS_PER_RESIDUE, 1),
+                "frac": round(algo_gops * exec_ops / ALGO_OPS_PER_RESIDUE / FP64_VALU_PEAK_GOPS, 4),
+                "source": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes over all kernels of a step, profiles/pmc_traffic.json"},
             "peak_Gops": FP64_VALU_PEAK_GOPS,
-            "frac": round(ALGO_OPS_PER_RESIDUE * total / (path_ms * 1e-3) / 1e9 / FP64_VALU_PEAK_GOPS, 4),
         },
     }
 
     # ---- rank 0: CPU baseline = the oracle (a port, not the Java reference: no JVM on this box) ----
-    cpu = None
+    cpu, rc = None, 0
     if not args.no_cpu_baseline:
         from oracle import oracle_ctypes as oc
-        Po = oc.build_params()
         nthreads = usable_cores()
-        n_s = min(nprot, 250000)
+        n_s = min(nprot, 500000)
         off_h = offsets[:n_s + 1].cpu().numpy().astype(np.uint64)
         codes_h = codes[:int(off_h[-1])].cpu().numpy()
-        n_1 = min(n_s, 8000)
-        oc.score_batch(Po, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)  # scratch warm-up
+        if two_pass:  # same two-pass parameters as the GPU step (counts of the WHOLE input)
+            Po = oc.build_params(alpha=alpha, bgcounts=cnt.cpu().numpy().astype(np.float64))
+        elif sweep_params:
+            Po = None
+        else:
+            Po = oc.build_params()
+        n_1 = min(n_s, 16000)
+        P1 = Po if Po is not None else oc.build_params()
+        oc.score_batch(P1, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)  # scratch warm-up
         t1 = time.perf_counter()
-        oc.score_batch(Po, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)
+        oc.score_batch(P1, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)
         dt1 = time.perf_counter() - t1
-        oc.score_batch(Po, codes_h, off_h, nthreads=nthreads)  # thread-pool and per-thread scratch warm-up
+        oc.score_batch(P1, codes_h, off_h, nthreads=nthreads)  # thread-pool and per-thread scratch warm-up
         t1 = time.perf_counter()
-        want = oc.score_batch(Po, codes_h, off_h, nthreads=nthreads)
+        want = oc.score_batch(P1, codes_h, off_h, nthreads=nthreads)
         dtn = time.perf_counter() - t1
-        got = rows[:n_s * native.ROW_BYTES].cpu().numpy().view(native.ROW_DTYPE)
+        if sweep_params:  # every point of the sweep against the oracle run with that point's parameters
+            n_c = min(n_s, 20000)
+            ok = True
+            for k, (a, c) in enumerate((a, c) for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)):
+                Pk = oc.build_params(alpha=a, corelength=c, bgcounts=counts.astype(np.float64))
+                wk = oc.score_batch(Pk, codes_h[:int(off_h[n_c])], off_h[:n_c + 1], nthreads=nthreads)
+                gk = sweep_rows[k][:n_c * native.ROW_BYTES].cpu().numpy()
+                ok = ok and gk.tobytes() == wk.tobytes()
+            match = ok
+        else:
+            got = rows[:n_s * native.ROW_BYTES].cpu().numpy().view(native.ROW_DTYPE)
+            match = bool(got.tobytes() == want.tobytes())
         cpu = {
             "value": round(int(off_h[-1]) / dtn, 1), "unit": "residues/s", "cores": nthreads, "kind": "port",
-            "sample": "first %d sequences (%d residues) of rank 0's shard on %d OpenMP threads, second of two runs; "
+            "sample": "first %d sequences (%d residues) of rank 0's proteome on %d OpenMP threads, second of two runs; "
                       "value_1core = first %d sequences on 1 thread; oracle/plaac_oracle.c restatement (not the Java "
                       "reference: no JVM on this box; its dead work omitted)" % (n_s, int(off_h[-1]), nthreads, n_1),
             "value_1core": round(int(off_h[n_1]) / dt1, 1),
-            "gpu_rows_match_oracle": bool(got.tobytes() == want.tobytes()),
+            "gpu_rows_match_oracle": match,
         }
+        if not match:
+            rc = 3
 
-    # when the operator supplies the real reference (a JVM on PATH and
-    # PLAAC_REF_JAR=/path/plaac.jar) time it too, single-threaded as it is, on a small sample
-    if cpu is not None:
-        cpu["reference_jar"] = time_reference_jar(codes, offsets, min(nprot, 8000))
+    # ---- rank 0, N = 1: end to end through the C++ host (FASTA bytes in -> TSV bytes out), SURVEY 8(d) M1 ----
+    e2e = None
+    if world == 1 and not args.no_e2e and not args.tracks and not args.sweep:
+        want_jar = cpu is not None and os.environ.get("PLAAC_REF_JAR")
+        e2e = run_e2e(torch, codes, offsets, min(nprot, args.e2e_nprot), keep_fasta=bool(want_jar))
+        fa = e2e.pop("_fasta", None)
+        # when the operator supplies the real reference (a JVM on PATH and
+        # PLAAC_REF_JAR=/path/plaac.jar) time it too, single-threaded as it is
+        if fa:
+            try:
+                cpu["reference_jar"] = time_reference_jar(fa, e2e.get("residues", 0))
+            finally:
+                os.unlink(fa)
+    if cpu is not None and "reference_jar" not in cpu:
+        cpu["reference_jar"] = time_reference_jar("", 0) if not os.environ.get("PLAAC_REF_JAR") else "skipped: no e2e leg"
 
+    wl = {2: "cfg2 yeast-shaped proteome (5,880 sequences)", 3: "cfg3 human-shaped proteome (20,600 sequences), "
+          "-a 0.5 with the background counted from the input inside every step (two-pass)",
+          4: "cfg4 UniRef50-shaped, 10M sequences"}[args.config]
+    if args.nprot:
+        wl += "; --nprot %d sequences per GPU" % nprot
+    elif args.shard:
+        wl += "; ONE proteome sharded over %d GPU(s) (strong scaling)" % world
+    elif world > 1:
+        wl += "; one whole proteome PER GPU (weak scaling, %d x the config)" % world
+    else:
+        wl += ("; 1.25M-sequence share in track mode (82 B/residue for 10M does not fit 288 GB)"
+               if args.tracks and args.config == 4 else "; all of it on 1 GPU")
     out = {
         "metric": "residues/sec", "value": round(job_res * npoints * args.steps / dt, 1), "unit": "residues/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong" if args.shard else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "proteins_per_sec": round(job_prot * npoints * args.steps / dt, 1),
         "config": {
-            "workload": {2: "cfg2 yeast-shaped proteome", 3: "cfg3 human-shaped proteome",
-                         4: "cfg4 UniRef50-shaped, 10M sequences over 8 GPUs = 1.25M sequences per GPU"}[
-                args.config],
+            "workload": wl,
             "mode": ("tracks" if args.tracks else "summary") + (" x 9-point alpha/core sweep (cfg5)" if args.sweep
                                                                   else ""), "sequences_per_gpu": nprot,
             "residues_per_gpu": total, "sequences_total": job_prot, "residues_total": job_res,
-            "params": "c=60 ww=41 alpha=1.0 fg=prd_freq_scer_28", "sharding": "by sequence, %d rank(s)" % world,
+            "params": "c=60 ww=41 alpha=%.1f fg=prd_freq_scer_28%s" % (alpha, " bg=input counts" if two_pass else ""),
+            "sharding": "by sequence, %d rank(s)" % world,
             "exchange": ("%s gather of 160 B rows to rank 0" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
             if world > 1 else "none (1 GPU)",
+            "timed_region_s": round(dt, 3),
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "e2e": e2e,
     }
     print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

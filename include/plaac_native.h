@@ -172,7 +172,9 @@ void plaac_batch_free(plaac_batch *b);
  * kernels (it needs one number back to size the work buffers) and then returns after enqueueing the scoring
  * kernels: synchronise the stream (or call plaac_ctx_sync when stream == NULL) before reading rows.
  * d_codes must be 16-byte aligned and readable up to the next 16-byte boundary after total_residues
- * (true of any hipMalloc / torch allocation). Work buffers are grown on demand and reused. */
+ * (true of any hipMalloc / torch allocation). Work buffers are grown on demand and reused: consecutive calls on one
+ * ctx are ordered after each other on the device whatever stream each is given (a ctx is still single-caller on
+ * the host side), and plaac_ctx_set_params waits for the last scored batch before it replaces the tables. */
 plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,
                                 uint64_t total_residues, plaac_row *d_rows, const plaac_tracks *d_tracks,
                                 void *stream);

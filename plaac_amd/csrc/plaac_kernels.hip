@@ -107,6 +107,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_lengths(const uint8_t *__
         const uint32_t bin = plan_bin((uint32_t)len);
         if (bin < (uint32_t)PLAN_LDS_BINS) atomicAdd(&h[bin], 1u);
         else atomicAdd(&hist[bin], 1u);
+        // hist[LEN_BINS] = "the batch holds a protein of >= LEN_BINS-1 residues": the stream form of the window kernel
+        // (32 proteins on one int32 position axis) then leaves the batch to the one-protein-at-a-time form
+        if (bin == (uint32_t)(LEN_BINS - 1)) hist[LEN_BINS] = 1u;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < PLAN_LDS_BINS; i += PLAN_THREADS)
@@ -1950,8 +1953,9 @@ template <bool TRACKS>
 __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ codes, const uint4 *__restrict__ order,
                                                   uint32_t nprot, uint64_t total, const DevTables *__restrict__ T,
                                                   const KbDivTab *__restrict__ DT, plaac_row *__restrict__ rows,
-                                                  TrackPtrs tr) {
+                                                  TrackPtrs tr, const uint32_t *__restrict__ huge) {
     static_assert(TW_CONST == TW, "KbDivTab is built for the fast path's half window");
+    if (*huge) return; // a protein too long for the int32 stream axis: k_tracks20 scores this batch
     constexpr int B = 4;
     using G = KbGeom<B>;
     constexpr int NP = KB_PROTEINS_PER_BLOCK;
@@ -2393,8 +2397,9 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
                                                  const uint32_t *__restrict__ neff,
                                                  const uint4 *__restrict__ order, uint32_t nprot, uint64_t total,
                                                  const DevTables *__restrict__ T, plaac_row *__restrict__ rows,
-                                                 TrackPtrs tr) {
+                                                 TrackPtrs tr, const uint32_t *__restrict__ huge, uint32_t only_if_huge) {
     __shared__ KbShared S;
+    if (only_if_huge && *huge == 0u) return; // the stream form scores this batch
     const int lane = threadIdx.x;
     if (lane < KC_ROWS) {
         const int k = lane < NAA ? lane : (lane == KC_DUP ? 13 : 0); // 22 -> X, 23 -> P
@@ -2695,7 +2700,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         for (auto &ev : set)
             if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void **)&ctx->d_tab, sizeof(DevTables))) != hipSuccess) return bail("hipMalloc(tables)", e);
-    if ((e = hipMalloc((void **)&ctx->d_hist, sizeof(uint32_t) * LEN_BINS)) != hipSuccess)
+    if ((e = hipMalloc((void **)&ctx->d_hist, sizeof(uint32_t) * (LEN_BINS + 1))) != hipSuccess)
         return bail("hipMalloc(hist)", e);
     if ((e = hipMalloc((void **)&ctx->d_counts, sizeof(unsigned long long) * NAA)) != hipSuccess)
         return bail("hipMalloc(counts)", e);
@@ -2722,8 +2727,12 @@ plaac_status plaac_ctx_set_params(plaac_ctx *ctx, const plaac_params *params) {
     DevTables *h = new (std::nothrow) DevTables();
     if (!h) return fail(ctx, PLAAC_ERR_NOMEM, "out of host memory");
     fill_tables(*params, *h);
-    // previous work on the ctx stream may still read the old tables
+    // The last scored batch may still be reading the old tables: its kernels run on the caller's stream and on the
+    // non-blocking side streams, none of which a null-stream copy waits for. Its join event (recorded on the caller's
+    // stream after every side stream has been joined) covers all of them.
     hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && ctx->ncalls > 0)
+        e = hipEventSynchronize(ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][10 /* E_JOIN */]);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tab, h, sizeof(DevTables), hipMemcpyHostToDevice);
     delete h;
     if (e != hipSuccess) {
@@ -2910,24 +2919,27 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,          \
                                ctx->d_neff, ctx->d_order, nprot, tab, rows, tp);                                   \
     } while (0)
-        // the stream form keeps 32 proteins on one int32 position axis: fall back to one protein at a time when a
-        // block's stream could not be indexed that way
-        if (fast20 && !ctx->per_protein_tracks && total_residues < 0x70000000ull) {
+        // the stream form keeps 32 proteins on one int32 position axis; a batch with a protein of >= 65535 residues is
+        // left to the one-protein-at-a-time form. The planner raises a device flag for such a batch and both kernels are
+        // enqueued: the one the flag rules out returns at once (no host round trip before the window kernel starts).
+        if (fast20) {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
-            if (d_tracks)
-                hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
-                                   total_residues, tab, ctx->d_divtab, rows, tp);
-            else
-                hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
-                                   total_residues, tab, ctx->d_divtab, rows, tp);
-        } else if (fast20) {
-            const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
+            const uint32_t *huge = ctx->d_hist + LEN_BINS;
+            const uint32_t only_if_huge = ctx->per_protein_tracks ? 0u : 1u; // PLAAC_KB_PER_PROTEIN=1: always this form
+            if (!ctx->per_protein_tracks) {
+                if (d_tracks)
+                    hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                                       total_residues, tab, ctx->d_divtab, rows, tp, huge);
+                else
+                    hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                                       total_residues, tab, ctx->d_divtab, rows, tp, huge);
+            }
             if (d_tracks)
                 hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, tab, rows, tp);
+                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge);
             else
                 hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, tab, rows, tp);
+                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge);
         } else if (wmax <= 32) LAUNCH_KB(128);
         else if (wmax <= 96) LAUNCH_KB(256);
         else LAUNCH_KB(1024);
@@ -2936,8 +2948,12 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         return PLAAC_OK;
     };
 
+    // the ctx's plan / scratch buffers are shared by consecutive calls: order this call after the previous one even
+    // when the caller hands in a different stream
+    if (ctx->ncalls > 0)
+        PL_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][E_JOIN], 0));
     PL_HIP(ctx, hipEventRecord(evs[E_START], st));
-    PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * LEN_BINS, st));
+    PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * (LEN_BINS + 1), st));
     const unsigned pb = (nprot + 255u) / 256u;
     const unsigned plb = (nprot + PLAN_THREADS * PLAN_ITEMS - 1) / (PLAN_THREADS * PLAN_ITEMS);
     hipLaunchKernelGGL(k_plan_lengths, dim3(plb), dim3(PLAN_THREADS), 0, st, d_codes, d_offsets, nprot, ctx->d_neff,

@@ -1,0 +1,64 @@
+"""-m gpu: the multi-GPU path with the HIP scorer. Two ranks (one process each, both on cuda:0 because the GPU box
+has one device; the exchange runs over gloo there, RCCL needs one device per rank) shard a proteome by sequence
+(plaac_amd.dist.shard_plan), all-reduce the background histogram, score their shards through the C ABI on their own
+HIP contexts and gather the 160-byte rows to rank 0 in input order. Rank 0 compares with a single-context run over
+the whole proteome and with the oracle (reference loop: cli/src/plaac.java:755, output in file order)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from plaac_amd import dist as pdist
+    from plaac_amd import native, synth
+    r, _, w = pdist.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    P0 = native.make_params()
+    codes, offs = synth.make_batch(3, nprot=2500, seed=77, fg=np.array(P0.fg), bg=np.array(P0.bg), stop_fraction=0.1)
+    plan = pdist.shard_plan(offs, world)
+    c_s, o_s = pdist.extract_shard(codes, offs, plan[rank])
+    with native.Context(P0, device=0) as ctx:
+        with ctx.upload(c_s, o_s) as batch:  # one upload for the background pass and the scoring pass
+            counts = pdist.allreduce_counts(batch.histogram())  # exchange (i)
+            P2 = native.make_params(alpha=0.5, bgcounts=counts.astype(np.float64))
+            ctx.set_params(P2)
+            rows_s = batch.score()  # data path: HIP kernels, no collective
+        out = pdist.gather_rows(rows_s, plan[rank], len(offs) - 1)  # exchange (ii)
+        if rank == 0:
+            assert np.array_equal(counts, ctx.histogram(codes, offs))
+            whole = ctx.score(codes, offs)
+            assert out.tobytes() == whole.tobytes(), "gathered shard rows differ from a single-context run"
+            from oracle import oracle_ctypes as oc
+            want = oc.score_batch(oc.build_params(alpha=0.5, bgcounts=counts.astype(np.float64)), codes, offs, nthreads=4)
+            assert out.tobytes() == want.tobytes(), "gathered rows differ from the oracle"
+            open(os.path.join(tmp, "ok"), "w").write("ok %d rows" % (len(offs) - 1))
+        else:
+            assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_hip_contexts_histogram_allreduce_and_row_gather(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").read_text().startswith("ok")

@@ -383,3 +383,56 @@ def test_hip_path_reproduces_the_committed_rows(native, ctx, key, fasta, kw):
             else:
                 assert int(r[fld]) == w[fld], "%s %s %s" % (key, w["name"], fld)
     ctx.set_params(native.make_params())
+
+
+def test_set_params_waits_for_the_batch_in_flight_on_a_caller_stream(native, oracle):
+    """plaac_ctx_set_params between two plaac_score_device calls on an external (non-blocking) stream: the table upload
+    must wait for the kernels of the first call (they read the tables on the caller's stream and on the side streams),
+    and the second call must see the new tables. Both results are checked against the oracle."""
+    torch = pytest.importorskip("torch")
+    from plaac_amd import synth
+    P1, O1 = both_params(native, oracle)
+    codes, offs = synth.make_batch(4, nprot=60000, seed=5, fg=np.array(P1.fg), bg=np.array(P1.bg))
+    counts = oracle.histogram(codes, offs).astype(np.float64)
+    P2, O2 = both_params(native, oracle, alpha=0.0, corelength=30, bgcounts=counts)
+    dev = torch.device("cuda:0")
+    d_codes = torch.from_numpy(codes).to(dev)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    n, total = len(offs) - 1, int(offs[-1])
+    r1 = torch.zeros(n * native.ROW_BYTES, dtype=torch.uint8, device=dev)
+    r2 = torch.zeros_like(r1)
+    st = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    want1 = oracle.score_batch(O1, codes, offs, nthreads=8)
+    want2 = oracle.score_batch(O2, codes, offs, nthreads=8)
+    with native.Context(P1) as c:
+        for rep in range(3):  # several rounds: the race (if any) depends on timing
+            c.set_params(P1)
+            c.score_device(d_codes.data_ptr(), d_offs.data_ptr(), n, total, r1.data_ptr(), stream=st.cuda_stream)
+            c.set_params(P2)  # no host sync in between
+            c.score_device(d_codes.data_ptr(), d_offs.data_ptr(), n, total, r2.data_ptr(), stream=st.cuda_stream)
+            st.synchronize()
+            assert_rows_equal(r1.cpu().numpy().view(native.ROW_DTYPE), want1, what="first call, round %d" % rep)
+            assert_rows_equal(r2.cpu().numpy().view(native.ROW_DTYPE), want2, what="second call, round %d" % rep)
+
+
+def test_consecutive_calls_on_different_caller_streams_are_ordered(native, oracle):
+    """the ctx's plan / scratch buffers are shared by consecutive calls: two calls on two different streams must not race"""
+    torch = pytest.importorskip("torch")
+    from plaac_amd import synth
+    P, O = both_params(native, oracle)
+    dev = torch.device("cuda:0")
+    batches = []
+    for seed, nprot in ((31, 30000), (32, 9000)):
+        codes, offs = synth.make_batch(4, nprot=nprot, seed=seed, fg=np.array(P.fg), bg=np.array(P.bg))
+        batches.append((codes, offs, torch.from_numpy(codes).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev),
+                        torch.zeros(nprot * native.ROW_BYTES, dtype=torch.uint8, device=dev)))
+    s = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize()
+    with native.Context(P) as c:
+        for k, (codes, offs, dc, do, dr) in enumerate(batches):
+            c.score_device(dc.data_ptr(), do.data_ptr(), len(offs) - 1, int(offs[-1]), dr.data_ptr(),
+                           stream=s[k].cuda_stream)
+        torch.cuda.synchronize()
+        for codes, offs, _, _, dr in batches:
+            assert_rows_equal(dr.cpu().numpy().view(native.ROW_DTYPE), oracle.score_batch(O, codes, offs, nthreads=8))

@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-KEYS = ("k_tracks20", "k_tracks<", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
+KEYS = ("k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
         "k_plan_scatter", "k_pack", "k_group_rows", "k_scan_u32")
 
 
@@ -63,12 +63,18 @@ def main(root):
             "expected_read_bytes": expect, "fetch_raw_bytes": traffic["k_hist"]["fetch_raw_bytes"],
             "raw_over_expected": traffic["k_hist"]["fetch_raw_bytes"] / expect}
     json.dump(summary, open(os.path.join(root, "summary.json"), "w"), indent=1, sort_keys=True)
+    # fp64 operations the kernels EXECUTED (wave instructions x 64 lanes), per residue, over one step
+    f64 = sum(c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_FMA_F64", 0)
+              for k, c in mean.items() if k != "k_hist")
     if R:
         mode = cfg.get("mode") == "tracks"
         wl = {"cfg2": 2, "cfg3": 3, "cfg4": 4}.get(cfg.get("workload", "")[:4], 4)
         json.dump({"workload": [wl, P, mode], "source": "tools/pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                    "passes); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md gfx950 correction",
-                   "bytes_per_launch": {k: round(v["hbm_bytes_gfx950_corrected"]) for k, v in traffic.items()}},
+                   "bytes_per_launch": {k: round(v["hbm_bytes_gfx950_corrected"]) for k, v in traffic.items()},
+                   "bytes_per_step": round(sum(v["hbm_bytes_gfx950_corrected"] for k, v in traffic.items()
+                                               if k != "k_hist")),
+                   "fp64_ops_per_residue_executed": round(f64 * 64 / R, 1) if f64 else None},
                   open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     for k in sorted(mean):
         t = traffic.get(k, {})
