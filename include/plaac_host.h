@@ -39,6 +39,16 @@ typedef struct plaac_fasta {
 plaac_status plaac_fasta_read(const char *path, plaac_fasta **out);
 void plaac_fasta_free(plaac_fasta *f);
 
+/* The same reader as a stream of batches, for inputs of any size in bounded memory (the reference reads record by
+ * record: fastareader.hasmorefastas / nextfasta, plaac.java:4302-4375). plaac_fasta_next returns the next batch of
+ * at most max_records records and about max_bytes bytes of file text (a record is never split; every batch holds
+ * at least one record), *out = NULL at the end of the file. Batches are ordinary plaac_fasta objects (free each with
+ * plaac_fasta_free); concatenated they equal what plaac_fasta_read returns for the file. */
+typedef struct plaac_fasta_stream plaac_fasta_stream;
+plaac_status plaac_fasta_open(const char *path, plaac_fasta_stream **out);
+plaac_status plaac_fasta_next(plaac_fasta_stream *s, uint32_t max_records, uint64_t max_bytes, plaac_fasta **out);
+void plaac_fasta_close(plaac_fasta_stream *s);
+
 /* Worker threads the host helpers use for parsing / formatting: hardware threads, capped by the cgroup CPU
  * quota, overridable with PLAAC_THREADS. plaac_fasta_read parses records in parallel (they are independent once
  * the header lines are located). */

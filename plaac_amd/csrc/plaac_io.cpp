@@ -253,27 +253,27 @@ unsigned host_threads() {
 
 extern "C" {
 
-plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
-    if (!path || !out) return PLAAC_ERR_ARG;
-    *out = nullptr;
-    FileView file;
-    if (!file.open(path)) return PLAAC_ERR_IO;
+// Parses the records that start inside [rb0, re0) of the file image d[0, nbytes): re0 is a record start or the end
+// of the file, so every record of the range is whole. `trim_first`: the range's first record is the first of the
+// file or follows a record that ended in a blank line (its name is then trimmed, see below). `last_blank` (nullable)
+// receives how the last record ended, for the next range.
+static plaac_status parse_records(const char *d, size_t nbytes, size_t rb0, size_t re0, bool trim_first,
+                                  plaac_fasta **out, bool *last_blank) {
     // Record starts = lines beginning with '>' (fastareader :4325-4372: a header ends the previous record
     // whether that record was still being read or was being skipped after a blank line). Everything between two
     // starts is one record, so records can be parsed independently; only the trimming of a name depends on how
     // the PREVIOUS record ended (first record / after a blank line: found by hasmorefastas, trimmed).
-    const char *d = file.data;
-    const size_t nbytes = file.size;
     const unsigned nthreads = host_threads();
+    const size_t span = re0 - rb0;
     // a '>' starts a line iff it is the first byte or follows a line terminator (\n, \r or \r\n): found per byte
     // range in parallel, concatenated in order
     std::vector<size_t> starts;
     {
-        const unsigned nt = nbytes < (8u << 20) ? 1u : nthreads;
+        const unsigned nt = span < (8u << 20) ? 1u : nthreads;
         std::vector<std::vector<size_t>> part(nt);
         auto scan = [&](unsigned t) {
-            size_t p = nbytes / nt * t;
-            const size_t e = t + 1 == nt ? nbytes : nbytes / nt * (t + 1);
+            size_t p = rb0 + span / nt * t;
+            const size_t e = t + 1 == nt ? re0 : rb0 + span / nt * (t + 1);
             std::vector<size_t> &out = part[t];
             while (p < e) {
                 const char *q = (const char *)memchr(d + p, '>', e - p);
@@ -296,6 +296,7 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
         for (auto &v : part) starts.insert(starts.end(), v.begin(), v.end());
     }
     const size_t nrec = starts.size();
+    if (nrec > 0xffffffffull) return PLAAC_ERR_ARG; // a batch is indexed with 32 bits: read such a file as a stream
     struct Rec {
         size_t name_b = 0, name_e = 0; // header text after '>' (untrimmed)
         size_t seq_len = 0;
@@ -307,9 +308,8 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
     const uint64_t *name_off = nullptr;
     // pass 1 (parallel): header extent, sequence length, how the record ended
     auto parse_range = [&](size_t r0, size_t r1, uint8_t *codes_out, const uint64_t *offs) {
-        std::string line;
         for (size_t i = r0; i < r1; ++i) {
-            const size_t rb = starts[i], re = i + 1 < nrec ? starts[i + 1] : nbytes;
+            const size_t rb = starts[i], re = i + 1 < nrec ? starts[i + 1] : re0;
             size_t p = rb;
             auto next_line = [&](size_t &lb, size_t &le) -> bool { // BufferedReader.readLine on [p, re)
                 if (p >= re) return false;
@@ -359,7 +359,7 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
         // split by bytes, not by record count, so threads get equal work
         size_t r0 = 0;
         for (unsigned t = 0; t < nthreads; ++t) {
-            const size_t target = nbytes / nthreads * (t + 1);
+            const size_t target = rb0 + span / nthreads * (t + 1);
             size_t r1 = t + 1 == nthreads ? nrec
                                           : (size_t)(std::lower_bound(starts.begin(), starts.end(), target) - starts.begin());
             if (r1 < r0) r1 = r0;
@@ -383,7 +383,7 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
     uint64_t off = 0, noff = 0;
     for (size_t i = 0; i < nrec; ++i) {
         size_t b = recs[i].name_b, e = recs[i].name_e;
-        if (i == 0 || recs[i - 1].blank_end) { // hasmorefastas: line.trim().substring(1)
+        if (i == 0 ? trim_first : recs[i - 1].blank_end) { // hasmorefastas: line.trim().substring(1)
             while (e > b && (unsigned char)d[e - 1] <= ' ') --e;
             // leading blanks cannot precede '>' (the line starts with it); blanks after '>' stay
         }
@@ -406,9 +406,103 @@ plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
     names_out = f->names;
     name_off = f->name_off;
     run_parallel(f->codes, f->offsets); // pass 2 (parallel): encode and copy names straight into the final buffers
+    if (last_blank && nrec) *last_blank = recs[nrec - 1].blank_end;
     *out = f;
     return PLAAC_OK;
 }
+
+plaac_status plaac_fasta_read(const char *path, plaac_fasta **out) {
+    if (!path || !out) return PLAAC_ERR_ARG;
+    *out = nullptr;
+    FileView file;
+    if (!file.open(path)) return PLAAC_ERR_IO;
+    return parse_records(file.data, file.size, 0, file.size, true, out, nullptr);
+}
+
+// ---- the same reader as a stream of batches: bounded memory whatever the size of the file (the reference reads
+//      record by record, fastareader.hasmorefastas / nextfasta :4302-4375) ----
+struct plaac_fasta_stream {
+    FileView file;
+    size_t cursor = 0;     // a record start, or 0 before the first batch
+    size_t released = 0;   // bytes of the mapping already handed back to the kernel
+    bool trim_next = true; // the next record is the file's first or follows a blank-line-terminated one
+};
+
+plaac_status plaac_fasta_open(const char *path, plaac_fasta_stream **out) {
+    if (!path || !out) return PLAAC_ERR_ARG;
+    *out = nullptr;
+    plaac_fasta_stream *s = new (std::nothrow) plaac_fasta_stream();
+    if (!s) return PLAAC_ERR_NOMEM;
+    if (!s->file.open(path)) {
+        delete s;
+        return PLAAC_ERR_IO;
+    }
+    *out = s;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_fasta_next(plaac_fasta_stream *s, uint32_t max_records, uint64_t max_bytes, plaac_fasta **out) {
+    if (!s || !out) return PLAAC_ERR_ARG;
+    *out = nullptr;
+    const char *d = s->file.data;
+    const size_t nbytes = s->file.size;
+    if (max_records == 0) max_records = 1;
+    if (max_bytes == 0) max_bytes = 1;
+    auto is_start = [&](size_t p) { return d[p] == '>' && (p == 0 || d[p - 1] == '\n' || d[p - 1] == '\r'); };
+    while (s->cursor < nbytes) {
+        // the batch ends at the first record start at or after cursor + max_bytes (a record is never split) ...
+        size_t e = nbytes;
+        if (nbytes - s->cursor > max_bytes) {
+            size_t p = s->cursor + (size_t)max_bytes;
+            while (p < nbytes) {
+                const char *q = (const char *)memchr(d + p, '>', nbytes - p);
+                if (!q) break;
+                p = (size_t)(q - d);
+                if (is_start(p)) {
+                    e = p;
+                    break;
+                }
+                ++p;
+            }
+        }
+        // ... or after max_records records
+        {
+            size_t p = s->cursor, n = 0;
+            while (p < e) {
+                const char *q = (const char *)memchr(d + p, '>', e - p);
+                if (!q) break;
+                p = (size_t)(q - d);
+                if (is_start(p) && n++ == max_records) {
+                    e = p;
+                    break;
+                }
+                ++p;
+            }
+        }
+        plaac_fasta *f = nullptr;
+        bool last_blank = false;
+        const plaac_status st = parse_records(d, nbytes, s->cursor, e, s->trim_next, &f, &last_blank);
+        if (st != PLAAC_OK) return st;
+        s->cursor = e;
+        if (s->file.map) { // pages behind the cursor are not needed again: keep the resident set bounded
+            const size_t page = 4096, upto = e & ~(page - 1);
+            if (upto > s->released) {
+                ::madvise((char *)s->file.map + s->released, upto - s->released, MADV_DONTNEED);
+                s->released = upto;
+            }
+        }
+        if (f->nrec == 0) { // bytes before the first header (hasmorefastas skips them)
+            plaac_fasta_free(f);
+            continue;
+        }
+        s->trim_next = last_blank;
+        *out = f;
+        return PLAAC_OK;
+    }
+    return PLAAC_OK; // end of file: *out stays NULL
+}
+
+void plaac_fasta_close(plaac_fasta_stream *s) { delete s; }
 
 void plaac_fasta_free(plaac_fasta *f) {
     if (!f) return;

@@ -17,7 +17,7 @@ HOST_EXPORTS = (
     "plaac_fasta_read", "plaac_fasta_free", "plaac_read_aa_params", "plaac_format_fixed",
     "plaac_format_double_tostring", "plaac_format_summary_row", "plaac_summary_header", "plaac_tracks_header",
     "plaac_format_track_rows", "plaac_track_rows_bound", "plaac_format_param_block", "plaac_format_aa_params",
-    "plaac_host_threads", "plaac_format_hmm_dot",
+    "plaac_host_threads", "plaac_format_hmm_dot", "plaac_fasta_open", "plaac_fasta_next", "plaac_fasta_close",
 )
 
 _ready = False
@@ -30,6 +30,10 @@ def _lib():
         L.plaac_fasta_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(_Fasta))]
         L.plaac_fasta_free.argtypes = [C.POINTER(_Fasta)]
         L.plaac_fasta_free.restype = None
+        L.plaac_fasta_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.plaac_fasta_next.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(_Fasta))]
+        L.plaac_fasta_close.argtypes = [C.c_void_p]
+        L.plaac_fasta_close.restype = None
         L.plaac_read_aa_params.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
         L.plaac_format_fixed.argtypes = [C.c_double, C.c_int, C.c_char_p, C.c_size_t]
         L.plaac_format_double_tostring.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
@@ -53,12 +57,8 @@ def _lib():
     return L
 
 
-def read_fasta(path):
-    """-> (names list[bytes], codes u8, offsets u64) exactly as the reference's fastareader splits the file"""
-    pf = C.POINTER(_Fasta)()
-    st = _lib().plaac_fasta_read(str(path).encode(), C.byref(pf))
-    if st != native.PLAAC_OK:
-        raise native.PlaacError(st, "cannot read " + str(path))
+def _take(pf):
+    """(names, codes, offsets) out of a plaac_fasta*, which is freed"""
     f = pf.contents
     n = f.nrec
     codes = np.ctypeslib.as_array(f.codes, shape=(max(int(f.nres), 1),))[:int(f.nres)].copy()
@@ -68,6 +68,35 @@ def read_fasta(path):
     names = [blob[int(noff[i]):int(noff[i + 1]) - 1] for i in range(n)]
     _lib().plaac_fasta_free(pf)
     return names, codes, offs
+
+
+def read_fasta(path):
+    """-> (names list[bytes], codes u8, offsets u64) exactly as the reference's fastareader splits the file"""
+    pf = C.POINTER(_Fasta)()
+    st = _lib().plaac_fasta_read(str(path).encode(), C.byref(pf))
+    if st != native.PLAAC_OK:
+        raise native.PlaacError(st, "cannot read " + str(path))
+    return _take(pf)
+
+
+def stream_fasta(path, max_records=262144, max_bytes=128 << 20):
+    """the same records as read_fasta, as a generator of (names, codes, offsets) batches (plaac_fasta_open / _next)"""
+    L = _lib()
+    h = C.c_void_p()
+    st = L.plaac_fasta_open(str(path).encode(), C.byref(h))
+    if st != native.PLAAC_OK:
+        raise native.PlaacError(st, "cannot read " + str(path))
+    try:
+        while True:
+            pf = C.POINTER(_Fasta)()
+            st = L.plaac_fasta_next(h, int(max_records), int(max_bytes), C.byref(pf))
+            if st != native.PLAAC_OK:
+                raise native.PlaacError(st, "plaac_fasta_next")
+            if not pf:
+                return
+            yield _take(pf)
+    finally:
+        L.plaac_fasta_close(h)
 
 
 def read_aa_params(path):

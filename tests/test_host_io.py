@@ -239,6 +239,43 @@ def test_parallel_fasta_reader_matches_serial_semantics(io, native, tmp_path, mo
         assert got == [bytes(native.encode(s)) for _, s in want]
 
 
+@pytest.mark.parametrize("max_records,max_bytes", [(1, 1 << 30), (3, 1 << 30), (1000, 1 << 30), (1 << 20, 1), (1 << 20, 700),
+                                                   (1 << 20, 50000), (977, 33333)])
+def test_streamed_batches_concatenate_to_the_whole_file_read(io, tmp_path, max_records, max_bytes):
+    """plaac_fasta_open/_next (bounded-memory reader): any batch size gives the records, names (trimming depends on how
+    the PREVIOUS record ended, also across a batch boundary) and residues of plaac_fasta_read"""
+    rng = np.random.default_rng(5)
+    aas = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYacdXB* ->", dtype=np.uint8)  # '>' inside a line is not a header
+    out = [b"leading junk\n>first header after junk  \n"]
+    for r in range(1500):
+        out.append(b">rec%d text%s" % (r, b" \t " if r % 3 == 0 else b"") + (b"\r\n" if r % 5 == 0 else b"\n"))
+        for _ in range(int(rng.integers(0, 4))):
+            out.append(b"A" + bytes(rng.choice(aas, int(rng.integers(1, 70)))) + (b"\r" if r % 11 == 0 else b"\n"))
+        if r % 4 == 0:
+            out.append(b"\nskipped\n")
+    p = tmp_path / "s.fa"
+    p.write_bytes(b"".join(out))
+    names, codes, offs = io.read_fasta(p)
+    got_names, got_seqs, nb = [], [], 0
+    for bn, bc, bo in io.stream_fasta(p, max_records, max_bytes):
+        assert 1 <= len(bn) <= max_records
+        nb += 1
+        got_names += bn
+        got_seqs += [bytes(bc[int(bo[i]):int(bo[i + 1])]) for i in range(len(bn))]
+    assert got_names == names
+    assert got_seqs == [bytes(codes[int(offs[i]):int(offs[i + 1])]) for i in range(len(names))]
+    if max_records == 1:
+        assert nb == len(names)
+
+
+def test_streamed_reader_on_empty_and_headerless_files(io, tmp_path):
+    for name, data in (("e.fa", b""), ("j.fa", b"no header at all\nMKV\n")):
+        p = tmp_path / name
+        p.write_bytes(data)
+        assert list(io.stream_fasta(p)) == []
+        assert io.read_fasta(p)[0] == []
+
+
 def test_hmm_dot_export(io, native):
     """-h: the GraphViz text of hmm.dottify(file, true) for prionhmm1 (plaac.java:4209-4287)"""
     P = native.make_params()
