@@ -206,6 +206,12 @@ plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]);
  * the last 32). This is how bench.py times the kernels over its whole timed region without a sync per step. */
 plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]);
 
+/* Summary mode scores the FoldIndex / PAPA window tracks in two tiers: a filter that decides from error-bounded
+ * prefix sums, and the exact fixed-order kernel for every protein the bounds cannot decide (results are identical
+ * either way; PLAAC_KB_FILTER=0 at ctx creation sends everything to the exact kernel). This returns how many
+ * proteins of the most recent scored batch took the exact tier. Blocks until that batch has completed. */
+plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count);
+
 #ifdef __cplusplus
 }
 #endif

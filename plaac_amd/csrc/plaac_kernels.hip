@@ -2301,6 +2301,494 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K-B, summary mode: FILTER + EXACT REFINE  (k_tracks20f -> k_refine_centres -> k_tracks20 over a list)
+//
+// The summary row keeps no window track, only decisions made on them and four values at one position:
+//   * the sign of FoldIndex at every position (run statistics, :5010-5059),
+//   * which position has the largest doubly smoothed PAPA score among those with negative doubly smoothed
+//     FoldIndex (:4932-4948),
+//   * papax2 / fix2 / plaacllr / plaacllrx2 AT that position.
+// A fixed-order 41-term sum cannot be shared between neighbouring positions, but a DECISION does not need the
+// reference's bits, only a value with a rigorous error bound that excludes the other outcome. So the filter kernel
+// computes every window sum as a difference of two running prefix sums (one fp64 wave scan per 448 positions instead
+// of 41 adds per position), carries a bound on |approximate - reference| through both smoothing levels, and decides
+// with it. Whatever it cannot decide with certainty (a FoldIndex within the bound of zero, two PAPA candidates
+// within the bound of each other - exact ties are typical of perfect repeats) sends the WHOLE protein to the exact
+// kernel (k_tracks20 over the fallback list), so correctness never rests on the filter, only speed does. The four
+// values at the chosen centre are then computed in the reference's exact order by k_refine_centres (3 x 41 first-
+// level windows + 3 second-level sums per protein instead of 6 x 41 adds per residue).
+//
+// Error bounds (u = 2^-53; every fp64 add/mul/fma rounds once; a summation tree of depth d over terms a_t has error
+// <= d u sum|a_t| (1 + O(du))). P = running prefix over the block's stream, depth <= nch = iterations + 16 (in-lane
+// chain 6, wave scan 7, carry chain <= iterations, two final adds), magnitude <= L*A (L = stream length, A = max
+// |table value|):  E_P = nch * 2u * L * A   (2u instead of u: slack for the O(du) terms).
+//   window sum   ~S = P[i+21] - P[i-20]:   |~S - S_ref| <= 2 E_P + 256u * 41 A           =: E_S   (reference: 40 u 41 A)
+//   G = cc0 ~S_h + cc1 |C| + cc2 m  (= m * FoldIndex in real arithmetic; C, m exact integers):
+//                 |G - m fi_ref| <= |cc0| E_S + 256u * 41 CC  =: E_G,   CC = |cc0| A_h + |cc1| + |cc2|
+//                 so |G| > E_G fixes the sign of the reference's fi (m > 0), and wt*fi_ref = m fi_ref is G within 2 E_G
+//   second level  ~T = Q[k+21] - Q[k-20] over f = G (resp. ~S_p):  E_T = 2 E_Q + 41 * 2 E_G + 256u * 1681 CC, with
+//                 E_Q = nch * 2u * L * 41 CC (resp. A_p for CC);  fix2_ref < 0 <=> T_ref < 0 (positive denominator)
+//   papax2        v = ~T_p / den, den >= 41:  E_v = E_Tp / 41 + 256u * A_p
+// Candidates: positions whose fix2 is certainly negative; a unique one above (best - 2 E_v), no uncertain-fix2
+// position above that mark either, is the reference's arg-max (strict >, first maximum).
+// ------------------------------------------------------------------------------------------------
+constexpr int FB = 7;                 // positions per lane
+constexpr int FC = 64 * FB;           // positions per iteration (448)
+constexpr int FLAG1 = 21, FLAG2 = 42; // stage lags: multiples of FB, >= 20 and >= FLAG1 + 21
+constexpr int FRING = 512;            // prefix rings, indexed by stream position & 511 (live span <= 490)
+static_assert(FLAG1 % FB == 0 && FLAG2 % FB == 0 && FLAG1 >= TW && FLAG2 >= FLAG1 + TW + 1, "stage lags");
+static_assert(FC + FLAG1 + TW + 1 <= FRING && FC + TW + 1 + TW <= FRING, "ring too small");
+
+__device__ __forceinline__ double wave_scan_add_f64(double s) { // inclusive, lane order
+    s = s + dpp_move_f64<0x111, 0xf>(0.0, s);
+    s = s + dpp_move_f64<0x112, 0xf>(0.0, s);
+    s = s + dpp_move_f64<0x114, 0xf>(0.0, s);
+    s = s + dpp_move_f64<0x118, 0xf>(0.0, s);
+    s = s + dpp_move_f64<0x142, 0xa>(0.0, s);
+    s = s + dpp_move_f64<0x143, 0xc>(0.0, s);
+    return s;
+}
+__device__ __forceinline__ double wave_shr1_f64(double fill, double v) { return dpp_move_f64<0x138, 0xf>(fill, v); }
+
+struct KfShared {
+    alignas(16) kb_d2 p1[FRING]; // (P_h, P_p): exclusive prefix sums of hydropathy / PAPA log-odds at stream position x
+    alignas(16) kb_d2 p2[FRING]; // (Q_f, Q_p): exclusive prefix sums of G (= m * FoldIndex) / PAPA window sums
+    int pre[FRING];              // exclusive prefix counts of the charge
+    double t_h[KC_ROWS], t_p[KC_ROWS];
+    int t_chg[KC_ROWS];
+    int segS[KB_PROTEINS_PER_BLOCK + 1];
+    int segN[KB_PROTEINS_PER_BLOCK];
+    uint32_t segP[KB_PROTEINS_PER_BLOCK];
+    uint64_t segOff[KB_PROTEINS_PER_BLOCK];
+    int acc_numaa[KB_PROTEINS_PER_BLOCK], acc_maxlen[KB_PROTEINS_PER_BLOCK], seg_amb[KB_PROTEINS_PER_BLOCK];
+    uint2 cl[KB_PROTEINS_PER_BLOCK]; // proteins with a centre: {plan index, centre}
+    int ncl;
+};
+
+struct KfCand { // one lane's PAPA candidates of one segment: best and second best certain ones, best uncertain one
+    int tag, cen;
+    double best, runner, ambv;
+};
+
+__global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ codes, const uint4 *__restrict__ order,
+                                                  uint32_t nprot, uint64_t total, const DevTables *__restrict__ T,
+                                                  const KbDivTab *__restrict__ DT, plaac_row *__restrict__ rows,
+                                                  const uint32_t *__restrict__ huge, uint2 *__restrict__ clist,
+                                                  uint32_t *__restrict__ ccount, uint32_t *__restrict__ fblist,
+                                                  uint32_t *__restrict__ fbcount) {
+    constexpr int NP = KB_PROTEINS_PER_BLOCK;
+    __shared__ KfShared Z;
+    if (*huge) return; // a protein too long for the int32 stream axis: k_tracks20 scores the whole batch
+    const int lane = threadIdx.x;
+    double amax_h = 0.0, amax_p = 0.0;
+    if (lane < KC_ROWS) {
+        const int k = lane < NAA ? lane : (lane == KC_DUP ? 13 : 0); // 22 -> X, 23 -> P
+        const bool none = lane == KC_NONE;
+        const double vh = none ? 0.0 : T->hyd[k], vp = (none || lane == KC_DUP) ? 0.0 : T->lod[k];
+        Z.t_h[lane] = vh;
+        Z.t_p[lane] = vp;
+        Z.t_chg[lane] = none ? 0 : T->chg[k];
+        amax_h = fabs(vh);
+        amax_p = fabs(vp);
+    }
+    for (int i = lane; i < FRING; i += 64) {
+        Z.p1[i] = kb_d2{0.0, 0.0};
+        Z.p2[i] = kb_d2{0.0, 0.0};
+        Z.pre[i] = 0;
+    }
+    // ---- segment table (as k_tracks20s; segments start at multiples of FB, followed by >= 20 empty positions)
+    {
+        uint4 it = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t idx = blockIdx.x + (uint32_t)lane * gridDim.x;
+        const bool have = lane < NP && idx < nprot;
+        if (have) it = order[idx];
+        const int n = have ? (int)it.z : 0;
+        const int span = n > 0 ? ((n + KS_GAP + FB - 1) / FB) * FB : 0;
+        const int incl = wave_scan_add(span);
+        if (lane < NP) {
+            Z.segS[lane] = incl - span;
+            Z.segN[lane] = n;
+            Z.segP[lane] = it.w;
+            Z.segOff[lane] = ((uint64_t)it.y << 32) | it.x;
+            Z.acc_numaa[lane] = 0;
+            Z.acc_maxlen[lane] = 0;
+            Z.seg_amb[lane] = 0;
+            if (lane == NP - 1) Z.segS[NP] = incl;
+            if (have && n == 0) { // skipped record (:762): zero the fields this kernel owns
+                plaac_row *row = rows + it.w;
+                row->papa_combo = row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = 0.0;
+                row->fi_numaa = row->fi_maxrun = row->papa_cen = 0;
+            }
+        }
+        if (lane == 0) Z.ncl = 0;
+    }
+    wave_sync();
+    const int stream_end = Z.segS[NP]; // wave-uniform
+    if (stream_end == 0) {
+        if (lane == 0) ccount[blockIdx.x] = 0u;
+        return;
+    }
+    const uint8_t *cend = codes + total;
+    const int ww1 = T->ww1, ww2 = T->ww2;
+    const bool adjust = T->adjustprolines != 0;
+    const double cc0 = T->cc[0], cc1 = T->cc[1], cc2 = T->cc[2];
+    const int plo = (ww2 - 1) / 2;
+    const int nchunks = (stream_end - KS_GAP + FLAG2 + FC - 1) / FC;
+    // ---- error bounds of this block (see the header comment)
+    double E_G, E_T, E_v;
+    {
+        const double A_h = wave_max_f64(amax_h), A_p = wave_max_f64(amax_p);
+        const double CC = fabs(cc0) * A_h + fabs(cc1) + fabs(cc2);
+        const double u2 = 0x1p-52, slack = 0x1p-45; // 2u, 256u
+        const double nch = (double)(nchunks + 16), L = (double)stream_end;
+        const double E_Ph = nch * u2 * L * A_h, E_Pp = nch * u2 * L * A_p;
+        const double E_Sh = 2.0 * E_Ph + slack * 41.0 * A_h, E_Sp = 2.0 * E_Pp + slack * 41.0 * A_p;
+        E_G = fabs(cc0) * E_Sh + slack * 41.0 * CC;
+        const double E_Qf = nch * u2 * L * 41.0 * CC, E_Qp = nch * u2 * L * 41.0 * A_p;
+        E_T = 2.0 * E_Qf + 82.0 * E_G + slack * 1681.0 * CC;
+        const double E_Tp = 2.0 * E_Qp + 41.0 * E_Sp + slack * 1681.0 * A_p;
+        E_v = E_Tp * (1.0 / 41.0) + slack * A_p;
+    }
+    const double ninf = -INFINITY;
+
+    auto seg_of = [&](int s, int cur, int last) {
+        int k = cur;
+        for (int kk = cur + 1; kk < NP; ++kk) { // wave-uniform trip count: segments that start inside the iteration
+            const int sk = __builtin_amdgcn_readfirstlane(Z.segS[kk]);
+            if (sk > last) break;
+            k = s >= sk ? kk : k;
+        }
+        return k;
+    };
+    auto advance = [&](int cur, int first) { // largest k with segS[k] <= first
+        while (cur + 1 < NP && __builtin_amdgcn_readfirstlane(Z.segS[cur + 1]) <= first) ++cur;
+        return cur;
+    };
+
+    KfCand cur{-1, -1, ninf, ninf, ninf}, prv{-1, -1, ninf, ninf, ninf};
+    double carry_h = 0.0, carry_p = 0.0, carry_f = 0.0, carry_q = 0.0;
+    int carry_c = 0, last_zero = -1, last_flag = 0;
+    int c0 = 0, c1 = 0, c2 = 0, fin = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        // ---- stage 0: residues -> table values and charges of the lane's FB positions; running prefix sums
+        {
+            const int s = FC * c + FB * lane;
+            c0 = advance(c0, FC * c);
+            const int k = seg_of(s, c0, FC * c + FC - 1);
+            const int n = Z.segN[k], i0 = s - Z.segS[k];
+            double ah[FB], ap[FB];
+            int ch[FB];
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                ah[j] = 0.0;
+                ap[j] = 0.0;
+                ch[j] = 0;
+            }
+            if (i0 < n) {
+                const uint8_t *x = codes + Z.segOff[k];
+                uint32_t cb[FB + 2]; // residues i0-2 .. i0+6
+                const uint32_t wa = load4(x + i0 - 2, codes, cend), wb = load4(x + i0 + 2, codes, cend);
+                const uint32_t wc = load4(x + i0 + 6, codes, cend);
+                cb[0] = i0 >= 2 ? (wa & 0xffu) : 255u;
+                cb[1] = i0 >= 1 ? ((wa >> 8) & 0xffu) : 255u;
+                cb[2] = (wa >> 16) & 0xffu;
+                cb[3] = wa >> 24;
+                cb[4] = wb & 0xffu;
+                cb[5] = (wb >> 8) & 0xffu;
+                cb[6] = (wb >> 16) & 0xffu;
+                cb[7] = wb >> 24;
+                cb[8] = wc & 0xffu;
+#pragma unroll
+                for (int j = 0; j < FB; ++j) {
+                    const bool in = i0 + j < n;
+                    const uint32_t cd = cb[2 + j] < 22u ? cb[2 + j] : 22u;
+                    const bool dup = adjust && cd == 13u && (cb[1 + j] == 13u || cb[j] == 13u); // (:2653-2654)
+                    const uint32_t kc = in ? cd : (uint32_t)KC_NONE;
+                    ah[j] = Z.t_h[kc];
+                    ap[j] = dup ? 0.0 : Z.t_p[kc];
+                    ch[j] = Z.t_chg[kc];
+                }
+            }
+            // inclusive in-lane prefixes, wave scan of the lane totals, exclusive lane base
+#pragma unroll
+            for (int j = 1; j < FB; ++j) {
+                ah[j] = ah[j - 1] + ah[j];
+                ap[j] = ap[j - 1] + ap[j];
+                ch[j] = ch[j - 1] + ch[j];
+            }
+            const double sh = wave_scan_add_f64(ah[FB - 1]), sp = wave_scan_add_f64(ap[FB - 1]);
+            const int sc = wave_scan_add(ch[FB - 1]);
+            const double bh = carry_h + wave_shr1_f64(0.0, sh), bp = carry_p + wave_shr1_f64(0.0, sp);
+            const int bc = carry_c + wave_shr1(0, sc);
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const int pi = (s + j + 1) & (FRING - 1);
+                Z.p1[pi] = kb_d2{bh + ah[j], bp + ap[j]};
+                Z.pre[pi] = bc + ch[j];
+            }
+            carry_h = carry_h + bcast_lane(sh, 63);
+            carry_p = carry_p + bcast_lane(sp, 63);
+            carry_c += bcast_lane(sc, 63);
+        }
+        wave_sync();
+        // ---- stage 1: window sums FLAG1 positions behind; FoldIndex sign, run statistics; second-level prefix sums
+        {
+            const int s = FC * c + FB * lane - FLAG1;
+            c1 = advance(c1, FC * c - FLAG1);
+            const int k = seg_of(s, c1, FC * c + FC - 1 - FLAG1);
+            const int n = Z.segN[k], sg = Z.segS[k], i0 = s - sg;
+            const int we = n - 1 < TW ? n - 1 : TW; // (:2588-2589)
+            int halfw = (ww1 - 1) / 2;              // (:5010-5013)
+            halfw = halfw > n / 2 ? n / 2 : halfw;
+            const int dlo = halfw, dhi = n - halfw - 1;
+            double gf[FB], gp[FB];
+            int zpos[FB];
+            bool amb = false;
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const int i = i0 + j;
+                const bool live = i >= 0 && i < n;
+                const kb_d2 hi = Z.p1[(s + j + TW + 1) & (FRING - 1)], lo = Z.p1[(s + j - TW) & (FRING - 1)];
+                const int csum = Z.pre[(s + j + TW + 1) & (FRING - 1)] - Z.pre[(s + j - TW) & (FRING - 1)];
+                const double S_h = hi.x - lo.x, S_p = hi.y - lo.y;
+                const int m = 1 + imin(i, we) + imin(n - i - 1, we); // residues under the window = weight (live only)
+                // G = m * FoldIndex in real arithmetic (axpbypc :2050 times the window count)
+                const double G = __builtin_fma(cc0, S_h, __builtin_fma(cc1, (double)(csum < 0 ? -csum : csum), cc2 * (double)m));
+                gf[j] = live ? G : 0.0;
+                gp[j] = live ? S_p : 0.0;
+                const bool dom = live && i >= dlo && i <= dhi;
+                const bool neg = dom && G < -E_G;
+                amb |= dom && !(G < -E_G) && !(G > E_G);
+                zpos[j] = neg ? INT_MIN : s + j;
+            }
+            if (amb) Z.seg_amb[k] = 1; // a FoldIndex the bound cannot sign: the exact kernel scores this protein
+            // second-level prefix sums
+#pragma unroll
+            for (int j = 1; j < FB; ++j) {
+                gf[j] = gf[j - 1] + gf[j];
+                gp[j] = gp[j - 1] + gp[j];
+            }
+            const double sf = wave_scan_add_f64(gf[FB - 1]), sq = wave_scan_add_f64(gp[FB - 1]);
+            const double bf = carry_f + wave_shr1_f64(0.0, sf), bq = carry_q + wave_shr1_f64(0.0, sq);
+#pragma unroll
+            for (int j = 0; j < FB; ++j) Z.p2[(s + j + 1) & (FRING - 1)] = kb_d2{bf + gf[j], bq + gp[j]};
+            carry_f = carry_f + bcast_lane(sf, 63);
+            carry_q = carry_q + bcast_lane(sq, 63);
+            // FoldIndex<0 runs (:5020-5058), as in k_tracks20s
+            {
+                int lanemax = zpos[0];
+#pragma unroll
+                for (int j = 1; j < FB; ++j) lanemax = imax(lanemax, zpos[j]);
+                const int sc = wave_scan_max(lanemax);
+                int before = imax(wave_shr1(INT_MIN, sc), last_zero);
+                int prevflag = wave_shr1(last_flag, zpos[FB - 1] == INT_MIN ? 1 : 0);
+                int numaa = 0, maxlen = 0;
+#pragma unroll
+                for (int j = 0; j < FB; ++j) {
+                    const bool flagged = zpos[j] == INT_MIN;
+                    int rs = before + 1 - sg, re = i0 + j - 1; // the run that ends here, in protein coordinates
+                    rs = rs == dlo ? 0 : rs;
+                    re = re == dhi ? n - 1 : re;
+                    const int len = re - rs + 1;
+                    const int cnt = (!flagged && prevflag != 0 && len >= 5) ? len : 0;
+                    numaa += cnt;
+                    maxlen = imax(maxlen, cnt);
+                    before = imax(before, zpos[j]);
+                    prevflag = flagged ? 1 : 0;
+                }
+                if (numaa) {
+                    atomicAdd(&Z.acc_numaa[k], numaa);
+                    atomicMax(&Z.acc_maxlen[k], maxlen);
+                }
+                last_zero = imax(last_zero, bcast_lane(sc, 63));
+                last_flag = bcast_lane(prevflag, 63);
+            }
+        }
+        wave_sync();
+        // ---- stage 2: second smoothing FLAG2 positions behind; PAPA candidates with their certainty
+        {
+            const int s = FC * c + FB * lane - FLAG2;
+            c2 = advance(c2, FC * c - FLAG2);
+            const int k = seg_of(s, c2, FC * c + FC - 1 - FLAG2);
+            const int n = Z.segN[k], i0 = s - Z.segS[k];
+            const int phi = n - plo; // PAPA centres in [plo, phi) (:4942); such a protein has n >= 41, so w = 20
+            if (k != cur.tag) {
+                prv = cur;
+                cur = KfCand{k, -1, ninf, ninf, ninf};
+            }
+            if (i0 + FB > plo && i0 < phi) { // some position of this lane can be a centre
+#pragma unroll
+                for (int j = 0; j < FB; ++j) {
+                    const int i = i0 + j;
+                    const bool cand = i >= plo && i < phi && i >= TW && i <= n - TW - 1; // in range and defined (:2597-2600)
+                    const kb_d2 hi = Z.p2[(s + j + TW + 1) & (FRING - 1)], lo = Z.p2[(s + j - TW) & (FRING - 1)];
+                    const double Tf = hi.x - lo.x, Tp = hi.y - lo.y;
+                    const int ml = imax(0, 2 * TW - i), mr = imax(0, 2 * TW - (n - 1 - i));
+                    const double rden = DT->second[cand ? ml * (2 * TW + 1) + mr : 0].y;
+                    const double v = Tp * rden;
+                    const bool def = cand && Tf < -E_T;                  // fix2 certainly negative
+                    const bool unc = cand && !(Tf < -E_T) && !(Tf > E_T); // fix2 within the bound of zero
+                    const bool upd = def && v > cur.best;
+                    cur.runner = def ? (upd ? cur.best : __builtin_fmax(cur.runner, v)) : cur.runner;
+                    cur.best = upd ? v : cur.best;
+                    cur.cen = upd ? i : cur.cen;
+                    cur.ambv = unc ? __builtin_fmax(cur.ambv, v) : cur.ambv;
+                }
+            }
+        }
+        // ---- proteins whose last residue stage 2 has passed in this iteration
+        const int passed = FC * c + FC - 1 - FLAG2;
+        while (fin < NP) { // wave-uniform
+            const int n = __builtin_amdgcn_readfirstlane(Z.segN[fin]);
+            const int sg = __builtin_amdgcn_readfirstlane(Z.segS[fin]);
+            if (n > 0 && sg + n - 1 > passed) break;
+            if (n > 0) {
+                const bool mc = cur.tag == fin, mp = prv.tag == fin;
+                const int mine = mc ? cur.cen : (mp ? prv.cen : -1);
+                const double mbest = mine >= 0 ? (mc ? cur.best : prv.best) : ninf;
+                const double mrun = mc ? cur.runner : (mp ? prv.runner : ninf);
+                const double mamb = mc ? cur.ambv : (mp ? prv.ambv : ninf);
+                const double g1 = wave_max_f64(mbest);
+                const double mark = g1 - 2.0 * E_v; // -inf when there is no certain candidate
+                const unsigned long long close = __ballot(mine >= 0 && mbest >= mark);
+                const bool others = __ballot((mrun > ninf && mrun >= mark) || (mamb > ninf && mamb >= mark)) != 0ull;
+                wave_sync(); // seg_amb / accumulators of this segment are complete (all its stage-1 lanes have run)
+                const bool fallback = Z.seg_amb[fin] != 0 || __popcll(close) > 1 || others;
+                const int pcen = (close != 0ull) ? __builtin_amdgcn_readlane(mine, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(close))) : -1;
+                if (lane == 0) {
+                    const uint32_t pidx = blockIdx.x + (uint32_t)fin * gridDim.x; // plan index of this protein
+                    if (fallback) {
+                        fblist[atomicAdd(fbcount, 1u)] = pidx;
+                    } else {
+                        plaac_row *row = rows + Z.segP[fin];
+                        row->fi_numaa = Z.acc_numaa[fin];
+                        row->fi_maxrun = Z.acc_maxlen[fin];
+                        row->papa_cen = pcen;
+                        if (pcen >= 0) {
+                            Z.cl[Z.ncl++] = make_uint2(pidx, (uint32_t)pcen); // values at the centre: k_refine_centres
+                        } else {
+                            row->papa_combo = -INFINITY;
+                            row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
+                        }
+                    }
+                }
+            }
+            ++fin;
+        }
+    }
+    wave_sync();
+    const int ncl = Z.ncl;
+    if (lane < ncl) clist[(size_t)blockIdx.x * NP + lane] = Z.cl[lane];
+    if (lane == 0) ccount[blockIdx.x] = (uint32_t)ncl;
+}
+
+// The four values at the PAPA centre in the reference's own operation order (disorderreport :4877-4905 at one
+// position): first-level windows of hydropathy / charge / llr / PAPA log-odds at the 41 positions c-20 .. c+20
+// (one thread each, 41 fixed-order taps; taps outside the protein add +0.0), FoldIndex, the weights, then the
+// three weighted second-level sums over those 41 values. A block serves the centres of one k_tracks20f block,
+// six proteins at a time (6 x 41 = 246 of 256 threads).
+constexpr int RF_SLOTS = 6, RF_SPAN = 4 * TW + 1; // 81 residues under the two window levels
+__global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restrict__ codes, const uint4 *__restrict__ order,
+                                                        uint64_t total, const DevTables *__restrict__ T,
+                                                        plaac_row *__restrict__ rows, const uint32_t *__restrict__ huge,
+                                                        const uint2 *__restrict__ clist,
+                                                        const uint32_t *__restrict__ ccount) {
+    __shared__ alignas(16) kb_d2 t_hl[KC_ROWS];
+    __shared__ double t_lod[KC_ROWS];
+    __shared__ int t_chg[KC_ROWS];
+    __shared__ uint8_t s_wc[RF_SLOTS][RF_SPAN + 3];
+    __shared__ double s_w[RF_SLOTS][3][2 * TW + 2];
+    __shared__ double s_llr1[RF_SLOTS];
+    if (*huge) return;
+    const uint32_t cnt = ccount[blockIdx.x];
+    if (cnt == 0u) return;
+    const int tid = threadIdx.x;
+    if (tid < KC_ROWS) {
+        const int k = tid < NAA ? tid : (tid == KC_DUP ? 13 : 0);
+        const bool none = tid == KC_NONE;
+        t_hl[tid] = kb_d2{none ? 0.0 : T->hyd[k], none ? 0.0 : T->llr[k]};
+        t_lod[tid] = (none || tid == KC_DUP) ? 0.0 : T->lod[k];
+        t_chg[tid] = none ? 0 : T->chg[k];
+    }
+    const bool adjust = T->adjustprolines != 0;
+    const double cc0 = T->cc[0], cc1 = T->cc[1], cc2 = T->cc[2];
+    const int slot = tid / (2 * TW + 1), l = tid - slot * (2 * TW + 1);
+    const uint8_t *cend = codes + total;
+    for (uint32_t r0 = 0; r0 < cnt; r0 += RF_SLOTS) {
+        const bool act = slot < RF_SLOTS && r0 + (uint32_t)slot < cnt;
+        int n = 0, cen = 0;
+        const uint8_t *x = codes;
+        uint32_t p = 0;
+        if (act) {
+            const uint2 e = clist[(size_t)blockIdx.x * KB_PROTEINS_PER_BLOCK + r0 + slot];
+            const uint4 it = order[e.x];
+            n = (int)it.z;
+            p = it.w;
+            cen = (int)e.y;
+            x = codes + (((uint64_t)it.y << 32) | it.x);
+        }
+        __syncthreads(); // tables ready / previous round done with the staging arrays
+        if (act) { // window codes of positions cen-40 .. cen+40 (two per thread)
+            for (int t = l; t < RF_SPAN; t += 2 * TW + 1) {
+                const int q = cen - 2 * TW + t;
+                uint32_t kc = (uint32_t)KC_NONE;
+                if (q >= 0 && q < n) {
+                    const uint8_t *xq = x + q;
+                    const uint32_t c0 = (xq >= codes && xq < cend) ? *xq : 0u;
+                    const uint32_t cd = c0 < 22u ? c0 : 22u;
+                    const bool dup = adjust && cd == 13u && ((q >= 1 && xq[-1] == 13) || (q >= 2 && xq[-2] == 13));
+                    kc = dup ? (uint32_t)KC_DUP : cd;
+                }
+                s_wc[slot][t] = (uint8_t)kc;
+            }
+        }
+        __syncthreads();
+        if (act) { // first level at i = cen - 20 + l
+            const int i = cen - TW + l;
+            double sh = 0.0, sl = 0.0, sp = 0.0;
+            int sc = 0;
+#pragma unroll 4
+            for (int t = 0; t <= 2 * TW; ++t) { // increasing position
+                const uint32_t kc = s_wc[slot][l + t];
+                const kb_d2 hl = t_hl[kc];
+                sh = sh + hl.x;
+                sl = sl + hl.y;
+                sp = sp + t_lod[kc];
+                sc += t_chg[kc];
+            }
+            const int lo = imax(i - TW, 0), hi = imin(i + TW, n - 1);
+            const double cntd = (double)(hi - lo + 1);
+            const double hydro = sh / cntd, charge = (double)sc / cntd;
+            const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
+            const double llr1 = sl / cntd, papa = sp / cntd;
+            const double wt = (double)(1 + imin(i, TW) + imin(n - i - 1, TW));
+            s_w[slot][0][l] = wt * fi;
+            s_w[slot][1][l] = wt * llr1;
+            s_w[slot][2][l] = wt * papa;
+            if (l == TW) s_llr1[slot] = llr1;
+        }
+        __syncthreads();
+        if (act && l < 3) { // second level at the centre: thread l sums track l (fix2, plaacllrx2, papax2)
+            double s = 0.0;
+#pragma unroll 4
+            for (int t = 0; t <= 2 * TW; ++t) s = s + s_w[slot][l][t];
+            const int den = (2 * TW + 1) + window_weight_side(cen, TW) + window_weight_side(n - 1 - cen, TW);
+            const double q = s / (double)den;
+            plaac_row *row = rows + p;
+            if (l == 0) {
+                row->papa_fi = q;
+            } else if (l == 1) {
+                row->papa_llr2 = q;
+                row->papa_llr = s_llr1[slot];
+            } else {
+                row->papa_combo = q;
+                row->papa_prop = q;
+            }
+        }
+    }
+}
+
 // positions-per-lane variant that wastes the fewest slots for a protein of n residues: iterations x
 // (per-iteration cost ~ B + fixed part). A protein shorter than one iteration needs no pipeline lag.
 __device__ __forceinline__ int kb_choose_b(int n) {
@@ -2397,9 +2885,15 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
                                                  const uint32_t *__restrict__ neff,
                                                  const uint4 *__restrict__ order, uint32_t nprot, uint64_t total,
                                                  const DevTables *__restrict__ T, plaac_row *__restrict__ rows,
-                                                 TrackPtrs tr, const uint32_t *__restrict__ huge, uint32_t only_if_huge) {
+                                                 TrackPtrs tr, const uint32_t *__restrict__ huge, uint32_t only_if_huge,
+                                                 const uint32_t *__restrict__ list,
+                                                 const uint32_t *__restrict__ list_count) {
     __shared__ KbShared S;
-    if (only_if_huge && *huge == 0u) return; // the stream form scores this batch
+    // list == null: the whole plan (when the stream form cannot take the batch, or always with PLAAC_KB_PER_PROTEIN=1);
+    // else: the plan items the filter kernel could not decide (k_tracks20f's fallback list)
+    if (!list && only_if_huge && *huge == 0u) return;
+    if (list && *huge != 0u) return;
+    const uint32_t nitems = list ? *list_count : nprot;
     const int lane = threadIdx.x;
     if (lane < KC_ROWS) {
         const int k = lane < NAA ? lane : (lane == KC_DUP ? 13 : 0); // 22 -> X, 23 -> P
@@ -2423,13 +2917,14 @@ __global__ __launch_bounds__(64) void k_tracks20(const uint8_t *__restrict__ cod
     // metadata of the first protein of this block; the next one is prefetched while the current is scored
     uint32_t b = blockIdx.x;
     uint4 it_nxt = make_uint4(0u, 0u, 0u, 0u);
-    if (b < nprot) it_nxt = order[b];
+    auto item = [&](uint32_t k) { return order[list ? list[k] : k]; };
+    if (b < nitems) it_nxt = item(b);
 
-    for (; b < nprot; b += gridDim.x) {
+    for (; b < nitems; b += gridDim.x) {
         const uint32_t p = it_nxt.w;
         const int n = (int)it_nxt.z;
         const uint64_t off = ((uint64_t)it_nxt.y << 32) | it_nxt.x;
-        if (b + gridDim.x < nprot) it_nxt = order[b + gridDim.x]; // prefetch the next protein's plan item
+        if (b + gridDim.x < nitems) it_nxt = item(b + gridDim.x); // prefetch the next protein's plan item
         plaac_row *row = rows + p;
         if (n == 0) {
             if (lane == 0) {
@@ -2530,6 +3025,11 @@ struct plaac_ctx {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     uint32_t *d_flag = nullptr;
     KbDivTab *d_divtab = nullptr; // reciprocal tables of the window kernel
+    // summary-mode window kernel in filter form: centres per filter block, fallback list, [0] = its length
+    uint2 *d_clist = nullptr;
+    uint32_t *d_ccount = nullptr, *d_fblist = nullptr, *d_fbcount = nullptr;
+    size_t cap_clist = 0, cap_ccount = 0, cap_fblist = 0;
+    bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
     size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_bwd = 0, cap_grow = 0, cap_packed = 0;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
@@ -2695,6 +3195,8 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         ctx->generic_tracks = gen && gen[0] == '1';
         const char *ppt = std::getenv("PLAAC_KB_PER_PROTEIN");
         ctx->per_protein_tracks = ppt && ppt[0] == '1';
+        const char *kbf = std::getenv("PLAAC_KB_FILTER");
+        ctx->kb_filter = !(kbf && kbf[0] == '0');
     }
     for (auto &set : ctx->ev)
         for (auto &ev : set)
@@ -2707,6 +3209,8 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     if ((e = hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_divtab, sizeof(KbDivTab))) != hipSuccess) return bail("hipMalloc(divtab)", e);
+    if ((e = hipMalloc((void **)&ctx->d_fbcount, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(fbcount)", e);
+    if ((e = hipMemset(ctx->d_fbcount, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(fbcount)", e);
     hipLaunchKernelGGL(k_build_divtab, dim3(((2 * TW + 1) * (2 * TW + 1) + 256) / 256), dim3(256), 0, ctx->stream,
                        ctx->d_divtab);
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail("k_build_divtab", e);
@@ -2757,6 +3261,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
+    for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount})
+        if (b) (void)hipFree(b);
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &set : ctx->ev)
@@ -2845,6 +3351,12 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if ((rc = grow(ctx, ctx->d_order, ctx->cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
     const uint32_t ngroups = (nprot + 63u) / 64u;
     if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 1)) != PLAAC_OK) return rc;
+    if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
+        const size_t kb_blocks = ((size_t)nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
+        if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, kb_blocks * KB_PROTEINS_PER_BLOCK)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_ccount, ctx->cap_ccount, kb_blocks)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_fblist, ctx->cap_fblist, (size_t)nprot)) != PLAAC_OK) return rc;
+    }
     // device tables: slot 0 keeps the ctx parameters (single-point calls), sweep groups use slots 1..ng
     const DevTables *gtab0 = ctx->d_tab;
     if (!(npoints == 1 && std::memcmp(&points[0], &ctx->params, sizeof(plaac_params)) == 0)) {
@@ -2927,19 +3439,32 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             const uint32_t *huge = ctx->d_hist + LEN_BINS;
             const uint32_t only_if_huge = ctx->per_protein_tracks ? 0u : 1u; // PLAAC_KB_PER_PROTEIN=1: always this form
             if (!ctx->per_protein_tracks) {
-                if (d_tracks)
+                if (d_tracks) {
                     hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
                                        total_residues, tab, ctx->d_divtab, rows, tp, huge);
-                else
+                } else if (ctx->kb_filter) {
+                    // summary mode: decisions from error-bounded prefix sums, exact values at the chosen centre only,
+                    // whatever the bounds cannot decide goes to the exact per-protein kernel through the fallback list
+                    PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), st));
+                    hipLaunchKernelGGL(k_tracks20f, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                                       total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_ccount,
+                                       ctx->d_fblist, ctx->d_fbcount);
+                    hipLaunchKernelGGL(k_refine_centres, dim3(kb_grid), dim3(256), 0, st, d_codes, ctx->d_order,
+                                       total_residues, tab, rows, huge, ctx->d_clist, ctx->d_ccount);
+                    hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, st, d_codes,
+                                       d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
+                                       0u, ctx->d_fblist, ctx->d_fbcount);
+                } else {
                     hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
                                        total_residues, tab, ctx->d_divtab, rows, tp, huge);
+                }
             }
             if (d_tracks)
                 hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge);
+                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
             else
                 hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge);
+                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
         } else if (wmax <= 32) LAUNCH_KB(128);
         else if (wmax <= 96) LAUNCH_KB(256);
         else LAUNCH_KB(1024);
@@ -3137,6 +3662,16 @@ plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
 }
 
 plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]) { return plaac_timings_mean(ctx, 1, ms); }
+
+plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count) {
+    if (!ctx || !count) return PLAAC_ERR_ARG;
+    *count = 0;
+    if (ctx->ncalls == 0) return PLAAC_OK;
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PL_HIP(ctx, hipEventSynchronize(ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
+    PL_HIP(ctx, hipMemcpy(count, ctx->d_fbcount, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PLAAC_OK;
+}
 
 plaac_status plaac_histogram_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
                                     uint32_t nprot, int64_t *d_counts, void *stream_) {

@@ -69,7 +69,7 @@ EXPORTS = (
     "plaac_encode", "plaac_ctx_create", "plaac_ctx_set_params", "plaac_ctx_destroy", "plaac_last_error",
     "plaac_histogram", "plaac_score", "plaac_score_device", "plaac_histogram_device", "plaac_ctx_sync",
     "plaac_last_timings", "plaac_timings_mean", "plaac_batch_upload", "plaac_batch_histogram", "plaac_batch_score",
-    "plaac_batch_free", "plaac_batch_sweep", "plaac_score_sweep_device",
+    "plaac_batch_free", "plaac_batch_sweep", "plaac_score_sweep_device", "plaac_last_exact_fallbacks",
 )
 
 _lib = None
@@ -119,6 +119,7 @@ def load():
     L.plaac_ctx_sync.argtypes = [C.c_void_p]
     L.plaac_last_timings.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_timings_mean.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.plaac_last_exact_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.plaac_batch_histogram.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -264,6 +265,12 @@ class Context:
 
     def sync(self):
         self._check(self._L.plaac_ctx_sync(self._h))
+
+    def last_exact_fallbacks(self):
+        """proteins of the last scored batch that the window-track filter handed to the exact kernel"""
+        n = C.c_uint32(0)
+        self._check(self._L.plaac_last_exact_fallbacks(self._h, C.addressof(n)))
+        return int(n.value)
 
     def last_timings(self, ncalls=1):
         """device ms (HIP events on each kernel's launch stream), mean over the last `ncalls` scored batches.

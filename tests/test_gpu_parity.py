@@ -85,6 +85,8 @@ def check_batch(native, oracle, ctx, codes, offsets, tracks=True, what="", **kw)
     if tracks:
         assert_rows_equal(got[0], want[0], what)
         assert_tracks_equal(got[1], want[1], codes, offsets, what)
+        # summary mode takes another window kernel (filter tier + exact tier): same rows
+        assert_rows_equal(ctx.score(codes, offsets), want[0], what + " (summary mode)")
         return got[0]
     assert_rows_equal(got, want, what)
     return got
@@ -436,3 +438,60 @@ def test_consecutive_calls_on_different_caller_streams_are_ordered(native, oracl
         torch.cuda.synchronize()
         for codes, offs, _, _, dr in batches:
             assert_rows_equal(dr.cpu().numpy().view(native.ROW_DTYPE), oracle.score_batch(O, codes, offs, nthreads=8))
+
+
+# ---- summary-mode window kernel in filter form (k_tracks20f + k_refine_centres + exact fallback) ----
+def _adversarial_batch(native):
+    """sequences built to defeat the filter's certainty: exact ties (perfect repeats, homopolymers), FoldIndex sitting on
+    zero, PAPA plateaus, proline runs (the PP / PxP rule), X / stop codes, every short length"""
+    rng = np.random.default_rng(2024)
+    seqs = ["Q" * 200, "N" * 41, "QN" * 100, "A" * 500, "P" * 300, "PAP" * 90, "KE" * 150, "G" * 40, "S" * 42,
+            "QQQQQQQQQQNNNNNNNNNN" * 12, ("MKVLAAGIVG" * 9 + "QNQNQNYYGS" * 9) * 3, "DEDEDEKRKR" * 30,
+            "X" * 100, "QX" * 60, "Q" * 100 + "*", "W" * 45 + "Q" * 45 + "W" * 45]
+    aas = "ACDEFGHIKLMNPQRSTVWY"
+    for n in list(range(1, 131)) + [163, 164, 165, 447, 448, 449, 895, 896, 897, 1500]:
+        seqs.append("".join(rng.choice(list(aas), n)))
+    unit = "".join(rng.choice(list(aas), 97))
+    seqs += [unit * 8, (unit + "Q") * 5, unit[:50] * 11]  # perfect repeats longer than both window levels
+    for n in (60, 200, 600):  # low-complexity, FoldIndex near its threshold
+        seqs.append("".join(rng.choice(list("GSQNYAP"), n)))
+        seqs.append("".join(rng.choice(list("LIVFKE"), n)))
+    rng.shuffle(seqs)
+    return native.pack(seqs)
+
+
+def test_filter_window_kernel_on_adversarial_sequences(native, oracle, ctx):
+    codes, offs = _adversarial_batch(native)
+    for kw in ({}, {"ww1": 40, "ww2": 40}, {"alpha": 0.3, "corelength": 25, "bgcounts": np.arange(22.0) + 5},
+               {"adjustprolines": False}):
+        check_batch(native, oracle, ctx, codes, offs, tracks=False, what="adversarial %s" % kw, **kw)
+    ctx.set_params(native.make_params())
+    ctx.score(codes, offs)
+    assert ctx.last_exact_fallbacks() > 0  # homopolymers / repeats tie exactly: the exact kernel must have taken them
+
+
+def test_filter_window_kernel_decides_random_proteins_itself(native, oracle):
+    """on HMM-sampled proteomes the filter tier must decide (nearly) everything: the exact tier is a safety net, not
+    the usual path"""
+    from plaac_amd import synth
+    P, O = both_params(native, oracle)
+    codes, offs = synth.make_batch(4, nprot=40000, seed=91, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.05)
+    with native.Context(P) as c:
+        got = c.score(codes, offs)
+        nfb = c.last_exact_fallbacks()
+    assert_rows_equal(got, oracle.score_batch(O, codes, offs, nthreads=8), what="filter tier")
+    assert nfb <= 40, "%d of 40000 random proteins fell back to the exact kernel" % nfb
+
+
+def test_filter_and_exact_window_kernels_agree(native, monkeypatch):
+    from plaac_amd import synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(3, nprot=3000, seed=8, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+    a_codes, a_offs = _adversarial_batch(native)
+    with native.Context(P) as c:
+        r1, r2 = c.score(codes, offs), c.score(a_codes, a_offs)
+    monkeypatch.setenv("PLAAC_KB_FILTER", "0")
+    with native.Context(P) as c:
+        e1, e2 = c.score(codes, offs), c.score(a_codes, a_offs)
+        assert c.last_exact_fallbacks() == 0
+    assert r1.tobytes() == e1.tobytes() and r2.tobytes() == e2.tobytes()
