@@ -9,7 +9,7 @@ LIB       = plaac_amd/libplaac_native.so
 
 all: $(LIB) oracle $(if $(wildcard $(CSRC)/plaac_cli.cpp),cli)
 
-LIBSRC    = $(CSRC)/plaac_kernels.hip $(CSRC)/plaac_host.cpp $(wildcard $(CSRC)/plaac_io.cpp)
+LIBSRC    = $(CSRC)/plaac_kernels.hip $(CSRC)/plaac_host.cpp $(CSRC)/plaac_node.cpp $(wildcard $(CSRC)/plaac_io.cpp)
 $(LIB): $(LIBSRC) $(wildcard include/*.h)
 	$(HIPCC) $(HIPFLAGS) -Iinclude -shared -o $@ $(LIBSRC) -Wl,-rpath,/opt/rocm/lib
 

@@ -206,6 +206,27 @@ plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]);
  * the last 32). This is how bench.py times the kernels over its whole timed region without a sync per step. */
 plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]);
 
+/* ---- all GPUs of one node ---------------------------------------------------------
+ * The reference's serial per-protein loop (plaac.java:755, :610) sharded BY SEQUENCE: one plaac_ctx per listed
+ * device (a device may be listed more than once: two contexts on one GPU overlap the copies of one batch with the
+ * kernels of another), one host thread per context, contiguous record ranges of about equal residue counts, rows
+ * written in input order. No data-path collective; the 22 x int64 histogram is summed on the host. Results are
+ * identical to a single context's whatever the device list. device_ids == NULL or ndev <= 0: every visible device once.
+ * Same calling rules as a ctx: single-caller, no process globals, status codes + plaac_node_last_error. */
+typedef struct plaac_node plaac_node;
+int plaac_device_count(void); /* visible HIP devices (0 when there is none or the runtime fails) */
+plaac_status plaac_node_create(const plaac_params *params, const int *device_ids, int ndev, plaac_node **out);
+void plaac_node_destroy(plaac_node *node);
+int plaac_node_size(const plaac_node *node);      /* number of contexts */
+plaac_ctx *plaac_node_ctx(plaac_node *node, int k); /* borrowed: context k, for pipelines that feed the devices themselves */
+plaac_status plaac_node_set_params(plaac_node *node, const plaac_params *params);
+plaac_status plaac_node_histogram(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                                  int64_t counts[PLAAC_NAA]);
+plaac_status plaac_node_score(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                              plaac_row *rows, const plaac_tracks *tracks);
+/* message of the last failing call on this node (node == NULL: last failing plaac_node_create on this thread) */
+const char *plaac_node_last_error(const plaac_node *node);
+
 /* Summary mode scores the FoldIndex / PAPA window tracks in two tiers: a filter that decides from error-bounded
  * prefix sums, and the exact fixed-order kernel for every protein the bounds cannot decide (results are identical
  * either way; PLAAC_KB_FILTER=0 at ctx creation sends everything to the exact kernel). This returns how many

@@ -2335,16 +2335,26 @@ __global__ __launch_bounds__(64) void k_tracks20s(const uint8_t *__restrict__ co
 // ------------------------------------------------------------------------------------------------
 constexpr int FB = 7;                 // positions per lane
 constexpr int FC = 64 * FB;           // positions per iteration (448)
-constexpr int FLAG1 = 21, FLAG2 = 42; // stage lags: multiples of FB, >= 20 and >= FLAG1 + 21
-constexpr int FRING = 512;            // prefix rings, indexed by stream position & 511 (live span <= 490)
-static_assert(FLAG1 % FB == 0 && FLAG2 % FB == 0 && FLAG1 >= TW && FLAG2 >= FLAG1 + TW + 1, "stage lags");
-static_assert(FC + FLAG1 + TW + 1 <= FRING && FC + TW + 1 + TW <= FRING, "ring too small");
+constexpr int FLAG1 = TW + 1;         // stage 1 runs 21 positions behind stage 0: P[i+21] of a lane's positions are the
+                                      // prefix values the lane itself produced in stage 0 (registers, no LDS read)
+constexpr int FLAG2 = 2 * (TW + 1);   // stage 2 likewise 21 behind stage 1
+constexpr int FRING = 511;            // ring slots = stream position mod 511 = 73 * FB: a lane's FB-aligned group of
+                                      // slots never wraps, so every LDS access is base register + immediate
+static_assert(FLAG1 % FB == 0 && FRING % FB == 0 && FC + 2 * FLAG1 <= FRING, "ring geometry");
 
+// row_shr with bound_ctrl: lanes without a source lane read 0, no `old` operand to initialise
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr0_f64(double v) {
+    const long long u = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)((unsigned long long)u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_scan_add_f64(double s) { // inclusive, lane order
-    s = s + dpp_move_f64<0x111, 0xf>(0.0, s);
-    s = s + dpp_move_f64<0x112, 0xf>(0.0, s);
-    s = s + dpp_move_f64<0x114, 0xf>(0.0, s);
-    s = s + dpp_move_f64<0x118, 0xf>(0.0, s);
+    s = s + dpp_shr0_f64<0x111>(s);
+    s = s + dpp_shr0_f64<0x112>(s);
+    s = s + dpp_shr0_f64<0x114>(s);
+    s = s + dpp_shr0_f64<0x118>(s);
     s = s + dpp_move_f64<0x142, 0xa>(0.0, s);
     s = s + dpp_move_f64<0x143, 0xc>(0.0, s);
     return s;
@@ -2352,11 +2362,12 @@ __device__ __forceinline__ double wave_scan_add_f64(double s) { // inclusive, la
 __device__ __forceinline__ double wave_shr1_f64(double fill, double v) { return dpp_move_f64<0x138, 0xf>(fill, v); }
 
 struct KfShared {
-    alignas(16) kb_d2 p1[FRING]; // (P_h, P_p): exclusive prefix sums of hydropathy / PAPA log-odds at stream position x
-    alignas(16) kb_d2 p2[FRING]; // (Q_f, Q_p): exclusive prefix sums of G (= m * FoldIndex) / PAPA window sums
-    int pre[FRING];              // exclusive prefix counts of the charge
-    double t_h[KC_ROWS], t_p[KC_ROWS];
+    alignas(16) kb_d2 p1[FRING + 1]; // slot x-1: (P_h, P_p)[x], exclusive prefix sums of hydropathy / PAPA log-odds
+    alignas(16) kb_d2 p2[FRING + 1]; // slot x-1: (Q_f, Q_p)[x], exclusive prefix sums of G (= m * FoldIndex) / PAPA sums
+    int pre[FRING + 1];              // slot x-1: exclusive prefix count of the charge at x
+    alignas(16) kb_d2 t_hp[KC_ROWS]; // (hydropathy, PAPA log-odds) by window code
     int t_chg[KC_ROWS];
+    uint8_t lring[128];              // per lane slot (64 * iteration + lane) & 127: segment of the lane's positions
     int segS[KB_PROTEINS_PER_BLOCK + 1];
     int segN[KB_PROTEINS_PER_BLOCK];
     uint32_t segP[KB_PROTEINS_PER_BLOCK];
@@ -2370,6 +2381,11 @@ struct KfCand { // one lane's PAPA candidates of one segment: best and second be
     int tag, cen;
     double best, runner, ambv;
 };
+
+__device__ __forceinline__ int ring_back(int slot, int by) { // (slot - by) mod FRING for 0 <= slot < FRING
+    const int t = slot - by;
+    return t < 0 ? t + FRING : t;
+}
 
 __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ codes, const uint4 *__restrict__ order,
                                                   uint32_t nprot, uint64_t total, const DevTables *__restrict__ T,
@@ -2386,13 +2402,12 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
         const int k = lane < NAA ? lane : (lane == KC_DUP ? 13 : 0); // 22 -> X, 23 -> P
         const bool none = lane == KC_NONE;
         const double vh = none ? 0.0 : T->hyd[k], vp = (none || lane == KC_DUP) ? 0.0 : T->lod[k];
-        Z.t_h[lane] = vh;
-        Z.t_p[lane] = vp;
+        Z.t_hp[lane] = kb_d2{vh, vp};
         Z.t_chg[lane] = none ? 0 : T->chg[k];
         amax_h = fabs(vh);
         amax_p = fabs(vp);
     }
-    for (int i = lane; i < FRING; i += 64) {
+    for (int i = lane; i < FRING + 1; i += 64) {
         Z.p1[i] = kb_d2{0.0, 0.0};
         Z.p2[i] = kb_d2{0.0, 0.0};
         Z.pre[i] = 0;
@@ -2429,6 +2444,9 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
         if (lane == 0) ccount[blockIdx.x] = 0u;
         return;
     }
+    // positions before the stream start belong to "segment 0 at negative offsets": nothing there is live
+    Z.lring[lane] = (uint8_t)0;
+    Z.lring[64 + lane] = (uint8_t)0;
     const uint8_t *cend = codes + total;
     const int ww1 = T->ww1, ww2 = T->ww2;
     const bool adjust = T->adjustprolines != 0;
@@ -2451,189 +2469,230 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
         E_v = E_Tp * (1.0 / 41.0) + slack * A_p;
     }
     const double ninf = -INFINITY;
+    wave_sync();
 
-    auto seg_of = [&](int s, int cur, int last) {
-        int k = cur;
-        for (int kk = cur + 1; kk < NP; ++kk) { // wave-uniform trip count: segments that start inside the iteration
+    // segment of stream position s (stage 0 only; the later stages take it from the lane ring)
+    int c0 = 0;
+    struct Fetch { // what stage 0 of one iteration needs from memory: issued one iteration ahead
+        int sS, nk, i0;
+        uint32_t wa, wb, wc;
+    };
+    auto fetch = [&](int c) {
+        Fetch F;
+        const int s = FC * c + FB * lane;
+        while (c0 + 1 < NP && __builtin_amdgcn_readfirstlane(Z.segS[c0 + 1]) <= FC * c) ++c0; // wave-uniform
+        int k = c0;
+        for (int kk = c0 + 1; kk < NP; ++kk) { // wave-uniform trip count: segments that start inside the iteration
             const int sk = __builtin_amdgcn_readfirstlane(Z.segS[kk]);
-            if (sk > last) break;
+            if (sk > FC * c + FC - 1) break;
             k = s >= sk ? kk : k;
         }
-        return k;
-    };
-    auto advance = [&](int cur, int first) { // largest k with segS[k] <= first
-        while (cur + 1 < NP && __builtin_amdgcn_readfirstlane(Z.segS[cur + 1]) <= first) ++cur;
-        return cur;
+        const int n = Z.segN[k];
+        F.sS = Z.segS[k];
+        F.nk = n | (k << 16);
+        F.i0 = s - F.sS;
+        F.wa = F.wb = F.wc = 0u;
+        if (F.i0 < n) {
+            const uint8_t *x = codes + Z.segOff[k] + F.i0;
+            F.wa = load4(x - 2, codes, cend); // residues i0-2 .. i0+1
+            F.wb = load4(x + 2, codes, cend); //          i0+2 .. i0+5
+            F.wc = load4(x + 6, codes, cend); //          i0+6
+        }
+        return F;
     };
 
     KfCand cur{-1, -1, ninf, ninf, ninf}, prv{-1, -1, ninf, ninf, ninf};
     double carry_h = 0.0, carry_p = 0.0, carry_f = 0.0, carry_q = 0.0;
-    int carry_c = 0, last_zero = -1, last_flag = 0;
-    int c0 = 0, c1 = 0, c2 = 0, fin = 0;
+    int carry_c = 0, last_zero = -1, last_flag = 0, fin = 0;
+    int w0 = FB * lane; // ring slot of stream position s = FC * c + FB * lane
+    Fetch nxt = fetch(0);
     for (int c = 0; c < nchunks; ++c) {
-        // ---- stage 0: residues -> table values and charges of the lane's FB positions; running prefix sums
+        const int s = FC * c + FB * lane;
+        const Fetch F = nxt;
+        // ---- stage 0: residues -> table values and charges of the lane's FB positions; running prefix sums.
+        //      hP[j] = (P_h, P_p)[s + j], cP[j] = charge prefix at s + j  (j = 0 .. FB; [0] = the lane's exclusive base)
+        double hPh[FB + 1], hPp[FB + 1];
+        int cP[FB + 1];
         {
-            const int s = FC * c + FB * lane;
-            c0 = advance(c0, FC * c);
-            const int k = seg_of(s, c0, FC * c + FC - 1);
-            const int n = Z.segN[k], i0 = s - Z.segS[k];
+            const int n = F.nk & 0xffff;
             double ah[FB], ap[FB];
             int ch[FB];
+            uint32_t cb[FB + 2]; // residues i0-2 .. i0+6
+            cb[0] = F.i0 >= 2 ? (F.wa & 0xffu) : 255u;
+            cb[1] = F.i0 >= 1 ? ((F.wa >> 8) & 0xffu) : 255u;
+            cb[2] = (F.wa >> 16) & 0xffu;
+            cb[3] = F.wa >> 24;
+            cb[4] = F.wb & 0xffu;
+            cb[5] = (F.wb >> 8) & 0xffu;
+            cb[6] = (F.wb >> 16) & 0xffu;
+            cb[7] = F.wb >> 24;
+            cb[8] = F.wc & 0xffu;
 #pragma unroll
             for (int j = 0; j < FB; ++j) {
-                ah[j] = 0.0;
-                ap[j] = 0.0;
-                ch[j] = 0;
+                const uint32_t cd = cb[2 + j] < 22u ? cb[2 + j] : 22u;
+                const bool dup = adjust && cd == 13u && (cb[1 + j] == 13u || cb[j] == 13u); // (:2653-2654)
+                const uint32_t kc = F.i0 + j < n ? (dup ? (uint32_t)KC_DUP : cd) : (uint32_t)KC_NONE;
+                const kb_d2 hp = Z.t_hp[kc];
+                ah[j] = hp.x;
+                ap[j] = hp.y;
+                ch[j] = Z.t_chg[kc];
             }
-            if (i0 < n) {
-                const uint8_t *x = codes + Z.segOff[k];
-                uint32_t cb[FB + 2]; // residues i0-2 .. i0+6
-                const uint32_t wa = load4(x + i0 - 2, codes, cend), wb = load4(x + i0 + 2, codes, cend);
-                const uint32_t wc = load4(x + i0 + 6, codes, cend);
-                cb[0] = i0 >= 2 ? (wa & 0xffu) : 255u;
-                cb[1] = i0 >= 1 ? ((wa >> 8) & 0xffu) : 255u;
-                cb[2] = (wa >> 16) & 0xffu;
-                cb[3] = wa >> 24;
-                cb[4] = wb & 0xffu;
-                cb[5] = (wb >> 8) & 0xffu;
-                cb[6] = (wb >> 16) & 0xffu;
-                cb[7] = wb >> 24;
-                cb[8] = wc & 0xffu;
 #pragma unroll
-                for (int j = 0; j < FB; ++j) {
-                    const bool in = i0 + j < n;
-                    const uint32_t cd = cb[2 + j] < 22u ? cb[2 + j] : 22u;
-                    const bool dup = adjust && cd == 13u && (cb[1 + j] == 13u || cb[j] == 13u); // (:2653-2654)
-                    const uint32_t kc = in ? cd : (uint32_t)KC_NONE;
-                    ah[j] = Z.t_h[kc];
-                    ap[j] = dup ? 0.0 : Z.t_p[kc];
-                    ch[j] = Z.t_chg[kc];
-                }
-            }
-            // inclusive in-lane prefixes, wave scan of the lane totals, exclusive lane base
-#pragma unroll
-            for (int j = 1; j < FB; ++j) {
+            for (int j = 1; j < FB; ++j) { // inclusive in-lane prefixes
                 ah[j] = ah[j - 1] + ah[j];
                 ap[j] = ap[j - 1] + ap[j];
                 ch[j] = ch[j - 1] + ch[j];
             }
             const double sh = wave_scan_add_f64(ah[FB - 1]), sp = wave_scan_add_f64(ap[FB - 1]);
             const int sc = wave_scan_add(ch[FB - 1]);
-            const double bh = carry_h + wave_shr1_f64(0.0, sh), bp = carry_p + wave_shr1_f64(0.0, sp);
-            const int bc = carry_c + wave_shr1(0, sc);
+            hPh[0] = carry_h + wave_shr1_f64(0.0, sh);
+            hPp[0] = carry_p + wave_shr1_f64(0.0, sp);
+            cP[0] = carry_c + wave_shr1(0, sc);
 #pragma unroll
             for (int j = 0; j < FB; ++j) {
-                const int pi = (s + j + 1) & (FRING - 1);
-                Z.p1[pi] = kb_d2{bh + ah[j], bp + ap[j]};
-                Z.pre[pi] = bc + ch[j];
+                hPh[j + 1] = hPh[0] + ah[j];
+                hPp[j + 1] = hPp[0] + ap[j];
+                cP[j + 1] = cP[0] + ch[j];
+                Z.p1[w0 + j] = kb_d2{hPh[j + 1], hPp[j + 1]}; // prefix at x = s + j + 1 -> slot x - 1
+                Z.pre[w0 + j] = cP[j + 1];
             }
+            Z.lring[(64 * c + lane) & 127] = (uint8_t)(F.nk >> 16);
             carry_h = carry_h + bcast_lane(sh, 63);
             carry_p = carry_p + bcast_lane(sp, 63);
             carry_c += bcast_lane(sc, 63);
         }
+        if (c + 1 < nchunks) nxt = fetch(c + 1); // in flight during the rest of this iteration
         wave_sync();
-        // ---- stage 1: window sums FLAG1 positions behind; FoldIndex sign, run statistics; second-level prefix sums
+        // ---- stage 2 operands that come from memory: the reciprocal of the second-level denominator of every position
+        const int k2 = Z.lring[(64 * c + lane - 6) & 127];
+        const int n2 = Z.segN[k2], i2 = s - FLAG2 - Z.segS[k2];
+        int clo = imax(plo, TW), cspan = imin(n2 - plo - 1, n2 - TW - 1) - clo; // centres: in range and defined
+        if (cspan < 0) {
+            clo = 0x40000000;
+            cspan = 0;
+        }
+        const bool any_cand = i2 + FB > clo && i2 <= clo + cspan;
+        double rden[FB];
+#pragma unroll
+        for (int j = 0; j < FB; ++j) rden[j] = 0.0;
+        if (any_cand) {
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const int i = i2 + j;
+                const int ml = imin(imax(0, 2 * TW - i), 2 * TW), mr = imin(imax(0, 2 * TW - (n2 - 1 - i)), 2 * TW);
+                rden[j] = DT->second[ml * (2 * TW + 1) + mr].y;
+            }
+        }
+        // ---- stage 1: window sums 21 positions behind; FoldIndex sign, run statistics; second-level prefix sums
+        double hQf[FB + 1], hQq[FB + 1];
         {
-            const int s = FC * c + FB * lane - FLAG1;
-            c1 = advance(c1, FC * c - FLAG1);
-            const int k = seg_of(s, c1, FC * c + FC - 1 - FLAG1);
-            const int n = Z.segN[k], sg = Z.segS[k], i0 = s - sg;
+            const int k = Z.lring[(64 * c + lane - 3) & 127];
+            const int n = Z.segN[k], sg = Z.segS[k], i0 = s - FLAG1 - sg;
             const int we = n - 1 < TW ? n - 1 : TW; // (:2588-2589)
             int halfw = (ww1 - 1) / 2;              // (:5010-5013)
             halfw = halfw > n / 2 ? n / 2 : halfw;
             const int dlo = halfw, dhi = n - halfw - 1;
+            int dl = dlo, dsp = dhi - dlo; // FoldIndex scan domain as one unsigned comparison
+            if (dsp < 0) {
+                dl = 0x40000000;
+                dsp = 0;
+            }
+            const int b1 = ring_back(w0, 2 * FLAG1); // slot of P[i - 20] for j = 0: position s - 42
             double gf[FB], gp[FB];
-            int zpos[FB];
+            uint32_t fm = 0u; // bit j: FoldIndex certainly negative at the lane's j-th position (inside the scan domain)
             bool amb = false;
 #pragma unroll
             for (int j = 0; j < FB; ++j) {
                 const int i = i0 + j;
-                const bool live = i >= 0 && i < n;
-                const kb_d2 hi = Z.p1[(s + j + TW + 1) & (FRING - 1)], lo = Z.p1[(s + j - TW) & (FRING - 1)];
-                const int csum = Z.pre[(s + j + TW + 1) & (FRING - 1)] - Z.pre[(s + j - TW) & (FRING - 1)];
-                const double S_h = hi.x - lo.x, S_p = hi.y - lo.y;
-                const int m = 1 + imin(i, we) + imin(n - i - 1, we); // residues under the window = weight (live only)
-                // G = m * FoldIndex in real arithmetic (axpbypc :2050 times the window count)
-                const double G = __builtin_fma(cc0, S_h, __builtin_fma(cc1, (double)(csum < 0 ? -csum : csum), cc2 * (double)m));
-                gf[j] = live ? G : 0.0;
-                gp[j] = live ? S_p : 0.0;
-                const bool dom = live && i >= dlo && i <= dhi;
-                const bool neg = dom && G < -E_G;
-                amb |= dom && !(G < -E_G) && !(G > E_G);
-                zpos[j] = neg ? INT_MIN : s + j;
+                const kb_d2 lo = Z.p1[b1 + j];
+                const int csum = cP[j] - Z.pre[b1 + j];
+                const double S_h = hPh[j] - lo.x, S_p = hPp[j] - lo.y;
+                const int m = 1 + imin(i, we) + imin(n - i - 1, we); // residues under the window = weight (live positions)
+                // G = m * FoldIndex in real arithmetic (axpbypc :2050 times the window count). Positions outside the
+                // protein give bounded garbage that no used second-level window contains.
+                const double G = __builtin_fma(cc0, S_h, __builtin_fma(cc1, fabs((double)csum), cc2 * (double)m));
+                gf[j] = G;
+                gp[j] = S_p;
+                const bool dom = (unsigned)(i - dl) <= (unsigned)dsp;
+                fm |= (dom && G < -E_G) ? (1u << j) : 0u;
+                amb |= dom && fabs(G) <= E_G;
             }
             if (amb) Z.seg_amb[k] = 1; // a FoldIndex the bound cannot sign: the exact kernel scores this protein
-            // second-level prefix sums
 #pragma unroll
-            for (int j = 1; j < FB; ++j) {
+            for (int j = 1; j < FB; ++j) { // second-level prefix sums
                 gf[j] = gf[j - 1] + gf[j];
                 gp[j] = gp[j - 1] + gp[j];
             }
             const double sf = wave_scan_add_f64(gf[FB - 1]), sq = wave_scan_add_f64(gp[FB - 1]);
-            const double bf = carry_f + wave_shr1_f64(0.0, sf), bq = carry_q + wave_shr1_f64(0.0, sq);
+            hQf[0] = carry_f + wave_shr1_f64(0.0, sf);
+            hQq[0] = carry_q + wave_shr1_f64(0.0, sq);
+            const int w1 = ring_back(w0, FLAG1);
 #pragma unroll
-            for (int j = 0; j < FB; ++j) Z.p2[(s + j + 1) & (FRING - 1)] = kb_d2{bf + gf[j], bq + gp[j]};
+            for (int j = 0; j < FB; ++j) {
+                hQf[j + 1] = hQf[0] + gf[j];
+                hQq[j + 1] = hQq[0] + gp[j];
+                Z.p2[w1 + j] = kb_d2{hQf[j + 1], hQq[j + 1]};
+            }
             carry_f = carry_f + bcast_lane(sf, 63);
             carry_q = carry_q + bcast_lane(sq, 63);
-            // FoldIndex<0 runs (:5020-5058), as in k_tracks20s
+            // FoldIndex<0 runs (:5020-5058): a run is accounted where it ENDS, i.e. at an unflagged position whose
+            // predecessor is flagged; its start is one past the last unflagged position before it (in-lane from the
+            // bit mask, else wave max-scan, else the carry). Only lanes that see a run end do the length arithmetic.
             {
-                int lanemax = zpos[0];
-#pragma unroll
-                for (int j = 1; j < FB; ++j) lanemax = imax(lanemax, zpos[j]);
+                const int s1 = s - FLAG1;
+                const uint32_t zm = ~fm & ((1u << FB) - 1u);
+                const int lanemax = zm ? s1 + (31 - __builtin_clz(zm)) : INT_MIN;
                 const int sc = wave_scan_max(lanemax);
-                int before = imax(wave_shr1(INT_MIN, sc), last_zero);
-                int prevflag = wave_shr1(last_flag, zpos[FB - 1] == INT_MIN ? 1 : 0);
-                int numaa = 0, maxlen = 0;
-#pragma unroll
-                for (int j = 0; j < FB; ++j) {
-                    const bool flagged = zpos[j] == INT_MIN;
-                    int rs = before + 1 - sg, re = i0 + j - 1; // the run that ends here, in protein coordinates
-                    rs = rs == dlo ? 0 : rs;
-                    re = re == dhi ? n - 1 : re;
-                    const int len = re - rs + 1;
-                    const int cnt = (!flagged && prevflag != 0 && len >= 5) ? len : 0;
-                    numaa += cnt;
-                    maxlen = imax(maxlen, cnt);
-                    before = imax(before, zpos[j]);
-                    prevflag = flagged ? 1 : 0;
-                }
-                if (numaa) {
-                    atomicAdd(&Z.acc_numaa[k], numaa);
-                    atomicMax(&Z.acc_maxlen[k], maxlen);
+                const int before0 = imax(wave_shr1(INT_MIN, sc), last_zero);
+                const uint32_t prev = (uint32_t)wave_shr1(last_flag, (int)(fm >> (FB - 1)));
+                uint32_t ends = zm & ((fm << 1) | prev);
+                if (ends) {
+                    int numaa = 0, maxlen = 0;
+                    do {
+                        const int j = __builtin_ctz(ends);
+                        ends &= ends - 1u;
+                        const uint32_t zb = j >= 1 ? (zm & ((1u << (j - 1)) - 1u)) : 0u; // unflagged ones below the run
+                        const int before = zb ? s1 + (31 - __builtin_clz(zb)) : before0;
+                        int rs = before + 1 - sg, re = i0 + j - 1; // the run that ends here, in protein coordinates
+                        rs = rs == dlo ? 0 : rs;
+                        re = re == dhi ? n - 1 : re;
+                        const int len = re - rs + 1;
+                        const int cnt = len >= 5 ? len : 0;
+                        numaa += cnt;
+                        maxlen = imax(maxlen, cnt);
+                    } while (ends);
+                    if (numaa) {
+                        atomicAdd(&Z.acc_numaa[k], numaa);
+                        atomicMax(&Z.acc_maxlen[k], maxlen);
+                    }
                 }
                 last_zero = imax(last_zero, bcast_lane(sc, 63));
-                last_flag = bcast_lane(prevflag, 63);
+                last_flag = bcast_lane((int)(fm >> (FB - 1)), 63);
             }
         }
         wave_sync();
-        // ---- stage 2: second smoothing FLAG2 positions behind; PAPA candidates with their certainty
+        // ---- stage 2: second smoothing another 21 positions behind; PAPA candidates with their certainty
         {
-            const int s = FC * c + FB * lane - FLAG2;
-            c2 = advance(c2, FC * c - FLAG2);
-            const int k = seg_of(s, c2, FC * c + FC - 1 - FLAG2);
-            const int n = Z.segN[k], i0 = s - Z.segS[k];
-            const int phi = n - plo; // PAPA centres in [plo, phi) (:4942); such a protein has n >= 41, so w = 20
-            if (k != cur.tag) {
+            if (k2 != cur.tag) {
                 prv = cur;
-                cur = KfCand{k, -1, ninf, ninf, ninf};
+                cur = KfCand{k2, -1, ninf, ninf, ninf};
             }
-            if (i0 + FB > plo && i0 < phi) { // some position of this lane can be a centre
+            if (any_cand) { // some position of this lane can be a centre
+                const int b2 = ring_back(w0, 3 * FLAG1); // slot of Q[k - 20] for j = 0: position s - 63
 #pragma unroll
                 for (int j = 0; j < FB; ++j) {
-                    const int i = i0 + j;
-                    const bool cand = i >= plo && i < phi && i >= TW && i <= n - TW - 1; // in range and defined (:2597-2600)
-                    const kb_d2 hi = Z.p2[(s + j + TW + 1) & (FRING - 1)], lo = Z.p2[(s + j - TW) & (FRING - 1)];
-                    const double Tf = hi.x - lo.x, Tp = hi.y - lo.y;
-                    const int ml = imax(0, 2 * TW - i), mr = imax(0, 2 * TW - (n - 1 - i));
-                    const double rden = DT->second[cand ? ml * (2 * TW + 1) + mr : 0].y;
-                    const double v = Tp * rden;
-                    const bool def = cand && Tf < -E_T;                  // fix2 certainly negative
-                    const bool unc = cand && !(Tf < -E_T) && !(Tf > E_T); // fix2 within the bound of zero
-                    const bool upd = def && v > cur.best;
-                    cur.runner = def ? (upd ? cur.best : __builtin_fmax(cur.runner, v)) : cur.runner;
-                    cur.best = upd ? v : cur.best;
-                    cur.cen = upd ? i : cur.cen;
-                    cur.ambv = unc ? __builtin_fmax(cur.ambv, v) : cur.ambv;
+                    const int i = i2 + j;
+                    const bool cand = (unsigned)(i - clo) <= (unsigned)cspan;
+                    const kb_d2 lo = Z.p2[b2 + j];
+                    const double Tf = hQf[j] - lo.x, Tp = hQq[j] - lo.y;
+                    const double v = Tp * rden[j];
+                    const bool def = cand && Tf < -E_T;       // fix2 certainly negative
+                    const bool unc = cand && fabs(Tf) <= E_T; // fix2 within the bound of zero
+                    const double vv = def ? v : ninf;
+                    cur.runner = __builtin_fmax(cur.runner, __builtin_fmin(cur.best, vv)); // second best (ties included)
+                    cur.cen = vv > cur.best ? i : cur.cen;                               // strict >: first maximum
+                    cur.best = __builtin_fmax(cur.best, vv);
+                    cur.ambv = __builtin_fmax(cur.ambv, unc ? v : ninf);
                 }
             }
         }
@@ -2655,7 +2714,10 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
                 const bool others = __ballot((mrun > ninf && mrun >= mark) || (mamb > ninf && mamb >= mark)) != 0ull;
                 wave_sync(); // seg_amb / accumulators of this segment are complete (all its stage-1 lanes have run)
                 const bool fallback = Z.seg_amb[fin] != 0 || __popcll(close) > 1 || others;
-                const int pcen = (close != 0ull) ? __builtin_amdgcn_readlane(mine, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(close))) : -1;
+                const int pcen =
+                    (close != 0ull)
+                        ? __builtin_amdgcn_readlane(mine, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(close)))
+                        : -1;
                 if (lane == 0) {
                     const uint32_t pidx = blockIdx.x + (uint32_t)fin * gridDim.x; // plan index of this protein
                     if (fallback) {
@@ -2676,6 +2738,8 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
             }
             ++fin;
         }
+        w0 += FC - FRING; // FC mod FRING steps forward = 63 slots back
+        w0 = w0 < 0 ? w0 + FRING : w0;
     }
     wave_sync();
     const int ncl = Z.ncl;
@@ -2694,10 +2758,11 @@ __global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restric
                                                         plaac_row *__restrict__ rows, const uint32_t *__restrict__ huge,
                                                         const uint2 *__restrict__ clist,
                                                         const uint32_t *__restrict__ ccount) {
-    __shared__ alignas(16) kb_d2 t_hl[KC_ROWS];
-    __shared__ double t_lod[KC_ROWS];
-    __shared__ int t_chg[KC_ROWS];
-    __shared__ uint8_t s_wc[RF_SLOTS][RF_SPAN + 3];
+    __shared__ alignas(16) kb_d2 t_hl[KC_ROWS]; // (hydropathy, llr) by window code
+    __shared__ alignas(16) kb_d2 t_pc[KC_ROWS]; // (PAPA log-odds, charge as a double: sums of -1/0/1 are exact)
+    // per-position values of the 81 residues around the centre: a thread's 41 taps are consecutive entries, so the
+    // reads of neighbouring threads are conflict-free 16-byte reads with immediate offsets (no code -> table hop per tap)
+    __shared__ alignas(16) kb_d2 s_hl[RF_SLOTS][RF_SPAN + 1], s_pc[RF_SLOTS][RF_SPAN + 1];
     __shared__ double s_w[RF_SLOTS][3][2 * TW + 2];
     __shared__ double s_llr1[RF_SLOTS];
     if (*huge) return;
@@ -2708,8 +2773,7 @@ __global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restric
         const int k = tid < NAA ? tid : (tid == KC_DUP ? 13 : 0);
         const bool none = tid == KC_NONE;
         t_hl[tid] = kb_d2{none ? 0.0 : T->hyd[k], none ? 0.0 : T->llr[k]};
-        t_lod[tid] = (none || tid == KC_DUP) ? 0.0 : T->lod[k];
-        t_chg[tid] = none ? 0 : T->chg[k];
+        t_pc[tid] = kb_d2{(none || tid == KC_DUP) ? 0.0 : T->lod[k], none ? 0.0 : (double)T->chg[k]};
     }
     const bool adjust = T->adjustprolines != 0;
     const double cc0 = T->cc[0], cc1 = T->cc[1], cc2 = T->cc[2];
@@ -2729,7 +2793,7 @@ __global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restric
             x = codes + (((uint64_t)it.y << 32) | it.x);
         }
         __syncthreads(); // tables ready / previous round done with the staging arrays
-        if (act) { // window codes of positions cen-40 .. cen+40 (two per thread)
+        if (act) { // values of positions cen-40 .. cen+40 (two per thread); outside the protein: +0.0 everywhere
             for (int t = l; t < RF_SPAN; t += 2 * TW + 1) {
                 const int q = cen - 2 * TW + t;
                 uint32_t kc = (uint32_t)KC_NONE;
@@ -2740,28 +2804,28 @@ __global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restric
                     const bool dup = adjust && cd == 13u && ((q >= 1 && xq[-1] == 13) || (q >= 2 && xq[-2] == 13));
                     kc = dup ? (uint32_t)KC_DUP : cd;
                 }
-                s_wc[slot][t] = (uint8_t)kc;
+                s_hl[slot][t] = t_hl[kc];
+                s_pc[slot][t] = t_pc[kc];
             }
         }
         __syncthreads();
         if (act) { // first level at i = cen - 20 + l
             const int i = cen - TW + l;
-            double sh = 0.0, sl = 0.0, sp = 0.0;
-            int sc = 0;
-#pragma unroll 4
+            double sh = 0.0, sl = 0.0, sp = 0.0, sc = 0.0;
+            const kb_d2 *__restrict__ vh = &s_hl[slot][l], *__restrict__ vp = &s_pc[slot][l];
+#pragma unroll
             for (int t = 0; t <= 2 * TW; ++t) { // increasing position
-                const uint32_t kc = s_wc[slot][l + t];
-                const kb_d2 hl = t_hl[kc];
-                sh = sh + hl.x;
-                sl = sl + hl.y;
-                sp = sp + t_lod[kc];
-                sc += t_chg[kc];
+                const kb_d2 a = vh[t], b = vp[t];
+                sh = sh + a.x;
+                sl = sl + a.y;
+                sp = sp + b.x;
+                sc = sc + b.y;
             }
             const int lo = imax(i - TW, 0), hi = imin(i + TW, n - 1);
-            const double cntd = (double)(hi - lo + 1);
-            const double hydro = sh / cntd, charge = (double)sc / cntd;
+            const SharedDiv div((double)(hi - lo + 1));
+            const double hydro = div(sh), charge = div(sc);
             const double fi = (cc0 * hydro + cc1 * fabs(charge)) + cc2; // axpbypc (:2050)
-            const double llr1 = sl / cntd, papa = sp / cntd;
+            const double llr1 = div(sl), papa = div(sp);
             const double wt = (double)(1 + imin(i, TW) + imin(n - i - 1, TW));
             s_w[slot][0][l] = wt * fi;
             s_w[slot][1][l] = wt * llr1;
@@ -3136,6 +3200,11 @@ plaac_status grow(plaac_ctx *ctx, Tp *&ptr, size_t &cap, size_t need) {
 extern "C" {
 
 const char *plaac_last_error(const plaac_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int plaac_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_ctx **out) {
     if (!params || !out) {

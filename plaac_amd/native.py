@@ -70,6 +70,8 @@ EXPORTS = (
     "plaac_histogram", "plaac_score", "plaac_score_device", "plaac_histogram_device", "plaac_ctx_sync",
     "plaac_last_timings", "plaac_timings_mean", "plaac_batch_upload", "plaac_batch_histogram", "plaac_batch_score",
     "plaac_batch_free", "plaac_batch_sweep", "plaac_score_sweep_device", "plaac_last_exact_fallbacks",
+    "plaac_device_count", "plaac_node_create", "plaac_node_destroy", "plaac_node_size", "plaac_node_ctx",
+    "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
 )
 
 _lib = None
@@ -120,6 +122,18 @@ def load():
     L.plaac_last_timings.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_timings_mean.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.plaac_last_exact_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
+    L.plaac_device_count.restype = C.c_int
+    L.plaac_node_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.plaac_node_destroy.argtypes = [C.c_void_p]
+    L.plaac_node_destroy.restype = None
+    L.plaac_node_size.argtypes = [C.c_void_p]
+    L.plaac_node_ctx.argtypes = [C.c_void_p, C.c_int]
+    L.plaac_node_ctx.restype = C.c_void_p
+    L.plaac_node_set_params.argtypes = [C.c_void_p, C.c_void_p]
+    L.plaac_node_histogram.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.plaac_node_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.plaac_node_last_error.argtypes = [C.c_void_p]
+    L.plaac_node_last_error.restype = C.c_char_p
     L.plaac_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.plaac_batch_histogram.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -279,6 +293,73 @@ class Context:
         self._check(self._L.plaac_timings_mean(self._h, int(ncalls), C.addressof(ms)))
         return {"total": ms[0], "plan": ms[1], "vit": ms[2], "fwd": ms[3], "win": ms[4], "tracks": ms[5],
                 "pack": ms[6], "bwd": ms[7]}
+
+
+class Node:
+    """plaac_node: one scoring context per listed device (None = every visible device), batches sharded by sequence."""
+
+    def __init__(self, params=None, devices=None):
+        self._L = load()
+        self._h = C.c_void_p()
+        self.params = params if params is not None else make_params()
+        ids = None if devices is None else (C.c_int * len(devices))(*[int(d) for d in devices])
+        st = self._L.plaac_node_create(C.addressof(self.params), ids, 0 if devices is None else len(devices),
+                                       C.byref(self._h))
+        if st != PLAAC_OK:
+            msg = self._L.plaac_node_last_error(None)
+            self._h = C.c_void_p()
+            raise PlaacError(st, msg.decode() if msg else "plaac_node_create failed")
+
+    def _check(self, st):
+        if st != PLAAC_OK:
+            msg = self._L.plaac_node_last_error(self._h)
+            raise PlaacError(st, msg.decode() if msg else "?")
+
+    def __len__(self):
+        return int(self._L.plaac_node_size(self._h))
+
+    def close(self):
+        if self._h:
+            self._L.plaac_node_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_params(self, params):
+        self._check(self._L.plaac_node_set_params(self._h, C.addressof(params)))
+        self.params = params
+
+    def histogram(self, codes, offsets):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        counts = np.zeros(NAA, dtype=np.int64)
+        self._check(self._L.plaac_node_histogram(self._h, codes.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                                 counts.ctypes.data))
+        return counts
+
+    def score(self, codes, offsets, tracks=False):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nprot = len(offsets) - 1
+        rows = np.zeros(nprot, dtype=ROW_DTYPE)
+        tr, tptr, T = None, None, None
+        if tracks:
+            tr = alloc_tracks(int(offsets[-1]) if nprot >= 0 else 0)
+            T = Tracks(**{k: tr[k].ctypes.data for k in TRACK_U8 + TRACK_F64})
+            tptr = C.addressof(T)
+        self._check(self._L.plaac_node_score(self._h, codes.ctypes.data, offsets.ctypes.data, nprot,
+                                             rows.ctypes.data, tptr))
+        return (rows, tr) if tracks else rows
+
+
+def device_count():
+    return int(load().plaac_device_count())
 
 
 class Batch:

@@ -62,3 +62,35 @@ def test_two_ranks_hip_contexts_histogram_allreduce_and_row_gather(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").read_text().startswith("ok")
+
+
+def test_node_over_two_contexts_equals_one_context():
+    """plaac_node_* (the multi-GPU form of the C ABI): a device list of {0, 0} (two contexts on the box's one GPU)
+    shards the batch by sequence; rows, tracks and histogram must equal a single context's, whatever the split"""
+    from plaac_amd import native, synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(3, nprot=1200, seed=4, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+    assert native.device_count() >= 1
+    with native.Context(P) as c:
+        want, wtr = c.score(codes, offs, tracks=True)
+        wcounts = c.histogram(codes, offs)
+    for devices in ([0], [0, 0], [0, 0, 0], None):
+        with native.Node(P, devices) as node:
+            assert len(node) == (len(devices) if devices else native.device_count())
+            assert np.array_equal(node.histogram(codes, offs), wcounts)
+            assert node.score(codes, offs).tobytes() == want.tobytes()
+            rows, tr = node.score(codes, offs, tracks=True)
+            assert rows.tobytes() == want.tobytes()
+            for k in native.TRACK_U8 + native.TRACK_F64:
+                a, b = tr[k], wtr[k]
+                assert a.tobytes() == b.tobytes(), k
+            P2 = native.make_params(alpha=0.25, corelength=40, bgcounts=wcounts.astype(np.float64))
+            node.set_params(P2)
+            with native.Context(P2) as c2:
+                assert node.score(codes, offs).tobytes() == c2.score(codes, offs).tobytes()
+    # more contexts than records, and an empty batch
+    with native.Node(P, [0, 0, 0]) as node:
+        assert node.score(codes[:int(offs[2])], offs[:3]).tobytes() == want[:2].tobytes()
+        assert len(node.score(np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
+    with pytest.raises(native.PlaacError):
+        native.Node(P, [99])
