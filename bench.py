@@ -100,7 +100,7 @@ def run_e2e(torch, codes, offsets, nseq, keep_fasta=False):
         t0 = time.perf_counter()
         fbytes, nres = write_fasta(torch, codes, offsets, nseq, fa)
         t_write = time.perf_counter() - t0
-        best, runs = None, []
+        best, runs, timing = None, [], []
         for _ in range(2):
             t0 = time.perf_counter()
             with open(tsv, "wb") as fh:
@@ -109,7 +109,8 @@ def run_e2e(torch, codes, offsets, nseq, keep_fasta=False):
             if r.returncode != 0:
                 return {"error": "bin/plaac exit %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
             runs.append(round(dt, 4))
-            best = dt if best is None or dt < best else best
+            if best is None or dt < best:
+                best, timing = dt, [l for l in r.stderr.decode(errors="replace").splitlines() if l.startswith("plaac-timing")]
         obytes = os.path.getsize(tsv)
         with open(tsv, "rb") as fh:
             nl = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
@@ -117,6 +118,8 @@ def run_e2e(torch, codes, offsets, nseq, keep_fasta=False):
                "wall_s": runs, "sequences": nseq, "residues": nres, "fasta_bytes": fbytes, "tsv_bytes": obytes,
                "tsv_lines": nl, "fasta_write_s": round(t_write, 3),
                "what": "bin/plaac -i <FASTA> > <TSV>, whole process incl. HIP start-up, best of two runs, 1 GPU"}
+        if timing:  # PLAAC_TIMING=1 in the environment: the host's own stage clock of the best run
+            out["stages"] = timing
         if keep_fasta:
             out["_fasta"] = fa
         return out

@@ -9,12 +9,24 @@
 // the -B file by mistake), histogram bins are 64-bit, records with an empty sequence are skipped with
 // a note on stderr instead of crashing, the -d column notes
 // and the usage text are worded independently. All scoring runs on the GPU; there is no CPU path.
+//
+// The input is STREAMED (the reference reads record by record, fastareader :4302-4375): a reader thread cuts the
+// FASTA into batches, one worker thread per scoring context (two contexts per visible GPU, every GPU of the node)
+// scores them, and the main thread formats and prints them in file order while later batches are still being read
+// and scored. Memory is bounded by the batches in flight, whatever the size of the file.
+//   PLAAC_BATCH_RECORDS / PLAAC_BATCH_BYTES   batch size (default 262144 records / 96 MiB of FASTA text)
+//   PLAAC_DEVICES=0,1,...                     devices to use, a device may be repeated (default: all, PLAAC_CTX_PER_DEVICE = 2 each)
+//   PLAAC_KEEP_BYTES                          the background pass keeps the parsed batches for the scoring pass up to this many
+//                                             bytes (default 2 GiB), beyond it the scoring pass reads the file again
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -115,49 +127,273 @@ void column_notes() {
     put("#######################################################################################\n");
 }
 
-bool die(plaac_ctx *ctx, const char *what, plaac_status st) {
-    std::fprintf(stderr, "plaac: %s failed (status %d): %s\n", what, (int)st, plaac_last_error(ctx));
-    return false;
+
+// ------------------------------------------------------------------------------------------------
+// pipeline plumbing
+// ------------------------------------------------------------------------------------------------
+uint64_t env_u64(const char *name, uint64_t dflt) {
+    const char *e = std::getenv(name);
+    if (!e || !*e) return dflt;
+    const long long v = std::atoll(e);
+    return v > 0 ? (uint64_t)v : dflt;
 }
 
-// counts of a FASTA on the device (computeaafreq :1655-1666)
-template <class GetCtx>
-bool count_background(GetCtx &&get_ctx, const std::string &path, double out[PLAAC_NAA], plaac_fasta **keep,
-                      plaac_batch **keep_batch) {
-    for (int i = 0; i < PLAAC_NAA; ++i) out[i] = 0.0;
+struct Batch {
+    uint64_t seq = 0;
     plaac_fasta *f = nullptr;
-    plaac_status st = plaac_fasta_read(path.c_str(), &f);
-    if (st == PLAAC_ERR_IO) {
-        put("# Couldn't open " + path + "\n"); // (:4318-4321) and carry on with zero counts
+    bool owned = true; // false: kept by the background pass, freed at exit
+    std::vector<plaac_row> rows;
+    // track mode: the selected records as their own batch
+    std::vector<uint32_t> pick;
+    std::vector<std::string> ids, names;
+    std::vector<uint8_t> pcodes;
+    std::vector<uint64_t> poffs;
+    std::vector<uint8_t> t8;
+    std::vector<double> t64;
+    plaac_tracks tr{};
+    plaac_status st = PLAAC_OK;
+    std::string err;
+    ~Batch() {
+        if (f && owned) plaac_fasta_free(f);
+    }
+};
+using BatchPtr = std::unique_ptr<Batch>;
+
+// bounded FIFO between the reader and the workers
+class Queue {
+    std::mutex m;
+    std::condition_variable cv_put, cv_get;
+    std::vector<BatchPtr> q;
+    size_t cap;
+    bool closed = false;
+
+  public:
+    explicit Queue(size_t c) : cap(c) {}
+    void put(BatchPtr b) {
+        std::unique_lock<std::mutex> l(m);
+        cv_put.wait(l, [&] { return q.size() < cap || closed; });
+        if (closed) return;
+        q.push_back(std::move(b));
+        cv_get.notify_one();
+    }
+    BatchPtr get() { // nullptr: closed and drained
+        std::unique_lock<std::mutex> l(m);
+        cv_get.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return nullptr;
+        BatchPtr b = std::move(q.front());
+        q.erase(q.begin());
+        cv_put.notify_one();
+        return b;
+    }
+    void close() {
+        std::lock_guard<std::mutex> l(m);
+        closed = true;
+        cv_put.notify_all();
+        cv_get.notify_all();
+    }
+};
+
+// scored batches, handed to the main thread in file order; at most `window` batches may be ahead of the printer
+class Reorder {
+    std::mutex m;
+    std::condition_variable cv, cv_room;
+    std::map<uint64_t, BatchPtr> done;
+    uint64_t next = 0, total = UINT64_MAX, window;
+
+  public:
+    explicit Reorder(uint64_t w) : window(w) {}
+    void wait_room(uint64_t seq) { // called by a worker BEFORE it scores batch `seq`
+        std::unique_lock<std::mutex> l(m);
+        cv_room.wait(l, [&] { return seq < next + window; });
+    }
+    void put(BatchPtr b) {
+        std::lock_guard<std::mutex> l(m);
+        const uint64_t s = b->seq;
+        done[s] = std::move(b);
+        cv.notify_all();
+    }
+    void set_total(uint64_t n) {
+        std::lock_guard<std::mutex> l(m);
+        total = n;
+        cv.notify_all();
+    }
+    BatchPtr take() { // next batch in file order; nullptr after the last one
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return done.count(next) || next >= total; });
+        if (next >= total) return nullptr;
+        BatchPtr b = std::move(done[next]);
+        done.erase(next);
+        ++next;
+        cv_room.notify_all();
+        return b;
+    }
+};
+
+const char *rec_name(const plaac_fasta *f, uint32_t i) { return f->names + f->name_off[i]; }
+
+struct Engine {
+    plaac_node *node = nullptr;
+    std::thread starter;
+    plaac_status st = PLAAC_OK;
+    std::string err;
+    bool started = false, joined = false;
+    void start(const plaac_params &P) { // HIP start-up takes a few hundred ms: it runs beside option handling / parsing
+        started = true;
+        starter = std::thread([this, P] {
+            std::vector<int> devs;
+            if (const char *e = std::getenv("PLAAC_DEVICES")) {
+                for (const char *p = e; *p;) {
+                    char *end = nullptr;
+                    const long d = std::strtol(p, &end, 10);
+                    if (end == p) break;
+                    devs.push_back((int)d);
+                    p = *end ? end + 1 : end;
+                }
+            }
+            if (devs.empty()) {
+                const int n = plaac_device_count();
+                const int per = (int)env_u64("PLAAC_CTX_PER_DEVICE", 2);
+                for (int k = 0; k < per; ++k)
+                    for (int d = 0; d < n; ++d) devs.push_back(d);
+            }
+            if (devs.empty()) {
+                st = PLAAC_ERR_DEVICE;
+                err = "no HIP device available";
+                return;
+            }
+            st = plaac_node_create(&P, devs.data(), (int)devs.size(), &node);
+            if (st != PLAAC_OK) err = plaac_node_last_error(nullptr);
+        });
+    }
+    bool ready(const plaac_params &P) {
+        if (!started) start(P);
+        if (!joined) {
+            starter.join();
+            joined = true;
+            g_timer.lap("wait for GPU contexts");
+        }
+        if (st != PLAAC_OK) {
+            std::fprintf(stderr, "plaac: no usable MI355X (gfx950) device: %s\n", err.c_str());
+            return false;
+        }
         return true;
     }
-    if (st != PLAAC_OK) return die(nullptr, "reading FASTA", st);
-    g_timer.lap("read+encode FASTA", (double)f->nres, "residues");
-    plaac_ctx *ctx = get_ctx();
-    if (!ctx) {
-        plaac_fasta_free(f);
+    ~Engine() {
+        if (started && !joined) starter.join();
+    }
+};
+
+struct Stream {
+    uint32_t batch_records;
+    uint64_t batch_bytes;
+};
+
+// Reads `path` batch by batch on a reader thread, runs `work(ctx, batch)` on one worker thread per context and hands
+// the batches to `sink` in file order on the calling thread. `replay` (nullable): batches kept by an earlier pass, used
+// instead of reading the file. `keep` (nullable): keep the parsed batches (up to keep_bytes) for a later pass.
+// opens `path` as a batch stream; a file that cannot be opened is reported the reference's way (:4318-4321) and
+// treated as empty (*fs stays null, the caller carries on with no records)
+bool open_stream(const std::string &path, plaac_fasta_stream **fs) {
+    *fs = nullptr;
+    const plaac_status st = plaac_fasta_open(path.c_str(), fs);
+    if (st == PLAAC_ERR_IO) {
+        put("# Couldn't open " + path + "\n");
+        return true;
+    }
+    if (st != PLAAC_OK) {
+        std::fprintf(stderr, "plaac: cannot read %s (status %d)\n", path.c_str(), (int)st);
         return false;
     }
-    int64_t counts[PLAAC_NAA];
-    plaac_batch *b = nullptr; // upload once: the scoring pass reuses the resident residues
-    st = plaac_batch_upload(ctx, f->codes, f->offsets, f->nrec, &b);
-    g_timer.lap("upload batch (H2D)", (double)f->nres, "residues");
-    if (st == PLAAC_OK) st = plaac_batch_histogram(b, counts);
-    g_timer.lap("background histogram (GPU)", (double)f->nres, "residues");
-    if (st != PLAAC_OK) {
-        plaac_batch_free(b);
-        plaac_fasta_free(f);
-        return die(ctx, "plaac_batch_histogram", st);
-    }
-    for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (double)counts[i];
-    if (keep) {
-        *keep = f;
-        *keep_batch = b;
-    } else {
-        plaac_batch_free(b);
-        plaac_fasta_free(f);
-    }
     return true;
+}
+
+template <class Prep, class Work, class Sink>
+bool run_pipeline(Engine &eng, const std::string &path, plaac_fasta_stream *fs, const Stream &sp,
+                  std::vector<plaac_fasta *> *replay, std::vector<plaac_fasta *> *keep, uint64_t keep_bytes, Prep &&prep,
+                  Work &&work, Sink &&sink) {
+    if (!fs && !replay) return true; // nothing to read
+    const int nctx = plaac_node_size(eng.node);
+    Queue q((size_t)nctx + 1);
+    Reorder ro((uint64_t)2 * nctx + 2);
+    std::atomic<bool> failed{false};
+    bool keeping = keep != nullptr, keep_overflow = false;
+    uint64_t kept_bytes = 0;
+    std::thread reader([&] {
+        uint64_t seq = 0;
+        for (;;) {
+            if (failed) break;
+            BatchPtr b(new Batch());
+            if (replay) {
+                if (seq >= replay->size()) break;
+                b->f = (*replay)[seq];
+                b->owned = false;
+            } else {
+                plaac_fasta *f = nullptr;
+                const plaac_status st = plaac_fasta_next(fs, sp.batch_records, sp.batch_bytes, &f);
+                if (st != PLAAC_OK) {
+                    std::fprintf(stderr, "plaac: reading %s failed (status %d)\n", path.c_str(), (int)st);
+                    failed = true;
+                    break;
+                }
+                if (!f) break;
+                b->f = f;
+                if (keeping) {
+                    kept_bytes += f->nres + 16ull * f->nrec + f->name_off[f->nrec];
+                    if (kept_bytes <= keep_bytes) {
+                        keep->push_back(f);
+                        b->owned = false;
+                    } else { // too large to keep: the later pass reads the file again (the batches kept so far may
+                        keeping = false; // still be in flight: they are released once the threads have been joined)
+                        keep_overflow = true;
+                    }
+                }
+            }
+            b->seq = seq++;
+            prep(*b);
+            q.put(std::move(b));
+        }
+        q.close();
+        ro.set_total(seq);
+    });
+    std::vector<std::thread> workers;
+    for (int k = 0; k < nctx; ++k)
+        workers.emplace_back([&, k] {
+            plaac_ctx *ctx = plaac_node_ctx(eng.node, k);
+            for (;;) {
+                BatchPtr b = q.get();
+                if (!b) break;
+                ro.wait_room(b->seq);
+                if (!failed) {
+                    b->st = work(ctx, *b);
+                    if (b->st != PLAAC_OK) {
+                        b->err = plaac_last_error(ctx);
+                        failed = true;
+                    }
+                }
+                ro.put(std::move(b));
+            }
+        });
+    bool ok = true;
+    for (;;) {
+        BatchPtr b = ro.take();
+        if (!b) break;
+        if (b->st != PLAAC_OK && ok) {
+            std::fprintf(stderr, "plaac: scoring failed (status %d): %s\n", (int)b->st, b->err.c_str());
+            ok = false;
+        }
+        if (ok && !failed && !sink(*b)) {
+            ok = false;
+            failed = true;
+        }
+    }
+    reader.join();
+    for (auto &w : workers) w.join();
+    if (fs) plaac_fasta_close(fs);
+    if (keep && (keep_overflow || !ok || failed)) {
+        for (plaac_fasta *k : *keep) plaac_fasta_free(k);
+        keep->clear();
+    }
+    return ok && !failed;
 }
 
 bool read_params_file(const std::string &path, double vec[PLAAC_NAA]) {
@@ -173,61 +409,6 @@ bool read_params_file(const std::string &path, double vec[PLAAC_NAA]) {
     }
     for (int i = 0; i < PLAAC_NAA; ++i)
         if (warn[i]) put("# warning: " + path + " does not have expected name in line" + std::to_string(i + 1) + "\n");
-    return true;
-}
-
-const char *rec_name(const plaac_fasta *f, uint32_t i) { return f->names + f->name_off[i]; }
-
-bool score_all(plaac_ctx *ctx, const plaac_fasta *f, plaac_batch *batch, const Options &o) {
-    if (o.headers) column_notes();
-    put(std::string(plaac_summary_header()) + "\n");
-    if (f->nrec == 0) return true;
-    // not value-initialised: the library overwrites every row, and its copy threads fault the pages in in parallel
-    std::unique_ptr<plaac_row[]> rows(new plaac_row[f->nrec]);
-    plaac_status st = batch ? plaac_batch_score(batch, rows.get(), nullptr)
-                            : plaac_score(ctx, f->codes, f->offsets, f->nrec, rows.get(), nullptr);
-    if (st != PLAAC_OK) return die(ctx, "plaac_score", st);
-    g_timer.lap(batch ? "score resident batch (GPU + D2H)" : "score (H2D + GPU + D2H)", (double)f->nres, "residues");
-    // format in parallel (contiguous row ranges per thread), print in file order
-    const unsigned nt = f->nrec < 2048 ? 1u : plaac_host_threads();
-    std::vector<std::string> part(nt);
-    std::vector<int> bad(nt, 0);
-    auto work = [&](unsigned t) {
-        const uint32_t r0 = (uint32_t)((uint64_t)f->nrec * t / nt), r1 = (uint32_t)((uint64_t)f->nrec * (t + 1) / nt);
-        std::vector<char> line;
-        std::string &out = part[t];
-        for (uint32_t i = r0; i < r1; ++i) {
-            const uint64_t len = f->offsets[i + 1] - f->offsets[i];
-            if (len == 0) {
-                std::fprintf(stderr, "plaac: record '%s' has no sequence, skipped\n", rec_name(f, i));
-                continue;
-            }
-            line.resize(len * 3 + std::strlen(rec_name(f, i)) + 2048);
-            long k = plaac_format_summary_row(&rows[i], rec_name(f, i), f->codes + f->offsets[i], len, o.corelength,
-                                              o.ww2, line.data(), line.size());
-            if (k < 0) {
-                bad[t] = 1;
-                return;
-            }
-            if (k == 0) continue; // nothing left after the stop trim (:762)
-            out.append(line.data(), (size_t)k);
-            out.push_back('\n');
-        }
-    };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t);
-        for (auto &th : pool) th.join();
-    }
-    g_timer.lap("format rows", (double)f->nrec, "rows");
-    for (unsigned t = 0; t < nt; ++t) {
-        if (bad[t]) return false;
-        put(part[t]);
-    }
-    std::fflush(stdout);
-    g_timer.lap("write table");
     return true;
 }
 
@@ -273,74 +454,165 @@ bool read_plot_list(const std::string &path, std::map<std::string, std::string> 
     return true;
 }
 
-bool plot_some(plaac_ctx *ctx, const plaac_fasta *f, const Options &o) {
+
+// ---- pass 1: residue counts of a FASTA on the GPUs (computeaafreq :1655-1666) ----
+bool count_background(Engine &eng, const plaac_params &P, const std::string &path, const Stream &sp,
+                      double out[PLAAC_NAA], std::vector<plaac_fasta *> *keep, uint64_t keep_bytes) {
+    for (int i = 0; i < PLAAC_NAA; ++i) out[i] = 0.0;
+    if (!eng.ready(P)) return false;
+    std::mutex m;
+    int64_t total[PLAAC_NAA] = {0};
+    uint64_t nres = 0;
+    plaac_fasta_stream *fs = nullptr;
+    if (!open_stream(path, &fs)) return false; // a missing file: reported, zero counts (:4318-4321)
+    const bool ok = run_pipeline(
+        eng, path, fs, sp, nullptr, keep, keep_bytes, [](Batch &) {},
+        [&](plaac_ctx *ctx, Batch &b) {
+            int64_t c[PLAAC_NAA];
+            const plaac_status st = plaac_histogram(ctx, b.f->codes, b.f->offsets, b.f->nrec, c);
+            if (st == PLAAC_OK) {
+                std::lock_guard<std::mutex> l(m);
+                for (int i = 0; i < PLAAC_NAA; ++i) total[i] += c[i];
+                nres += b.f->nres;
+            }
+            return st;
+        },
+        [](Batch &) { return true; });
+    for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (double)total[i];
+    g_timer.lap("background pass (read + H2D + histogram)", (double)nres, "residues");
+    return ok;
+}
+
+// ---- pass 2, summary mode (scoreallfastas :653-950) ----
+bool score_all(Engine &eng, const Options &o, const Stream &sp, std::vector<plaac_fasta *> *replay) {
+    if (o.headers) column_notes();
+    put(std::string(plaac_summary_header()) + "\n");
+    plaac_fasta_stream *fs = nullptr; // the reference opens the file after it has printed the header (:715-750)
+    if (!replay && !open_stream(o.input, &fs)) return false;
+    const unsigned nt_max = plaac_host_threads();
+    uint64_t nres = 0, nrec = 0;
+    const bool ok = run_pipeline(
+        eng, o.input, fs, sp, replay, nullptr, 0, [](Batch &) {},
+        [&](plaac_ctx *ctx, Batch &b) {
+            b.rows.resize(b.f->nrec);
+            return plaac_score(ctx, b.f->codes, b.f->offsets, b.f->nrec, b.rows.data(), nullptr);
+        },
+        [&](Batch &b) {
+            const plaac_fasta *f = b.f;
+            // format in parallel (contiguous row ranges per thread), print in file order
+            const unsigned nt = f->nrec < 2048 ? 1u : nt_max;
+            std::vector<std::string> part(nt);
+            std::vector<int> bad(nt, 0);
+            auto fmt = [&](unsigned t) {
+                const uint32_t r0 = (uint32_t)((uint64_t)f->nrec * t / nt), r1 = (uint32_t)((uint64_t)f->nrec * (t + 1) / nt);
+                std::vector<char> line;
+                std::string &out = part[t];
+                for (uint32_t i = r0; i < r1; ++i) {
+                    const uint64_t len = f->offsets[i + 1] - f->offsets[i];
+                    if (len == 0) {
+                        std::fprintf(stderr, "plaac: record '%s' has no sequence, skipped\n", rec_name(f, i));
+                        continue;
+                    }
+                    line.resize(len * 3 + std::strlen(rec_name(f, i)) + 2048);
+                    const long k = plaac_format_summary_row(&b.rows[i], rec_name(f, i), f->codes + f->offsets[i], len,
+                                                            o.corelength, o.ww2, line.data(), line.size());
+                    if (k < 0) {
+                        bad[t] = 1;
+                        return;
+                    }
+                    if (k == 0) continue; // nothing left after the stop trim (:762)
+                    out.append(line.data(), (size_t)k);
+                    out.push_back('\n');
+                }
+            };
+            if (nt == 1) {
+                fmt(0);
+            } else {
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < nt; ++t) pool.emplace_back(fmt, t);
+                for (auto &th : pool) th.join();
+            }
+            for (unsigned t = 0; t < nt; ++t) {
+                if (bad[t]) return false;
+                put(part[t]);
+            }
+            nres += f->nres;
+            nrec += f->nrec;
+            return true;
+        });
+    std::fflush(stdout);
+    g_timer.lap("scoring pass (read + H2D + GPU + D2H + format + write)", (double)nres, "residues");
+    return ok;
+}
+
+// ---- pass 2, track mode (plotsomefastas :587-649) ----
+bool plot_some(Engine &eng, const Options &o, const Stream &sp, std::vector<plaac_fasta *> *replay) {
     std::map<std::string, std::string> title, order;
     const bool all = o.plotlist == "all";
     if (!all && !read_plot_list(o.plotlist, title, order)) return false;
+    plaac_fasta_stream *fs = nullptr;
+    if (!replay && !open_stream(o.input, &fs)) return false;
     put(std::string(plaac_tracks_header()) + "\n");
-    // select records (:617) and build the sub-batch
-    std::vector<uint32_t> pick;
-    std::vector<std::string> ids, names;
-    int genecount = 1;
-    for (uint32_t i = 0; i < f->nrec; ++i) {
-        const std::string name = rec_name(f, i);
-        if (!(all || title.count(name) || title.count(">" + name))) continue;
-        const uint64_t b = f->offsets[i], e = f->offsets[i + 1];
-        uint64_t n = e - b;
-        if (n == 0) {
-            std::fprintf(stderr, "plaac: record '%s' has no sequence, skipped\n", name.c_str());
-            continue;
-        }
-        if (f->codes[e - 1] == 21) --n;
-        std::string id = std::to_string(genecount), nm = name;
-        if (title.count(name)) nm = title[name];
-        if (order.count(name)) id = order[name];
-        ++genecount;
-        if (n == 0) {
-            std::fprintf(stderr, "plaac: record '%s' is only a stop codon, skipped\n", name.c_str());
-            continue;
-        }
-        pick.push_back(i);
-        ids.push_back(id);
-        names.push_back(nm);
-    }
-    if (pick.empty()) return true;
-    std::vector<uint64_t> offs(pick.size() + 1, 0);
-    for (size_t k = 0; k < pick.size(); ++k)
-        offs[k + 1] = offs[k] + (f->offsets[pick[k] + 1] - f->offsets[pick[k]]);
-    const uint64_t total = offs.back();
-    std::vector<uint8_t> codes(total + 64);
-    for (size_t k = 0; k < pick.size(); ++k)
-        std::memcpy(codes.data() + offs[k], f->codes + f->offsets[pick[k]], offs[k + 1] - offs[k]);
-    std::vector<plaac_row> rows(pick.size());
-    std::vector<uint8_t> t8(2 * total + 2);
-    std::vector<double> t64(10 * total + 10);
-    plaac_tracks tr;
-    tr.vit = t8.data();
-    tr.map = t8.data() + total;
-    double *d = t64.data();
-    tr.charge = d;
-    tr.hydro = d + total;
-    tr.fi = d + 2 * total;
-    tr.plaacllr = d + 3 * total;
-    tr.papa = d + 4 * total;
-    tr.fix2 = d + 5 * total;
-    tr.plaacllrx2 = d + 6 * total;
-    tr.papax2 = d + 7 * total;
-    tr.post0 = d + 8 * total;
-    tr.post1 = d + 9 * total;
-    plaac_status st = plaac_score(ctx, codes.data(), offs.data(), (uint32_t)pick.size(), rows.data(), &tr);
-    if (st != PLAAC_OK) return die(ctx, "plaac_score", st);
-    std::vector<char> buf;
-    for (size_t k = 0; k < pick.size(); ++k) {
-        const uint32_t n = (uint32_t)rows[k].prot_len;
-        buf.resize(plaac_track_rows_bound(n, ids[k].size(), names[k].size()));
-        long len = plaac_format_track_rows(&tr, offs[k], codes.data() + offs[k], n, ids[k].c_str(), names[k].c_str(),
-                                           buf.data(), buf.size());
-        if (len < 0) return false;
-        std::fwrite(buf.data(), 1, (size_t)len, stdout);
-    }
-    return true;
+    int genecount = 1; // advanced by the reader thread only (records are selected in file order, :617)
+    const bool ok = run_pipeline(
+        eng, o.input, fs, sp, replay, nullptr, 0,
+        [&](Batch &b) { // select records and build the sub-batch that is scored
+            const plaac_fasta *f = b.f;
+            for (uint32_t i = 0; i < f->nrec; ++i) {
+                const std::string name = rec_name(f, i);
+                if (!(all || title.count(name) || title.count(">" + name))) continue;
+                const uint64_t bb = f->offsets[i], e = f->offsets[i + 1];
+                uint64_t n = e - bb;
+                if (n == 0) {
+                    std::fprintf(stderr, "plaac: record '%s' has no sequence, skipped\n", name.c_str());
+                    continue;
+                }
+                if (f->codes[e - 1] == 21) --n;
+                std::string id = std::to_string(genecount), nm = name;
+                if (title.count(name)) nm = title[name];
+                if (order.count(name)) id = order[name];
+                ++genecount;
+                if (n == 0) {
+                    std::fprintf(stderr, "plaac: record '%s' is only a stop codon, skipped\n", name.c_str());
+                    continue;
+                }
+                b.pick.push_back(i);
+                b.ids.push_back(id);
+                b.names.push_back(nm);
+            }
+            b.poffs.assign(b.pick.size() + 1, 0);
+            for (size_t k = 0; k < b.pick.size(); ++k)
+                b.poffs[k + 1] = b.poffs[k] + (f->offsets[b.pick[k] + 1] - f->offsets[b.pick[k]]);
+            b.pcodes.resize(b.poffs.back() + 64);
+            for (size_t k = 0; k < b.pick.size(); ++k)
+                std::memcpy(b.pcodes.data() + b.poffs[k], f->codes + f->offsets[b.pick[k]], b.poffs[k + 1] - b.poffs[k]);
+        },
+        [&](plaac_ctx *ctx, Batch &b) {
+            if (b.pick.empty()) return PLAAC_OK;
+            const uint64_t total = b.poffs.back();
+            b.rows.resize(b.pick.size());
+            b.t8.resize(2 * total + 2);
+            b.t64.resize(10 * total + 10);
+            double *d = b.t64.data();
+            b.tr = plaac_tracks{b.t8.data(), b.t8.data() + total, d,           d + total,     d + 2 * total, d + 3 * total,
+                                d + 4 * total, d + 5 * total,   d + 6 * total, d + 7 * total, d + 8 * total, d + 9 * total};
+            return plaac_score(ctx, b.pcodes.data(), b.poffs.data(), (uint32_t)b.pick.size(), b.rows.data(), &b.tr);
+        },
+        [&](Batch &b) {
+            std::vector<char> buf;
+            for (size_t k = 0; k < b.pick.size(); ++k) {
+                const uint32_t n = (uint32_t)b.rows[k].prot_len;
+                buf.resize(plaac_track_rows_bound(n, b.ids[k].size(), b.names[k].size()));
+                const long len = plaac_format_track_rows(&b.tr, b.poffs[k], b.pcodes.data() + b.poffs[k], n,
+                                                         b.ids[k].c_str(), b.names[k].c_str(), buf.data(), buf.size());
+                if (len < 0) return false;
+                std::fwrite(buf.data(), 1, (size_t)len, stdout);
+            }
+            return true;
+        });
+    std::fflush(stdout);
+    g_timer.lap("track pass");
+    return ok;
 }
 
 } // namespace
@@ -383,56 +655,27 @@ int main(int argc, char **argv) {
 
     plaac_params P;
     plaac_params_init(&P, nullptr, nullptr, 1.0, o.corelength, o.ww1, o.ww2, o.ww3, 1);
-    // The GPU context (HIP start-up, a few hundred ms) is created on a second thread while this one reads and
-    // encodes the FASTA; need_ctx() joins it the first time a device call is due.
-    plaac_ctx *ctx = nullptr;
-    std::string ctx_err;
-    plaac_status ctx_st = PLAAC_OK;
-    std::thread ctx_thread;
-    bool ctx_started = false, ctx_joined = false;
-    if (!o.input.empty() || !o.bgfile.empty()) {
-        ctx_started = true;
-        ctx_thread = std::thread([&, P0 = P] { // its own copy: main re-initialises P once the background is known
-            ctx_st = plaac_ctx_create(&P0, 0, &ctx);
-            if (ctx_st != PLAAC_OK) ctx_err = plaac_last_error(nullptr); // thread-local message: copy it here
-        });
-    }
-    auto need_ctx = [&]() -> bool {
-        if (!ctx_started) {
-            ctx_started = ctx_joined = true;
-            ctx_st = plaac_ctx_create(&P, 0, &ctx);
-            if (ctx_st != PLAAC_OK) ctx_err = plaac_last_error(nullptr);
-        } else if (!ctx_joined) {
-            ctx_thread.join();
-            ctx_joined = true;
-            g_timer.lap("wait for GPU context");
-        }
-        if (ctx_st != PLAAC_OK) {
-            std::fprintf(stderr, "plaac: no usable MI355X (gfx950) device: %s\n", ctx_err.c_str());
-            return false;
-        }
-        return true;
-    };
-    struct Joiner { // never leave main with the thread still joinable
-        std::thread &t;
-        bool &joined;
-        ~Joiner() {
-            if (t.joinable() && !joined) t.join();
-        }
-    } joiner{ctx_thread, ctx_joined};
+    Engine eng;
+    const bool need_gpu = !o.input.empty() || (!o.bgfile.empty() && o.bgfreq.empty());
+    if (need_gpu) eng.start(P); // HIP start-up runs beside the rest of the set-up
+    // track mode moves 82 bytes per residue through the host: smaller batches
+    Stream sp{(uint32_t)env_u64("PLAAC_BATCH_RECORDS", 262144),
+              env_u64("PLAAC_BATCH_BYTES", o.plotlist.empty() ? (96ull << 20) : (8ull << 20))};
+    const uint64_t keep_bytes = env_u64("PLAAC_KEEP_BYTES", 2ull << 30);
 
-    auto get_ctx = [&]() -> plaac_ctx * { return need_ctx() ? ctx : nullptr; };
     // background counts (:377-384)
     double bgf[PLAAC_NAA] = {0}, fgf[PLAAC_NAA];
-    plaac_fasta *input = nullptr;
-    plaac_batch *input_batch = nullptr;
-    bool ok = true;
+    std::vector<plaac_fasta *> kept; // parsed batches of the input, when the background pass read it
+    bool kept_valid = false, ok = true;
     if (!o.bgfreq.empty()) {
         ok = read_params_file(o.bgfreq, bgf);
     } else if (!o.bgfile.empty()) {
-        ok = count_background(get_ctx, o.bgfile, bgf, o.bgfile == o.input ? &input : nullptr, &input_batch);
+        const bool same = o.bgfile == o.input;
+        ok = count_background(eng, P, o.bgfile, sp, bgf, same ? &kept : nullptr, keep_bytes);
+        kept_valid = same && !kept.empty();
     } else if (!o.input.empty()) {
-        ok = count_background(get_ctx, o.input, bgf, &input, &input_batch);
+        ok = count_background(eng, P, o.input, sp, bgf, &kept, keep_bytes);
+        kept_valid = !kept.empty();
     }
     if (!ok) return 1;
     const bool have_fg = !o.fgfreq.empty();
@@ -442,7 +685,8 @@ int main(int argc, char **argv) {
     if ((!o.bgfile.empty() || !o.bgfreq.empty()) && o.input.empty()) { // (:394-403): dump and exit
         plaac_format_aa_params(bgf, text, sizeof text);
         put(text);
-        if (ctx) plaac_ctx_destroy(ctx);
+        std::fflush(stdout);
+        if (eng.started && eng.ready(P)) plaac_node_destroy(eng.node);
         return 0;
     }
     if (o.alpha > 1 || o.alpha < 0) { // (:444-447)
@@ -469,37 +713,21 @@ int main(int argc, char **argv) {
         }
     }
 
-    if (!need_ctx()) return 1;
-    if (plaac_ctx_set_params(ctx, &P) != PLAAC_OK) {
-        die(ctx, "plaac_ctx_set_params", PLAAC_ERR_ARG);
+    if (!eng.ready(P)) return 1;
+    if (plaac_node_set_params(eng.node, &P) != PLAAC_OK) {
+        std::fprintf(stderr, "plaac: plaac_node_set_params failed: %s\n", plaac_node_last_error(eng.node));
         return 1;
     }
-    if (!input) {
-        plaac_status st = plaac_fasta_read(o.input.c_str(), &input);
-        if (st == PLAAC_ERR_IO) {
-            put("# Couldn't open " + o.input + "\n");
-            plaac_fasta empty{};
-            uint64_t zero = 0;
-            empty.offsets = &zero;
-            ok = o.plotlist.empty() ? score_all(ctx, &empty, nullptr, o) : plot_some(ctx, &empty, o);
-            plaac_ctx_destroy(ctx);
-            return ok ? 0 : 1;
-        }
-        if (st != PLAAC_OK) {
-            die(nullptr, "reading FASTA", st);
-            return 1;
-        }
-    }
-    ok = o.plotlist.empty() ? score_all(ctx, input, input_batch, o) : plot_some(ctx, input, o);
-    // The output is complete and flushed. Leaving through _exit skips unmapping hundreds of MB of host and device
-    // buffers and the HIP runtime's own shutdown, which the operating system does faster (PLAAC_TEARDOWN=1 keeps
-    // the orderly path, e.g. under leak checkers).
+    ok = o.plotlist.empty() ? score_all(eng, o, sp, kept_valid ? &kept : nullptr)
+                            : plot_some(eng, o, sp, kept_valid ? &kept : nullptr);
+    // The output is complete and flushed. Leaving through _exit skips unmapping the host and device buffers and the
+    // HIP runtime's own shutdown, which the operating system does faster (PLAAC_TEARDOWN=1 keeps the orderly path,
+    // e.g. under leak checkers; the library itself always tears down in order when its handles are destroyed).
     std::fflush(stdout);
     std::fflush(stderr);
     if (!std::getenv("PLAAC_TEARDOWN")) ::_exit(ok ? 0 : 1);
-    plaac_batch_free(input_batch);
-    plaac_fasta_free(input);
-    plaac_ctx_destroy(ctx);
+    for (plaac_fasta *k : kept) plaac_fasta_free(k);
+    plaac_node_destroy(eng.node);
     g_timer.lap("teardown");
     return ok ? 0 : 1;
 }

@@ -116,3 +116,61 @@ def test_usage_and_missing_input():
     assert any("USAGE" in l for l in out)
     out = run("-i", "/nonexistent.fa", "-s")
     assert "# Couldn't open /nonexistent.fa" in out
+
+
+def run_env(env, *args):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=600, env=e)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")
+    return r.stdout
+
+
+def _write_fasta(path, codes, offs, stop_every=0):
+    letters = np.frombuffer(b"XACDEFGHIKLMNPQRSTVWY*", dtype=np.uint8)[codes]
+    with open(path, "wb") as fh:
+        for i in range(len(offs) - 1):
+            seq = letters[int(offs[i]):int(offs[i + 1])].tobytes()
+            fh.write(b">rec%05d some description\n" % i)
+            for k in range(0, len(seq), 60):  # wrapped lines, as real FASTA files are
+                fh.write(seq[k:k + 60] + b"\n")
+
+
+def test_streamed_pipeline_is_independent_of_batching_and_contexts(native, tmp_path):
+    """The CLI streams the input in batches over every scoring context: the table must not depend on the batch size,
+    on the number of contexts, on the device list, or on whether the scoring pass replays the batches the background
+    pass kept (small inputs) or reads the file again (large inputs). Reference order: plaac.java:755 (file order)."""
+    from plaac_amd import synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(3, nprot=1500, seed=12, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+    fa = tmp_path / "in.fa"
+    _write_fasta(fa, codes, offs)
+    args = ("-i", fa, "-a", 0.5, "-c", 40)
+    base = run_env({"PLAAC_DEVICES": "0"}, *args)  # one context, one batch
+    assert base.count(b"\n") > 1500
+    for env in ({"PLAAC_BATCH_RECORDS": 37}, {"PLAAC_BATCH_BYTES": 20000, "PLAAC_DEVICES": "0,0,0"},
+                {"PLAAC_BATCH_RECORDS": 100, "PLAAC_KEEP_BYTES": 1}, {"PLAAC_BATCH_RECORDS": 1, "PLAAC_DEVICES": "0,0"},
+                {"PLAAC_BATCH_RECORDS": 100, "PLAAC_KEEP_BYTES": 100000, "PLAAC_CTX_PER_DEVICE": 3},
+                {"PLAAC_TEARDOWN": 1, "PLAAC_BATCH_RECORDS": 500}):
+        assert run_env(env, *args) == base, env
+    # track mode streams too (8 MiB batches by default): every record, then a list
+    tbase = run_env({"PLAAC_DEVICES": "0"}, "-i", fa, "-p", "all", "-s")
+    assert run_env({"PLAAC_BATCH_RECORDS": 64, "PLAAC_DEVICES": "0,0"}, "-i", fa, "-p", "all", "-s") == tbase
+    lst = tmp_path / "list.txt"
+    lst.write_text("rec01400 some description\trenamed\nrec00003 some description\n")
+    t1 = run_env({"PLAAC_DEVICES": "0"}, "-i", fa, "-p", lst, "-s")
+    assert run_env({"PLAAC_BATCH_RECORDS": 10}, "-i", fa, "-p", lst, "-s") == t1
+    order = [l.split(b"\t")[:2] for l in t1.split(b"\n") if l and not l.startswith(b"#") and l.split(b"\t")[2:3] == [b"1"]]
+    assert order == [[b"2", b"rec00003 some description"], [b"1", b"renamed"]]
+
+
+def test_background_dump_streams_and_missing_background_is_reported(native, tmp_path):
+    from plaac_amd import synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(2, nprot=700, seed=3, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.3)
+    fa = tmp_path / "bg.fa"
+    _write_fasta(fa, codes, offs)
+    a = run_env({}, "-b", fa)
+    assert run_env({"PLAAC_BATCH_RECORDS": 33, "PLAAC_DEVICES": "0,0"}, "-b", fa) == a
+    out = run_env({}, "-b", "/nonexistent_bg.fa").decode()
+    assert "# Couldn't open /nonexistent_bg.fa" in out and "0.000000 # A" in out
