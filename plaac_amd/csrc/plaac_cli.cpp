@@ -17,7 +17,7 @@
 //   PLAAC_BATCH_RECORDS / PLAAC_BATCH_BYTES   batch size (default 262144 records / 96 MiB of FASTA text)
 //   PLAAC_DEVICES=0,1,...                     devices to use, a device may be repeated (default: all, PLAAC_CTX_PER_DEVICE = 2 each)
 //   PLAAC_KEEP_BYTES                          the background pass keeps the parsed batches for the scoring pass up to this many
-//                                             bytes (default 2 GiB), beyond it the scoring pass reads the file again
+//                                             bytes (default 4 GiB), beyond it the scoring pass reads the file again
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -229,6 +229,53 @@ class Reorder {
     }
 };
 
+// stdout writer on its own thread: the formatter hands over finished text and goes on with the next batch
+class Writer {
+    std::mutex m;
+    std::condition_variable cv_put, cv_get;
+    std::vector<std::string> q;
+    size_t bytes = 0;
+    bool closed = false;
+    std::thread th;
+    static constexpr size_t CAP = 256u << 20; // text waiting to be written
+
+  public:
+    Writer() {
+        th = std::thread([this] {
+            for (;;) {
+                std::vector<std::string> take;
+                {
+                    std::unique_lock<std::mutex> l(m);
+                    cv_get.wait(l, [&] { return !q.empty() || closed; });
+                    if (q.empty()) return;
+                    take.swap(q);
+                    bytes = 0;
+                    cv_put.notify_all();
+                }
+                for (const std::string &s : take) std::fwrite(s.data(), 1, s.size(), stdout);
+            }
+        });
+    }
+    void write(std::string &&s) {
+        if (s.empty()) return;
+        std::unique_lock<std::mutex> l(m);
+        cv_put.wait(l, [&] { return bytes < CAP; });
+        bytes += s.size();
+        q.push_back(std::move(s));
+        cv_get.notify_one();
+    }
+    void finish() { // everything handed over so far is in stdout's buffer when this returns
+        {
+            std::lock_guard<std::mutex> l(m);
+            closed = true;
+            cv_get.notify_all();
+        }
+        if (th.joinable()) th.join();
+        std::fflush(stdout);
+    }
+    ~Writer() { finish(); }
+};
+
 const char *rec_name(const plaac_fasta *f, uint32_t i) { return f->names + f->name_off[i]; }
 
 struct Engine {
@@ -308,14 +355,13 @@ bool open_stream(const std::string &path, plaac_fasta_stream **fs) {
 }
 
 template <class Prep, class Work, class Sink>
-bool run_pipeline(Engine &eng, const std::string &path, plaac_fasta_stream *fs, const Stream &sp,
+bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, plaac_fasta_stream *fs, const Stream &sp,
                   std::vector<plaac_fasta *> *replay, std::vector<plaac_fasta *> *keep, uint64_t keep_bytes, Prep &&prep,
                   Work &&work, Sink &&sink) {
     if (!fs && !replay) return true; // nothing to read
-    const int nctx = plaac_node_size(eng.node);
-    Queue q((size_t)nctx + 1);
-    Reorder ro((uint64_t)2 * nctx + 2);
+    Queue q(4);
     std::atomic<bool> failed{false};
+    std::atomic<uint64_t> nbatches{UINT64_MAX};
     bool keeping = keep != nullptr, keep_overflow = false;
     uint64_t kept_bytes = 0;
     std::thread reader([&] {
@@ -353,7 +399,21 @@ bool run_pipeline(Engine &eng, const std::string &path, plaac_fasta_stream *fs, 
             q.put(std::move(b));
         }
         q.close();
-        ro.set_total(seq);
+        nbatches = seq;
+    });
+    // the reader is already parsing while the GPU contexts come up (HIP start-up takes a few hundred ms)
+    if (!eng.ready(P0)) {
+        failed = true;
+        q.close();
+        reader.join();
+        if (fs) plaac_fasta_close(fs);
+        return false;
+    }
+    const int nctx = plaac_node_size(eng.node);
+    Reorder ro((uint64_t)2 * nctx + 2);
+    std::thread closer([&] { // tells the reorder buffer how many batches there are once the reader knows
+        while (nbatches.load() == UINT64_MAX) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        ro.set_total(nbatches.load());
     });
     std::vector<std::thread> workers;
     for (int k = 0; k < nctx; ++k)
@@ -387,6 +447,7 @@ bool run_pipeline(Engine &eng, const std::string &path, plaac_fasta_stream *fs, 
         }
     }
     reader.join();
+    closer.join();
     for (auto &w : workers) w.join();
     if (fs) plaac_fasta_close(fs);
     if (keep && (keep_overflow || !ok || failed)) {
@@ -459,14 +520,13 @@ bool read_plot_list(const std::string &path, std::map<std::string, std::string> 
 bool count_background(Engine &eng, const plaac_params &P, const std::string &path, const Stream &sp,
                       double out[PLAAC_NAA], std::vector<plaac_fasta *> *keep, uint64_t keep_bytes) {
     for (int i = 0; i < PLAAC_NAA; ++i) out[i] = 0.0;
-    if (!eng.ready(P)) return false;
     std::mutex m;
     int64_t total[PLAAC_NAA] = {0};
     uint64_t nres = 0;
     plaac_fasta_stream *fs = nullptr;
     if (!open_stream(path, &fs)) return false; // a missing file: reported, zero counts (:4318-4321)
     const bool ok = run_pipeline(
-        eng, path, fs, sp, nullptr, keep, keep_bytes, [](Batch &) {},
+        eng, P, path, fs, sp, nullptr, keep, keep_bytes, [](Batch &) {},
         [&](plaac_ctx *ctx, Batch &b) {
             int64_t c[PLAAC_NAA];
             const plaac_status st = plaac_histogram(ctx, b.f->codes, b.f->offsets, b.f->nrec, c);
@@ -484,15 +544,17 @@ bool count_background(Engine &eng, const plaac_params &P, const std::string &pat
 }
 
 // ---- pass 2, summary mode (scoreallfastas :653-950) ----
-bool score_all(Engine &eng, const Options &o, const Stream &sp, std::vector<plaac_fasta *> *replay) {
+bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Stream &sp, std::vector<plaac_fasta *> *replay) {
     if (o.headers) column_notes();
     put(std::string(plaac_summary_header()) + "\n");
     plaac_fasta_stream *fs = nullptr; // the reference opens the file after it has printed the header (:715-750)
     if (!replay && !open_stream(o.input, &fs)) return false;
     const unsigned nt_max = plaac_host_threads();
     uint64_t nres = 0, nrec = 0;
+    std::fflush(stdout);
+    Writer writer; // from here on the table goes through the writer thread
     const bool ok = run_pipeline(
-        eng, o.input, fs, sp, replay, nullptr, 0, [](Batch &) {},
+        eng, P, o.input, fs, sp, replay, nullptr, 0, [](Batch &) {},
         [&](plaac_ctx *ctx, Batch &b) {
             b.rows.resize(b.f->nrec);
             return plaac_score(ctx, b.f->codes, b.f->offsets, b.f->nrec, b.rows.data(), nullptr);
@@ -532,21 +594,20 @@ bool score_all(Engine &eng, const Options &o, const Stream &sp, std::vector<plaa
                 for (unsigned t = 0; t < nt; ++t) pool.emplace_back(fmt, t);
                 for (auto &th : pool) th.join();
             }
-            for (unsigned t = 0; t < nt; ++t) {
+            for (unsigned t = 0; t < nt; ++t)
                 if (bad[t]) return false;
-                put(part[t]);
-            }
+            for (unsigned t = 0; t < nt; ++t) writer.write(std::move(part[t]));
             nres += f->nres;
             nrec += f->nrec;
             return true;
         });
-    std::fflush(stdout);
+    writer.finish();
     g_timer.lap("scoring pass (read + H2D + GPU + D2H + format + write)", (double)nres, "residues");
     return ok;
 }
 
 // ---- pass 2, track mode (plotsomefastas :587-649) ----
-bool plot_some(Engine &eng, const Options &o, const Stream &sp, std::vector<plaac_fasta *> *replay) {
+bool plot_some(Engine &eng, const plaac_params &P, const Options &o, const Stream &sp, std::vector<plaac_fasta *> *replay) {
     std::map<std::string, std::string> title, order;
     const bool all = o.plotlist == "all";
     if (!all && !read_plot_list(o.plotlist, title, order)) return false;
@@ -555,7 +616,7 @@ bool plot_some(Engine &eng, const Options &o, const Stream &sp, std::vector<plaa
     put(std::string(plaac_tracks_header()) + "\n");
     int genecount = 1; // advanced by the reader thread only (records are selected in file order, :617)
     const bool ok = run_pipeline(
-        eng, o.input, fs, sp, replay, nullptr, 0,
+        eng, P, o.input, fs, sp, replay, nullptr, 0,
         [&](Batch &b) { // select records and build the sub-batch that is scored
             const plaac_fasta *f = b.f;
             for (uint32_t i = 0; i < f->nrec; ++i) {
@@ -661,7 +722,7 @@ int main(int argc, char **argv) {
     // track mode moves 82 bytes per residue through the host: smaller batches
     Stream sp{(uint32_t)env_u64("PLAAC_BATCH_RECORDS", 262144),
               env_u64("PLAAC_BATCH_BYTES", o.plotlist.empty() ? (96ull << 20) : (8ull << 20))};
-    const uint64_t keep_bytes = env_u64("PLAAC_KEEP_BYTES", 2ull << 30);
+    const uint64_t keep_bytes = env_u64("PLAAC_KEEP_BYTES", 4ull << 30);
 
     // background counts (:377-384)
     double bgf[PLAAC_NAA] = {0}, fgf[PLAAC_NAA];
@@ -718,8 +779,8 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "plaac: plaac_node_set_params failed: %s\n", plaac_node_last_error(eng.node));
         return 1;
     }
-    ok = o.plotlist.empty() ? score_all(eng, o, sp, kept_valid ? &kept : nullptr)
-                            : plot_some(eng, o, sp, kept_valid ? &kept : nullptr);
+    ok = o.plotlist.empty() ? score_all(eng, P, o, sp, kept_valid ? &kept : nullptr)
+                            : plot_some(eng, P, o, sp, kept_valid ? &kept : nullptr);
     // The output is complete and flushed. Leaving through _exit skips unmapping the host and device buffers and the
     // HIP runtime's own shutdown, which the operating system does faster (PLAAC_TEARDOWN=1 keeps the orderly path,
     // e.g. under leak checkers; the library itself always tears down in order when its handles are destroyed).
