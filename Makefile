@@ -7,7 +7,7 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-f
 CSRC      = plaac_amd/csrc
 LIB       = plaac_amd/libplaac_native.so
 
-all: $(LIB) oracle $(if $(wildcard $(CSRC)/plaac_cli.cpp),cli)
+all: $(LIB) oracle $(if $(wildcard $(CSRC)/plaac_cli.cpp),cli) $(if $(JNI_H),jni)
 
 LIBSRC    = $(CSRC)/plaac_kernels.hip $(CSRC)/plaac_host.cpp $(CSRC)/plaac_node.cpp $(wildcard $(CSRC)/plaac_io.cpp)
 $(LIB): $(LIBSRC) $(wildcard include/*.h)
@@ -22,6 +22,18 @@ bin/plaac: $(CSRC)/plaac_cli.cpp $(LIB)
 oracle:
 	$(MAKE) -C oracle
 
+# JNI shim for the reference's Java host (jni/PlaacNative.java + jni/plaac_jni.cpp -> jni/libplaac_jni.so,
+# jni/PlaacNative.class). Needs a JDK: built only where $(JAVA_HOME)/include/jni.h exists (not in this image).
+JAVA_HOME ?= $(shell dirname $$(dirname $$(readlink -f $$(command -v javac 2>/dev/null) 2>/dev/null) 2>/dev/null) 2>/dev/null)
+JNI_H      = $(wildcard $(JAVA_HOME)/include/jni.h)
+jni: $(if $(JNI_H),jni/libplaac_jni.so,jni-skipped)
+jni/libplaac_jni.so: jni/plaac_jni.cpp jni/PlaacNative.java $(LIB) include/plaac_native.h
+	g++ -O2 -std=c++17 -fPIC -shared -Iinclude -I$(JAVA_HOME)/include -I$(JAVA_HOME)/include/linux -o $@ jni/plaac_jni.cpp \
+		-Lplaac_amd -lplaac_native -Wl,-rpath,'$$ORIGIN/../plaac_amd' -Wl,-rpath,/opt/rocm/lib
+	$(JAVA_HOME)/bin/javac -d jni jni/PlaacNative.java
+jni-skipped:
+	@echo "jni: no JDK found (JAVA_HOME/include/jni.h missing) - shim not built"
+
 asm: $(CSRC)/plaac_kernels.hip
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -Iinclude --cuda-device-only -S -o build/plaac_kernels.s $(CSRC)/plaac_kernels.hip \
@@ -31,4 +43,4 @@ clean:
 	rm -f $(LIB) bin/plaac
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle cli asm clean
+.PHONY: all oracle cli asm clean jni jni-skipped

@@ -1,0 +1,40 @@
+// PlaacNative.java — the Java side of the JNI binding of libplaac_native.so (MI355X-native PLAAC engine).
+//
+// Goes next to plaac.java (cli/src/ of whitehead/plaac, default package like every class there). The natives replace
+// the bodies of the reference's per-protein loops:
+//   plaac.java:444-500 (table setup in main)            -> paramsInit
+//   plaac.java:1655-1666 (computeaafreq, pass 1)        -> histogram
+//   plaac.java:759-880 (scoreallfastas body)            -> score(..., null)
+//   plaac.java:625-633 (plotsomefastas body)            -> score(..., tracks)
+// All buffers are DIRECT ByteBuffers in native byte order (zero copy: the shim hands their addresses to the C ABI);
+// one JNI call per batch. A non-zero plaac_status becomes an IllegalStateException carrying plaac_last_error().
+import java.nio.ByteBuffer;
+
+final class PlaacNative {
+    static { System.loadLibrary("plaac_jni"); } // thin shim (jni/plaac_jni.cpp) linked against libplaac_native.so
+
+    static final int NAA = 22;        // X A C D E F G H I K L M N P Q R S T V W Y *  (plaac.java:26)
+    static final int ROW_BYTES = 160; // sizeof(plaac_row): 13 doubles then 14 ints, see include/plaac_native.h
+    static final int TRACKS = 12;     // vit, map (1 byte/residue); charge hydro fi plaacllr papa fix2 plaacllrx2 papax2 post0 post1
+
+    private PlaacNative() {}
+
+    /** visible gfx950 devices */
+    static native int deviceCount();
+    /** sizeof(plaac_params): capacity of the params buffers below */
+    static native int paramsBytes();
+    /** table setup of main (fg / bgCounts may be null = built-in prd_freq_scer_28 / all zero) */
+    static native void paramsInit(ByteBuffer paramsOut, double[] fg, double[] bgCounts, double alpha, int corelength,
+                                  int ww1, int ww2, int ww3, boolean adjustProlines);
+    /** string2aa: n text bytes -> n residue codes */
+    static native void encode(ByteBuffer text, int n, ByteBuffer codesOut);
+    /** one scoring context per listed device (null: every visible device); returns the plaac_node handle */
+    static native long nodeCreate(ByteBuffer params, int[] devices);
+    static native void nodeSetParams(long node, ByteBuffer params);
+    static native void nodeDestroy(long node);
+    /** 22 residue counts over the valid records of the batch (codes untrimmed, offsets = nprot + 1 longs) */
+    static native void histogram(long node, ByteBuffer codes, ByteBuffer offsets, int nprot, long[] counts22);
+    /** rowsOut: nprot * ROW_BYTES; tracks: null (summary mode) or TRACKS direct buffers of total-residue elements */
+    static native void score(long node, ByteBuffer codes, ByteBuffer offsets, int nprot, ByteBuffer rowsOut,
+                             ByteBuffer[] tracks);
+}

@@ -1,0 +1,134 @@
+// plaac_jni.cpp — JNI shim between PlaacNative.java and the C ABI of libplaac_native.so (include/plaac_native.h).
+// One C call per native, no logic of its own: direct-buffer addresses in, plaac_status out; a non-zero status is thrown
+// as java.lang.IllegalStateException(plaac_last_error) — the reference's own error convention at this seam is an
+// uncaught exception. Build: `make jni` (needs $(JAVA_HOME)/include/jni.h; this image has no JDK,
+// so the default build skips it; tests/test_abi.py compile-checks it against a declarations-only stand-in).
+#include <jni.h>
+
+#include <cstdint>
+#include <string>
+
+#include "plaac_native.h"
+
+namespace {
+
+void raise(JNIEnv *env, const char *msg) {
+    jclass cls = env->FindClass("java/lang/IllegalStateException");
+    if (cls) env->ThrowNew(cls, msg ? msg : "plaac_native failed");
+}
+
+// address of a direct buffer that must hold at least `need` bytes; throws and returns null otherwise
+void *direct(JNIEnv *env, jobject buf, uint64_t need, const char *what) {
+    void *p = buf ? env->GetDirectBufferAddress(buf) : nullptr;
+    if (!p || (uint64_t)env->GetDirectBufferCapacity(buf) < need) {
+        raise(env, (std::string(what) + ": a direct ByteBuffer of sufficient capacity is required").c_str());
+        return nullptr;
+    }
+    return p;
+}
+
+plaac_node *node_of(jlong h) { return reinterpret_cast<plaac_node *>(static_cast<intptr_t>(h)); }
+
+} // namespace
+
+extern "C" {
+
+JNIEXPORT jint JNICALL Java_PlaacNative_deviceCount(JNIEnv *, jclass) { return plaac_device_count(); }
+
+JNIEXPORT jint JNICALL Java_PlaacNative_paramsBytes(JNIEnv *, jclass) { return (jint)plaac_sizeof_params(); }
+
+JNIEXPORT void JNICALL Java_PlaacNative_paramsInit(JNIEnv *env, jclass, jobject paramsOut, jdoubleArray fg,
+                                                   jdoubleArray bgCounts, jdouble alpha, jint corelength, jint ww1,
+                                                   jint ww2, jint ww3, jboolean adjustProlines) {
+    plaac_params *P = (plaac_params *)direct(env, paramsOut, plaac_sizeof_params(), "paramsOut");
+    if (!P) return;
+    double f[PLAAC_NAA], b[PLAAC_NAA];
+    if (fg) {
+        if (env->GetArrayLength(fg) != PLAAC_NAA) return raise(env, "fg must have 22 entries");
+        env->GetDoubleArrayRegion(fg, 0, PLAAC_NAA, f);
+    }
+    if (bgCounts) {
+        if (env->GetArrayLength(bgCounts) != PLAAC_NAA) return raise(env, "bgCounts must have 22 entries");
+        env->GetDoubleArrayRegion(bgCounts, 0, PLAAC_NAA, b);
+    }
+    if (plaac_params_init(P, fg ? f : nullptr, bgCounts ? b : nullptr, alpha, corelength, ww1, ww2, ww3,
+                          adjustProlines ? 1 : 0) != PLAAC_OK)
+        raise(env, "plaac_params_init rejected its arguments");
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_encode(JNIEnv *env, jclass, jobject text, jint n, jobject codesOut) {
+    if (n < 0) return raise(env, "negative length");
+    const char *t = (const char *)direct(env, text, (uint64_t)n, "text");
+    uint8_t *c = t ? (uint8_t *)direct(env, codesOut, (uint64_t)n, "codesOut") : nullptr;
+    if (c) plaac_encode(t, (size_t)n, c);
+}
+
+JNIEXPORT jlong JNICALL Java_PlaacNative_nodeCreate(JNIEnv *env, jclass, jobject params, jintArray devices) {
+    const plaac_params *P = (const plaac_params *)direct(env, params, plaac_sizeof_params(), "params");
+    if (!P) return 0;
+    jint ids[64];
+    jsize nd = devices ? env->GetArrayLength(devices) : 0;
+    if (nd > 64) {
+        raise(env, "at most 64 contexts");
+        return 0;
+    }
+    if (nd > 0) env->GetIntArrayRegion(devices, 0, nd, ids);
+    int dev[64];
+    for (jsize i = 0; i < nd; ++i) dev[i] = (int)ids[i];
+    plaac_node *node = nullptr;
+    if (plaac_node_create(P, nd > 0 ? dev : nullptr, (int)nd, &node) != PLAAC_OK) {
+        raise(env, plaac_node_last_error(nullptr));
+        return 0;
+    }
+    return (jlong) reinterpret_cast<intptr_t>(node);
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_nodeSetParams(JNIEnv *env, jclass, jlong node, jobject params) {
+    const plaac_params *P = (const plaac_params *)direct(env, params, plaac_sizeof_params(), "params");
+    if (P && plaac_node_set_params(node_of(node), P) != PLAAC_OK) raise(env, plaac_node_last_error(node_of(node)));
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_nodeDestroy(JNIEnv *, jclass, jlong node) { plaac_node_destroy(node_of(node)); }
+
+JNIEXPORT void JNICALL Java_PlaacNative_histogram(JNIEnv *env, jclass, jlong node, jobject codes, jobject offsets,
+                                                  jint nprot, jlongArray counts22) {
+    if (nprot < 0 || !counts22 || env->GetArrayLength(counts22) != PLAAC_NAA)
+        return raise(env, "histogram: nprot >= 0 and a long[22] are required");
+    const uint64_t *off = (const uint64_t *)direct(env, offsets, 8ull * ((uint64_t)nprot + 1), "offsets");
+    if (!off) return;
+    const uint8_t *c = (const uint8_t *)direct(env, codes, off[nprot], "codes");
+    if (!c) return;
+    int64_t counts[PLAAC_NAA];
+    if (plaac_node_histogram(node_of(node), c, off, (uint32_t)nprot, counts) != PLAAC_OK)
+        return raise(env, plaac_node_last_error(node_of(node)));
+    jlong out[PLAAC_NAA];
+    for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (jlong)counts[i];
+    env->SetLongArrayRegion(counts22, 0, PLAAC_NAA, out);
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_score(JNIEnv *env, jclass, jlong node, jobject codes, jobject offsets,
+                                              jint nprot, jobject rowsOut, jobjectArray tracks) {
+    if (nprot < 0) return raise(env, "score: negative nprot");
+    const uint64_t *off = (const uint64_t *)direct(env, offsets, 8ull * ((uint64_t)nprot + 1), "offsets");
+    if (!off) return;
+    const uint64_t total = off[nprot];
+    const uint8_t *c = (const uint8_t *)direct(env, codes, total, "codes");
+    plaac_row *rows = c ? (plaac_row *)direct(env, rowsOut, (uint64_t)nprot * sizeof(plaac_row), "rowsOut") : nullptr;
+    if (!rows) return;
+    plaac_tracks t, *tp = nullptr;
+    if (tracks) {
+        if (env->GetArrayLength(tracks) != 12) return raise(env, "tracks must be 12 direct buffers");
+        void *a[12];
+        for (int i = 0; i < 12; ++i) {
+            a[i] = direct(env, env->GetObjectArrayElement(tracks, i), total * (i < 2 ? 1u : 8u), "tracks[i]");
+            if (!a[i]) return;
+        }
+        t = plaac_tracks{(uint8_t *)a[0], (uint8_t *)a[1], (double *)a[2], (double *)a[3], (double *)a[4], (double *)a[5],
+                         (double *)a[6],  (double *)a[7],  (double *)a[8], (double *)a[9], (double *)a[10], (double *)a[11]};
+        tp = &t;
+    }
+    if (plaac_node_score(node_of(node), c, off, (uint32_t)nprot, rows, tp) != PLAAC_OK)
+        raise(env, plaac_node_last_error(node_of(node)));
+}
+
+} // extern "C"

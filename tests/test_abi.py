@@ -85,3 +85,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_ctypes" not in src and "plaac_oracle" not in src and "libplaac_oracle" not in src, f
+
+
+def test_jni_shim_compiles_and_binds_every_native_of_the_java_class():
+    """jni/plaac_jni.cpp cannot be built here (no JDK): check its syntax against a declarations-only jni.h stand-in and
+    that it defines exactly the natives jni/PlaacNative.java declares (JNI name mangling: Java_<class>_<method>)."""
+    import subprocess
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "tests", "jni_stub"), os.path.join(ROOT, "jni", "plaac_jni.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    java = open(os.path.join(ROOT, "jni", "PlaacNative.java")).read()
+    natives = sorted(re.findall(r"static\s+native\s+\w+(?:\[\])?\s+(\w+)\s*\(", java))
+    cpp = open(os.path.join(ROOT, "jni", "plaac_jni.cpp")).read()
+    defined = sorted(re.findall(r"JNICALL\s+Java_PlaacNative_(\w+)\s*\(", cpp))
+    assert natives == defined and len(natives) >= 6, (natives, defined)
+    # every C-ABI function the shim calls is declared by the header
+    called = set(re.findall(r"\b(plaac_[a-z0-9_]+)\s*\(", cpp))
+    assert called <= set(header_functions()), called - set(header_functions())
