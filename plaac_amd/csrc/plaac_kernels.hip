@@ -418,7 +418,7 @@ struct VitState {
     double s0, s1, h0;
 };
 
-template <bool GUARD>
+template <bool GUARD, bool PIN = true>
 __device__ __forceinline__ uint32_t vit_block(VitState &S, const double *__restrict__ s_row, const uint4 cur,
                                               uint32_t t0, uint32_t n, double lt00, double lt01, double lt10,
                                               double lt11, double h0lt, int jfirst) {
@@ -428,7 +428,7 @@ __device__ __forceinline__ uint32_t vit_block(VitState &S, const double *__restr
         if (j < jfirst) continue; // the very first residue (t = 0) is the initialisation, not a step
         if (!GUARD || t0 + (uint32_t)j < n) {
             const double *__restrict__ r = s_row + block_code(cur, j) * R_W;
-            const double e0 = r[R_LE0], e1 = r[R_LE1], eh = r[R_LE0H];
+            const double e0 = r[R_LE0], e1 = r[R_LE1];
             // (:3087-3100): state 0 stays the arg-max on ties (strict >)
             const double v00 = lt00 + S.s0, v10 = lt10 + S.s1, v01 = lt01 + S.s0, v11 = lt11 + S.s1;
             const bool g0 = v10 > v00, g1 = v11 > v01;
@@ -436,13 +436,16 @@ __device__ __forceinline__ uint32_t vit_block(VitState &S, const double *__restr
             // two-register select; the tie rule lives in the traceback bit only
             S.s0 = __builtin_fmax(v00, v10) + e0;
             S.s1 = __builtin_fmax(v01, v11) + e1;
-            S.h0 = (h0lt + S.h0) + eh; // hmm0: Viterbi == forward == running sum
+            if (PIN) S.h0 = (h0lt + S.h0) + r[R_LE0H]; // hmm0: Viterbi == forward == running sum; the
+                                                      // latency form (PIN = false) leaves it to k_win / k_finish
             tbw |= ((uint32_t)g0 | ((uint32_t)g1 << 1)) << (2 * j);
         }
         // Left alone, the scheduler defers all 32 compares (they are off the critical chain) to the end of the block and
         // keeps their 64 operands alive: 180 VGPRs, so that a wave of this kernel never fits on a SIMD beside three
         // waves of the window kernel. Pinning the traceback word every four steps brings the kernel to 62 VGPRs.
-        if ((j & 3) == 3) {
+        // (PIN = false, latency mode: the wave with the longest protein has its SIMD to itself, registers are free, and
+        // without the barriers the LDS lookups of all 16 steps are issued ahead of the chain)
+        if (PIN && (j & 3) == 3) {
             asm volatile("" : "+v"(tbw));
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -471,10 +474,13 @@ __device__ __forceinline__ uint32_t traceback_block(uint32_t &state, int &cur, i
 // Parameter sweeps (BASELINE config 5): the Viterbi parse depends on the background mix alpha but not on the core
 // length, so ONE pass of sweeps 1-2 serves up to MAXC core lengths; sweep 3 then carries one trailing chain
 // and one best-window record per core length. NC = 1 is the ordinary single-parameter call.
+constexpr uint32_t CORE_LONG_ROWS = 128; // latency form: wave-groups with >= 2048-residue proteins (k_core_*)
+constexpr unsigned CORE_MAX_GROUPS = 2048;
 constexpr int MAXC = 4;
 struct SweepTargets {
     uint32_t c[MAXC];     // core lengths
     plaac_row *rows[MAXC]; // one row array per core length
+    uint32_t stop_after;   // DIAGNOSTIC (PLAAC_VIT_STOP): k_vit returns after this sweep (0: runs all three)
 };
 
 template <int NC>
@@ -512,7 +518,7 @@ __device__ __forceinline__ void core_block(CoreState<NC> &S, const double *__res
     }
 }
 
-template <int NC>
+template <int NC, bool LAT = false>
 __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
@@ -569,9 +575,9 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
             const uint4 cur = nxt;
             if (t0 + 16u < n) nxt = PL.chunk((t0 >> 4) + 1u);
             uint32_t tbw;
-            if (t0 == 0u) tbw = vit_block<true>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 1);
-            else if (t0 + 16u <= n) tbw = vit_block<false>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0);
-            else tbw = vit_block<true>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0);
+            if (t0 == 0u) tbw = vit_block<true, !LAT>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 1);
+            else if (t0 + 16u <= n) tbw = vit_block<false, !LAT>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0);
+            else tbw = vit_block<true, !LAT>(V, s_row, cur, t0, n, lt00, lt01, lt10, lt11, h0lt, 0);
             PL.set_word(t0 >> 4, tbw);
         }
     }
@@ -579,11 +585,12 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
     const double vend0 = V.s0 + lf0, vend1 = V.s1 + lf1;
     uint32_t state = vend1 > vend0 ? 1u : 0u;
     {
-        const double hv = (state ? vend1 : vend0) - (V.h0 + T->h0_lf0);
+        const double hv = LAT ? (state ? vend1 : vend0) : (state ? vend1 : vend0) - (V.h0 + T->h0_lf0);
 #pragma unroll
-        for (int k = 0; k < NC; ++k) tg.rows[k][J.p].hmm_vit = hv;
+        for (int k = 0; k < NC; ++k) tg.rows[k][J.p].hmm_vit = hv; // LAT: k_finish subtracts hmm0's total
     }
 
+    if (tg.stop_after == 1u) return;
     // ---------------- sweep 2: traceback t = n-1 .. 0 (:3111-3113), longest run ----------------
     {
         int cur = 0, maxrun = 0;
@@ -608,6 +615,11 @@ __global__ __launch_bounds__(KA_THREADS) void k_vit(const uint8_t *__restrict__ 
         for (int k = 0; k < NC; ++k) tg.rows[k][J.p].vit_maxrun = maxrun;
     }
 
+    if (tg.stop_after == 2u) return;
+    // latency form: the core window of the wave-groups with very long proteins is found by k_core_chain / _eval /
+    // _reduce (wave-uniform: nw of lane 0 ... the group's row count is the maximum over its lanes)
+    if (LAT && wave_max_u32(nw) >= CORE_LONG_ROWS && ((blockIdx.x * KA_THREADS + threadIdx.x) >> 6) < CORE_MAX_GROUPS)
+        return;
     // ---------------- sweep 3: masked core window(s) (:818-833) ----------------
     CoreState<NC> C;
     C.mL = 0.0;
@@ -799,6 +811,244 @@ __global__ __launch_bounds__(KA_THREADS) void k_fwd(const uint8_t *__restrict__ 
 
 }
 
+// ---- masked core window, latency form (wave-groups whose longest protein has >= CORE_LONG_ROWS rows) ----
+// In k_vit the third sweep walks every protein once more with ~22 instructions per step; for the wave that holds
+// the longest protein that is another n x 160 cycles on one SIMD while the chip idles. Only ONE thing in it is serial:
+// the masked prefix sum psum[i+1] = psum[i] + maa3[i] (:818-823, its rounding is part of the answer). So:
+//   k_core_chain   lane per protein: the prefix chain alone (lookup + add + store), P[t] = psum[t+1]
+//   k_core_eval    16 waves per group, a wave per packed row: every window d = P[t] - P[t-c] (the trailing chain of the
+//                  in-kernel form IS the leading chain c steps earlier, bit for bit), first maximum per row
+//   k_core_reduce  lane per protein: first maximum over the rows (strict >, increasing row), then PRD as in k_vit
+struct CorePart {
+    double d;
+    int start, pad;
+};
+
+__global__ __launch_bounds__(64) void k_core_chain(const uint4 *__restrict__ order, uint32_t nprot,
+                                                   const DevTables *__restrict__ T, const uint4 *__restrict__ packed,
+                                                   const uint32_t *__restrict__ grow, const uint32_t *__restrict__ bits,
+                                                   double *__restrict__ pfx) {
+    __shared__ double s_mask[64];
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    const uint32_t r0 = grow[g];
+    if (grow[g + 1] - r0 < CORE_LONG_ROWS) return;
+    {
+        const int k = lane & 31;
+        s_mask[lane] = lane < 32 ? T->big_neg : (k < NAA ? T->llr[k] : T->llr[0]);
+    }
+    __builtin_amdgcn_s_setprio(3);
+    __syncthreads();
+    const uint32_t gid = g * 64u + lane;
+    const uint32_t n = gid < nprot ? order[gid].z : 0u;
+    if (n == 0u) return;
+    const uint4 *__restrict__ pk = packed + (size_t)r0 * 64u + lane;
+    const uint32_t *__restrict__ wb = bits + (size_t)r0 * 64u + lane;
+    double *__restrict__ pf = pfx + (size_t)r0 * 1024u + lane;
+    double mL = 0.0;
+    uint4 nxt = pk[0];
+    uint32_t wnext = wb[0];
+    for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
+        const uint4 cur = nxt;
+        const uint32_t wl = wnext;
+        if (t0 + 16u < n) {
+            nxt = pk[(size_t)((t0 >> 4) + 1u) * 64u];
+            wnext = wb[(size_t)((t0 >> 4) + 1u) * 64u];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { // positions past the end of a shorter protein extend the chain harmlessly
+            mL = mL + s_mask[(((wl >> j) & 1u) << 5) | block_code(cur, j)]; // psum[i+1] = psum[i] + maa3[i]
+            pf[(size_t)(t0 + (uint32_t)j) * 64u] = mL;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_core_eval(const uint4 *__restrict__ order, uint32_t nprot, uint32_t ngroups,
+                                                  const uint32_t *__restrict__ grow, const double *__restrict__ pfx,
+                                                  CorePart *__restrict__ part, uint32_t c) {
+    const uint32_t r = blockIdx.x, lane = threadIdx.x; // one wave per packed row of the long wave-groups
+    const uint32_t glong = ngroups < CORE_MAX_GROUPS ? ngroups : CORE_MAX_GROUPS;
+    if (r >= grow[glong]) return; // the long groups are the first ones of the descending-length plan
+    // group of this row: the largest g with grow[g] <= r (64-ary search, wave-uniform; as k_post)
+    uint32_t lo = 0, hi = glong;
+    while (hi - lo > 1u) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint32_t idx = lo + (lane + 1u) * step;
+        const bool le = idx < hi && grow[idx] <= r;
+        const uint32_t k = (uint32_t)__popcll(__ballot(le));
+        lo += k * step;
+        hi = lo + step < hi ? lo + step : hi;
+    }
+    const uint32_t g = lo, r0 = grow[g];
+    if (grow[g + 1] - r0 < CORE_LONG_ROWS) return;
+    const uint32_t gid = g * 64u + lane;
+    const uint32_t n = gid < nprot ? order[gid].z : 0u;
+    const double *__restrict__ pf = pfx + (size_t)r0 * 1024u + lane;
+    double best = -INFINITY;
+    int bstart = -1;
+    const uint32_t t0 = (r - r0) << 4;
+    if (t0 < n) {
+        double lead[16], trail[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { // all 32 loads in flight together
+            const uint32_t t = t0 + (uint32_t)j;
+            const bool in = t < n && t + 1u >= c;
+            lead[j] = in ? pf[(size_t)t * 64u] : 0.0;
+            trail[j] = (in && t >= c) ? pf[(size_t)(t - c) * 64u] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t t = t0 + (uint32_t)j;
+            if (t < n && t + 1u >= c) { // window [t+1-c, t]
+                const double d = t + 1u == c ? lead[j] : lead[j] - trail[j]; // window 0: psum[c] itself (:1226)
+                const bool upd = d > best; // strict >: the first window wins ties
+                best = upd ? d : best;
+                bstart = upd ? (int)(t + 1u - c) : bstart;
+            }
+        }
+    }
+    part[(size_t)r * 64u + lane] = CorePart{best, bstart, 0};
+}
+
+__global__ __launch_bounds__(64) void k_core_reduce(const uint8_t *__restrict__ codes, const uint4 *__restrict__ order,
+                                                    uint32_t nprot, const DevTables *__restrict__ T,
+                                                    const uint32_t *__restrict__ grow, const uint32_t *__restrict__ bits,
+                                                    const CorePart *__restrict__ part, plaac_row *__restrict__ rows,
+                                                    uint32_t c) {
+    __shared__ double s_llr[ROWS];
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    const uint32_t r0 = grow[g];
+    if (grow[g + 1] - r0 < CORE_LONG_ROWS) return;
+    if (lane < (uint32_t)ROWS) s_llr[lane] = T->llr[lane < (uint32_t)NAA ? lane : 0];
+    __syncthreads();
+    const uint32_t gid = g * 64u + lane;
+    if (gid >= nprot) return;
+    const uint4 it = order[gid];
+    const uint32_t n = it.z;
+    if (n == 0u) return; // k_vit has zeroed the fields of a skipped record
+    plaac_row *row = rows + it.w;
+    const uint8_t *__restrict__ x = codes + (((uint64_t)it.y << 32) | it.x);
+    const CorePart *__restrict__ pt = part + (size_t)r0 * 64u + lane;
+    const uint32_t *__restrict__ wb = bits + (size_t)r0 * 64u + lane;
+    const uint32_t nw = (n + 15u) >> 4;
+    double best = -INFINITY;
+    int bstart = -1;
+    for (uint32_t r = 0; r < nw; r += 8u) { // eight independent loads in flight, then the ordered comparison
+        CorePart q[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) q[k] = r + k < nw ? pt[(size_t)(r + k) * 64u] : CorePart{-INFINITY, -1, 0};
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const bool upd = q[k].d > best;
+            best = upd ? q[k].d : best;
+            bstart = upd ? q[k].start : bstart;
+        }
+    }
+    if (best > T->big_neg / 2) { // :861 - a core exists; expand it to the whole Viterbi run (:863-866)
+        auto bit = [&](int q) { return (wb[(size_t)((uint32_t)q >> 4) * 64u] >> (q & 15)) & 1u; };
+        int a = bstart, z = bstart + (int)c - 1;
+        while (a > 0 && bit(a - 1)) --a;
+        while (z + 1 < (int)n && bit(z + 1)) ++z;
+        double prd = 0.0; // PRDscore: left-to-right sum over the run (:870-872)
+        for (int q = a; q <= z; ++q) {
+            const uint32_t cq = x[q];
+            prd = prd + s_llr[cq < 22u ? cq : 22u];
+        }
+        row->core_score = best;
+        row->core_start = bstart;
+        row->core_end = bstart + (int)c - 1;
+        row->prd_score = prd;
+        row->prd_start = a;
+        row->prd_end = z;
+    } else { // :873-880
+        row->core_score = __builtin_nan("");
+        row->core_start = -1;
+        row->core_end = -2;
+        row->prd_score = 0.0;
+        row->prd_start = -1;
+        row->prd_end = -2;
+    }
+}
+
+// ---- role F, latency form: TWO LANES PER PROTEIN (lane 2q: background state, lane 2q+1: PrD state). One wave
+//      instruction advances both states of 32 proteins, so the wave that holds the longest protein issues half the fp64
+//      operations per step (a single wave issues one fp64 operation per ~8 cycles: the chain of the longest protein,
+//      not throughput, bounds small batches). The partner's value crosses with one quad-permute DPP move per dword.
+//      hmm0's running sum is left to k_win (role 1); k_finish forms HMMall / HMMvit once both are known.
+__device__ __forceinline__ double dpp_pair_swap_f64(double v) { // lane 2q <-> lane 2q+1
+    const long long u = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u & 0xffffffffll), 0xB1, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)((unsigned long long)u >> 32), 0xB1, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void fwd_pair_block(double &a, const double *__restrict__ s_row,
+                                               const double *__restrict__ s_lut, const uint4 cur, uint32_t t0, uint32_t n,
+                                               double ltself, double ltcross, int ecol, int jfirst) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < jfirst) continue;
+        if (!GUARD || t0 + (uint32_t)j < n) {
+            const double e = s_row[block_code(cur, j) * R_W + ecol];
+            // (:3360-3368) a[i][t] = LSE(lt[0][i] + a[0][t-1], lt[1][i] + a[1][t-1]) + le[i][x_t]; the LUT-LSE is symmetric
+            const double f = lse_lut(s_lut, ltself + a, ltcross + dpp_pair_swap_f64(a));
+            a = f + e;
+        }
+    }
+}
+
+__global__ __launch_bounds__(KA_THREADS) void k_fwd_pair(const uint4 *__restrict__ order, uint32_t nprot,
+                                                         const DevTables *__restrict__ T,
+                                                         const uint4 *__restrict__ packed,
+                                                         const uint32_t *__restrict__ grow, double *__restrict__ lmarg) {
+    __shared__ double s_lut[LUTLEN + 1];
+    __shared__ double s_row[ROWS * R_W];
+    for (int i = threadIdx.x; i < LUTLEN; i += KA_THREADS) s_lut[i] = T->loglut[i];
+    if (threadIdx.x == 0) s_lut[LUTLEN] = 0.0;
+    load_rows(s_row, T);
+    __syncthreads();
+    const uint32_t st = threadIdx.x & 1u;                                  // this lane's state
+    const uint32_t gid = blockIdx.x * (KA_THREADS / 2) + (threadIdx.x >> 1); // plan index of the lane pair's protein
+    uint32_t n = 0, p = 0;
+    if (gid < nprot) {
+        const uint4 it = order[gid];
+        n = it.z;
+        p = it.w;
+    }
+    set_wave_priority(n);
+    if (gid >= nprot) return;
+    if (n == 0) {
+        if (st == 0u) lmarg[p] = 0.0;
+        return;
+    }
+    const uint4 *__restrict__ pk = packed + (size_t)grow[gid >> 6] * 64u + (gid & 63u);
+    const double ltself = T->lt[st][st], ltcross = T->lt[1u - st][st], lf = T->lf[st];
+    const int ecol = st ? R_LE1 : R_LE0;
+    uint4 nxt = pk[0];
+    double a = T->li[st] + s_row[block_code(nxt, 0) * R_W + ecol];
+    for (uint32_t t0 = 0; t0 < n; t0 += 16u) {
+        const uint4 cur = nxt;
+        if (t0 + 16u < n) nxt = pk[(size_t)((t0 >> 4) + 1u) * 64u];
+        if (t0 == 0u) fwd_pair_block<true>(a, s_row, s_lut, cur, t0, n, ltself, ltcross, ecol, 1);
+        else if (t0 + 16u <= n) fwd_pair_block<false>(a, s_row, s_lut, cur, t0, n, ltself, ltcross, ecol, 0);
+        else fwd_pair_block<true>(a, s_row, s_lut, cur, t0, n, ltself, ltcross, ecol, 0);
+    }
+    const double mine = a + lf; // (:3369-3375)
+    const double lm = lse_lut(s_lut, mine, dpp_pair_swap_f64(mine));
+    if (st == 0u) lmarg[p] = lm;
+}
+
+// latency forms: HMMall = lmarginalprob(hmm1) - total(hmm0), HMMvit = lviterbiprob(hmm1) - total(hmm0) (:797-798) once the
+// three kernels that produced the terms have finished (k_fwd_pair -> lmarg, k_vit<.,true> -> row.hmm_vit, k_win role 1 -> h0)
+__global__ void k_finish(plaac_row *__restrict__ rows, const double *__restrict__ lmarg, const double *__restrict__ h0,
+                         uint32_t nprot) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprot) return;
+    const double h = h0[p];
+    rows[p].hmm_all = lmarg[p] - h;
+    rows[p].hmm_vit = rows[p].hmm_vit - h;
+}
+
 // ---- role B (track mode): backward recurrence (:3377-3391). It does not depend on the forward values, so it is
 //      its own chain on its own stream, concurrent with k_fwd; k_post combines the two. ----
 __global__ __launch_bounds__(KA_THREADS) void k_bwd(const uint64_t *__restrict__ offsets,
@@ -916,7 +1166,7 @@ __global__ __launch_bounds__(64) void k_post(const uint64_t *__restrict__ offset
 //      min == max), mean hydropathy / charge / FoldIndex (:4877-4885) ----
 template <int NC>
 struct WinState {
-    double hydsum, psL;
+    double hydsum, psL, h0;
     double psT[NC], llrbest[NC];
     int chg, cntL, cntT, mwbest, mwstart;
     int llrstart[NC];
@@ -925,35 +1175,45 @@ struct WinState {
 __device__ __forceinline__ int is_nq(uint32_t c) { return (c == 12u || c == 14u) ? 1 : 0; }
 
 // STEADY: the whole block has t >= max(c, 80): all trailing streams run and every step closes every window
-template <bool GUARD, bool STEADY, int NC>
+// ROLE 0: everything; 1: MW window + means; 2: LLR window(s); 3: role 1 + hmm0's running sum (for k_finish). When the step is bound by the serial chain of the
+// longest protein (small batches, very long proteins) the two halves run as two kernels side by side: each wave then
+// issues about half the instructions per step.
+template <bool GUARD, bool STEADY, int NC, int ROLE>
 __device__ __forceinline__ void win_block(WinState<NC> &S, const double *__restrict__ s_row, const uint4 cur,
                                           const uint4 (&ccur)[NC], const uint4 mcur, uint32_t t0, uint32_t n,
-                                          const uint32_t (&c)[NC], uint32_t mw) {
+                                          const uint32_t (&c)[NC], uint32_t mw, double h0li, double h0lt) {
+    constexpr bool DO_MW = ROLE != 2, DO_LLR = ROLE == 0 || ROLE == 2, DO_H0 = ROLE == 3;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t t = t0 + (uint32_t)j;
         if (!GUARD || t < n) {
             const uint32_t xc = block_code(cur, j);
             const double *__restrict__ r = s_row + xc * R_W;
-            S.hydsum = S.hydsum + r[R_HYD]; // mean (:1584-1588)
-            S.chg += (xc == 3u || xc == 4u) ? 1 : ((xc == 9u || xc == 15u) ? -1 : 0);
-            S.cntL += is_nq(xc);
-            if (STEADY || t >= 80u) S.cntT += is_nq(block_code(mcur, j)); // only reached when mw == 80
-            if (STEADY) {
-                const int d = S.cntL - S.cntT;
-                const bool upd = d > S.mwbest;
-                S.mwbest = upd ? d : S.mwbest;
-                S.mwstart = upd ? (int)(t + 1u - 80u) : S.mwstart;
-            } else {
-                const int d = S.cntL - S.cntT;
-                const bool upd = (t + 1 >= mw) && (t + 1 == mw || d > S.mwbest);
-                S.mwbest = upd ? d : S.mwbest;
-                S.mwstart = upd ? (int)(t + 1 - mw) : S.mwstart;
+            if (DO_H0) { // hmm0: S = li0 + le0[x0]; S = (lt00 + S) + le0[xt]
+                const double eh = r[R_LE0H];
+                S.h0 = (!STEADY && t == 0u) ? h0li + eh : (h0lt + S.h0) + eh;
+            }
+            if (DO_MW) {
+                S.hydsum = S.hydsum + r[R_HYD]; // mean (:1584-1588)
+                S.chg += (xc == 3u || xc == 4u) ? 1 : ((xc == 9u || xc == 15u) ? -1 : 0);
+                S.cntL += is_nq(xc);
+                if (STEADY || t >= 80u) S.cntT += is_nq(block_code(mcur, j)); // only reached when mw == 80
+                if (STEADY) {
+                    const int d = S.cntL - S.cntT;
+                    const bool upd = d > S.mwbest;
+                    S.mwbest = upd ? d : S.mwbest;
+                    S.mwstart = upd ? (int)(t + 1u - 80u) : S.mwstart;
+                } else {
+                    const int d = S.cntL - S.cntT;
+                    const bool upd = (t + 1 >= mw) && (t + 1 == mw || d > S.mwbest);
+                    S.mwbest = upd ? d : S.mwbest;
+                    S.mwstart = upd ? (int)(t + 1 - mw) : S.mwstart;
+                }
             }
             // psum[i+1] = psum[i] + llr[x_i]; each trailing prefix sum is the same chain c steps later
-            S.psL = S.psL + r[R_LLR];
+            if (DO_LLR) S.psL = S.psL + r[R_LLR];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) {
+            for (int k = 0; k < (DO_LLR ? NC : 0); ++k) {
                 if (STEADY || t >= c[k]) S.psT[k] = S.psT[k] + s_row[block_code(ccur[k], j) * R_W + R_LLR];
                 if (STEADY || t + 1 >= c[k]) {
                     const bool first = !STEADY && t + 1 == c[k];
@@ -964,7 +1224,7 @@ __device__ __forceinline__ void win_block(WinState<NC> &S, const double *__restr
                 }
             }
         }
-        if ((j & 3) == 3) { // keeps the integer side work of four steps from piling up at the block's end (80 VGPRs
+        if (ROLE == 0 && (j & 3) == 3) { // keeps the integer side work of four steps from piling up at the block's end (80 VGPRs
                             // instead of 86: the wave then fits beside three window-kernel waves of 144)
             asm volatile("" : "+v"(S.mwbest), "+v"(S.chg));
             __builtin_amdgcn_sched_barrier(0);
@@ -972,14 +1232,16 @@ __device__ __forceinline__ void win_block(WinState<NC> &S, const double *__restr
     }
 }
 
-template <int NC>
+template <int NC, int ROLE>
 __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ codes,
                                                     const uint64_t *__restrict__ offsets,
                                                     const uint32_t *__restrict__ neff,
                                                     const uint4 *__restrict__ order, uint32_t nprot,
                                                     const DevTables *__restrict__ T,
                                                     const uint4 *__restrict__ packed,
-                                                    const uint32_t *__restrict__ grow, SweepTargets tg) {
+                                                    const uint32_t *__restrict__ grow, SweepTargets tg,
+                                                    double *__restrict__ h0out) {
+    constexpr bool DO_MW = ROLE != 2, DO_LLR = ROLE == 0 || ROLE == 2, DO_H0 = ROLE == 3;
     __shared__ double s_row[ROWS * R_W];
     load_rows(s_row, T);
     __syncthreads();
@@ -988,12 +1250,19 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
     set_wave_priority(n);
     if (blockIdx.x * KA_THREADS + threadIdx.x >= nprot) return;
     if (n == 0) {
+        if (DO_H0) h0out[J.p] = 0.0;
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             plaac_row *row = tg.rows[k] + J.p;
-            row->llr_score = row->fi_meanhydro = row->fi_meancharge = row->fi_meancombo = 0.0;
-            row->mw_score = row->mw_start = row->mw_end = row->llr_start = row->llr_end = 0;
-            row->prot_len = 0;
+            if (DO_MW) {
+                row->fi_meanhydro = row->fi_meancharge = row->fi_meancombo = 0.0;
+                row->mw_score = row->mw_start = row->mw_end = 0;
+                row->prot_len = 0;
+            }
+            if (DO_LLR) {
+                row->llr_score = 0.0;
+                row->llr_start = row->llr_end = 0;
+            }
         }
         return;
     }
@@ -1008,7 +1277,8 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
     const uint32_t mw = n < 80u ? n : 80u; // :769-770 (a protein shorter than 80 has a single window)
 
     WinState<NC> W;
-    W.hydsum = W.psL = 0.0;
+    W.hydsum = W.psL = W.h0 = 0.0;
+    const double h0li = T->h0_li0, h0lt = T->h0_lt00;
     W.chg = W.cntL = W.cntT = W.mwbest = W.mwstart = 0;
     // phase-locked streams: residues at t, at t - c[k] (LLR windows) and at t - 80 (MW window)
     uint4 nxt = PL.chunk(0), cnxt[NC], mnxt = make_uint4(0u, 0u, 0u, 0u);
@@ -1028,37 +1298,42 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
         if (t0 + 16u < n) {
             nxt = PL.chunk((t0 >> 4) + 1u);
             const int sm = (int)t0 + 16 - 80;
-            if (sm + 15 >= 0) mnxt = PL.window(sm);
+            if (DO_MW && sm + 15 >= 0) mnxt = PL.window(sm);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 const int sc = (int)t0 + 16 - (int)c[k];
-                if (sc + 15 >= 0) cnxt[k] = PL.window(sc);
+                if (DO_LLR && sc + 15 >= 0) cnxt[k] = PL.window(sc);
             }
         }
         const bool full = t0 + 16u <= n;
         if (t0 >= steady_from) { // wave-uniform
-            if (full) win_block<false, true, NC>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
-            else win_block<true, true, NC>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
+            if (full) win_block<false, true, NC, ROLE>(W, s_row, cur, ccur, mcur, t0, n, c, mw, h0li, h0lt);
+            else win_block<true, true, NC, ROLE>(W, s_row, cur, ccur, mcur, t0, n, c, mw, h0li, h0lt);
         } else {
-            win_block<true, false, NC>(W, s_row, cur, ccur, mcur, t0, n, c, mw);
+            win_block<true, false, NC, ROLE>(W, s_row, cur, ccur, mcur, t0, n, c, mw, h0li, h0lt);
         }
     }
+    if (DO_H0) h0out[J.p] = W.h0 + T->h0_lf0; // hmm0.lviterbiprob == hmm0.lmarginalprob
     const double meanhydro = (1.0 * W.hydsum) / (double)(int)n;
     const double meancharge = (1.0 * (double)W.chg) / (double)(int)n;
     const double meanfi = (T->cc[2] + T->cc[1] * fabs(meancharge)) + T->cc[0] * meanhydro; // :4885
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         plaac_row *row = tg.rows[k] + J.p;
-        row->prot_len = (int32_t)n;
-        row->mw_score = W.mwbest;
-        row->mw_start = W.mwstart;
-        row->mw_end = W.mwstart + (int)mw - 1;
-        row->llr_score = W.llrbest[k];
-        row->llr_start = W.llrstart[k];
-        row->llr_end = W.llrstart[k] < 0 ? -2 : W.llrstart[k] + (int)c[k] - 1;
-        row->fi_meanhydro = meanhydro;
-        row->fi_meancharge = meancharge;
-        row->fi_meancombo = meanfi;
+        if (DO_MW) {
+            row->prot_len = (int32_t)n;
+            row->mw_score = W.mwbest;
+            row->mw_start = W.mwstart;
+            row->mw_end = W.mwstart + (int)mw - 1;
+            row->fi_meanhydro = meanhydro;
+            row->fi_meancharge = meancharge;
+            row->fi_meancombo = meanfi;
+        }
+        if (DO_LLR) {
+            row->llr_score = W.llrbest[k];
+            row->llr_start = W.llrstart[k];
+            row->llr_end = W.llrstart[k] < 0 ? -2 : W.llrstart[k] + (int)c[k] - 1;
+        }
     }
 }
 
@@ -3075,7 +3350,7 @@ struct plaac_ctx {
     std::vector<hipEvent_t> gev;  // per-group "forward pass done" events of a sweep
     std::vector<hipStream_t> gstreams; // side streams of the 2nd, 3rd ... group of a sweep (three each)
     std::vector<hipEvent_t> gjev;      // their join events
-    hipEvent_t jev[4] = {nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
+    hipEvent_t jev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
     uint32_t *d_neff = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
@@ -3093,6 +3368,11 @@ struct plaac_ctx {
     uint2 *d_clist = nullptr;
     uint32_t *d_ccount = nullptr, *d_fblist = nullptr, *d_fbcount = nullptr;
     size_t cap_clist = 0, cap_ccount = 0, cap_fblist = 0;
+    double *d_lat = nullptr; // latency forms: [0, nprot) lmarginalprob of hmm1, [nprot, 2 nprot) total of hmm0
+    size_t cap_lat = 0;
+    double *d_corep = nullptr; // latency forms: masked prefix sums of the long wave-groups, packed row numbering
+    void *d_corepart = nullptr; // their per-row best windows
+    size_t cap_corep = 0, cap_corepart = 0;
     bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
     size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_bwd = 0, cap_grow = 0, cap_packed = 0;
     // staging for the host-buffer entry points
@@ -3107,7 +3387,9 @@ struct plaac_ctx {
     static constexpr int EV_PER = 15;  // start, planned, {begin,end} x {vit,fwd,win,tracks}, joined, {begin,end} x {pack,bwd}
     hipEvent_t ev[EV_SETS][EV_PER] = {};
     uint64_t ncalls = 0;
-    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; // high-priority side streams of the K-A roles
+    hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // high-priority side streams of the K-A roles
+    uint32_t vit_stop = 0; // DIAGNOSTIC, PLAAC_VIT_STOP=1|2: k_vit stops after that sweep (timing the sweeps; results are wrong)
+    int latency_mode = -1; // PLAAC_LATENCY_MODE=0/1 forces the throughput / latency forms of the K-A kernels (-1: per batch)
     bool serial = false;                              // PLAAC_SERIAL_STREAMS=1: everything on one stream
     bool generic_tracks = false;                      // PLAAC_GENERIC_TRACKS=1: never use the ww=41 fast path
     bool per_protein_tracks = false;                  // PLAAC_KB_PER_PROTEIN=1: ww=41 fast path, one protein at a time
@@ -3266,6 +3548,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         ctx->per_protein_tracks = ppt && ppt[0] == '1';
         const char *kbf = std::getenv("PLAAC_KB_FILTER");
         ctx->kb_filter = !(kbf && kbf[0] == '0');
+        if (const char *vs = std::getenv("PLAAC_VIT_STOP")) ctx->vit_stop = (uint32_t)std::atoi(vs);
+        const char *lat = std::getenv("PLAAC_LATENCY_MODE");
+        if (lat && (lat[0] == '0' || lat[0] == '1')) ctx->latency_mode = lat[0] - '0';
     }
     for (auto &set : ctx->ev)
         for (auto &ev : set)
@@ -3330,7 +3615,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
-    for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount})
+    for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount,
+                    (void *)ctx->d_lat, (void *)ctx->d_corep, ctx->d_corepart})
         if (b) (void)hipFree(b);
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -3420,6 +3706,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if ((rc = grow(ctx, ctx->d_order, ctx->cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
     const uint32_t ngroups = (nprot + 63u) / 64u;
     if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 1)) != PLAAC_OK) return rc;
+    if (!d_tracks && npoints == 1 && (rc = grow(ctx, ctx->d_lat, ctx->cap_lat, 2 * (size_t)nprot)) != PLAAC_OK) return rc;
     if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
         const size_t kb_blocks = ((size_t)nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
         if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, kb_blocks * KB_PROTEINS_PER_BLOCK)) != PLAAC_OK) return rc;
@@ -3458,7 +3745,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     hipEvent_t *evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
     enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10, E_PACK = 11, E_BWD = 13 };
     hipStream_t sv = ctx->serial ? st : ctx->aux[0], sf = ctx->serial ? st : ctx->aux[1],
-                sw = ctx->serial ? st : ctx->aux[2], sb = ctx->serial ? st : ctx->aux[3];
+                sw = ctx->serial ? st : ctx->aux[2], sb = ctx->serial ? st : ctx->aux[3],
+                sw2 = ctx->serial ? st : ctx->aux[4];
 
     // K-B base of a group: an earlier group whose window tracks differ only through the llr table (another alpha of
     // a sweep); such a group needs PAPAllr / PAPAllr2 at the known PAPA centre only (k_llr_at_centre)
@@ -3569,8 +3857,21 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                        ngroups, ctx->d_grow);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, sv, ctx->d_grow, ngroups);
     PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_grow + ngroups, sizeof(uint32_t), hipMemcpyDeviceToHost, sv));
+    PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 2, ctx->d_grow + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, sv));
     PL_HIP(ctx, hipStreamSynchronize(sv));
     const size_t total_rows = ctx->h_pin[0];
+    // Is this batch bound by the serial chain of its longest protein (16-residue rows of the first wave-group x ~150 ns
+    // per residue) rather than by throughput (~12 ps per residue)? Then the lane-per-protein kernels take the forms
+    // that shorten one wave's chain (k_win as two kernels) at the price of a few more instructions in total.
+    const bool latency_mode =
+        !ctx->serial && !d_tracks && npoints == 1 &&
+        (ctx->latency_mode >= 0 ? ctx->latency_mode == 1 : (uint64_t)ctx->h_pin[2] * 384000ull > total_residues);
+    if (latency_mode && ctx->h_pin[2] >= CORE_LONG_ROWS) { // scratch of k_core_*: the rows of the long wave-groups
+        const size_t lrows = std::min<size_t>(total_rows, (size_t)CORE_MAX_GROUPS * ctx->h_pin[2]);
+        if ((rc = grow(ctx, ctx->d_corep, ctx->cap_corep, lrows * 1024u)) != PLAAC_OK) return rc;
+        char *&cp = reinterpret_cast<char *&>(ctx->d_corepart);
+        if ((rc = grow(ctx, cp, ctx->cap_corepart, lrows * 64u * sizeof(CorePart))) != PLAAC_OK) return rc;
+    }
     if ((rc = grow(ctx, ctx->d_packed, ctx->cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
     const size_t bits_stride = total_rows * 64u + 64u; // one traceback-bit buffer per group
     if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, bits_stride * ng)) != PLAAC_OK) return rc;
@@ -3582,7 +3883,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
     if (!ctx->serial) {
-        for (hipStream_t a : {sf, sw, sb}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
+        for (hipStream_t a : {sf, sw, sb, sw2}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
         for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(ctx->gstreams[k], evs[E_PACK + 1], 0));
     }
     const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
@@ -3613,7 +3914,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         }
         // forward pass: once per group
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
-        if (d_tracks)
+        if (latency_mode)
+            hipLaunchKernelGGL(k_fwd_pair, dim3((nprot + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, sf,
+                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_lat);
+        else if (d_tracks)
             hipLaunchKernelGGL(k_fwd<true>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
                                ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, ctx->d_fwd);
         else
@@ -3630,10 +3934,25 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                 tg.rows[k] = d_rows[idx];
             }
             const bool t0 = timed && m0 == 0;
+            tg.stop_after = ctx->vit_stop;
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
 #define LAUNCH_VIT(NC)                                                                                             \
     hipLaunchKernelGGL((k_vit<NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff, ctx->d_order, \
                        nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg)
+            if (latency_mode) {
+                hipLaunchKernelGGL((k_vit<1, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
+                                   ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg);
+                if (tg.stop_after == 0u && ctx->h_pin[2] >= CORE_LONG_ROWS) { // some group is long: its core window
+                    const unsigned lg = std::min<unsigned>(ngroups, CORE_MAX_GROUPS);
+                    hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, sv, ctx->d_order, nprot, tab, ctx->d_packed,
+                                       ctx->d_grow, gbits, ctx->d_corep);
+                    const size_t lrows = std::min<size_t>(total_rows, (size_t)CORE_MAX_GROUPS * ctx->h_pin[2]);
+                    hipLaunchKernelGGL(k_core_eval, dim3((unsigned)lrows), dim3(64), 0, sv, ctx->d_order, nprot, ngroups,
+                                       ctx->d_grow, ctx->d_corep, (CorePart *)ctx->d_corepart, tg.c[0]);
+                    hipLaunchKernelGGL(k_core_reduce, dim3(lg), dim3(64), 0, sv, d_codes, ctx->d_order, nprot, tab,
+                                       ctx->d_grow, gbits, (const CorePart *)ctx->d_corepart, tg.rows[0], tg.c[0]);
+                }
+            } else
             switch (nc) {
             case 1: LAUNCH_VIT(1); break;
             case 2: LAUNCH_VIT(2); break;
@@ -3643,14 +3962,20 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
 #undef LAUNCH_VIT
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT + 1], sv));
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_WIN], sw));
-#define LAUNCH_WIN(NC)                                                                                             \
-    hipLaunchKernelGGL((k_win<NC>), dim3(ab), dim3(KA_THREADS), 0, sw, d_codes, d_offsets, ctx->d_neff, ctx->d_order, \
-                       nprot, tab, ctx->d_packed, ctx->d_grow, tg)
-            switch (nc) {
-            case 1: LAUNCH_WIN(1); break;
-            case 2: LAUNCH_WIN(2); break;
-            case 3: LAUNCH_WIN(3); break;
-            default: LAUNCH_WIN(4); break;
+#define LAUNCH_WIN(NC, ROLE, STREAM)                                                                               \
+    hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(ab), dim3(KA_THREADS), 0, STREAM, d_codes, d_offsets, ctx->d_neff,  \
+                       ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, tg,                                   \
+                       ctx->d_lat ? ctx->d_lat + nprot : (double *)nullptr)
+            if (latency_mode) { // the two halves side by side; the MW half also carries hmm0's running sum
+                LAUNCH_WIN(1, 2, sw);
+                LAUNCH_WIN(1, 3, sw2);
+            } else {
+                switch (nc) {
+                case 1: LAUNCH_WIN(1, 0, sw); break;
+                case 2: LAUNCH_WIN(2, 0, sw); break;
+                case 3: LAUNCH_WIN(3, 0, sw); break;
+                default: LAUNCH_WIN(4, 0, sw); break;
+                }
             }
 #undef LAUNCH_WIN
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_WIN + 1], sw));
@@ -3678,12 +4003,15 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[1], sf));
         PL_HIP(ctx, hipEventRecord(ctx->jev[2], sw));
         PL_HIP(ctx, hipEventRecord(ctx->jev[3], sb));
+        PL_HIP(ctx, hipEventRecord(ctx->jev[4], sw2));
         for (hipEvent_t e : ctx->jev) PL_HIP(ctx, hipStreamWaitEvent(st, e, 0));
         for (size_t k = 0; k < 3 * (ng - 1); ++k) {
             PL_HIP(ctx, hipEventRecord(ctx->gjev[k], ctx->gstreams[k]));
             PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
         }
     }
+    if (latency_mode)
+        hipLaunchKernelGGL(k_finish, dim3(pb), dim3(256), 0, st, d_rows[0], ctx->d_lat, ctx->d_lat + nprot, nprot);
     if (d_tracks && total_rows) // posteriors, MAP, Viterbi bytes: needs k_fwd, k_bwd and the path bits (k_vit)
         hipLaunchKernelGGL(k_post, dim3((unsigned)total_rows), dim3(64), 0, st, d_offsets, ctx->d_neff, ctx->d_order,
                            nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp);
