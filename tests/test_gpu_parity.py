@@ -495,3 +495,26 @@ def test_filter_and_exact_window_kernels_agree(native, monkeypatch):
         e1, e2 = c.score(codes, offs), c.score(a_codes, a_offs)
         assert c.last_exact_fallbacks() == 0
     assert r1.tobytes() == e1.tobytes() and r2.tobytes() == e2.tobytes()
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_throughput_and_latency_forms_of_the_chain_kernels(native, oracle, monkeypatch, mode):
+    """The lane-per-protein kernels exist in a throughput form (large batches) and a latency form (batches bound by the
+    chain of their longest protein: paired-lane forward, split window kernel, core window of the long wave-groups as
+    prefix chain + evaluation + reduction, k_finish); the library picks per batch, PLAAC_LATENCY_MODE forces one.
+    Both must reproduce the oracle bit for bit, on proteins around the 2048-residue threshold of the long-group path,
+    with core lengths on either side of the 16-residue block size and windows that straddle the first block."""
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_LATENCY_MODE", mode)
+    P0 = native.make_params()
+    rng = np.random.default_rng(606)
+    lens = np.concatenate([[2047, 2048, 2049, 5000, 3001, 36000, 1, 2, 15, 16, 17, 59, 60, 61, 79, 80, 81],
+                           rng.integers(1, 700, 300)])
+    rng.shuffle(lens)
+    codes, offs = synth.residues(lens, np.array(P0.fg), np.array(P0.bg), rng, stop_fraction=0.1)
+    for kw in ({}, {"corelength": 7}, {"corelength": 16}, {"corelength": 100, "alpha": 0.4, "bgcounts": np.arange(22.0) + 1},
+               {"corelength": 3000}):
+        Pn, Po = both_params(native, oracle, **kw)
+        with native.Context(Pn) as c:
+            got = c.score(codes, offs)
+        assert_rows_equal(got, oracle.score_batch(Po, codes, offs, nthreads=8), what="mode %s %s" % (mode, kw))
