@@ -245,3 +245,61 @@ def test_oracle_reproduces_its_committed_rows(oracle, key, fasta, kw):
     assert [w["name"] for w in want] == [n for n, _ in recs]
     for r, w in zip(rows, want):
         _same_row(r, w, key + " " + w["name"])
+
+
+def _compare_with_twin(oracle, P, codes, offs, what):
+    from oracle import plaac_oracle_py as twin
+    rows, tr = oracle.score_batch(P, codes, offs, tracks=True)
+    D = params_to_dict(P)
+    for i in range(len(offs) - 1):
+        x = codes[int(offs[i]):int(offs[i + 1])].tolist()
+        if x and x[-1] == 21:
+            x = x[:-1]  # the batch entry point drops one trailing stop (:758); the twin scores one trimmed protein
+        if not x:
+            assert rows["prot_len"][i] == 0  # skipped record (:762)
+            continue
+        r, t = twin.score_protein(D, x)
+        for k, v in r.items():
+            w = rows[k][i]
+            assert (v == w) or (isinstance(v, float) and math.isnan(v) and math.isnan(w)), (what, i, k, v, w)
+        n = len(x)
+        for k, v in t.items():
+            w = tr[k][int(offs[i]):int(offs[i]) + n]
+            a = np.asarray(v[:n], dtype=w.dtype)
+            assert a.tobytes() == w.tobytes(), (what, i, k)
+
+
+def test_differential_c_oracle_vs_python_twin_hypothesis(oracle):
+    """Unpinned floats (no reference golden values exist: SURVEY 8(c) C3): two independently written restatements of
+    plaac.java must agree bit for bit over randomly drawn parameters (alpha, core length, three window sizes, fg / bg
+    tables, proline rule) and sequences rich in X / stop / proline runs / homopolymers / very short lengths."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    residue = st.sampled_from(list(range(22)) + [13, 13, 13, 12, 14, 12, 14, 0, 21])
+    run = st.tuples(residue, st.integers(1, 30)).map(lambda cr: [cr[0]] * cr[1])
+    seq = st.lists(st.one_of(residue.map(lambda c: [c]), run), min_size=1, max_size=40).map(
+        lambda parts: [c for p in parts for c in p])
+    table = st.lists(st.floats(0.0, 1000.0, allow_nan=False), min_size=22, max_size=22)
+
+    @settings(max_examples=400, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(seqs=st.lists(seq, min_size=1, max_size=6), alpha=st.floats(-0.5, 1.5), c=st.integers(1, 90),
+           ww1=st.integers(1, 61), ww2=st.integers(1, 61), fg=st.one_of(st.none(), table), bg=st.one_of(st.none(), table),
+           adjust=st.booleans(), stop=st.booleans())
+    def run_case(seqs, alpha, c, ww1, ww2, fg, bg, adjust, stop):
+        kw = dict(alpha=alpha, corelength=c, ww1=ww1, ww2=ww2, adjustprolines=adjust)
+        if fg is not None and sum(fg[1:21]) > 0:
+            kw["fg"] = np.array(fg)
+        if bg is not None:
+            kw["bgcounts"] = np.array(bg)
+        P = oracle.build_params(**kw)
+        if not np.all(np.isfinite(np.array(P.llr))):  # a zero frequency: log(0) poisons both sides alike, nothing to learn
+            return
+        if stop:
+            seqs = [s + [21] for s in seqs]
+        codes = np.array([c_ for s in seqs for c_ in s], dtype=np.uint8)
+        offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(s) for s in seqs])
+        _compare_with_twin(oracle, P, codes, offs, kw)
+
+    run_case()
