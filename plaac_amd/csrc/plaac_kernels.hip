@@ -3040,6 +3040,8 @@ __global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restric
     __shared__ alignas(16) kb_d2 s_hl[RF_SLOTS][RF_SPAN + 1], s_pc[RF_SLOTS][RF_SPAN + 1];
     __shared__ double s_w[RF_SLOTS][3][2 * TW + 2];
     __shared__ double s_llr1[RF_SLOTS];
+    __shared__ int s_n[RF_SLOTS], s_cen[RF_SLOTS];
+    __shared__ uint32_t s_p[RF_SLOTS];
     if (*huge) return;
     const uint32_t cnt = ccount[blockIdx.x];
     if (cnt == 0u) return;
@@ -3057,17 +3059,22 @@ __global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restric
     for (uint32_t r0 = 0; r0 < cnt; r0 += RF_SLOTS) {
         const bool act = slot < RF_SLOTS && r0 + (uint32_t)slot < cnt;
         int n = 0, cen = 0;
+        uint32_t pidx = 0;
         const uint8_t *x = codes;
-        uint32_t p = 0;
         if (act) {
             const uint2 e = clist[(size_t)blockIdx.x * KB_PROTEINS_PER_BLOCK + r0 + slot];
             const uint4 it = order[e.x];
             n = (int)it.z;
-            p = it.w;
             cen = (int)e.y;
             x = codes + (((uint64_t)it.y << 32) | it.x);
+            pidx = it.w;
         }
-        __syncthreads(); // tables ready / previous round done with the staging arrays
+        __syncthreads(); // tables ready / previous round done with the staging arrays and the slot records
+        if (act && l == 0) {
+            s_n[slot] = n;
+            s_cen[slot] = cen;
+            s_p[slot] = pidx;
+        }
         if (act) { // values of positions cen-40 .. cen+40 (two per thread); outside the protein: +0.0 everywhere
             for (int t = l; t < RF_SPAN; t += 2 * TW + 1) {
                 const int q = cen - 2 * TW + t;
@@ -3084,8 +3091,7 @@ __global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restric
             }
         }
         __syncthreads();
-        if (act) { // first level at i = cen - 20 + l
-            const int i = cen - TW + l;
+        if (act) { // first level at i = cen - 20 + l: fixed-order 41-term sums
             double sh = 0.0, sl = 0.0, sp = 0.0, sc = 0.0;
             const kb_d2 *__restrict__ vh = &s_hl[slot][l], *__restrict__ vp = &s_pc[slot][l];
 #pragma unroll
@@ -3096,6 +3102,8 @@ __global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restric
                 sp = sp + b.x;
                 sc = sc + b.y;
             }
+            // quotients, FoldIndex, weights
+            const int i = cen - TW + l;
             const int lo = imax(i - TW, 0), hi = imin(i + TW, n - 1);
             const SharedDiv div((double)(hi - lo + 1));
             const double hydro = div(sh), charge = div(sc);
@@ -3108,21 +3116,26 @@ __global__ __launch_bounds__(256) void k_refine_centres(const uint8_t *__restric
             if (l == TW) s_llr1[slot] = llr1;
         }
         __syncthreads();
-        if (act && l < 3) { // second level at the centre: thread l sums track l (fix2, plaacllrx2, papax2)
-            double s = 0.0;
+        // second level at the centres: the 18 fixed-order sums (6 proteins x 3 tracks) on 18 lanes of ONE wave
+        if (tid < 3 * RF_SLOTS) {
+            const int sl2 = tid / 3, trk = tid - 3 * sl2;
+            if (r0 + (uint32_t)sl2 < cnt) {
+                double s2 = 0.0;
 #pragma unroll 4
-            for (int t = 0; t <= 2 * TW; ++t) s = s + s_w[slot][l][t];
-            const int den = (2 * TW + 1) + window_weight_side(cen, TW) + window_weight_side(n - 1 - cen, TW);
-            const double q = s / (double)den;
-            plaac_row *row = rows + p;
-            if (l == 0) {
-                row->papa_fi = q;
-            } else if (l == 1) {
-                row->papa_llr2 = q;
-                row->papa_llr = s_llr1[slot];
-            } else {
-                row->papa_combo = q;
-                row->papa_prop = q;
+                for (int t = 0; t <= 2 * TW; ++t) s2 = s2 + s_w[sl2][trk][t];
+                const int n2 = s_n[sl2], c2 = s_cen[sl2];
+                const int den = (2 * TW + 1) + window_weight_side(c2, TW) + window_weight_side(n2 - 1 - c2, TW);
+                const double q = s2 / (double)den;
+                plaac_row *row = rows + s_p[sl2];
+                if (trk == 0) {
+                    row->papa_fi = q;
+                } else if (trk == 1) {
+                    row->papa_llr2 = q;
+                    row->papa_llr = s_llr1[sl2];
+                } else {
+                    row->papa_combo = q;
+                    row->papa_prop = q;
+                }
             }
         }
     }
