@@ -149,8 +149,8 @@ def main():
                     "sweep-aware scheduler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the FASTA-in -> TSV-out leg through bin/plaac")
-    ap.add_argument("--e2e-nprot", type=int, default=2_000_000, help="sequences of the resident proteome written "
-                    "as FASTA for the end-to-end leg")
+    ap.add_argument("--e2e-nprot", type=int, default=0, help="sequences of the resident proteome written as FASTA "
+                    "for the end-to-end leg (default: all of them, i.e. the 10 M sequences / 3.0 GB of cfg4)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' + --one-device lets two ranks share one GPU for a plumbing check")
     ap.add_argument("--one-device", action="store_true", help="TEST ONLY: every rank uses cuda:0")
@@ -333,17 +333,19 @@ def main():
     # HBM traffic and executed instruction counts: PMC counters cannot be read from inside this process;
     # tools/pmc.sh collects them for this same workload and leaves the per-launch figures under profiles/
     traffic, traffic_all, exec_ops = None, None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            tj = json.load(fh)
-        if tj.get("workload") == [args.config, nprot, bool(args.tracks)]:
-            per = tj["bytes_per_launch"]
-            names = [k for k in per if k.startswith(dom)]  # k_tracks -> k_tracks20s / k_tracks20 / k_tracks
-            traffic = max(per[k] for k in names) if names else None
-            traffic_all = tj.get("bytes_per_step")
-            exec_ops = tj.get("fp64_ops_per_residue_executed")
-    except (OSError, ValueError, KeyError):
-        pass
+    import glob
+    for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+        try:
+            with open(pth) as fh:
+                tj = json.load(fh)
+            if tj.get("workload") == [args.config, nprot, bool(args.tracks)] and not args.sweep:
+                per = tj["bytes_per_launch"]
+                names = [k for k in per if k.startswith(dom)]  # k_tracks -> k_tracks20f / k_tracks20s / k_tracks20
+                traffic = max(per[k] for k in names) if names else None
+                traffic_all = tj.get("bytes_per_step")
+                exec_ops = tj.get("fp64_ops_per_residue_executed")
+        except (OSError, ValueError, KeyError):
+            pass
     path_ms = ktimes["total"]
     algo_gops = ALGO_OPS_PER_RESIDUE * total / (path_ms * 1e-3) / 1e9
     roofline = {
@@ -415,16 +417,17 @@ def main():
     # ---- rank 0, N = 1: end to end through the C++ host (FASTA bytes in -> TSV bytes out), SURVEY 8(d) M1 ----
     e2e = None
     if world == 1 and not args.no_e2e and not args.tracks and not args.sweep:
-        want_jar = cpu is not None and os.environ.get("PLAAC_REF_JAR")
-        e2e = run_e2e(torch, codes, offsets, min(nprot, args.e2e_nprot), keep_fasta=bool(want_jar))
-        fa = e2e.pop("_fasta", None)
+        e2e = run_e2e(torch, codes, offsets, min(nprot, args.e2e_nprot or nprot))
         # when the operator supplies the real reference (a JVM on PATH and
-        # PLAAC_REF_JAR=/path/plaac.jar) time it too, single-threaded as it is
-        if fa:
+        # PLAAC_REF_JAR=/path/plaac.jar) time it too, single-threaded as it is, on a bounded sample
+        if cpu is not None and os.environ.get("PLAAC_REF_JAR"):
+            fa = os.path.join(os.environ.get("TMPDIR", "/tmp"), "plaac_bench_ref_%d.fa" % os.getpid())
             try:
-                cpu["reference_jar"] = time_reference_jar(fa, e2e.get("residues", 0))
+                _, nres_s = write_fasta(torch, codes, offsets, min(nprot, 8000), fa)
+                cpu["reference_jar"] = time_reference_jar(fa, nres_s)
             finally:
-                os.unlink(fa)
+                if os.path.exists(fa):
+                    os.unlink(fa)
     if cpu is not None and "reference_jar" not in cpu:
         cpu["reference_jar"] = time_reference_jar("", 0) if not os.environ.get("PLAAC_REF_JAR") else "skipped: no e2e leg"
 
