@@ -28,7 +28,30 @@ int main(int argc, char **argv) {
             row.prot_len = (int)len;
             if (len) plaac_format_summary_row(&row, f->names + f->name_off[i], f->codes + f->offsets[i], len, 60, 41, line.data(), line.size());
         }
+        // the same file as a stream of batches of several sizes: record and residue totals must agree
+        const uint32_t nrec_whole = f->nrec;
+        const unsigned long long nres_whole = f->nres;
         plaac_fasta_free(f);
+        const uint64_t sizes[][2] = {{1, 1ull << 30}, {7, 1ull << 30}, {1u << 20, 1}, {1u << 20, 4096}, {1000, 100000}};
+        for (const auto &sz : sizes) {
+            plaac_fasta_stream *fs = nullptr;
+            if (plaac_fasta_open(argv[a], &fs) != PLAAC_OK) return 3;
+            unsigned long long nrec = 0, nres = 0;
+            for (;;) {
+                plaac_fasta *b = nullptr;
+                if (plaac_fasta_next(fs, (uint32_t)sz[0], sz[1], &b) != PLAAC_OK) return 4;
+                if (!b) break;
+                if (b->nrec == 0 || b->nrec > sz[0]) return 5;
+                nrec += b->nrec;
+                nres += b->nres;
+                plaac_fasta_free(b);
+            }
+            plaac_fasta_close(fs);
+            if (nrec != nrec_whole || nres != nres_whole) {
+                std::printf("stream totals differ for %s\n", argv[a]);
+                return 6;
+            }
+        }
     }
     char b[64];
     const double vals[] = {0.0, -0.0, 1.0005, 2.5, 1e-7, 123456.7895, -1e300, 1.0 / 0.0, -1.0 / 0.0, 0.0 / 0.0};
