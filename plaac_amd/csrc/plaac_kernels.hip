@@ -67,7 +67,7 @@ struct DevTables {
     double cc[3];
     double big_neg;
     int32_t corelength, ww1, ww2, ww3, adjustprolines, pad1_;
-    double loglut[LUTLEN];
+    double loglut[LUTLEN + 1]; // [LUTLEN] = 0.0: lse_lut clamps out-of-range differences onto (LUTLEN-1, LUTLEN)
 };
 
 struct TrackPtrs {
@@ -201,11 +201,15 @@ __device__ __forceinline__ double lse_lut(const double *__restrict__ lut, double
     const double lo = __builtin_fmin(a, b);
     const double c = hi - lo;
     const bool inrange = c < 40.0;
-    const double x = 100.0 * (inrange ? c : 0.0);
-    const double dexf = floor(x);
-    const int dex = (int)dexf;
-    // (dex + 1 - 100c) of the reference: x - floor(x) is exact, so 1 - (x - dexf) is the same real number rounded once
-    const double fr = x - dexf;
+    // The dependent chain of this function bounds the forward kernel for a long protein, so it is kept short: out-of-range
+    // differences (c >= 40, +inf, NaN) are clamped onto the padded last table entry by one min (their result is
+    // discarded below) instead of a select in front of the multiply; the integer part comes from a truncating
+    // conversion of x itself (x >= 0: trunc == floor) and the fraction from v_fract, side by side, instead of
+    // floor -> convert and floor -> subtract. x - floor(x) is exact, so fract(x) has the same bits.
+    const double x = __builtin_fmin(100.0 * c, (double)(LUTLEN - 1));
+    const int dex = (int)x;
+    // (dex + 1 - 100c) of the reference: 1 - (x - floor(x)) is the same real number rounded once
+    const double fr = __builtin_amdgcn_fract(x);
     const double r = hi + (fr * lut[dex + 1] + (1.0 - fr) * lut[dex]);
     return inrange ? r : hi;
 }
@@ -1175,14 +1179,16 @@ struct WinState {
 __device__ __forceinline__ int is_nq(uint32_t c) { return (c == 12u || c == 14u) ? 1 : 0; }
 
 // STEADY: the whole block has t >= max(c, 80): all trailing streams run and every step closes every window
-// ROLE 0: everything; 1: MW window + means; 2: LLR window(s); 3: role 1 + hmm0's running sum (for k_finish). When the step is bound by the serial chain of the
+// ROLE 0: everything; 1: MW window + means; 2: LLR window(s); 3: role 1 + hmm0's running sum (for k_finish); 4: MW window;
+// 5: means + hmm0's running sum. When the step is bound by the serial chain of the
 // longest protein (small batches, very long proteins) the two halves run as two kernels side by side: each wave then
 // issues about half the instructions per step.
 template <bool GUARD, bool STEADY, int NC, int ROLE>
 __device__ __forceinline__ void win_block(WinState<NC> &S, const double *__restrict__ s_row, const uint4 cur,
                                           const uint4 (&ccur)[NC], const uint4 mcur, uint32_t t0, uint32_t n,
                                           const uint32_t (&c)[NC], uint32_t mw, double h0li, double h0lt) {
-    constexpr bool DO_MW = ROLE != 2, DO_LLR = ROLE == 0 || ROLE == 2, DO_H0 = ROLE == 3;
+    constexpr bool DO_MW = ROLE == 0 || ROLE == 1 || ROLE == 3 || ROLE == 4, DO_MEAN = ROLE == 0 || ROLE == 1 || ROLE == 3 || ROLE == 5,
+                   DO_LLR = ROLE == 0 || ROLE == 2, DO_H0 = ROLE == 3 || ROLE == 5;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t t = t0 + (uint32_t)j;
@@ -1193,9 +1199,11 @@ __device__ __forceinline__ void win_block(WinState<NC> &S, const double *__restr
                 const double eh = r[R_LE0H];
                 S.h0 = (!STEADY && t == 0u) ? h0li + eh : (h0lt + S.h0) + eh;
             }
-            if (DO_MW) {
+            if (DO_MEAN) {
                 S.hydsum = S.hydsum + r[R_HYD]; // mean (:1584-1588)
                 S.chg += (xc == 3u || xc == 4u) ? 1 : ((xc == 9u || xc == 15u) ? -1 : 0);
+            }
+            if (DO_MW) {
                 S.cntL += is_nq(xc);
                 if (STEADY || t >= 80u) S.cntT += is_nq(block_code(mcur, j)); // only reached when mw == 80
                 if (STEADY) {
@@ -1241,7 +1249,8 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
                                                     const uint4 *__restrict__ packed,
                                                     const uint32_t *__restrict__ grow, SweepTargets tg,
                                                     double *__restrict__ h0out) {
-    constexpr bool DO_MW = ROLE != 2, DO_LLR = ROLE == 0 || ROLE == 2, DO_H0 = ROLE == 3;
+    constexpr bool DO_MW = ROLE == 0 || ROLE == 1 || ROLE == 3 || ROLE == 4, DO_MEAN = ROLE == 0 || ROLE == 1 || ROLE == 3 || ROLE == 5,
+                   DO_LLR = ROLE == 0 || ROLE == 2, DO_H0 = ROLE == 3 || ROLE == 5;
     __shared__ double s_row[ROWS * R_W];
     load_rows(s_row, T);
     __syncthreads();
@@ -1254,8 +1263,8 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             plaac_row *row = tg.rows[k] + J.p;
+            if (DO_MEAN) row->fi_meanhydro = row->fi_meancharge = row->fi_meancombo = 0.0;
             if (DO_MW) {
-                row->fi_meanhydro = row->fi_meancharge = row->fi_meancombo = 0.0;
                 row->mw_score = row->mw_start = row->mw_end = 0;
                 row->prot_len = 0;
             }
@@ -1325,6 +1334,8 @@ __global__ __launch_bounds__(KA_THREADS) void k_win(const uint8_t *__restrict__ 
             row->mw_score = W.mwbest;
             row->mw_start = W.mwstart;
             row->mw_end = W.mwstart + (int)mw - 1;
+        }
+        if (DO_MEAN) {
             row->fi_meanhydro = meanhydro;
             row->fi_meancharge = meancharge;
             row->fi_meancombo = meanfi;
@@ -3455,7 +3466,7 @@ void fill_tables(const plaac_params &P, DevTables &D) {
     D.ww2 = P.ww2;
     D.ww3 = P.ww3;
     D.adjustprolines = P.adjustprolines;
-    std::memcpy(D.loglut, P.loglut, sizeof D.loglut);
+    std::memcpy(D.loglut, P.loglut, sizeof P.loglut); // D.loglut[LUTLEN] stays 0.0
 }
 
 // The kernels exploit the structure of the reference's two models; refuse anything else loudly.
@@ -3979,9 +3990,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(ab), dim3(KA_THREADS), 0, STREAM, d_codes, d_offsets, ctx->d_neff,  \
                        ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, tg,                                   \
                        ctx->d_lat ? ctx->d_lat + nprot : (double *)nullptr)
-            if (latency_mode) { // the two halves side by side; the MW half also carries hmm0's running sum
+            if (latency_mode) { // three thirds side by side (LLR window | MW window | means + hmm0's running sum)
                 LAUNCH_WIN(1, 2, sw);
-                LAUNCH_WIN(1, 3, sw2);
+                LAUNCH_WIN(1, 4, sw2);
+                LAUNCH_WIN(1, 5, sb); // the backward stream is idle in summary mode
             } else {
                 switch (nc) {
                 case 1: LAUNCH_WIN(1, 0, sw); break;
