@@ -2209,6 +2209,17 @@ __device__ __forceinline__ double wave_max_f64(double s) { // values are never N
     s = __builtin_fmax(s, dpp_move_f64<0x143, 0xc>(ninf, s));
     return bcast_lane(s, 63);
 }
+__device__ __forceinline__ float wave_max_f32(float s) { // values are never NaN here; returned wave-uniform
+    const int ninf = (int)0xff800000u;
+    auto step = [&](float v, int moved) { return __builtin_fmaxf(v, __builtin_bit_cast(float, moved)); };
+    s = step(s, dpp_move<0x111, 0xf>(ninf, __builtin_bit_cast(int, s)));
+    s = step(s, dpp_move<0x112, 0xf>(ninf, __builtin_bit_cast(int, s)));
+    s = step(s, dpp_move<0x114, 0xf>(ninf, __builtin_bit_cast(int, s)));
+    s = step(s, dpp_move<0x118, 0xf>(ninf, __builtin_bit_cast(int, s)));
+    s = step(s, dpp_move<0x142, 0xa>(ninf, __builtin_bit_cast(int, s)));
+    s = step(s, dpp_move<0x143, 0xc>(ninf, __builtin_bit_cast(int, s)));
+    return __builtin_bit_cast(float, bcast_lane(__builtin_bit_cast(int, s), 63));
+}
 __device__ __forceinline__ int wave_min_i32(int s) {
     s = imin(s, dpp_move<0x111, 0xf>(INT_MAX, s));
     s = imin(s, dpp_move<0x112, 0xf>(INT_MAX, s));
@@ -2659,8 +2670,7 @@ struct KfShared {
     uint32_t segP[KB_PROTEINS_PER_BLOCK];
     uint64_t segOff[KB_PROTEINS_PER_BLOCK];
     int acc_numaa[KB_PROTEINS_PER_BLOCK], acc_maxlen[KB_PROTEINS_PER_BLOCK], seg_amb[KB_PROTEINS_PER_BLOCK];
-    uint2 cl[KB_PROTEINS_PER_BLOCK]; // proteins with a centre: {plan index, centre}
-    int ncl;
+    int res[KB_PROTEINS_PER_BLOCK]; // PAPA centre of a finished protein (-1: none, -2: undecided)
 };
 
 struct KfCand { // one lane's PAPA candidates of one segment: best and second best certain ones, best uncertain one
@@ -2715,6 +2725,7 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
             Z.acc_numaa[lane] = 0;
             Z.acc_maxlen[lane] = 0;
             Z.seg_amb[lane] = 0;
+            Z.res[lane] = -2; // undecided until the stream has passed the protein
             if (lane == NP - 1) Z.segS[NP] = incl;
             if (have && n == 0) { // skipped record (:762): zero the fields this kernel owns
                 plaac_row *row = rows + it.w;
@@ -2722,7 +2733,6 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
                 row->fi_numaa = row->fi_maxrun = row->papa_cen = 0;
             }
         }
-        if (lane == 0) Z.ncl = 0;
     }
     wave_sync();
     const int stream_end = Z.segS[NP]; // wave-uniform
@@ -2982,7 +2992,7 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
                 }
             }
         }
-        // ---- proteins whose last residue stage 2 has passed in this iteration
+        // ---- proteins whose last residue stage 2 has passed in this iteration: which centre, or "undecided"
         const int passed = FC * c + FC - 1 - FLAG2;
         while (fin < NP) { // wave-uniform
             const int n = __builtin_amdgcn_readfirstlane(Z.segN[fin]);
@@ -2994,33 +3004,20 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
                 const double mbest = mine >= 0 ? (mc ? cur.best : prv.best) : ninf;
                 const double mrun = mc ? cur.runner : (mp ? prv.runner : ninf);
                 const double mamb = mc ? cur.ambv : (mp ? prv.ambv : ninf);
-                const double g1 = wave_max_f64(mbest);
+                // The lane that holds the largest certain candidate, found on single-precision keys (rounding to float
+                // is monotone: a lane whose key is below the unique largest key holds a smaller double); the exact
+                // closeness test below is on the doubles. Two lanes with the same key: left to the exact kernel.
+                const float key = (float)mbest;
+                const float kmax = wave_max_f32(key);
+                const unsigned long long top = __ballot(mine >= 0 && key == kmax);
+                const int wl = top ? (int)__builtin_ctzll(top) : 0;
+                const double g1 = top ? bcast_lane_dyn(mbest, wl) : ninf;
                 const double mark = g1 - 2.0 * E_v; // -inf when there is no certain candidate
                 const unsigned long long close = __ballot(mine >= 0 && mbest >= mark);
                 const bool others = __ballot((mrun > ninf && mrun >= mark) || (mamb > ninf && mamb >= mark)) != 0ull;
-                wave_sync(); // seg_amb / accumulators of this segment are complete (all its stage-1 lanes have run)
-                const bool fallback = Z.seg_amb[fin] != 0 || __popcll(close) > 1 || others;
-                const int pcen =
-                    (close != 0ull)
-                        ? __builtin_amdgcn_readlane(mine, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(close)))
-                        : -1;
-                if (lane == 0) {
-                    const uint32_t pidx = blockIdx.x + (uint32_t)fin * gridDim.x; // plan index of this protein
-                    if (fallback) {
-                        fblist[atomicAdd(fbcount, 1u)] = pidx;
-                    } else {
-                        plaac_row *row = rows + Z.segP[fin];
-                        row->fi_numaa = Z.acc_numaa[fin];
-                        row->fi_maxrun = Z.acc_maxlen[fin];
-                        row->papa_cen = pcen;
-                        if (pcen >= 0) {
-                            Z.cl[Z.ncl++] = make_uint2(pidx, (uint32_t)pcen); // values at the centre: k_refine_centres
-                        } else {
-                            row->papa_combo = -INFINITY;
-                            row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
-                        }
-                    }
-                }
+                const bool undecided = __popcll(top) > 1 || __popcll(close) > 1 || others;
+                const int pcen = top ? __builtin_amdgcn_readlane(mine, __builtin_amdgcn_readfirstlane(wl)) : -1;
+                if (lane == 0) Z.res[fin] = undecided ? -2 : pcen;
             }
             ++fin;
         }
@@ -3028,9 +3025,35 @@ __global__ __launch_bounds__(64) void k_tracks20f(const uint8_t *__restrict__ co
         w0 = w0 < 0 ? w0 + FRING : w0;
     }
     wave_sync();
-    const int ncl = Z.ncl;
-    if (lane < ncl) clist[(size_t)blockIdx.x * NP + lane] = Z.cl[lane];
-    if (lane == 0) ccount[blockIdx.x] = (uint32_t)ncl;
+    // ---- per-protein results, one lane per protein of the block: rows of the decided ones, the refine list (proteins
+    //      with a centre), the fallback list (a FoldIndex or PAPA decision the bounds could not make)
+    {
+        const bool have = lane < NP && Z.segN[lane < NP ? lane : 0] > 0;
+        const int res = have ? Z.res[lane] : -1;
+        const bool fb = have && (res == -2 || Z.seg_amb[lane] != 0);
+        const bool cen = have && !fb && res >= 0;
+        const uint32_t pidx = blockIdx.x + (uint32_t)lane * gridDim.x; // plan index of this lane's protein
+        const unsigned long long mfb = __ballot(fb), mcen = __ballot(cen);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (mfb) { // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(fbcount, (uint32_t)__popcll(mfb));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (fb) fblist[base + (uint32_t)__popcll(mfb & below)] = pidx;
+        }
+        if (cen) clist[(size_t)blockIdx.x * NP + (uint32_t)__popcll(mcen & below)] = make_uint2(pidx, (uint32_t)res);
+        if (lane == 0) ccount[blockIdx.x] = (uint32_t)__popcll(mcen);
+        if (have && !fb) {
+            plaac_row *row = rows + Z.segP[lane];
+            row->fi_numaa = Z.acc_numaa[lane];
+            row->fi_maxrun = Z.acc_maxlen[lane];
+            row->papa_cen = res;
+            if (res < 0) {
+                row->papa_combo = -INFINITY;
+                row->papa_prop = row->papa_fi = row->papa_llr = row->papa_llr2 = __builtin_nan("");
+            }
+        }
+    }
 }
 
 // The four values at the PAPA centre in the reference's own operation order (disorderreport :4877-4905 at one
