@@ -3882,6 +3882,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if (ctx->ncalls > 0)
         PL_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][E_JOIN], 0));
     PL_HIP(ctx, hipEventRecord(evs[E_START], st));
+    PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), st)); // plaac_last_exact_fallbacks: this call's count
     PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * (LEN_BINS + 1), st));
     const unsigned pb = (nprot + 255u) / 256u;
     const unsigned plb = (nprot + PLAN_THREADS * PLAN_ITEMS - 1) / (PLAN_THREADS * PLAN_ITEMS);
