@@ -10,7 +10,7 @@ LIB       = plaac_amd/libplaac_native.so
 all: $(LIB) oracle $(if $(wildcard $(CSRC)/plaac_cli.cpp),cli) $(if $(JNI_H),jni)
 
 LIBSRC    = $(CSRC)/plaac_kernels.hip $(CSRC)/plaac_host.cpp $(CSRC)/plaac_node.cpp $(wildcard $(CSRC)/plaac_io.cpp)
-$(LIB): $(LIBSRC) $(wildcard include/*.h)
+$(LIB): $(LIBSRC) $(wildcard $(CSRC)/*.hip.inc) $(wildcard include/*.h)
 	$(HIPCC) $(HIPFLAGS) -Iinclude -shared -o $@ $(LIBSRC) -Wl,-rpath,/opt/rocm/lib
 
 cli: bin/plaac
@@ -34,7 +34,7 @@ jni/libplaac_jni.so: jni/plaac_jni.cpp jni/PlaacNative.java $(LIB) include/plaac
 jni-skipped:
 	@echo "jni: no JDK found (JAVA_HOME/include/jni.h missing) - shim not built"
 
-asm: $(CSRC)/plaac_kernels.hip
+asm: $(CSRC)/plaac_kernels.hip $(wildcard $(CSRC)/*.hip.inc)
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -Iinclude --cuda-device-only -S -o build/plaac_kernels.s $(CSRC)/plaac_kernels.hip \
 		-Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || true
