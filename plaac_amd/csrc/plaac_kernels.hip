@@ -65,6 +65,7 @@ struct plaac_ctx {
     std::vector<hipStream_t> gstreams; // side streams of the 2nd, 3rd ... group of a sweep (three each)
     std::vector<hipEvent_t> gjev;      // their join events
     hipEvent_t jev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
+    hipEvent_t fev[2] = {nullptr, nullptr};                            // k_finish waits for the forward / window streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
     uint32_t *d_neff = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
@@ -254,6 +255,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         for (auto &je : ctx->jev)
             if ((e = hipEventCreateWithFlags(&je, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
+        for (auto &fe : ctx->fev)
+            if ((e = hipEventCreateWithFlags(&fe, hipEventDisableTiming)) != hipSuccess)
+                return bail("hipEventCreate", e);
         const char *ser = std::getenv("PLAAC_SERIAL_STREAMS");
         ctx->serial = ser && ser[0] == '1';
         const char *gen = std::getenv("PLAAC_GENERIC_TRACKS");
@@ -353,6 +357,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->jev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->fev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_tabs) (void)hipFree(ctx->d_tabs);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -420,7 +426,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if ((rc = grow(ctx, ctx->d_order, ctx->cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
     const uint32_t ngroups = (nprot + 63u) / 64u;
     if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 1)) != PLAAC_OK) return rc;
-    if (!d_tracks && npoints == 1 && (rc = grow(ctx, ctx->d_lat, ctx->cap_lat, 2 * (size_t)nprot)) != PLAAC_OK) return rc;
+    const bool single = npoints == 1; // one parameter point: hmm0's running sum is computed once (k_fwd / k_win), k_finish
+    if (single && (rc = grow(ctx, ctx->d_lat, ctx->cap_lat, 2 * (size_t)nprot)) != PLAAC_OK) return rc;
     if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
         const size_t kb_blocks = ((size_t)nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
         if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, kb_blocks * KB_PROTEINS_PER_BLOCK)) != PLAAC_OK) return rc;
@@ -629,15 +636,18 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         }
         // forward pass: once per group
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
+#define LAUNCH_FWD(TRK, EXTF)                                                                                      \
+    hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,     \
+                       ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, \
+                       ctx->d_lat)
         if (latency_mode)
             hipLaunchKernelGGL(k_fwd_pair, dim3((nprot + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, sf,
                                ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_lat);
-        else if (d_tracks)
-            hipLaunchKernelGGL(k_fwd<true>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, ctx->d_fwd);
-        else
-            hipLaunchKernelGGL(k_fwd<false>, dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,
-                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, (double2 *)nullptr);
+        else if (d_tracks && single) LAUNCH_FWD(true, true);
+        else if (d_tracks) LAUNCH_FWD(true, false);
+        else if (single) LAUNCH_FWD(false, true);
+        else LAUNCH_FWD(false, false);
+#undef LAUNCH_FWD
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
         // Viterbi / windows: up to MAXC core lengths per launch
         for (size_t m0 = 0; m0 < G.members.size(); m0 += MAXC) {
@@ -655,7 +665,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     hipLaunchKernelGGL((k_vit<NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff, ctx->d_order, \
                        nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg)
             if (latency_mode) {
-                hipLaunchKernelGGL((k_vit<1, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
+                hipLaunchKernelGGL((k_vit<1, true, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
                                    ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg);
                 if (tg.stop_after == 0u && ctx->h_pin[2] >= CORE_LONG_ROWS) { // some group is long: its core window
                     const unsigned lg = std::min<unsigned>(ngroups, CORE_MAX_GROUPS);
@@ -667,6 +677,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     hipLaunchKernelGGL(k_core_reduce, dim3(lg), dim3(64), 0, sv, d_codes, ctx->d_order, nprot, tab,
                                        ctx->d_grow, gbits, (const CorePart *)ctx->d_corepart, tg.rows[0], tg.c[0]);
                 }
+            } else if (single) { // hmm0's running sum is k_fwd's (k_finish)
+                hipLaunchKernelGGL((k_vit<1, false, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,
+                                   ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg);
             } else
             switch (nc) {
             case 1: LAUNCH_VIT(1); break;
@@ -713,6 +726,16 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             }
         }
     }
+    if (single) { // HMMall / HMMvit from lmarginalprob, lviterbiprob (in the row) and hmm0's total: on the Viterbi stream,
+                  // behind the kernels that produced the other two terms, so that it runs beside the window kernel
+        if (!ctx->serial) {
+            PL_HIP(ctx, hipEventRecord(ctx->fev[0], sf));
+            PL_HIP(ctx, hipEventRecord(ctx->fev[1], sb)); // latency mode: hmm0's total comes from k_win<1,5> on this stream
+            PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[0], 0));
+            PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[1], 0));
+        }
+        hipLaunchKernelGGL(k_finish, dim3(pb), dim3(256), 0, sv, d_rows[0], ctx->d_lat, ctx->d_lat + nprot, nprot);
+    }
     if (!ctx->serial) {
         // join: everything enqueued on the side streams so far
         PL_HIP(ctx, hipEventRecord(ctx->jev[0], sv));
@@ -726,8 +749,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
         }
     }
-    if (latency_mode)
-        hipLaunchKernelGGL(k_finish, dim3(pb), dim3(256), 0, st, d_rows[0], ctx->d_lat, ctx->d_lat + nprot, nprot);
     if (d_tracks && total_rows) // posteriors, MAP, Viterbi bytes: needs k_fwd, k_bwd and the path bits (k_vit)
         hipLaunchKernelGGL(k_post, dim3((unsigned)total_rows), dim3(64), 0, st, d_offsets, ctx->d_neff, ctx->d_order,
                            nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp);
