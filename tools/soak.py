@@ -31,6 +31,9 @@ for rep in range(12):
         with ctx.upload(*batches[3]) as b:
             b.histogram()
             b.sweep([native.make_params(alpha=a, corelength=c) for a in (1.0, 0.5) for c in (30, 60)])
+    with native.Node(P, [0, 0]) as node:  # two contexts on the device, batches sharded by sequence
+        for k in (1, 3):
+            assert node.score(*batches[k]).tobytes() == ref[k], "node rows differ (batch %d, rep %d)" % (k, rep)
     torch.cuda.synchronize()
     free, total = torch.cuda.mem_get_info()
     if rep == 1:
