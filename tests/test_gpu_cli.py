@@ -151,7 +151,7 @@ def test_streamed_pipeline_is_independent_of_batching_and_contexts(native, tmp_p
     for env in ({"PLAAC_BATCH_RECORDS": 37}, {"PLAAC_BATCH_BYTES": 20000, "PLAAC_DEVICES": "0,0,0"},
                 {"PLAAC_BATCH_RECORDS": 100, "PLAAC_KEEP_BYTES": 1}, {"PLAAC_BATCH_RECORDS": 1, "PLAAC_DEVICES": "0,0"},
                 {"PLAAC_BATCH_RECORDS": 100, "PLAAC_KEEP_BYTES": 100000, "PLAAC_CTX_PER_DEVICE": 3},
-                {"PLAAC_FAST_EXIT": 1, "PLAAC_BATCH_RECORDS": 500}):
+                {"PLAAC_FAST_EXIT": 1, "PLAAC_BATCH_RECORDS": 500}, {"PLAAC_TEARDOWN": 1, "PLAAC_BATCH_RECORDS": 300}):
         assert run_env(env, *args) == base, env
     # track mode streams too (8 MiB batches by default): every record, then a list
     tbase = run_env({"PLAAC_DEVICES": "0"}, "-i", fa, "-p", "all", "-s")
