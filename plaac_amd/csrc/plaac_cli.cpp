@@ -202,6 +202,11 @@ class Reorder {
 
   public:
     explicit Reorder(uint64_t w) : window(w) {}
+    void set_window(uint64_t w) {
+        std::lock_guard<std::mutex> l(m);
+        window = w;
+        cv_room.notify_all();
+    }
     void wait_room(uint64_t seq) { // called by a worker BEFORE it scores batch `seq`
         std::unique_lock<std::mutex> l(m);
         cv_room.wait(l, [&] { return seq < next + window; });
@@ -360,8 +365,8 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                   Work &&work, Sink &&sink) {
     if (!fs && !replay) return true; // nothing to read
     Queue q(4);
+    Reorder ro(4); // widened once the number of contexts is known
     std::atomic<bool> failed{false};
-    std::atomic<uint64_t> nbatches{UINT64_MAX};
     bool keeping = keep != nullptr, keep_overflow = false;
     uint64_t kept_bytes = 0;
     std::thread reader([&] {
@@ -399,7 +404,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
             q.put(std::move(b));
         }
         q.close();
-        nbatches = seq;
+        ro.set_total(seq);
     });
     // the reader is already parsing while the GPU contexts come up (HIP start-up takes a few hundred ms)
     if (!eng.ready(P0)) {
@@ -410,11 +415,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
         return false;
     }
     const int nctx = plaac_node_size(eng.node);
-    Reorder ro((uint64_t)2 * nctx + 2);
-    std::thread closer([&] { // tells the reorder buffer how many batches there are once the reader knows
-        while (nbatches.load() == UINT64_MAX) std::this_thread::sleep_for(std::chrono::milliseconds(1));
-        ro.set_total(nbatches.load());
-    });
+    ro.set_window((uint64_t)2 * nctx + 2);
     std::vector<std::thread> workers;
     for (int k = 0; k < nctx; ++k)
         workers.emplace_back([&, k] {
@@ -447,7 +448,6 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
         }
     }
     reader.join();
-    closer.join();
     for (auto &w : workers) w.join();
     if (fs) plaac_fasta_close(fs);
     if (keep && (keep_overflow || !ok || failed)) {
