@@ -103,3 +103,22 @@ def test_jni_shim_compiles_and_binds_every_native_of_the_java_class():
     # every C-ABI function the shim calls is declared by the header
     called = set(re.findall(r"\b(plaac_[a-z0-9_]+)\s*\(", cpp))
     assert called <= set(header_functions()), called - set(header_functions())
+
+
+def test_cli_fails_loudly_without_a_gpu(tmp_path):
+    """no CPU fallback anywhere: the command-line host must refuse to score without a gfx950 device (exit 1, message
+    on stderr, nothing but the reference's own comment lines on stdout) - and still serve the flags that need no GPU"""
+    import subprocess
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "bin", "plaac")
+    if not os.path.exists(exe):
+        pytest.skip("bin/plaac not built")
+    fa = os.path.join(ROOT, "tests", "golden", "four_classic_prions.fasta")
+    r = subprocess.run([exe, "-i", fa], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no usable MI355X" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l and not l.startswith("#")]
+    r = subprocess.run([exe, "-B", os.path.join(ROOT, "tests", "golden", "prd_freq_scer_04.txt")], capture_output=True,
+                       text=True, timeout=120)  # -B without -i: print the table, no device needed (:394-403)
+    assert r.returncode == 0 and r.stdout.splitlines()[0] == "0.000000 # X" and len(r.stdout.splitlines()) == 22
