@@ -527,8 +527,17 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     hipLaunchKernelGGL(k_tracks20f, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
                                        total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_ccount,
                                        ctx->d_fblist, ctx->d_fbcount);
-                    hipLaunchKernelGGL(k_refine_centres, dim3(kb_grid), dim3(256), 0, st, d_codes, ctx->d_order,
-                                       total_residues, tab, rows, huge, ctx->d_clist, ctx->d_ccount);
+#define LAUNCH_REFINE(TH)                                                                                          \
+    hipLaunchKernelGGL(k_refine_centres<TH>, dim3(kb_grid), dim3(TH), 0, st, d_codes, ctx->d_order, total_residues,   \
+                       tab, rows, huge, ctx->d_clist, ctx->d_ccount)
+                    {
+                        static const int rf = std::getenv("PLAAC_RF_THREADS") ? std::atoi(std::getenv("PLAAC_RF_THREADS")) : 56;
+                        if (rf == 56) LAUNCH_REFINE(56);
+                        else if (rf == 112) LAUNCH_REFINE(112);
+                        else if (rf == 448) LAUNCH_REFINE(448);
+                        else LAUNCH_REFINE(224);
+                    }
+#undef LAUNCH_REFINE
                     hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, st, d_codes,
                                        d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
                                        0u, ctx->d_fblist, ctx->d_fbcount);
