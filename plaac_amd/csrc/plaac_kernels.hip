@@ -80,7 +80,10 @@ struct plaac_ctx {
     uint32_t *d_flag = nullptr;
     KbDivTab *d_divtab = nullptr; // reciprocal tables of the window kernel
     // summary-mode window kernel in filter form: centres per filter block, fallback list, [0] = its length
-    uint2 *d_clist = nullptr;
+    uint4 *d_clist = nullptr; // refine list: (offset lo, offset hi, length, centre) + row index in d_crow
+    uint32_t *d_crow = nullptr;
+    size_t cap_crow = 0;
+    unsigned rf_grid = 256u * 8u; // blocks of k_refine_centres (it strides over the list)
     uint32_t *d_ccount = nullptr, *d_fblist = nullptr, *d_fbcount = nullptr;
     size_t cap_clist = 0, cap_ccount = 0, cap_fblist = 0;
     double *d_lat = nullptr; // latency forms: [0, nprot) lmarginalprob of hmm1, [nprot, 2 nprot) total of hmm0
@@ -264,6 +267,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         ctx->generic_tracks = gen && gen[0] == '1';
         const char *ppt = std::getenv("PLAAC_KB_PER_PROTEIN");
         ctx->per_protein_tracks = ppt && ppt[0] == '1';
+        if (const char *rg = std::getenv("PLAAC_RF_GRID")) ctx->rf_grid = (unsigned)std::max(1, std::atoi(rg));
         const char *kbf = std::getenv("PLAAC_KB_FILTER");
         ctx->kb_filter = !(kbf && kbf[0] == '0');
         if (const char *vs = std::getenv("PLAAC_VIT_STOP")) ctx->vit_stop = (uint32_t)std::atoi(vs);
@@ -333,7 +337,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
-    for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount,
+    for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_crow, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount,
                     (void *)ctx->d_lat, (void *)ctx->d_corep, ctx->d_corepart})
         if (b) (void)hipFree(b);
     for (void *b : bufs)
@@ -429,9 +433,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const bool single = npoints == 1; // one parameter point: hmm0's running sum is computed once (k_fwd / k_win), k_finish
     if (single && (rc = grow(ctx, ctx->d_lat, ctx->cap_lat, 2 * (size_t)nprot)) != PLAAC_OK) return rc;
     if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
-        const size_t kb_blocks = ((size_t)nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
-        if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, kb_blocks * KB_PROTEINS_PER_BLOCK)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, ctx->d_ccount, ctx->cap_ccount, kb_blocks)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, (size_t)nprot)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_crow, ctx->cap_crow, (size_t)nprot)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_ccount, ctx->cap_ccount, (size_t)1)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_fblist, ctx->cap_fblist, (size_t)nprot)) != PLAAC_OK) return rc;
     }
     // device tables: slot 0 keeps the ctx parameters (single-point calls), sweep groups use slots 1..ng
@@ -524,20 +528,13 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // summary mode: decisions from error-bounded prefix sums, exact values at the chosen centre only,
                     // whatever the bounds cannot decide goes to the exact per-protein kernel through the fallback list
                     PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), st));
+                    PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t), st));
                     hipLaunchKernelGGL(k_tracks20f, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
-                                       total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_ccount,
-                                       ctx->d_fblist, ctx->d_fbcount);
-#define LAUNCH_REFINE(TH)                                                                                          \
-    hipLaunchKernelGGL(k_refine_centres<TH>, dim3(kb_grid), dim3(TH), 0, st, d_codes, ctx->d_order, total_residues,   \
-                       tab, rows, huge, ctx->d_clist, ctx->d_ccount)
-                    {
-                        static const int rf = std::getenv("PLAAC_RF_THREADS") ? std::atoi(std::getenv("PLAAC_RF_THREADS")) : 56;
-                        if (rf == 56) LAUNCH_REFINE(56);
-                        else if (rf == 112) LAUNCH_REFINE(112);
-                        else if (rf == 448) LAUNCH_REFINE(448);
-                        else LAUNCH_REFINE(224);
-                    }
-#undef LAUNCH_REFINE
+                                       total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
+                                       ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
+                    hipLaunchKernelGGL(k_refine_centres, dim3(std::min((nprot + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)), dim3(64),
+                                       0, st, d_codes, total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist,
+                                       ctx->d_crow, ctx->d_ccount);
                     hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, st, d_codes,
                                        d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
                                        0u, ctx->d_fblist, ctx->d_fbcount);
