@@ -92,6 +92,8 @@ struct plaac_ctx {
     void *d_corepart = nullptr; // their per-row best windows
     size_t cap_corep = 0, cap_corepart = 0;
     bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
+    bool fi_int = false;   // the tables in d_tab qualify for FoldIndex in integers (derive_fi_int)
+    bool fi_int_allowed = true; // PLAAC_FI_INT=0: always the fp64 form of the filter kernel
     size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_bwd = 0, cap_grow = 0, cap_packed = 0;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
@@ -132,6 +134,8 @@ plaac_status fail(plaac_ctx *ctx, plaac_status st, const char *msg) {
     return st;
 }
 
+void derive_fi_int(const plaac_params &P, DevTables &D);
+
 void fill_tables(const plaac_params &P, DevTables &D) {
     std::memset(&D, 0, sizeof D);
     for (int k = 0; k < NAA; ++k) {
@@ -161,6 +165,82 @@ void fill_tables(const plaac_params &P, DevTables &D) {
     D.ww3 = P.ww3;
     D.adjustprolines = P.adjustprolines;
     std::memcpy(D.loglut, P.loglut, sizeof P.loglut); // D.loglut[LUTLEN] stays 0.0
+    derive_fi_int(P, D);
+}
+
+// FoldIndex in integers. The reference's hydropathy table is aahydro/9 + 0.5 with one-decimal aahydro (:90) and
+// cc = {2.785, -1, -1.151} (:4885): rationals H_k/SH and c_i/SC with SH = 90, SC = 1000. In exact arithmetic
+//   m * fi = cc0 S_h + cc1 |C| + cc2 m = (c0 K + c1 SH |C| + c2 SH m) / (SH SC) =: I / (SH SC),   K = sum of H over the window,
+// an integer over a fixed denominator: either I = 0 or |m fi| >= 1/(SH SC), while the reference's fp64 evaluation is
+// within E_G (~1e-12) of it. So for I != 0 the sign of the reference's FoldIndex is the sign of I, with certainty and
+// without fp64; likewise the doubly smoothed FoldIndex (its weights are the window counts m, :2640-2646) has the sign
+// of the 41-term sum of I. I = 0 (either level) is left to the exact kernel as before. This function looks for the
+// denominators, checks every range the kernel relies on (bit fields of the packed prefix sum, 24-bit multiplier
+// operands, int32 window sums) and the margin 1/(SH SC) >> E_T; tables that do not qualify keep the fp64 form.
+void derive_fi_int(const plaac_params &P, DevTables &D) {
+    D.fi_int = 0;
+    D.fi_A2 = D.fi_B2 = D.fi_C2 = 0;
+    for (int k = 0; k < NAA; ++k) D.fi_iv[k] = 0u;
+    constexpr long double TOL = 1e-14L;
+    long H[NAA] = {0};
+    long double dh = 0.0L, dc = 0.0L;
+    int SH = 0, SC = 0;
+    for (int s = 1; s <= 20000 && !SH; ++s) {
+        bool ok = true;
+        long double worst = 0.0L;
+        for (int k = 0; k < NAA && ok; ++k) {
+            const long double x = (long double)P.hydro2[k] * s, r = nearbyintl(x);
+            ok = std::isfinite(P.hydro2[k]) && fabsl(x - r) <= TOL * s;
+            H[k] = (long)r;
+            worst = std::max(worst, fabsl(x - r) / s);
+        }
+        if (ok) {
+            SH = s;
+            dh = worst;
+        }
+    }
+    long cI[3] = {0, 0, 0};
+    for (int s = 1; s <= 100000 && !SC; ++s) {
+        bool ok = true;
+        long double worst = 0.0L;
+        for (int i = 0; i < 3 && ok; ++i) {
+            const long double x = (long double)P.cc[i] * s, r = nearbyintl(x);
+            ok = std::isfinite(P.cc[i]) && fabsl(x - r) <= TOL * s;
+            cI[i] = (long)r;
+            worst = std::max(worst, fabsl(x - r) / s);
+        }
+        if (ok) {
+            SC = s;
+            dc = worst;
+        }
+    }
+    if (!SH || !SC) return;
+    long hmin = H[0], hmax = H[0];
+    double A_h = 0.0;
+    for (int k = 0; k < NAA; ++k) {
+        hmin = std::min(hmin, H[k]);
+        hmax = std::max(hmax, H[k]);
+        A_h = std::max(A_h, std::fabs(P.hydro2[k]));
+        if (P.charge[k] != -1.0 && P.charge[k] != 0.0 && P.charge[k] != 1.0) return;
+    }
+    constexpr long W = 2 * TW + 1;
+    const long range = hmax - hmin;
+    const long A2 = 2 * cI[0], B2 = 2 * (cI[0] * hmin + cI[2] * (long)SH), C2 = 2 * cI[1] * (long)SH;
+    if (W * range >= (1L << 19)) return;                                   // K' field: bits 13..31
+    if (std::labs(A2) >= (1L << 23) || std::labs(B2) >= (1L << 23) || std::labs(C2) >= (1L << 23)) return; // v_mad_i32_i24
+    const long maxI2 = std::labs(A2) * W * range + std::labs(B2) * W + std::labs(C2) * W + 1;
+    if (maxI2 * W >= (1L << 31) - 1024) return;                            // second-level window sums in int32
+    const long double u = 0x1p-53L, CC = fabsl((long double)P.cc[0]) * A_h + fabsl((long double)P.cc[1]) + fabsl((long double)P.cc[2]);
+    const long double E_S = 256 * u * W * A_h + W * dh;
+    const long double E_G = fabsl((long double)P.cc[0]) * E_S + 256 * u * W * CC + W * dc * (A_h + 2.0L);
+    const long double E_T = 2 * W * E_G + 256 * u * W * W * CC;
+    if (1.0L / ((long double)SH * SC) < 1024.0L * E_T) return;             // margin between I = +-1 and the rounding noise
+    D.fi_int = 1;
+    D.fi_A2 = (int32_t)A2;
+    D.fi_B2 = (int32_t)B2;
+    D.fi_C2 = (int32_t)C2;
+    for (int k = 0; k < NAA; ++k)
+        D.fi_iv[k] = 1u | ((uint32_t)((int)P.charge[k] + 1) << 6) | ((uint32_t)(H[k] - hmin) << 13);
 }
 
 // The kernels exploit the structure of the reference's two models; refuse anything else loudly.
@@ -270,6 +350,8 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         if (const char *rg = std::getenv("PLAAC_RF_GRID")) ctx->rf_grid = (unsigned)std::max(1, std::atoi(rg));
         const char *kbf = std::getenv("PLAAC_KB_FILTER");
         ctx->kb_filter = !(kbf && kbf[0] == '0');
+        const char *fii = std::getenv("PLAAC_FI_INT");
+        ctx->fi_int_allowed = !(fii && fii[0] == '0');
         if (const char *vs = std::getenv("PLAAC_VIT_STOP")) ctx->vit_stop = (uint32_t)std::atoi(vs);
         const char *lat = std::getenv("PLAAC_LATENCY_MODE");
         if (lat && (lat[0] == '0' || lat[0] == '1')) ctx->latency_mode = lat[0] - '0';
@@ -307,6 +389,7 @@ plaac_status plaac_ctx_set_params(plaac_ctx *ctx, const plaac_params *params) {
     DevTables *h = new (std::nothrow) DevTables();
     if (!h) return fail(ctx, PLAAC_ERR_NOMEM, "out of host memory");
     fill_tables(*params, *h);
+    const bool fi_int = h->fi_int != 0;
     // The last scored batch may still be reading the old tables: its kernels run on the caller's stream and on the
     // non-blocking side streams, none of which a null-stream copy waits for. Its join event (recorded on the caller's
     // stream after every side stream has been joined) covers all of them.
@@ -320,6 +403,7 @@ plaac_status plaac_ctx_set_params(plaac_ctx *ctx, const plaac_params *params) {
         return PLAAC_ERR_DEVICE;
     }
     ctx->params = *params;
+    ctx->fi_int = fi_int;
     return PLAAC_OK;
 }
 
@@ -440,10 +524,14 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     }
     // device tables: slot 0 keeps the ctx parameters (single-point calls), sweep groups use slots 1..ng
     const DevTables *gtab0 = ctx->d_tab;
+    std::vector<char> gfi(ng, ctx->fi_int ? 1 : 0); // per group: FoldIndex in integers
     if (!(npoints == 1 && std::memcmp(&points[0], &ctx->params, sizeof(plaac_params)) == 0)) {
         if ((rc = grow(ctx, ctx->d_tabs, ctx->cap_tabs, ng)) != PLAAC_OK) return rc;
         std::vector<DevTables> host(ng);
-        for (size_t g = 0; g < ng; ++g) fill_tables(points[groups[g].first], host[g]);
+        for (size_t g = 0; g < ng; ++g) {
+            fill_tables(points[groups[g].first], host[g]);
+            gfi[g] = host[g].fi_int != 0;
+        }
         PL_HIP(ctx, hipMemcpyAsync(ctx->d_tabs, host.data(), sizeof(DevTables) * ng, hipMemcpyHostToDevice, st));
         PL_HIP(ctx, hipStreamSynchronize(st)); // `host` is a temporary
         gtab0 = ctx->d_tabs;
@@ -529,9 +617,14 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // whatever the bounds cannot decide goes to the exact per-protein kernel through the fallback list
                     PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), st));
                     PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t), st));
-                    hipLaunchKernelGGL(k_tracks20f, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
-                                       total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
-                                       ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
+                    if (gfi[g] && ctx->fi_int_allowed)
+                        hipLaunchKernelGGL(k_tracks20f<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                                           total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
+                                           ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
+                    else
+                        hipLaunchKernelGGL(k_tracks20f<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                                           total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
+                                           ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
                     hipLaunchKernelGGL(k_refine_centres, dim3(std::min((nprot + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)), dim3(64),
                                        0, st, d_codes, total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist,
                                        ctx->d_crow, ctx->d_ccount);
