@@ -707,11 +707,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         for (hipStream_t a : {sf, sw, sb, sw2}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
         for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(ctx->gstreams[k], evs[E_PACK + 1], 0));
     }
-    const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
+    const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS, fb = (nprot + KF_THREADS - 1) / KF_THREADS;
     // track mode: the backward recurrence is a chain of its own, beside the forward one
     PL_HIP(ctx, hipEventRecord(evs[E_BWD], sb));
     if (d_tracks)
-        hipLaunchKernelGGL(k_bwd, dim3(ab), dim3(KA_THREADS), 0, sb, d_offsets, ctx->d_neff, ctx->d_order, nprot, gtab0,
+        hipLaunchKernelGGL(k_bwd, dim3(fb), dim3(KF_THREADS), 0, sb, d_offsets, ctx->d_neff, ctx->d_order, nprot, gtab0,
                            ctx->d_packed, ctx->d_grow, ctx->d_bwd);
     PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
 
@@ -736,7 +736,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         // forward pass: once per group
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
 #define LAUNCH_FWD(TRK, EXTF)                                                                                      \
-    hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3(ab), dim3(KA_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,     \
+    hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3(fb), dim3(KF_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,     \
                        ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, \
                        ctx->d_lat)
         if (latency_mode)
