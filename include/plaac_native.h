@@ -233,6 +233,16 @@ const char *plaac_node_last_error(const plaac_node *node);
  * proteins of the most recent scored batch took the exact tier. Blocks until that batch has completed. */
 plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count);
 
+/* The filter tier needs the SIGN of FoldIndex (plaac.java:4885, :5020-5058) and of its second smoothing (:4903, :4944)
+ * at every position. When hydro2[] and cc[] are rationals with small denominators - the reference's own tables are:
+ * aahydro / 9 + 0.5 with one-decimal aahydro (:90), cc = {2.785, -1, -1.151} - m * FoldIndex is an integer over the
+ * fixed denominator SH * SC, so the sign comes from exact 32-bit integer arithmetic (no error bound involved); other
+ * tables keep the error-bounded fp64 form. Returns 1 when `params` qualify for the integer form (and the library will
+ * use it; PLAAC_FI_INT=0 at ctx creation forces the fp64 form), else 0. info (nullable) receives
+ * {A2, B2, C2, SH, SC, Hmin}: I2 = A2 * sum(H - Hmin) + B2 * count + C2 * |charge sum| - 1 = 2 * SH * SC * m * fi - 1.
+ * Host-only: needs no device. */
+int plaac_fi_integer_form(const plaac_params *params, int32_t info[6]);
+
 #ifdef __cplusplus
 }
 #endif

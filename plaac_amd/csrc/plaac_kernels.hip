@@ -134,7 +134,7 @@ plaac_status fail(plaac_ctx *ctx, plaac_status st, const char *msg) {
     return st;
 }
 
-void derive_fi_int(const plaac_params &P, DevTables &D);
+void derive_fi_int(const plaac_params &P, DevTables &D, int32_t *info = nullptr);
 
 void fill_tables(const plaac_params &P, DevTables &D) {
     std::memset(&D, 0, sizeof D);
@@ -177,7 +177,7 @@ void fill_tables(const plaac_params &P, DevTables &D) {
 // of the 41-term sum of I. I = 0 (either level) is left to the exact kernel as before. This function looks for the
 // denominators, checks every range the kernel relies on (bit fields of the packed prefix sum, 24-bit multiplier
 // operands, int32 window sums) and the margin 1/(SH SC) >> E_T; tables that do not qualify keep the fp64 form.
-void derive_fi_int(const plaac_params &P, DevTables &D) {
+void derive_fi_int(const plaac_params &P, DevTables &D, int32_t *info) {
     D.fi_int = 0;
     D.fi_A2 = D.fi_B2 = D.fi_C2 = 0;
     for (int k = 0; k < NAA; ++k) D.fi_iv[k] = 0u;
@@ -235,6 +235,11 @@ void derive_fi_int(const plaac_params &P, DevTables &D) {
     const long double E_G = fabsl((long double)P.cc[0]) * E_S + 256 * u * W * CC + W * dc * (A_h + 2.0L);
     const long double E_T = 2 * W * E_G + 256 * u * W * W * CC;
     if (1.0L / ((long double)SH * SC) < 1024.0L * E_T) return;             // margin between I = +-1 and the rounding noise
+    if (info) {
+        info[3] = SH;
+        info[4] = SC;
+        info[5] = (int32_t)hmin;
+    }
     D.fi_int = 1;
     D.fi_A2 = (int32_t)A2;
     D.fi_B2 = (int32_t)B2;
@@ -895,6 +900,22 @@ plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
 }
 
 plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]) { return plaac_timings_mean(ctx, 1, ms); }
+
+int plaac_fi_integer_form(const plaac_params *params, int32_t info[6]) {
+    if (!params) return 0;
+    DevTables *h = new (std::nothrow) DevTables();
+    if (!h) return 0;
+    int32_t tmp[6] = {0, 0, 0, 0, 0, 0};
+    derive_fi_int(*params, *h, tmp);
+    const int ok = h->fi_int;
+    tmp[0] = h->fi_A2;
+    tmp[1] = h->fi_B2;
+    tmp[2] = h->fi_C2;
+    delete h;
+    if (info)
+        for (int i = 0; i < 6; ++i) info[i] = ok ? tmp[i] : 0;
+    return ok;
+}
 
 plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count) {
     if (!ctx || !count) return PLAAC_ERR_ARG;

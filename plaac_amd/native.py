@@ -70,6 +70,7 @@ EXPORTS = (
     "plaac_histogram", "plaac_score", "plaac_score_device", "plaac_histogram_device", "plaac_ctx_sync",
     "plaac_last_timings", "plaac_timings_mean", "plaac_batch_upload", "plaac_batch_histogram", "plaac_batch_score",
     "plaac_batch_free", "plaac_batch_sweep", "plaac_score_sweep_device", "plaac_last_exact_fallbacks",
+    "plaac_fi_integer_form",
     "plaac_device_count", "plaac_node_create", "plaac_node_destroy", "plaac_node_size", "plaac_node_ctx",
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
 )
@@ -122,6 +123,8 @@ def load():
     L.plaac_last_timings.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_timings_mean.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.plaac_last_exact_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
+    L.plaac_fi_integer_form.argtypes = [C.c_void_p, C.c_void_p]
+    L.plaac_fi_integer_form.restype = C.c_int
     L.plaac_device_count.restype = C.c_int
     L.plaac_node_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.plaac_node_destroy.argtypes = [C.c_void_p]
@@ -163,6 +166,13 @@ def make_params(fg=None, bgcounts=None, alpha=1.0, corelength=60, ww1=41, ww2=41
     if st != PLAAC_OK:
         raise PlaacError(st, "plaac_params_init rejected its arguments")
     return P
+
+
+def fi_integer_form(P):
+    """plaac_fi_integer_form: (qualifies, {A2, B2, C2, SH, SC, Hmin}) - does the filter tier sign FoldIndex in integers?"""
+    info = (C.c_int32 * 6)()
+    ok = load().plaac_fi_integer_form(C.addressof(P), C.addressof(info))
+    return bool(ok), dict(zip(("A2", "B2", "C2", "SH", "SC", "Hmin"), list(info)))
 
 
 def encode(seq):

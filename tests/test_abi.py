@@ -66,6 +66,35 @@ def test_builtin_tables_and_encode(native, oracle):
     assert native.encode("XACDEFGHIKLMNPQRSTVWY*").tolist() == list(range(22))
 
 
+def test_fi_integer_form_is_derived_from_the_tables(native):
+    """host-side check behind the integer form of the filter tier (plaac_fi_integer_form): the reference's tables are
+    rationals over 90 and 1000; other rational tables qualify with their own denominators; irrational ones do not"""
+    import numpy as np
+    P = native.make_params()
+    ok, info = native.fi_integer_form(P)
+    # hydro2 = aahydro/9 + 0.5 -> H = 10 aahydro + 45 in 0..90 (R = -4.5 -> 0); cc = {2.785, -1, -1.151}
+    assert ok and info == {"A2": 2 * 2785, "B2": 2 * (-1151 * 90), "C2": 2 * (-1000 * 90), "SH": 90, "SC": 1000, "Hmin": 0}
+    Q = native.make_params()
+    for k in range(22):
+        Q.hydro2[k] = (3 * k - 20) / 7.0
+    Q.cc[0], Q.cc[1], Q.cc[2] = 1.5, -2.0, -0.25
+    ok, info = native.fi_integer_form(Q)
+    assert ok and info["SH"] == 7 and info["SC"] == 4 and info["Hmin"] == -20
+    assert info["A2"] == 2 * 6 and info["B2"] == 2 * (6 * -20 + -1 * 7) and info["C2"] == 2 * (-8 * 7)
+    rng = np.random.default_rng(5)
+    R = native.make_params()
+    for k in range(22):
+        R.hydro2[k] = float(rng.random())
+    assert native.fi_integer_form(R) == (False, dict.fromkeys(("A2", "B2", "C2", "SH", "SC", "Hmin"), 0))
+    S = native.make_params()
+    S.cc[0] = float(np.pi)
+    assert not native.fi_integer_form(S)[0]
+    W = native.make_params()  # rational but too wide for the bit fields / int32 window sums
+    for k in range(22):
+        W.hydro2[k] = 1000.0 * k
+    assert not native.fi_integer_form(W)[0]
+
+
 def test_no_gpu_means_loud_failure_not_fallback(native):
     """On a machine without a usable gfx950 device the product must refuse to compute."""
     import torch

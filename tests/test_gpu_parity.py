@@ -497,6 +497,44 @@ def test_filter_and_exact_window_kernels_agree(native, monkeypatch):
     assert r1.tobytes() == e1.tobytes() and r2.tobytes() == e2.tobytes()
 
 
+def _with_tables(native, oracle, hydro2=None, cc=None, **kw):
+    Pn, Po = both_params(native, oracle, **kw)
+    for P in (Pn, Po):
+        if hydro2 is not None:
+            for k in range(22):
+                P.hydro2[k] = float(hydro2[k])
+        if cc is not None:
+            for i in range(3):
+                P.cc[i] = float(cc[i])
+    return Pn, Po
+
+
+@pytest.mark.parametrize("tables", ["reference", "other_rationals", "irrational", "forced_fp64"])
+def test_filter_tier_signs_foldindex_in_integers_or_in_bounded_fp64(native, oracle, monkeypatch, tables):
+    """the filter tier takes FoldIndex signs from exact integers when the hydropathy table and cc are small rationals
+    (the reference's are) and from error-bounded fp64 prefix sums otherwise: both forms against the oracle, on random and
+    on adversarial sequences, with tables of either kind"""
+    from plaac_amd import synth
+    rng = np.random.default_rng(77)
+    if tables == "other_rationals":
+        Pn, Po = _with_tables(native, oracle, hydro2=(rng.integers(-30, 60, 22)) / 7.0, cc=(1.5, -2.0, -0.25))
+    elif tables == "irrational":
+        Pn, Po = _with_tables(native, oracle, hydro2=rng.random(22) * 1.3 - 0.2, cc=(np.e, -1.0, -1.0 / 3.0))
+    else:
+        Pn, Po = both_params(native, oracle)
+    assert native.fi_integer_form(Pn)[0] == (tables != "irrational")
+    if tables == "forced_fp64":
+        monkeypatch.setenv("PLAAC_FI_INT", "0")
+    codes, offs = synth.make_batch(4, nprot=6000, seed=17, fg=np.array(Pn.fg), bg=np.array(Pn.bg), stop_fraction=0.05)
+    a_codes, a_offs = _adversarial_batch(native)
+    with native.Context(Pn) as c:
+        assert_rows_equal(c.score(codes, offs), oracle.score_batch(Po, codes, offs, nthreads=8), what=tables)
+        nfb = c.last_exact_fallbacks()
+        assert_rows_equal(c.score(a_codes, a_offs), oracle.score_batch(Po, a_codes, a_offs, nthreads=8),
+                          what=tables + " adversarial")
+    assert nfb <= 60, "%d of 6000 random proteins fell back to the exact kernel (%s)" % (nfb, tables)
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 def test_throughput_and_latency_forms_of_the_chain_kernels(native, oracle, monkeypatch, mode):
     """The lane-per-protein kernels exist in a throughput form (large batches) and a latency form (batches bound by the
