@@ -108,6 +108,10 @@ struct plaac_ctx {
     hipEvent_t ev[EV_SETS][EV_PER] = {};
     uint64_t ncalls = 0;
     hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // high-priority side streams of the K-A roles
+    // the same roles at normal priority, for throughput-bound batches: there the step is the sum of all kernels' issue
+    // time, and high-priority chain kernels only keep the window kernel's waves out of the SIMDs until they are done
+    // (chains, then windows, one after the other); at equal priority the two mix and hide each other's latencies
+    hipStream_t auxn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t vit_stop = 0; // DIAGNOSTIC, PLAAC_VIT_STOP=1|2: k_vit stops after that sweep (timing the sweeps; results are wrong)
     int latency_mode = -1; // PLAAC_LATENCY_MODE=0/1 forces the throughput / latency forms of the K-A kernels (-1: per batch)
     bool serial = false;                              // PLAAC_SERIAL_STREAMS=1: everything on one stream
@@ -340,6 +344,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         for (auto &a : ctx->aux)
             if ((e = hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest)) != hipSuccess)
                 return bail("hipStreamCreateWithPriority", e);
+        for (auto &a : ctx->auxn)
+            if ((e = hipStreamCreateWithPriority(&a, hipStreamNonBlocking, 0)) != hipSuccess)
+                return bail("hipStreamCreateWithPriority", e);
         for (auto &je : ctx->jev)
             if ((e = hipEventCreateWithFlags(&je, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
@@ -435,6 +442,11 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         for (auto &ev : set)
             if (ev) (void)hipEventDestroy(ev);
     for (auto &a : ctx->aux)
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
+    for (auto &a : ctx->auxn)
         if (a) {
             (void)hipStreamSynchronize(a);
             (void)hipStreamDestroy(a);
@@ -689,9 +701,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // Is this batch bound by the serial chain of its longest protein (16-residue rows of the first wave-group x ~150 ns
     // per residue) rather than by throughput (~12 ps per residue)? Then the lane-per-protein kernels take the forms
     // that shorten one wave's chain (k_win as two kernels) at the price of a few more instructions in total.
-    const bool latency_mode =
-        !ctx->serial && !d_tracks && npoints == 1 &&
-        (ctx->latency_mode >= 0 ? ctx->latency_mode == 1 : (uint64_t)ctx->h_pin[2] * 384000ull > total_residues);
+    const bool chain_bound =
+        ctx->latency_mode >= 0 ? ctx->latency_mode == 1 : (uint64_t)ctx->h_pin[2] * 384000ull > total_residues;
+    const bool latency_mode = !ctx->serial && !d_tracks && npoints == 1 && chain_bound;
     if (latency_mode && ctx->h_pin[2] >= CORE_LONG_ROWS) { // scratch of k_core_*: the rows of the long wave-groups
         const size_t lrows = std::min<size_t>(total_rows, (size_t)CORE_MAX_GROUPS * ctx->h_pin[2]);
         if ((rc = grow(ctx, ctx->d_corep, ctx->cap_corep, lrows * 1024u)) != PLAAC_OK) return rc;
@@ -709,6 +721,14 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
     if (!ctx->serial) {
+        if (!chain_bound) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn)
+            sv = ctx->auxn[0];
+            sf = ctx->auxn[1];
+            sw = ctx->auxn[2];
+            sb = ctx->auxn[3];
+            sw2 = ctx->auxn[4];
+            PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PACK + 1], 0));
+        }
         for (hipStream_t a : {sf, sw, sb, sw2}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
         for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(ctx->gstreams[k], evs[E_PACK + 1], 0));
     }
