@@ -92,6 +92,9 @@ struct plaac_ctx {
     void *d_corepart = nullptr; // their per-row best windows
     size_t cap_corep = 0, cap_corepart = 0;
     bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
+    uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
+    size_t cap_corelist = 0, cap_corecount = 0;
+    bool core_list = true; // PLAAC_CORE_LIST=0: sweep 3 inside k_vit for every batch
     bool fi_int = false;   // the tables in d_tab qualify for FoldIndex in integers (derive_fi_int)
     bool fi_int_allowed = true; // PLAAC_FI_INT=0: always the fp64 form of the filter kernel
     size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_bwd = 0, cap_grow = 0, cap_packed = 0;
@@ -362,6 +365,8 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         if (const char *rg = std::getenv("PLAAC_RF_GRID")) ctx->rf_grid = (unsigned)std::max(1, std::atoi(rg));
         const char *kbf = std::getenv("PLAAC_KB_FILTER");
         ctx->kb_filter = !(kbf && kbf[0] == '0');
+        const char *cl = std::getenv("PLAAC_CORE_LIST");
+        ctx->core_list = !(cl && cl[0] == '0');
         const char *fii = std::getenv("PLAAC_FI_INT");
         ctx->fi_int_allowed = !(fii && fii[0] == '0');
         if (const char *vs = std::getenv("PLAAC_VIT_STOP")) ctx->vit_stop = (uint32_t)std::atoi(vs);
@@ -434,6 +439,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
     for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_crow, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount,
+                    (void *)ctx->d_corelist, (void *)ctx->d_corecount,
                     (void *)ctx->d_lat, (void *)ctx->d_corep, ctx->d_corepart})
         if (b) (void)hipFree(b);
     for (void *b : bufs)
@@ -710,6 +716,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         char *&cp = reinterpret_cast<char *&>(ctx->d_corepart);
         if ((rc = grow(ctx, cp, ctx->cap_corepart, lrows * 64u * sizeof(CorePart))) != PLAAC_OK) return rc;
     }
+    const bool use_core_list = ctx->core_list && single && !latency_mode && !chain_bound;
+    if (use_core_list) {
+        if ((rc = grow(ctx, ctx->d_corelist, ctx->cap_corelist, (size_t)nprot)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_corecount, ctx->cap_corecount, (size_t)1)) != PLAAC_OK) return rc;
+    }
     if ((rc = grow(ctx, ctx->d_packed, ctx->cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
     const size_t bits_stride = total_rows * 64u + 64u; // one traceback-bit buffer per group
     if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, bits_stride * ng)) != PLAAC_OK) return rc;
@@ -801,6 +812,14 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     hipLaunchKernelGGL(k_core_reduce, dim3(lg), dim3(64), 0, sv, d_codes, ctx->d_order, nprot, tab,
                                        ctx->d_grow, gbits, (const CorePart *)ctx->d_corepart, tg.rows[0], tg.c[0]);
                 }
+            } else if (single && use_core_list) { // throughput-bound: sweep 3 only for proteins that can have a core
+                PL_HIP(ctx, hipMemsetAsync(ctx->d_corecount, 0, sizeof(uint32_t), sv));
+                hipLaunchKernelGGL((k_vit<1, false, true, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,
+                                   ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg,
+                                   ctx->d_corelist, ctx->d_corecount);
+                if (tg.stop_after == 0u)
+                    hipLaunchKernelGGL(k_core_list, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes, ctx->d_order,
+                                       tab, ctx->d_packed, ctx->d_grow, gbits, tg, ctx->d_corelist, ctx->d_corecount);
             } else if (single) { // hmm0's running sum is k_fwd's (k_finish)
                 hipLaunchKernelGGL((k_vit<1, false, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,
                                    ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg);
