@@ -171,7 +171,7 @@ void fill_tables(const plaac_params &P, DevTables &D) {
     D.ww2 = P.ww2;
     D.ww3 = P.ww3;
     D.adjustprolines = P.adjustprolines;
-    std::memcpy(D.loglut, P.loglut, sizeof P.loglut); // D.loglut[LUTLEN] stays 0.0
+    std::memcpy(D.loglut, P.loglut, sizeof P.loglut); // D.loglut[LUTLEN], [LUTLEN + 1] stay 0.0
     derive_fi_int(P, D);
 }
 
