@@ -332,7 +332,7 @@ def main():
     achieved = path_bytes / (dom_ms * 1e-3) / 1e9
     # HBM traffic and executed instruction counts: PMC counters cannot be read from inside this process;
     # tools/pmc.sh collects them for this same workload and leaves the per-launch figures under profiles/
-    traffic, traffic_all, exec_ops = None, None, None
+    traffic, traffic_all, exec_ops, issue_instr = None, None, None, None
     import glob
     for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
         try:
@@ -340,10 +340,15 @@ def main():
                 tj = json.load(fh)
             if tj.get("workload") == [args.config, nprot, bool(args.tracks)] and not args.sweep:
                 per = tj["bytes_per_launch"]
-                names = [k for k in per if k.startswith(dom)]  # k_tracks -> k_tracks20f / k_tracks20s / k_tracks20
-                traffic = max(per[k] for k in names) if names else None
+                # the kernels timed under `dom`: k_tracks = the window stream (filter + refine + exact tier, or the exact
+                # stream kernel), k_vit = Viterbi + the core list
+                names = [k for k in per if k.startswith(dom)]
+                names += [k for k in per if (dom == "k_tracks" and k == "k_refine_centres") or
+                          (dom == "k_vit" and k.startswith("k_core"))]
+                traffic = sum(per[k] for k in names) if names else None
                 traffic_all = tj.get("bytes_per_step")
                 exec_ops = tj.get("fp64_ops_per_residue_executed")
+                issue_instr = tj.get("valu_lds_wave_instructions_per_step")
         except (OSError, ValueError, KeyError):
             pass
     path_ms = ktimes["total"]
@@ -365,6 +370,13 @@ def main():
                 "source": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes over all kernels of a step, profiles/pmc_traffic.json"},
             "peak_Gops": FP64_VALU_PEAK_GOPS,
         },
+        # the roof that binds: every vector-ALU / LDS wave-instruction occupies its SIMD's issue port for 4 cycles
+        # (1024 SIMDs, 2.4 GHz peak clock); instruction counts from the PMC passes of tools/pmc.sh (same workload)
+        "issue": None if not issue_instr else {
+            "valu_lds_wave_instructions_per_step": issue_instr,
+            "ms_at_peak_issue": round(issue_instr * 4 / 1024 / 2.4e9 * 1e3, 3),
+            "frac": round(issue_instr * 4 / 1024 / 2.4e9 * 1e3 / path_ms, 4),
+            "source": "SQ_INSTS_VALU + SQ_INSTS_LDS over all kernels of a step, profiles/pmc_traffic.json"},
     }
 
     # ---- rank 0: CPU baseline = the oracle (a port, not the Java reference: no JVM on this box) ----

@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-KEYS = ("k_tracks20f", "k_refine_centres", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
+KEYS = ("k_tracks20f", "k_refine_centres", "k_core_list", "k_core_chain", "k_core_eval", "k_core_reduce", "k_fwd_pair", "k_finish", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
         "k_plan_scatter", "k_pack", "k_group_rows", "k_scan_u32")
 
 
@@ -74,7 +74,11 @@ def main(root):
                    "bytes_per_launch": {k: round(v["hbm_bytes_gfx950_corrected"]) for k, v in traffic.items()},
                    "bytes_per_step": round(sum(v["hbm_bytes_gfx950_corrected"] for k, v in traffic.items()
                                                if k != "k_hist")),
-                   "fp64_ops_per_residue_executed": round(f64 * 64 / R, 1) if f64 else None},
+                   "fp64_ops_per_residue_executed": round(f64 * 64 / R, 1) if f64 else None,
+                   # what actually bounds the path: vector-ALU and LDS wave-instructions issued per step (SQ_INSTS_VALU +
+                   # SQ_INSTS_LDS over all kernels of a step); a SIMD issues one per 4 cycles at best
+                   "valu_lds_wave_instructions_per_step": round(sum(
+                       c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_LDS", 0) for k, c in mean.items() if k != "k_hist"))},
                   open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     for k in sorted(mean):
         t = traffic.get(k, {})
