@@ -60,6 +60,10 @@ plaac_status plaac_read_aa_params(const char *path, double vec[PLAAC_NAA], int *
 
 /* java.util.Formatter "%.<decimals>f" of v into buf (cap >= 400). Returns the length written. */
 int plaac_format_fixed(double v, int decimals, char *buf, size_t cap);
+/* The same text by the digit-string path alone (shortest round-trip digits, HALF_UP on them): plaac_format_fixed and
+ * the row formatters take an arithmetic short cut for values that are not within rounding noise of a tie and fall
+ * back to this path otherwise; the two must agree on every double (differential test). */
+int plaac_format_fixed_reference(double v, int decimals, char *buf, size_t cap);
 /* java.lang.Double.toString(v) (used for alpha in the parameter block). */
 int plaac_format_double_tostring(double v, char *buf, size_t cap);
 

@@ -169,6 +169,11 @@ class Queue {
 
   public:
     explicit Queue(size_t c) : cap(c) {}
+    void set_cap(size_t c) {
+        std::lock_guard<std::mutex> l(m);
+        cap = c;
+        cv_put.notify_all();
+    }
     void put(BatchPtr b) {
         std::unique_lock<std::mutex> l(m);
         cv_put.wait(l, [&] { return q.size() < cap || closed; });
@@ -364,7 +369,10 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                   std::vector<plaac_fasta *> *replay, std::vector<plaac_fasta *> *keep, uint64_t keep_bytes, Prep &&prep,
                   Work &&work, Sink &&sink) {
     if (!fs && !replay) return true; // nothing to read
-    Queue q(4);
+    // A pass that keeps its parsed batches anyway (the background pass, up to keep_bytes) lets the reader run as far
+    // ahead as it likes: it parses through the few hundred ms in which the GPU contexts come up instead of stopping
+    // four batches in. A pass that does not keep them is bounded to four batches in flight.
+    Queue q(keep ? (size_t)1 << 30 : 4);
     Reorder ro(4); // widened once the number of contexts is known
     std::atomic<bool> failed{false};
     bool keeping = keep != nullptr, keep_overflow = false;
@@ -396,6 +404,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                     } else { // too large to keep: the later pass reads the file again (the batches kept so far may
                         keeping = false; // still be in flight: they are released once the threads have been joined)
                         keep_overflow = true;
+                        q.set_cap(4);
                     }
                 }
             }

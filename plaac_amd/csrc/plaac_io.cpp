@@ -106,6 +106,43 @@ std::string fixed_string(double v, int decimals) {
     return out;
 }
 
+// %.Nf of java.util.Formatter appended to `s` without the digit strings of fixed_string. Scaled by 10^decimals, a value
+// whose fraction is not within `err` of one half rounds the same way whether one looks at the double's exact expansion,
+// at its shortest round-trip digits (what the Formatter does) or at the rounded product y: the three differ by less
+// than y * 2^-51. Everything else (ties and near-ties, huge values, NaN / infinities) takes fixed_string.
+void append_fixed(std::string &s, double v, int decimals) {
+    static const double p10[10] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+    const double av = std::fabs(v);
+    if (decimals >= 0 && decimals <= 9 && av < 1e9) { // (false for NaN)
+        const double y = av * p10[decimals];
+        const double fl = std::floor(y), f = y - fl, err = y * 0x1p-51 + 0x1p-60;
+        if (std::fabs(f - 0.5) > err && err < 0.25) {
+            unsigned long long r = (unsigned long long)fl + (f > 0.5 ? 1ull : 0ull);
+            char tmp[40];
+            int k = 40;
+            for (int i = 0; i < decimals; ++i) {
+                tmp[--k] = (char)('0' + r % 10);
+                r /= 10;
+            }
+            if (decimals > 0) tmp[--k] = '.';
+            do {
+                tmp[--k] = (char)('0' + r % 10);
+                r /= 10;
+            } while (r);
+            if (std::signbit(v)) tmp[--k] = '-';
+            s.append(tmp + k, (size_t)(40 - k));
+            return;
+        }
+    }
+    s += fixed_string(v, decimals);
+}
+
+void append_int(std::string &s, long v) {
+    char tmp[24];
+    auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
+    s.append(tmp, (size_t)(r.ptr - tmp));
+}
+
 // java.lang.Double.toString
 std::string java_double_tostring(double v) {
     if (std::isnan(v)) return "NaN";
@@ -546,6 +583,13 @@ plaac_status plaac_read_aa_params(const char *path, double vec[PLAAC_NAA], int *
 unsigned plaac_host_threads(void) { return host_threads(); }
 
 int plaac_format_fixed(double v, int decimals, char *buf, size_t cap) {
+    std::string s;
+    append_fixed(s, v, decimals);
+    return (int)emit(s, buf, cap);
+}
+
+// the digit-string path alone (what append_fixed falls back to): the differential test compares the two
+int plaac_format_fixed_reference(double v, int decimals, char *buf, size_t cap) {
     return (int)emit(fixed_string(v, decimals), buf, cap);
 }
 
@@ -571,9 +615,10 @@ long plaac_format_summary_row(const plaac_row *r, const char *name, const uint8_
     if (r->prot_len <= 0) return 0; // skipped record (:762)
     const int n = r->prot_len;
     (void)reclen;
-    std::string s(name);
-    auto I = [&](long v) { s += '\t'; s += std::to_string(v); };
-    auto F = [&](double v) { s += '\t'; s += fixed_string(v, 3); };
+    thread_local std::string s; // one buffer per formatter thread: no allocation per row
+    s.assign(name);
+    auto I = [&](long v) { s += '\t'; append_int(s, v); };
+    auto F = [&](double v) { s += '\t'; append_fixed(s, v, 3); };
     // one-based indices; the -1/-2 sentinels are shifted too, as the reference does (:902-913)
     I(r->mw_score);
     I(r->mw_start + 1);
@@ -640,23 +685,23 @@ long plaac_format_track_rows(const plaac_tracks *t, uint64_t first, const uint8_
         s += '\t';
         s += name;
         s += '\t';
-        s += std::to_string(i + 1);
+        append_int(s, (long)i + 1);
         s += '\t';
         s += kAlphabet[codes[i] <= 21 ? codes[i] : 0];
         s += '\t';
-        s += std::to_string((int)t->vit[k]);
+        append_int(s, (long)t->vit[k]);
         s += '\t';
-        s += std::to_string((int)t->map[k]);
+        append_int(s, (long)t->map[k]);
         const double v[8] = {t->charge[k], t->hydro[k], t->fi[k], t->plaacllr[k], t->papa[k], t->fix2[k],
                              t->plaacllrx2[k], t->papax2[k]};
         for (int j = 0; j < 8; ++j) {
             s += '\t';
-            s += fixed_string(v[j], prec[j]);
+            append_fixed(s, v[j], prec[j]);
         }
         s += '\t';
-        s += fixed_string(t->post0[k], 4);
+        append_fixed(s, t->post0[k], 4);
         s += '\t';
-        s += fixed_string(t->post1[k], 4);
+        append_fixed(s, t->post1[k], 4);
         s += '\n';
     }
     s += "########################################################\n";

@@ -15,6 +15,7 @@ class _Fasta(C.Structure):
 
 HOST_EXPORTS = (
     "plaac_fasta_read", "plaac_fasta_free", "plaac_read_aa_params", "plaac_format_fixed",
+    "plaac_format_fixed_reference",
     "plaac_format_double_tostring", "plaac_format_summary_row", "plaac_summary_header", "plaac_tracks_header",
     "plaac_format_track_rows", "plaac_track_rows_bound", "plaac_format_param_block", "plaac_format_aa_params",
     "plaac_host_threads", "plaac_format_hmm_dot", "plaac_fasta_open", "plaac_fasta_next", "plaac_fasta_close",
@@ -36,6 +37,7 @@ def _lib():
         L.plaac_fasta_close.restype = None
         L.plaac_read_aa_params.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
         L.plaac_format_fixed.argtypes = [C.c_double, C.c_int, C.c_char_p, C.c_size_t]
+        L.plaac_format_fixed_reference.argtypes = [C.c_double, C.c_int, C.c_char_p, C.c_size_t]
         L.plaac_format_double_tostring.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
         L.plaac_format_summary_row.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
                                                C.c_char_p, C.c_size_t]
@@ -111,6 +113,12 @@ def read_aa_params(path):
 def format_fixed(v, decimals):
     buf = C.create_string_buffer(512)
     _lib().plaac_format_fixed(float(v), int(decimals), buf, 512)
+    return buf.value.decode()
+
+
+def format_fixed_reference(v, decimals):
+    buf = C.create_string_buffer(512)
+    _lib().plaac_format_fixed_reference(float(v), int(decimals), buf, 512)
     return buf.value.decode()
 
 

@@ -27,6 +27,27 @@ def test_host_header_exports(native):
         assert hasattr(L, name), name
 
 
+def test_fixed_formatting_short_cut_agrees_with_the_digit_string_path_and_with_decimal(io):
+    """the arithmetic short cut of %.Nf (values away from a tie) against the digit-string path and against an independent
+    statement of the rule: shortest round-trip digits (Python's repr), then ROUND_HALF_UP at the requested place"""
+    import decimal
+    import numpy as np
+    rng = np.random.default_rng(314)
+    vals = [0.0, -0.0, 0.0005, 0.00049999999999999994, 0.0625, 0.1875, 1.0005, 2.5e-4, 123456.7895, 999999.9995,
+            4.5e6, 1e9 - 1e-3, 1e9, 3.3e15, 5e-324, 1e-300, 0.9995, 0.99949999999999994]
+    vals += list(rng.normal(0, 50, 20000)) + list(rng.random(20000) * 10.0 ** rng.integers(-6, 9, 20000))
+    for k in rng.integers(0, 10 ** 7, 20000):  # exact and nearly exact ties at three and four decimals
+        for d in (1000.0, 10000.0):
+            t = (k + 0.5) / d
+            vals += [t, np.nextafter(t, 0.0), np.nextafter(t, np.inf)]
+    for v in vals:
+        for dec in (3, 4, 8):
+            got = io.format_fixed(v, dec)
+            assert got == io.format_fixed_reference(v, dec), (v, dec)
+            want = decimal.Decimal(repr(abs(float(v)))).quantize(decimal.Decimal(1).scaleb(-dec), decimal.ROUND_HALF_UP)
+            assert got == ("-" if np.signbit(v) else "") + format(want, "f"), (v, dec, got)
+
+
 def test_java_fixed_formatting(io):
     f = io.format_fixed
     assert f(51.21464835140835, 3) == "51.215"
