@@ -350,8 +350,11 @@ static plaac_status parse_records(const char *d, size_t nbytes, size_t rb0, size
             size_t p = rb;
             auto next_line = [&](size_t &lb, size_t &le) -> bool { // BufferedReader.readLine on [p, re)
                 if (p >= re) return false;
-                size_t e = p;
-                while (e < re && d[e] != '\n' && d[e] != '\r') ++e;
+                // the line ends at the first \n or \r: two library scans (vectorised) instead of a byte loop - the \n
+                // first, then a \r inside what it found (absent from Unix files: one more pass over a short line)
+                const char *nl = (const char *)memchr(d + p, '\n', re - p);
+                size_t e = nl ? (size_t)(nl - d) : re;
+                if (const char *cr = (const char *)memchr(d + p, '\r', e - p)) e = (size_t)(cr - d);
                 lb = p;
                 le = e;
                 if (e < re) {
