@@ -62,7 +62,8 @@ struct plaac_ctx {
     DevTables *d_tabs = nullptr;  // tables of the groups of a sweep
     size_t cap_tabs = 0;
     std::vector<hipEvent_t> gev;  // per-group "forward pass done" events of a sweep
-    std::vector<hipStream_t> gstreams; // side streams of the 2nd, 3rd ... group of a sweep (three each)
+    std::vector<hipStream_t> gstreams; // side streams of the 2nd, 3rd ... group of a sweep (three each), high priority
+    std::vector<hipStream_t> gstreams_n; // the same at normal priority (throughput-bound batches, see auxn)
     std::vector<hipEvent_t> gjev;      // their join events
     hipEvent_t jev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
     hipEvent_t fev[2] = {nullptr, nullptr};                            // k_finish waits for the forward / window streams
@@ -459,11 +460,12 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         }
     for (hipEvent_t e : ctx->gev)
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t a : ctx->gstreams)
-        if (a) {
-            (void)hipStreamSynchronize(a);
-            (void)hipStreamDestroy(a);
-        }
+    for (auto *gs : {&ctx->gstreams, &ctx->gstreams_n})
+        for (hipStream_t a : *gs)
+            if (a) {
+                (void)hipStreamSynchronize(a);
+                (void)hipStreamDestroy(a);
+            }
     for (hipEvent_t e : ctx->gjev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->jev)
@@ -573,6 +575,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         hipStream_t a = nullptr;
         PL_HIP(ctx, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest));
         ctx->gstreams.push_back(a);
+        a = nullptr;
+        PL_HIP(ctx, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, 0));
+        ctx->gstreams_n.push_back(a);
         hipEvent_t e = nullptr;
         PL_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->gjev.push_back(e);
@@ -716,10 +721,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         char *&cp = reinterpret_cast<char *&>(ctx->d_corepart);
         if ((rc = grow(ctx, cp, ctx->cap_corepart, lrows * 64u * sizeof(CorePart))) != PLAAC_OK) return rc;
     }
-    const bool use_core_list = ctx->core_list && single && !latency_mode && !chain_bound;
+    const bool use_core_list = ctx->core_list && !latency_mode && !chain_bound; // (sweeps: one list per group)
     if (use_core_list) {
-        if ((rc = grow(ctx, ctx->d_corelist, ctx->cap_corelist, (size_t)nprot)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, ctx->d_corecount, ctx->cap_corecount, (size_t)1)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_corelist, ctx->cap_corelist, (size_t)nprot * ng)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_corecount, ctx->cap_corecount, ng)) != PLAAC_OK) return rc;
     }
     if ((rc = grow(ctx, ctx->d_packed, ctx->cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
     const size_t bits_stride = total_rows * 64u + 64u; // one traceback-bit buffer per group
@@ -731,6 +736,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     hipLaunchKernelGGL(k_pack, dim3((nprot + 15u) / 16u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
+    const std::vector<hipStream_t> &gs = chain_bound ? ctx->gstreams : ctx->gstreams_n;
     if (!ctx->serial) {
         if (!chain_bound) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn)
             sv = ctx->auxn[0];
@@ -741,7 +747,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PACK + 1], 0));
         }
         for (hipStream_t a : {sf, sw, sb, sw2}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
-        for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(ctx->gstreams[k], evs[E_PACK + 1], 0));
+        for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(gs[k], evs[E_PACK + 1], 0));
     }
     const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS, fb = (nprot + KF_THREADS - 1) / KF_THREADS;
     // track mode: the backward recurrence is a chain of its own, beside the forward one
@@ -760,9 +766,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         // streams of this group
         hipStream_t sv = sv0, sf = sf0, sw = sw0;
         if (g > 0 && !ctx->serial) {
-            sv = ctx->gstreams[3 * (g - 1)];
-            sf = ctx->gstreams[3 * (g - 1) + 1];
-            sw = ctx->gstreams[3 * (g - 1) + 2];
+            sv = gs[3 * (g - 1)];
+            sf = gs[3 * (g - 1) + 1];
+            sw = gs[3 * (g - 1) + 2];
         }
         uint32_t *gbits = ctx->d_bits + bits_stride * g;
         // K-B of this group (group 0 was launched before the host round trip; serialised mode launches it last)
@@ -818,8 +824,26 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                                    ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg,
                                    ctx->d_corelist, ctx->d_corecount);
                 if (tg.stop_after == 0u)
-                    hipLaunchKernelGGL(k_core_list, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes, ctx->d_order,
+                    hipLaunchKernelGGL(k_core_list<1>, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes, ctx->d_order,
                                        tab, ctx->d_packed, ctx->d_grow, gbits, tg, ctx->d_corelist, ctx->d_corecount);
+            } else if (use_core_list) { // sweep groups: the group's own list, reused by its launches (same stream)
+                uint32_t *gl = ctx->d_corelist + (size_t)nprot * g, *gc = ctx->d_corecount + g;
+                PL_HIP(ctx, hipMemsetAsync(gc, 0, sizeof(uint32_t), sv));
+#define LAUNCH_VIT_LIST(NC)                                                                                        \
+    do {                                                                                                           \
+        hipLaunchKernelGGL((k_vit<NC, false, false, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, \
+                           ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg, gl, gc);   \
+        if (tg.stop_after == 0u)                                                                                   \
+            hipLaunchKernelGGL(k_core_list<NC>, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes,        \
+                               ctx->d_order, tab, ctx->d_packed, ctx->d_grow, gbits, tg, gl, gc);                   \
+    } while (0)
+                switch (nc) {
+                case 1: LAUNCH_VIT_LIST(1); break;
+                case 2: LAUNCH_VIT_LIST(2); break;
+                case 3: LAUNCH_VIT_LIST(3); break;
+                default: LAUNCH_VIT_LIST(4); break;
+                }
+#undef LAUNCH_VIT_LIST
             } else if (single) { // hmm0's running sum is k_fwd's (k_finish)
                 hipLaunchKernelGGL((k_vit<1, false, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,
                                    ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg);
@@ -888,7 +912,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[4], sw2));
         for (hipEvent_t e : ctx->jev) PL_HIP(ctx, hipStreamWaitEvent(st, e, 0));
         for (size_t k = 0; k < 3 * (ng - 1); ++k) {
-            PL_HIP(ctx, hipEventRecord(ctx->gjev[k], ctx->gstreams[k]));
+            PL_HIP(ctx, hipEventRecord(ctx->gjev[k], gs[k]));
             PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
         }
     }
