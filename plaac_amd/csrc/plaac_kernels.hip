@@ -824,8 +824,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                                    ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg,
                                    ctx->d_corelist, ctx->d_corecount);
                 if (tg.stop_after == 0u)
-                    hipLaunchKernelGGL(k_core_list<1>, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes, ctx->d_order,
-                                       tab, ctx->d_packed, ctx->d_grow, gbits, tg, ctx->d_corelist, ctx->d_corecount);
+                    hipLaunchKernelGGL(k_core_list<1>, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes,
+                                       total_residues, ctx->d_order, tab, ctx->d_packed, ctx->d_grow, gbits, tg,
+                                       ctx->d_corelist, ctx->d_corecount);
             } else if (use_core_list) { // sweep groups: the group's own list, reused by its launches (same stream)
                 uint32_t *gl = ctx->d_corelist + (size_t)nprot * g, *gc = ctx->d_corecount + g;
                 PL_HIP(ctx, hipMemsetAsync(gc, 0, sizeof(uint32_t), sv));
@@ -835,7 +836,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                            ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg, gl, gc);   \
         if (tg.stop_after == 0u)                                                                                   \
             hipLaunchKernelGGL(k_core_list<NC>, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes,        \
-                               ctx->d_order, tab, ctx->d_packed, ctx->d_grow, gbits, tg, gl, gc);                   \
+                               total_residues, ctx->d_order, tab, ctx->d_packed, ctx->d_grow, gbits, tg, gl, gc);   \
     } while (0)
                 switch (nc) {
                 case 1: LAUNCH_VIT_LIST(1); break;
