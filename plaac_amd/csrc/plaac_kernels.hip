@@ -604,13 +604,29 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         }
         return -1;
     };
+    long filter_group = -1; // the group whose filter-tier lists (centres, fallbacks) the ctx buffers hold
     auto launch_tracks = [&](size_t g) -> plaac_status { // K-B: needs only the order, not the packed copy
         if (!d_tracks) {
             const long base = kb_base(g);
             if (base >= 0) {
-                hipLaunchKernelGGL(k_llr_at_centre, dim3((nprot + 3u) / 4u), dim3(256), 0, st, d_codes, d_offsets,
-                                   ctx->d_neff, nprot, gtab0 + g, d_rows[groups[(size_t)base].first],
-                                   d_rows[groups[g].first]);
+                const plaac_row *src = d_rows[groups[(size_t)base].first];
+                plaac_row *dst = d_rows[groups[g].first];
+                if (base == filter_group) {
+                    // the base group went through the filter tier: its list of centres is still in place. Copy the
+                    // fields that do not depend on llr, then the llr track alone at the listed centres (nine proteins
+                    // per wave), and the one-wave-per-protein kernel only for what the exact tier scored
+                    const uint32_t *huge = ctx->d_hist + LEN_BINS;
+                    hipLaunchKernelGGL(k_copy_window_fields, dim3((nprot + 255u) / 256u), dim3(256), 0, st, src, dst, nprot);
+                    hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min((nprot + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)),
+                                       dim3(64), 0, st, d_codes, total_residues, gtab0 + g, ctx->d_divtab, dst, huge,
+                                       ctx->d_clist, ctx->d_crow, ctx->d_ccount);
+                    hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, st, d_codes,
+                                       d_offsets, ctx->d_neff, nprot, gtab0 + g, src, dst, ctx->d_order, ctx->d_fblist,
+                                       ctx->d_fbcount, huge);
+                } else {
+                    hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 1u << 20)), dim3(256), 0, st, d_codes,
+                                       d_offsets, ctx->d_neff, nprot, gtab0 + g, src, dst);
+                }
                 return PLAAC_OK;
             }
         }
@@ -653,7 +669,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                         hipLaunchKernelGGL(k_tracks20f<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
                                            total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
                                            ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
-                    hipLaunchKernelGGL(k_refine_centres, dim3(std::min((nprot + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)), dim3(64),
+                    filter_group = (long)g;
+                    hipLaunchKernelGGL(k_refine_centres<false>, dim3(std::min((nprot + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)), dim3(64),
                                        0, st, d_codes, total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist,
                                        ctx->d_crow, ctx->d_ccount);
                     hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, st, d_codes,

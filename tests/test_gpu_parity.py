@@ -286,6 +286,30 @@ def test_resident_batch_histogram_score_and_sweep(native, oracle, ctx):
         assert_tracks_equal(tr, wtr, codes, offs)
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_sweep_on_adversarial_sequences_in_both_scheduling_modes(native, oracle, monkeypatch, mode):
+    """a sweep whose dependent alpha groups take plaacllr / plaacllrx2 from the llr-only refine kernel (listed centres)
+    and from the one-wave-per-protein kernel (what the exact tier scored: the adversarial set is full of those), with
+    the core lists of the throughput-bound schedule (mode 0) and the in-kernel core sweep of the chain-bound one (1)"""
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_LATENCY_MODE", mode)
+    P = native.make_params()
+    c1, o1 = _adversarial_batch(native)
+    c2, o2 = synth.make_batch(4, nprot=3000, seed=77, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.05)
+    codes = np.concatenate([c1, c2])
+    offs = np.concatenate([o1, o2[1:] + o1[-1]]).astype(np.uint64)
+    points = [(a, c) for a in (1.0, 0.0, 0.5) for c in (30, 60, 90, 20, 45)]  # five core lengths: two launches per group
+    with native.Context(P) as c:
+        with c.upload(codes, offs) as batch:
+            bg = batch.histogram().astype(np.float64)
+            got = batch.sweep([native.make_params(alpha=a, corelength=cl, bgcounts=bg) for a, cl in points])
+            nfb = c.last_exact_fallbacks()
+    assert nfb > 0
+    for (a, cl), rows in zip(points, got):
+        want = oracle.score_batch(oracle.build_params(alpha=a, corelength=cl, bgcounts=bg), codes, offs, nthreads=8)
+        assert_rows_equal(rows, want, "alpha=%s c=%d mode=%s" % (a, cl, mode))
+
+
 def test_proteins_beyond_the_last_length_bin(native, oracle, ctx):
     """lengths >= 65535 share one (unsorted) length bin of the planner: group row counts must use the true max"""
     from plaac_amd import synth
