@@ -22,6 +22,7 @@ python3 bench.py --config 3 --steps 100 --no-e2e > $O/bench_cfg3_two_pass.json 2
 python3 bench.py --nprot 1250000 --no-e2e > $O/bench_cfg4_shard_1250k.json 2>/dev/null
 python3 bench.py --tracks --steps 10 --no-e2e > $O/bench_tracks_1250k.json 2>/dev/null
 python3 bench.py --sweep --nprot 1250000 --steps 5 --no-e2e > $O/bench_sweep_1250k.json 2>/dev/null
+python3 bench.py --sweep --steps 5 --no-e2e > $O/bench_sweep_10M.json 2>/dev/null
 python3 bench.py --sweep --naive-sweep --nprot 1250000 --steps 3 --no-e2e > $O/bench_sweep_naive_1250k.json 2>/dev/null
 # two ranks on the one device, exchange over gloo (RCCL needs one device per rank): HIP contexts + row gather together
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py \
