@@ -310,6 +310,7 @@ def main():
 
     if args.calibrate:
         ctx.histogram_device(codes.data_ptr(), offsets.data_ptr(), nprot, cnt.data_ptr(), stream=stream.cuda_stream)
+        ctx.calibration_reads(codes.data_ptr(), total, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
     if rank != 0:
         ctx.close()
@@ -332,7 +333,7 @@ def main():
     achieved = path_bytes / (dom_ms * 1e-3) / 1e9
     # HBM traffic and executed instruction counts: PMC counters cannot be read from inside this process;
     # tools/pmc.sh collects them for this same workload and leaves the per-launch figures under profiles/
-    traffic, traffic_all, exec_ops, issue_instr = None, None, None, None
+    traffic, traffic_all, exec_ops, issue_instr, traffic_cal, traffic_all_cal, fetch_cal = (None,) * 7
     import glob
     for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
         try:
@@ -347,6 +348,11 @@ def main():
                           (dom == "k_vit" and k.startswith("k_core"))]
                 traffic = sum(per[k] for k in names) if names else None
                 traffic_all = tj.get("bytes_per_step")
+                perc = tj.get("bytes_per_launch_calibrated")
+                if perc:  # read factor measured on this repo's own access shapes instead of the guide's x2 for all
+                    traffic_cal = sum(perc[k] for k in names if k in perc)
+                    traffic_all_cal = tj.get("bytes_per_step_calibrated")
+                    fetch_cal = tj.get("fetch_calibration")
                 exec_ops = tj.get("fp64_ops_per_residue_executed")
                 issue_instr = tj.get("valu_lds_wave_instructions_per_step")
         except (OSError, ValueError, KeyError):
@@ -356,6 +362,8 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_all_kernels": traffic_all,
+        "traffic_calibrated": traffic_cal, "traffic_all_kernels_calibrated": traffic_all_cal,
+        "fetch_calibration": fetch_cal,
         "algorithmic_bytes": path_bytes, "measured_copy_GBps": copy_gbps,
         "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
         "kernels_overlap": "k_vit, k_fwd, k_win, k_tracks run concurrently on 4 HIP streams; total = first launch -> join",

@@ -233,6 +233,12 @@ const char *plaac_node_last_error(const plaac_node *node);
  * proteins of the most recent scored batch took the exact tier. Blocks until that batch has completed. */
 plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count);
 
+/* DIAGNOSTIC (tools/pmc.sh): three kernels that stream once over the resident residue buffer - 16 bytes per lane,
+ * aligned dwords, unaligned dwords - so that a rocprofv3 PMC pass over the same process can calibrate FETCH_SIZE on a
+ * known byte count in the access shapes of the scoring kernels (MI355X_MICROARCH.md: the counter is uncalibrated for
+ * anything but wide streaming reads). Asynchronous on `stream` (NULL = the ctx's own). No result. */
+plaac_status plaac_calibration_reads(plaac_ctx *ctx, const uint8_t *d_codes, uint64_t total_residues, void *stream);
+
 /* The filter tier needs the SIGN of FoldIndex (plaac.java:4885, :5020-5058) and of its second smoothing (:4903, :4944)
  * at every position. When hydro2[] and cc[] are rationals with small denominators - the reference's own tables are:
  * aahydro / 9 + 0.5 with one-decimal aahydro (:90), cc = {2.785, -1, -1.151} - m * FoldIndex is an integer over the

@@ -982,6 +982,20 @@ plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
 
 plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]) { return plaac_timings_mean(ctx, 1, ms); }
 
+plaac_status plaac_calibration_reads(plaac_ctx *ctx, const uint8_t *d_codes, uint64_t total_residues, void *stream_) {
+    if (!ctx || !d_codes) return PLAAC_ERR_ARG;
+    if ((uintptr_t)d_codes & 15u) return fail(ctx, PLAAC_ERR_ARG, "d_codes must be 16-byte aligned");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    if (!ctx->d_flag) PL_HIP(ctx, hipMalloc((void **)&ctx->d_flag, sizeof(uint32_t)));
+    const unsigned grid = (unsigned)ctx->num_cus * 16u;
+    hipLaunchKernelGGL((k_calib_read<16, 0>), dim3(grid), dim3(256), 0, st, d_codes, total_residues, ctx->d_flag);
+    hipLaunchKernelGGL((k_calib_read<4, 0>), dim3(grid), dim3(256), 0, st, d_codes, total_residues, ctx->d_flag);
+    hipLaunchKernelGGL((k_calib_read<4, 1>), dim3(grid), dim3(256), 0, st, d_codes, total_residues, ctx->d_flag);
+    PL_HIP(ctx, hipGetLastError());
+    return PLAAC_OK;
+}
+
 int plaac_fi_integer_form(const plaac_params *params, int32_t info[6]) {
     if (!params) return 0;
     DevTables *h = new (std::nothrow) DevTables();

@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-KEYS = ("k_tracks20f", "k_refine_centres", "k_core_list", "k_core_chain", "k_core_eval", "k_core_reduce", "k_fwd_pair", "k_finish", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
+KEYS = ("k_calib_read<16, 0>", "k_calib_read<4, 0>", "k_calib_read<4, 1>", "k_tracks20f", "k_refine_centres", "k_core_list", "k_core_chain", "k_core_eval", "k_core_reduce", "k_fwd_pair", "k_finish", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
         "k_plan_scatter", "k_pack", "k_group_rows", "k_scan_u32")
 
 
@@ -56,6 +56,22 @@ def main(root):
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             traffic[k] = {"fetch_raw_bytes": c["FETCH_SIZE"] * 1024, "write_bytes": c["WRITE_SIZE"] * 1024,
                           "hbm_bytes_gfx950_corrected": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024}
+    # calibration on known byte counts (plaac_calibration_reads streams R bytes in three access shapes): bytes the
+    # counter reports per byte read, for 16-byte-per-lane loads and for dword loads; each scoring kernel is then
+    # corrected with the factor of the loads that dominate its reads
+    calib = {}
+    for key, name in (("k_calib_read<16, 0>", "wide16"), ("k_calib_read<4, 0>", "dword"), ("k_calib_read<4, 1>", "dword_unaligned")):
+        if R and key in traffic and traffic[key]["fetch_raw_bytes"] > 0:
+            calib[name] = {"fetch_raw_bytes": traffic[key]["fetch_raw_bytes"], "bytes_read": R,
+                           "bytes_per_reported_byte": R / traffic[key]["fetch_raw_bytes"]}
+    summary["fetch_calibration_reads"] = calib
+    NARROW = ("k_tracks20f", "k_refine_centres", "k_tracks20s", "k_tracks20", "k_tracks", "k_hist", "k_plan_lengths",
+              "k_llr_at_centre")  # residues read as (unaligned) dwords / bytes; every other kernel reads 16 bytes per lane
+    if "wide16" in calib and "dword_unaligned" in calib:
+        for k, t in traffic.items():
+            f = calib["dword_unaligned" if k in NARROW else "wide16"]["bytes_per_reported_byte"]
+            t["fetch_factor_calibrated"] = f
+            t["hbm_bytes_calibrated"] = f * t["fetch_raw_bytes"] + t["write_bytes"]
     summary["traffic"] = traffic
     if R and "k_hist" in traffic:
         expect = 2 * R + 8 * P
@@ -65,20 +81,28 @@ def main(root):
     json.dump(summary, open(os.path.join(root, "summary.json"), "w"), indent=1, sort_keys=True)
     # fp64 operations the kernels EXECUTED (wave instructions x 64 lanes), per residue, over one step
     f64 = sum(c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_FMA_F64", 0)
-              for k, c in mean.items() if k != "k_hist")
+              for k, c in mean.items() if k != "k_hist" and not k.startswith("k_calib"))
     if R:
         mode = cfg.get("mode") == "tracks"
         wl = {"cfg2": 2, "cfg3": 3, "cfg4": 4}.get(cfg.get("workload", "")[:4], 4)
         json.dump({"workload": [wl, P, mode], "source": "tools/pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                    "passes); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md gfx950 correction",
-                   "bytes_per_launch": {k: round(v["hbm_bytes_gfx950_corrected"]) for k, v in traffic.items()},
+                   "bytes_per_launch": {k: round(v["hbm_bytes_gfx950_corrected"]) for k, v in traffic.items()
+                                        if not k.startswith("k_calib")},
                    "bytes_per_step": round(sum(v["hbm_bytes_gfx950_corrected"] for k, v in traffic.items()
-                                               if k != "k_hist")),
+                                               if k != "k_hist" and not k.startswith("k_calib"))),
+                   # the same with the read factor measured on this repo's own access shapes (fetch_calibration_reads)
+                   "bytes_per_launch_calibrated": {k: round(v["hbm_bytes_calibrated"]) for k, v in traffic.items()
+                                                   if "hbm_bytes_calibrated" in v and not k.startswith("k_calib")} or None,
+                   "bytes_per_step_calibrated": round(sum(v.get("hbm_bytes_calibrated", 0) for k, v in traffic.items()
+                                                          if k != "k_hist" and not k.startswith("k_calib"))) or None,
+                   "fetch_calibration": {k: round(v["bytes_per_reported_byte"], 3) for k, v in calib.items()},
                    "fp64_ops_per_residue_executed": round(f64 * 64 / R, 1) if f64 else None,
                    # what actually bounds the path: vector-ALU and LDS wave-instructions issued per step (SQ_INSTS_VALU +
                    # SQ_INSTS_LDS over all kernels of a step); a SIMD issues one per 4 cycles at best
                    "valu_lds_wave_instructions_per_step": round(sum(
-                       c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_LDS", 0) for k, c in mean.items() if k != "k_hist"))},
+                       c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_LDS", 0) for k, c in mean.items()
+                       if k != "k_hist" and not k.startswith("k_calib")))},
                   open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     for k in sorted(mean):
         t = traffic.get(k, {})
