@@ -96,6 +96,9 @@ struct plaac_ctx {
     uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
     size_t cap_corelist = 0, cap_corecount = 0;
     bool core_list = true; // PLAAC_CORE_LIST=0: sweep 3 inside k_vit for every batch
+    uint32_t *d_coreflags = nullptr; // k_core_par -> k_core_chain: proteins of the long groups left to the serial chain
+    bool core_par = true;  // PLAAC_CORE_PAR=0: always the serial masked prefix chain (k_core_chain) in the latency form
+    bool core_par_ok = false; // the tables in d_tab pass core_par_tables_ok
     bool fi_int = false;   // the tables in d_tab qualify for FoldIndex in integers (derive_fi_int)
     bool fi_int_allowed = true; // PLAAC_FI_INT=0: always the fp64 form of the filter kernel
     size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_bwd = 0, cap_grow = 0, cap_packed = 0;
@@ -256,6 +259,30 @@ void derive_fi_int(const plaac_params &P, DevTables &D, int32_t *info) {
         D.fi_iv[k] = 1u | ((uint32_t)((int)P.charge[k] + 1) << 6) | ((uint32_t)(H[k] - hmin) << 13);
 }
 
+// k_core_par replaces the serial masked prefix chain by exact sums on the grid of the binade of k * |big_neg| (see the
+// kernel). That needs rn_q(llr) to be tie-free for every grid the chain can reach: q = 2^(e-52) for the binades e of
+// k * |big_neg|, k = 1 .. 65535; a tie needs the lowest set bit of an llr value to be exactly q/2.
+bool core_par_tables_ok(const plaac_params &P) {
+    if (!(P.big_neg < 0.0) || !std::isfinite(P.big_neg)) return false;
+    int e_lo = 0, e_hi = 0;
+    (void)std::frexp(-P.big_neg, &e_lo);           // -big_neg = f * 2^e_lo, f in [0.5, 1): binade exponent e_lo - 1
+    (void)std::frexp(-P.big_neg * 65535.0, &e_hi);
+    e_lo -= 1;
+    e_hi -= 1;
+    if (e_lo < 8) return false; // |big_neg| must dwarf the llr values (the reference's is 1e6)
+    for (int k = 0; k < NAA; ++k) {
+        const double t = P.llr[k];
+        if (!std::isfinite(t)) return false;
+        if (t == 0.0) continue;
+        int e = 0;
+        const double f = std::frexp(std::fabs(t), &e); // |t| = f * 2^e
+        const unsigned long long m = (unsigned long long)std::ldexp(f, 53); // 53-bit integer mantissa: |t| = m * 2^(e-53)
+        const int low = e - 53 + __builtin_ctzll(m);                        // exponent of the lowest set bit
+        if (low >= e_lo - 53 && low <= e_hi - 53) return false;             // = q/2 for some reachable q = 2^(eb-52)
+    }
+    return true;
+}
+
 // The kernels exploit the structure of the reference's two models; refuse anything else loudly.
 const char *check_params(const plaac_params &P) {
     if (P.corelength < 1) return "corelength must be >= 1";
@@ -366,6 +393,8 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         if (const char *rg = std::getenv("PLAAC_RF_GRID")) ctx->rf_grid = (unsigned)std::max(1, std::atoi(rg));
         const char *kbf = std::getenv("PLAAC_KB_FILTER");
         ctx->kb_filter = !(kbf && kbf[0] == '0');
+        const char *cp = std::getenv("PLAAC_CORE_PAR");
+        ctx->core_par = !(cp && cp[0] == '0');
         const char *cl = std::getenv("PLAAC_CORE_LIST");
         ctx->core_list = !(cl && cl[0] == '0');
         const char *fii = std::getenv("PLAAC_FI_INT");
@@ -408,6 +437,7 @@ plaac_status plaac_ctx_set_params(plaac_ctx *ctx, const plaac_params *params) {
     if (!h) return fail(ctx, PLAAC_ERR_NOMEM, "out of host memory");
     fill_tables(*params, *h);
     const bool fi_int = h->fi_int != 0;
+    const bool cpar = core_par_tables_ok(*params);
     // The last scored batch may still be reading the old tables: its kernels run on the caller's stream and on the
     // non-blocking side streams, none of which a null-stream copy waits for. Its join event (recorded on the caller's
     // stream after every side stream has been joined) covers all of them.
@@ -422,6 +452,7 @@ plaac_status plaac_ctx_set_params(plaac_ctx *ctx, const plaac_params *params) {
     }
     ctx->params = *params;
     ctx->fi_int = fi_int;
+    ctx->core_par_ok = cpar;
     return PLAAC_OK;
 }
 
@@ -440,7 +471,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
     for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_crow, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount,
-                    (void *)ctx->d_corelist, (void *)ctx->d_corecount,
+                    (void *)ctx->d_corelist, (void *)ctx->d_corecount, (void *)ctx->d_coreflags,
                     (void *)ctx->d_lat, (void *)ctx->d_corep, ctx->d_corepart})
         if (b) (void)hipFree(b);
     for (void *b : bufs)
@@ -827,8 +858,19 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                                    ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg);
                 if (tg.stop_after == 0u && ctx->h_pin[2] >= CORE_LONG_ROWS) { // some group is long: its core window
                     const unsigned lg = std::min<unsigned>(ngroups, CORE_MAX_GROUPS);
+                    // masked prefix sums of the long groups: position-parallel on the chain's rounding grid where the
+                    // tables and the protein allow it (k_core_par), the serial chain for whatever it flags
+                    const bool par = ctx->core_par && ctx->core_par_ok &&
+                                     std::memcmp(&points[G.first], &ctx->params, sizeof(plaac_params)) == 0;
+                    if (par) {
+                        if (!ctx->d_coreflags)
+                            PL_HIP(ctx, hipMalloc((void **)&ctx->d_coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
+                        PL_HIP(ctx, hipMemsetAsync(ctx->d_coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, sv));
+                        hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64), 0, sv, d_codes, ctx->d_order, nprot, tab,
+                                           ctx->d_grow, gbits, ctx->d_corep, ctx->d_coreflags);
+                    }
                     hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, sv, ctx->d_order, nprot, tab, ctx->d_packed,
-                                       ctx->d_grow, gbits, ctx->d_corep);
+                                       ctx->d_grow, gbits, ctx->d_corep, par ? ctx->d_coreflags : (const uint32_t *)nullptr);
                     const size_t lrows = std::min<size_t>(total_rows, (size_t)CORE_MAX_GROUPS * ctx->h_pin[2]);
                     hipLaunchKernelGGL(k_core_eval, dim3((unsigned)lrows), dim3(64), 0, sv, ctx->d_order, nprot, ngroups,
                                        ctx->d_grow, ctx->d_corep, (CorePart *)ctx->d_corepart, tg.c[0]);

@@ -310,6 +310,40 @@ def test_sweep_on_adversarial_sequences_in_both_scheduling_modes(native, oracle,
         assert_rows_equal(rows, want, "alpha=%s c=%d mode=%s" % (a, cl, mode))
 
 
+@pytest.mark.parametrize("par", ["1", "0"])
+def test_masked_core_of_long_proteins_parallel_and_serial(native, oracle, monkeypatch, par):
+    """latency form, long wave-groups: the masked prefix sums come from k_core_par (exact sums on the rounding grid of the
+    chain, position-parallel) or, with PLAAC_CORE_PAR=0, from the serial chain. Proteins that begin inside a PrD run
+    (no masked residue yet: the serial part of k_core_par), that consist of one run, with many short runs, with runs
+    after thousands of masked residues, and ordinary ones; several core lengths."""
+    monkeypatch.setenv("PLAAC_LATENCY_MODE", "1")
+    monkeypatch.setenv("PLAAC_CORE_PAR", par)
+    rng = np.random.default_rng(4242)
+    aas = "ACDEFGHIKLMNPQRSTVWY"
+    bgp = np.array(native.make_params().bg)[1:21]
+    bgp = bgp / bgp.sum()
+
+    def bgseq(n):
+        return "".join(rng.choice(list(aas), n, p=bgp))
+
+    def prd(n):
+        return "".join(rng.choice(list("QNQNSGYQ"), n))
+
+    seqs = [prd(400) + bgseq(9000) + prd(200) + bgseq(300),              # begins in a run
+            prd(5000),                                                    # one run, never masked
+            bgseq(30000) + prd(150) + bgseq(3000) + prd(90) + bgseq(500),  # runs after tens of thousands of masked residues
+            "".join(bgseq(150) + prd(int(k)) for k in rng.integers(20, 200, 40)),  # many runs of all sizes
+            prd(59) + bgseq(4000) + prd(60) + bgseq(10),                  # runs of c-1 and c residues
+            bgseq(2500), bgseq(36000) + prd(300), prd(70) + "X" * 3 + prd(70) + bgseq(3000)]
+    seqs += [bgseq(int(n)) + prd(int(m)) + bgseq(200) for n, m in zip(rng.integers(10, 3000, 70), rng.integers(0, 150, 70))]
+    codes, offs = native.pack(seqs)
+    for kw in ({}, {"corelength": 30}, {"corelength": 140, "alpha": 0.4, "bgcounts": np.arange(22.0) + 3}):
+        Pn, Po = both_params(native, oracle, **kw)
+        with native.Context(Pn) as c:
+            assert_rows_equal(c.score(codes, offs), oracle.score_batch(Po, codes, offs, nthreads=8),
+                              what="core par=%s %s" % (par, kw))
+
+
 def test_proteins_beyond_the_last_length_bin(native, oracle, ctx):
     """lengths >= 65535 share one (unsorted) length bin of the planner: group row counts must use the true max"""
     from plaac_amd import synth
