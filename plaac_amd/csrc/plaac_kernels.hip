@@ -866,7 +866,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                         if (!ctx->d_coreflags)
                             PL_HIP(ctx, hipMalloc((void **)&ctx->d_coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
                         PL_HIP(ctx, hipMemsetAsync(ctx->d_coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, sv));
-                        hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64), 0, sv, d_codes, ctx->d_order, nprot, tab,
+                        hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, sv, d_codes, ctx->d_order, nprot, tab,
                                            ctx->d_grow, gbits, ctx->d_corep, ctx->d_coreflags);
                     }
                     hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, sv, ctx->d_order, nprot, tab, ctx->d_packed,
@@ -874,7 +874,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     const size_t lrows = std::min<size_t>(total_rows, (size_t)CORE_MAX_GROUPS * ctx->h_pin[2]);
                     hipLaunchKernelGGL(k_core_eval, dim3((unsigned)lrows), dim3(64), 0, sv, ctx->d_order, nprot, ngroups,
                                        ctx->d_grow, ctx->d_corep, (CorePart *)ctx->d_corepart, tg.c[0]);
-                    hipLaunchKernelGGL(k_core_reduce, dim3(lg), dim3(64), 0, sv, d_codes, ctx->d_order, nprot, tab,
+                    hipLaunchKernelGGL(k_core_reduce, dim3(lg * 64u), dim3(64), 0, sv, d_codes, ctx->d_order, nprot, tab,
                                        ctx->d_grow, gbits, (const CorePart *)ctx->d_corepart, tg.rows[0], tg.c[0]);
                 }
             } else if (single && use_core_list) { // throughput-bound: sweep 3 only for proteins that can have a core
@@ -923,8 +923,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                        ctx->d_lat ? ctx->d_lat + nprot : (double *)nullptr)
             if (latency_mode) { // three thirds side by side (LLR window | MW window | means + hmm0's running sum)
                 LAUNCH_WIN(1, 2, sw);
-                LAUNCH_WIN(1, 4, sw2);
-                LAUNCH_WIN(1, 5, sb); // the backward stream is idle in summary mode
+                // MW window + means + hmm0's running sum as ONE kernel beside the LLR kernel. (As two kernels on two more
+                // streams they were measured back to back, not side by side: the runtime maps streams onto four hardware
+                // queues, the fifth and sixth stream share theirs, and 1.6 + 1.3 ms in a row outlast the forward chain.)
+                LAUNCH_WIN(1, 3, sw2);
             } else {
                 switch (nc) {
                 case 1: LAUNCH_WIN(1, 0, sw); break;
@@ -957,7 +959,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                   // behind the kernels that produced the other two terms, so that it runs beside the window kernel
         if (!ctx->serial) {
             PL_HIP(ctx, hipEventRecord(ctx->fev[0], sf));
-            PL_HIP(ctx, hipEventRecord(ctx->fev[1], sb)); // latency mode: hmm0's total comes from k_win<1,5> on this stream
+            PL_HIP(ctx, hipEventRecord(ctx->fev[1], latency_mode ? sw2 : sb)); // latency mode: hmm0's total comes from k_win<1,3>
             PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[0], 0));
             PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[1], 0));
         }
