@@ -569,7 +569,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if ((rc = grow(ctx, ctx->d_neff, ctx->cap_prot, (size_t)nprot)) != PLAAC_OK) return rc;
     if ((rc = grow(ctx, ctx->d_order, ctx->cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
     const uint32_t ngroups = (nprot + 63u) / 64u;
-    if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 1)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 3)) != PLAAC_OK) return rc;
     const bool single = npoints == 1; // one parameter point: hmm0's running sum is computed once (k_fwd / k_win), k_finish
     if (single && (rc = grow(ctx, ctx->d_lat, ctx->cap_lat, 2 * (size_t)nprot)) != PLAAC_OK) return rc;
     if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
@@ -752,9 +752,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     PL_HIP(ctx, hipEventRecord(evs[E_PACK], sv));
     hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, sv, ctx->d_neff, ctx->d_order, nprot,
                        ngroups, ctx->d_grow);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, sv, ctx->d_grow, ngroups);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, sv, ctx->d_grow, ngroups, CORE_LONG_ROWS, CORE_MAX_GROUPS);
     PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_grow + ngroups, sizeof(uint32_t), hipMemcpyDeviceToHost, sv));
     PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 2, ctx->d_grow + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, sv));
+    PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 3, ctx->d_grow + ngroups + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               sv)); // [3] the long wave-groups the k_core_* kernels serve (a prefix of the plan), [4] their rows
     PL_HIP(ctx, hipStreamSynchronize(sv));
     const size_t total_rows = ctx->h_pin[0];
     // Is this batch bound by the serial chain of its longest protein (16-residue rows of the first wave-group x ~150 ns
@@ -763,13 +765,19 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const bool chain_bound =
         ctx->latency_mode >= 0 ? ctx->latency_mode == 1 : (uint64_t)ctx->h_pin[2] * 384000ull > total_residues;
     const bool latency_mode = !ctx->serial && !d_tracks && npoints == 1 && chain_bound;
-    if (latency_mode && ctx->h_pin[2] >= CORE_LONG_ROWS) { // scratch of k_core_*: the rows of the long wave-groups
-        const size_t lrows = std::min<size_t>(total_rows, (size_t)CORE_MAX_GROUPS * ctx->h_pin[2]);
+    const bool use_core_list = ctx->core_list && !latency_mode && !chain_bound; // (sweeps: one list per group)
+    // the long wave-groups (proteins of >= 2048 residues) of a single-point call take the position-parallel core search
+    // (PLAAC_CORE_LONG_LIST=1, EXPERIMENT: also in the list form of throughput-bound batches, where the listed long
+    // proteins are k_core_list's tail. Measured at 10 M sequences: 23.0 against 22.2 ms - the tail was hidden, the extra
+    // kernels are not.)
+    static const bool long_in_list = std::getenv("PLAAC_CORE_LONG_LIST") && std::getenv("PLAAC_CORE_LONG_LIST")[0] == '1';
+    const bool core_long = single && (latency_mode || (use_core_list && long_in_list)) && ctx->h_pin[2] >= CORE_LONG_ROWS;
+    if (core_long) { // scratch of k_core_*: the rows of the first CORE_MAX_GROUPS wave-groups
+        const size_t lrows = ctx->h_pin[4];
         if ((rc = grow(ctx, ctx->d_corep, ctx->cap_corep, lrows * 1024u)) != PLAAC_OK) return rc;
         char *&cp = reinterpret_cast<char *&>(ctx->d_corepart);
         if ((rc = grow(ctx, cp, ctx->cap_corepart, lrows * 64u * sizeof(CorePart))) != PLAAC_OK) return rc;
     }
-    const bool use_core_list = ctx->core_list && !latency_mode && !chain_bound; // (sweeps: one list per group)
     if (use_core_list) {
         if ((rc = grow(ctx, ctx->d_corelist, ctx->cap_corelist, (size_t)nprot * ng)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_corecount, ctx->cap_corecount, ng)) != PLAAC_OK) return rc;
@@ -805,6 +813,29 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                            ctx->d_packed, ctx->d_grow, ctx->d_bwd);
     PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
 
+    // masked core window of the long wave-groups (single-point calls): prefix sums position-parallel on the chain's
+    // rounding grid where the tables and the protein allow it (k_core_par), the serial chain for whatever it flags, then
+    // every window per packed row and the ordered reduction
+    auto launch_core_long = [&](const DevTables *tab, uint32_t *gbits, const SweepTargets &tg, hipStream_t s,
+                                uint32_t point) -> plaac_status {
+        const unsigned lg = ctx->h_pin[3]; // (the kernels re-check every group: lengths >= 65535 are not ordered)
+        const bool par = ctx->core_par && ctx->core_par_ok &&
+                         std::memcmp(&points[point], &ctx->params, sizeof(plaac_params)) == 0;
+        if (par) {
+            if (!ctx->d_coreflags)
+                PL_HIP(ctx, hipMalloc((void **)&ctx->d_coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
+            PL_HIP(ctx, hipMemsetAsync(ctx->d_coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, s));
+            hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, s, d_codes, ctx->d_order, nprot, tab,
+                               ctx->d_grow, gbits, ctx->d_corep, ctx->d_coreflags);
+        }
+        hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, s, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow,
+                           gbits, ctx->d_corep, par ? ctx->d_coreflags : (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_core_eval, dim3(ctx->h_pin[4]), dim3(64), 0, s, ctx->d_order, nprot, ngroups, ctx->d_grow,
+                           ctx->d_corep, (CorePart *)ctx->d_corepart, tg.c[0]);
+        hipLaunchKernelGGL(k_core_reduce, dim3(lg * 64u), dim3(64), 0, s, d_codes, ctx->d_order, nprot, tab, ctx->d_grow,
+                           gbits, (const CorePart *)ctx->d_corepart, tg.rows[0], tg.c[0]);
+        return PLAAC_OK;
+    };
     const hipStream_t sv0 = sv, sf0 = sf, sw0 = sw;
     for (size_t g = 0; g < ng; ++g) {
         const Group &G = groups[g];
@@ -849,6 +880,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             }
             const bool t0 = timed && m0 == 0;
             tg.stop_after = ctx->vit_stop;
+            tg.long_groups_elsewhere = core_long ? 1u : 0u;
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
 #define LAUNCH_VIT(NC)                                                                                             \
     hipLaunchKernelGGL((k_vit<NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff, ctx->d_order, \
@@ -856,36 +888,22 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             if (latency_mode) {
                 hipLaunchKernelGGL((k_vit<1, true, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
                                    ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg);
-                if (tg.stop_after == 0u && ctx->h_pin[2] >= CORE_LONG_ROWS) { // some group is long: its core window
-                    const unsigned lg = std::min<unsigned>(ngroups, CORE_MAX_GROUPS);
-                    // masked prefix sums of the long groups: position-parallel on the chain's rounding grid where the
-                    // tables and the protein allow it (k_core_par), the serial chain for whatever it flags
-                    const bool par = ctx->core_par && ctx->core_par_ok &&
-                                     std::memcmp(&points[G.first], &ctx->params, sizeof(plaac_params)) == 0;
-                    if (par) {
-                        if (!ctx->d_coreflags)
-                            PL_HIP(ctx, hipMalloc((void **)&ctx->d_coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
-                        PL_HIP(ctx, hipMemsetAsync(ctx->d_coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, sv));
-                        hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, sv, d_codes, ctx->d_order, nprot, tab,
-                                           ctx->d_grow, gbits, ctx->d_corep, ctx->d_coreflags);
-                    }
-                    hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, sv, ctx->d_order, nprot, tab, ctx->d_packed,
-                                       ctx->d_grow, gbits, ctx->d_corep, par ? ctx->d_coreflags : (const uint32_t *)nullptr);
-                    const size_t lrows = std::min<size_t>(total_rows, (size_t)CORE_MAX_GROUPS * ctx->h_pin[2]);
-                    hipLaunchKernelGGL(k_core_eval, dim3((unsigned)lrows), dim3(64), 0, sv, ctx->d_order, nprot, ngroups,
-                                       ctx->d_grow, ctx->d_corep, (CorePart *)ctx->d_corepart, tg.c[0]);
-                    hipLaunchKernelGGL(k_core_reduce, dim3(lg * 64u), dim3(64), 0, sv, d_codes, ctx->d_order, nprot, tab,
-                                       ctx->d_grow, gbits, (const CorePart *)ctx->d_corepart, tg.rows[0], tg.c[0]);
+                if (tg.stop_after == 0u && core_long) { // some group is long: its core window
+                    if ((rc = launch_core_long(tab, gbits, tg, sv, G.first)) != PLAAC_OK) return rc;
                 }
             } else if (single && use_core_list) { // throughput-bound: sweep 3 only for proteins that can have a core
                 PL_HIP(ctx, hipMemsetAsync(ctx->d_corecount, 0, sizeof(uint32_t), sv));
                 hipLaunchKernelGGL((k_vit<1, false, true, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,
                                    ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg,
                                    ctx->d_corelist, ctx->d_corecount);
-                if (tg.stop_after == 0u)
+                if (tg.stop_after == 0u) {
+                    // the long wave-groups first: the chain of a 36,000-residue protein on the list would be the tail of
+                    // the whole step
+                    if (core_long && (rc = launch_core_long(tab, gbits, tg, sv, G.first)) != PLAAC_OK) return rc;
                     hipLaunchKernelGGL(k_core_list<1>, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes,
                                        total_residues, ctx->d_order, tab, ctx->d_packed, ctx->d_grow, gbits, tg,
                                        ctx->d_corelist, ctx->d_corecount);
+                }
             } else if (use_core_list) { // sweep groups: the group's own list, reused by its launches (same stream)
                 uint32_t *gl = ctx->d_corelist + (size_t)nprot * g, *gc = ctx->d_corecount + g;
                 PL_HIP(ctx, hipMemsetAsync(gc, 0, sizeof(uint32_t), sv));
