@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — PLAAC scoring hot path on MI355X: residues/s with roofline, CPU baseline and end-to-end leg.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--nprot P] [--shard] [--tracks] [--sweep]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--nprot P] [--weak] [--tracks] [--sweep]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (BASELINE.json configs[3], the one `metric` is quoted on): UniRef50-shaped synthetic proteome,
-10 M sequences (~2.85 G residues), default parameters. It fits one GPU, so N = 1 scores ALL of it; at N > 1
-every rank scores its own 10 M-sequence proteome (weak scaling: per-GPU work fixed; `--shard` instead splits
-the one 10 M-sequence proteome over the ranks = BASELINE's "sharded 8 x MI355X", 1.25 M sequences per GPU at
-N = 8). The 160-byte summary rows are gathered to rank 0 over RCCL (the only exchange of the path).
+10 M sequences (~2.9 G residues), default parameters. It fits one GPU, so N = 1 scores ALL of it. At N > 1 the SAME
+10 M-sequence proteome (every rank generates it from the same seeds) is cut by sequence over the ranks with
+plaac_amd.dist.shard_plan (equal residue counts; 1.25 M sequences per GPU at N = 8 = BASELINE's "sharded 8 x MI355X"):
+strong scaling, and the same line carries a `weak` object (every rank scores the whole proteome; `--weak` makes that the
+headline instead). The 160-byte summary rows are gathered to rank 0 over RCCL and put back into input order there
+(the only exchange of the path, inside the timed region).
 A step = one pass of the whole hot path (plan + pack + recurrence kernels + window-track kernel [+ row
 gather]) over the resident proteome (reference loop replaced: cli/src/plaac.java:755-948).
 Inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0.
@@ -131,16 +133,37 @@ def run_e2e(torch, codes, offsets, nseq, keep_fasta=False):
                 pass
 
 
+def check_slices(nfull):
+    """(start, count) slices of the batch whose rows are re-scored by the oracle after the timed region: the first
+    500 k sequences (also the CPU baseline's sample) and ten more slices of 50 k spread over the rest of the batch, the
+    last one = the final 100 k sequences (residue offsets beyond 2^31 in the 10 M-sequence batch)."""
+    first = min(nfull, 500_000)
+    out = [(0, first)]
+    if nfull >= first + 200_000:
+        last = 100_000
+        span = nfull - first - last
+        out += [(first + (span - 50_000) * k // 8, 50_000) for k in range(9)]
+        out.append((nfull - last, last))
+    elif nfull > first:
+        out.append((first, nfull - first))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4))
-    ap.add_argument("--nprot", type=int, default=0, help="sequences per GPU (default: the whole config: cfg4 = "
-                    "10,000,000; track mode 1,250,000 because 82 B/residue of tracks for 10 M do not fit)")
-    ap.add_argument("--shard", action="store_true", help="split ONE proteome of the config's size over the ranks "
-                    "(strong scaling; cfg4 at N = 8 is BASELINE's 1.25 M sequences per GPU) instead of one per rank")
+    ap.add_argument("--nprot", type=int, default=0, help="sequences PER GPU, each rank its own (default: the whole "
+                    "config - cfg4 = 10,000,000 - cut over the ranks; track mode 1,250,000 because 82 B/residue of "
+                    "tracks for 10 M do not fit)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: headline = every rank scores its own whole proteome "
+                    "(per-GPU work fixed) instead of ONE proteome cut over the ranks")
+    ap.add_argument("--shard", action="store_true", help="(default since round 3; kept for old command lines)")
+    ap.add_argument("--contexts", type=int, default=0, help="scoring contexts per GPU, used alternately so that "
+                    "consecutive steps overlap (the serial chain of one step's longest protein beside the next step's "
+                    "windows). 0 = 2 for batches below 5 M sequences per GPU, else 1")
     ap.add_argument("--tracks", action="store_true", help="per-residue track mode (82 B/residue written)")
     ap.add_argument("--sweep", action="store_true", help="BASELINE config 5: a step = the 9-point sweep "
                     "alpha in {0,0.5,1} x core length in {30,60,90} over the resident shard (value counts every "
@@ -149,6 +172,7 @@ def main():
                     "sweep-aware scheduler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the FASTA-in -> TSV-out leg through bin/plaac")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
     ap.add_argument("--e2e-nprot", type=int, default=0, help="sequences of the resident proteome written as FASTA "
                     "for the end-to-end leg (default: all of them, i.e. the 10 M sequences / 3.0 GB of cfg4)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
@@ -172,124 +196,171 @@ def main():
         raise SystemExit("bench.py needs a GPU: the scoring path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    RB = native.ROW_BYTES
 
-    nprot = args.nprot
-    if not nprot:
-        nprot = CFG_NPROT[args.config]
-        if args.tracks and args.config == 4:
-            nprot = 1_250_000
-        if args.shard:
-            nprot = (nprot + world - 1) // world
+    strong = world > 1 and not args.weak and not args.nprot  # ONE proteome cut over the ranks
+    nfull = args.nprot or (1_250_000 if (args.tracks and args.config == 4) else CFG_NPROT[args.config])
     two_pass = args.config == 3 and not args.sweep  # cfg3: -a 0.5, background from the scored input
     alpha = 0.5 if args.config == 3 else 1.0
     P = native.make_params()  # defaults: c=60, ww=41, alpha=1, fg28 (cfg3 replaces it inside every step)
-    ctx = native.Context(P, device=local_rank)
 
-    # ---- synthetic proteome, generated in HBM piece by piece (seed differs per rank and piece) ---------------
+    # ---- synthetic proteome, generated in HBM piece by piece. Strong scaling: the same seeds on every rank (every
+    # rank builds the whole proteome and keeps its share); otherwise the seed differs per rank.
+    seed_rank = 0 if strong else rank
     pieces, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=dev)], 0
-    for ci, start in enumerate(range(0, nprot, SYNTH_CHUNK)):
-        c_, o_ = synth.make_batch_torch(args.config, min(SYNTH_CHUNK, nprot - start), np.array(P.fg), np.array(P.bg),
-                                        dev, seed=synth.SEED0 + args.config + 1000 * rank + 100000 * ci)
+    for ci, start in enumerate(range(0, nfull, SYNTH_CHUNK)):
+        c_, o_ = synth.make_batch_torch(args.config, min(SYNTH_CHUNK, nfull - start), np.array(P.fg), np.array(P.bg),
+                                        dev, seed=synth.SEED0 + args.config + 1000 * seed_rank + 100000 * ci)
         pieces.append(c_)
         offs.append(o_[1:] + base)
         base += int(o_[-1].item())
-    codes = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
-    offsets = torch.cat(offs)
+    codes_full = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
+    offsets_full = torch.cat(offs)
     del pieces, offs
-    total = int(offsets[-1].item())
-    rows = torch.zeros(nprot * native.ROW_BYTES, dtype=torch.uint8, device=dev)
-    d_tracks = None
-    if args.tracks:
-        trk = {k: torch.zeros(total, dtype=torch.uint8, device=dev) for k in native.TRACK_U8}
-        trk.update({k: torch.zeros(total, dtype=torch.float64, device=dev) for k in native.TRACK_F64})
-        d_tracks = {k: v.data_ptr() for k, v in trk.items()}
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [torch.empty_like(rows) for _ in range(world)]
-    # N > 1: the row gather of step k (rank 0 <- every rank, RCCL) runs on its own stream and overlaps the kernels
-    # of step k+1, which write the other of two row buffers; everything is drained inside the timed region
-    rows_pp = [rows, torch.zeros_like(rows)] if world > 1 else [rows]
-    comm = torch.cuda.Stream(dev) if world > 1 else None
-    scored = [torch.cuda.Event() for _ in rows_pp]
-    gathered = [torch.cuda.Event() for _ in rows_pp]
-    step_no = [0]
-    # a real (non-null) HIP stream: the kernels are launched on it, the HIP events that time them are
-    # recorded on it, and RCCL orders the row gather after it
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.synchronize(dev)
+    total_full = int(offsets_full[-1].item())
 
+    class Work:
+        """one resident batch of this rank"""
+        def __init__(self, codes, offsets, plans, nmax):
+            self.codes, self.offsets = codes, offsets
+            self.nprot, self.total = offsets.numel() - 1, int(offsets[-1].item())
+            self.plans = plans  # strong scaling, rank 0: the input indices of every rank's rows (else None)
+            self.nmax = nmax    # rows per gathered block (dist.gather wants equal blocks)
+
+    if strong:
+        mine = pdist.shard_plan_torch(offsets_full, world, rank)
+        c_s, o_s = pdist.extract_shard_torch(codes_full, offsets_full, mine)
+        plans = [pdist.shard_plan_torch(offsets_full, world, r) for r in range(world)] if rank == 0 else None
+        main_work = Work(c_s, o_s, plans, (nfull + world - 1) // world)
+        del mine
+    else:
+        main_work = Work(codes_full, offsets_full, None, nfull)
+    nctx = args.contexts or (2 if main_work.nprot < 5_000_000 and not args.tracks else 1)
+    ctxs = [native.Context(P, device=local_rank) for _ in range(nctx)]
+    # real (non-null) HIP streams: the kernels are launched on them, the HIP events that time them are recorded on
+    # them, and RCCL orders the row gather after them
+    streams = [torch.cuda.Stream(dev) for _ in range(nctx)]
+    comm = torch.cuda.Stream(dev) if world > 1 else None
     cnt = torch.zeros(22, dtype=torch.int64, device=dev)
 
-    def background_counts():
+    def background_counts(W, ctx, stream):
         """pass 1 of the reference (plaac.java:377-384): histogram of the input, summed over the ranks"""
-        ctx.histogram_device(codes.data_ptr(), offsets.data_ptr(), nprot, cnt.data_ptr(), stream=stream.cuda_stream)
+        ctx.histogram_device(W.codes.data_ptr(), W.offsets.data_ptr(), W.nprot, cnt.data_ptr(), stream=stream.cuda_stream)
         if world > 1:
             with torch.cuda.stream(stream):
                 dist.all_reduce(cnt, op=dist.ReduceOp.SUM)  # exchange (i): 22 x int64
         stream.synchronize()
         return cnt.cpu().numpy()
 
-    sweep_params = None
+    sweep_params = counts = None
     if args.sweep:
-        counts = background_counts()
+        counts = background_counts(main_work, ctxs[0], streams[0])
         sweep_params = [native.make_params(alpha=a, corelength=c, bgcounts=counts.astype(np.float64))
                         for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)]
     npoints = len(sweep_params) if sweep_params else 1
 
-    sweep_rows = [torch.zeros_like(rows) for _ in range(npoints)] if sweep_params else None
+    def run_region(W, nsteps, nwarm, with_tracks):
+        """nwarm untimed + nsteps timed steps over W -> (seconds [max over ranks], buffers)"""
+        nslots = max(nctx, 2 if world > 1 else 1)
+        rows_pp = [torch.zeros(W.nmax * RB, dtype=torch.uint8, device=dev) for _ in range(nslots)]
+        d_tracks = trk = None
+        if with_tracks:
+            trk = {k: torch.zeros(W.total, dtype=torch.uint8, device=dev) for k in native.TRACK_U8}
+            trk.update({k: torch.zeros(W.total, dtype=torch.float64, device=dev) for k in native.TRACK_F64})
+            d_tracks = {k: v.data_ptr() for k, v in trk.items()}
+        gather_list = final = None
+        if world > 1 and rank == 0:
+            gather_list = [torch.empty(W.nmax * RB, dtype=torch.uint8, device=dev) for _ in range(world)]
+            if W.plans is not None:
+                final = torch.zeros(nfull, RB, dtype=torch.uint8, device=dev)
+        sweep_rows = [torch.zeros(W.nmax * RB, dtype=torch.uint8, device=dev) for _ in range(npoints)] if sweep_params else None
+        scored = [torch.cuda.Event() for _ in range(nslots)]
+        gathered = [torch.cuda.Event() for _ in range(nslots)]
+        step_no = [0]
 
-    def step():
-        with torch.cuda.stream(stream):
-            if sweep_params and not args.naive_sweep:  # one planned pass, shared per-alpha work
-                ctx.score_sweep_device(codes.data_ptr(), offsets.data_ptr(), nprot, total, sweep_params,
-                                       [r.data_ptr() for r in sweep_rows], stream=stream.cuda_stream)
-                if world > 1:
-                    for r in sweep_rows:
-                        dist.gather(r, gather_list, dst=0)
-                return
-            if two_pass:  # cfg3: background pass, table setup (plaac.java:444-500) and upload are part of the step
-                ctx.set_params(native.make_params(alpha=alpha, bgcounts=background_counts().astype(np.float64)))
-            for k in range(npoints):
-                if sweep_params:
-                    ctx.set_params(sweep_params[k])
-                b = step_no[0] % len(rows_pp)
-                step_no[0] += 1
-                if world > 1 and step_no[0] > len(rows_pp):
+        def gather(buf):
+            """exchange (ii): rows of every rank -> rank 0 (RCCL over xGMI), input order restored there"""
+            dist.gather(buf, gather_list, dst=0)
+            if final is not None:
+                for r in range(world):
+                    final[W.plans[r]] = gather_list[r].view(-1, RB)[:W.plans[r].numel()]
+
+        def step():
+            b = step_no[0] % nslots
+            ctx, stream = ctxs[b % nctx], streams[b % nctx]
+            step_no[0] += 1
+            with torch.cuda.stream(stream):
+                if world > 1 and step_no[0] > nslots:
                     stream.wait_event(gathered[b])  # the gather that last read this buffer has finished
-                ctx.score_device(codes.data_ptr(), offsets.data_ptr(), nprot, total, rows_pp[b].data_ptr(), d_tracks,
-                                 stream=stream.cuda_stream)
-                if sweep_params:
-                    sweep_rows[k].copy_(rows_pp[b], non_blocking=True)
-                if world > 1:  # final gather of per-protein summary rows, ordered after this step's kernels
-                    scored[b].record(stream)
-                    with torch.cuda.stream(comm):
-                        comm.wait_event(scored[b])
-                        dist.gather(rows_pp[b], gather_list, dst=0)
-                        gathered[b].record(comm)
+                if sweep_params and not args.naive_sweep:  # one planned pass, shared per-alpha work
+                    ctx.score_sweep_device(W.codes.data_ptr(), W.offsets.data_ptr(), W.nprot, W.total, sweep_params,
+                                           [r.data_ptr() for r in sweep_rows], stream=stream.cuda_stream)
+                    if world > 1:
+                        for r in sweep_rows:
+                            gather(r)
+                    return
+                if two_pass:  # cfg3: background pass, table setup (plaac.java:444-500) and upload are part of the step
+                    ctx.set_params(native.make_params(alpha=alpha, bgcounts=background_counts(W, ctx, stream).astype(np.float64)))
+                for k in range(npoints):
+                    if sweep_params:
+                        ctx.set_params(sweep_params[k])
+                    ctx.score_device(W.codes.data_ptr(), W.offsets.data_ptr(), W.nprot, W.total, rows_pp[b].data_ptr(),
+                                     d_tracks, stream=stream.cuda_stream)
+                    if sweep_params:
+                        sweep_rows[k].copy_(rows_pp[b], non_blocking=True)
+                    if world > 1:  # final gather of per-protein summary rows, ordered after this step's kernels
+                        scored[b].record(stream)
+                        with torch.cuda.stream(comm):
+                            comm.wait_event(scored[b])
+                            gather(rows_pp[b])
+                            gathered[b].record(comm)
 
-    def fence():
-        torch.cuda.synchronize(dev)
+        def fence():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        for _ in range(nwarm):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, {"rows": rows_pp[0], "final": final, "gather_list": gather_list, "sweep_rows": sweep_rows, "trk": trk}
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt, bufs = run_region(main_work, args.steps, args.warmup, args.tracks)
+    nprot, total = main_work.nprot, main_work.total
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
         tot = torch.tensor([total, nprot], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         job_res, job_prot = int(tot[0].item()), int(tot[1].item())
     else:
         job_res, job_prot = total, nprot
+    # kernel times of the main region (HIP events on each kernel's launch stream, mean over the timed steps)
+    per_ctx = max(1, min(args.steps * (npoints if args.naive_sweep else 1) // nctx, 32))
+    kt = [c.last_timings(per_ctx) for c in ctxs]
+    ktimes = {k: sum(t[k] for t in kt) / len(kt) for k in kt[0]}
+    fallbacks = ctxs[0].last_exact_fallbacks() if not args.tracks else None
+
+    # ---- N > 1, strong scaling: the weak-scaling figure beside it (every rank scores the WHOLE proteome it generated)
+    weak = None
+    if strong and not args.no_weak_leg and not args.tracks and not args.sweep:
+        keep_final = bufs["final"]
+        bufs["gather_list"] = bufs["rows"] = None
+        wdt, wb = run_region(Work(codes_full, offsets_full, None, nfull), args.steps, 1, False)
+        del wb
+        weak = {"value": round(total_full * world * args.steps / wdt, 1), "unit": "residues/s",
+                "ms_per_step": round(wdt / args.steps * 1e3, 4), "scaling": "weak",
+                "what": "every rank scores the whole %d-sequence proteome; rows gathered to rank 0" % nfull}
+        bufs["final"] = keep_final
+        torch.cuda.empty_cache()
 
     # achievable HBM copy rate on this box (SURVEY 8d M3 asks for it next to the nominal 8 TB/s): 1 GiB
     # device-to-device copy = 2 GiB of traffic, outside the timed region
@@ -308,18 +379,30 @@ def main():
         copy_gbps = round(5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
         del a_, b_
 
+    hist_ms = None
+    if rank == 0:  # the background pass alone (it is inside the step only for cfg3): HIP events on its launch stream
+        st = streams[0]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        with torch.cuda.stream(st):
+            ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt.data_ptr(), stream=st.cuda_stream)
+            ev[0].record(st)
+            for _ in range(3):
+                ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt.data_ptr(), stream=st.cuda_stream)
+            ev[1].record(st)
+        st.synchronize()
+        hist_ms = ev[0].elapsed_time(ev[1]) / 3
     if args.calibrate:
-        ctx.histogram_device(codes.data_ptr(), offsets.data_ptr(), nprot, cnt.data_ptr(), stream=stream.cuda_stream)
-        ctx.calibration_reads(codes.data_ptr(), total, stream=stream.cuda_stream)
+        ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt.data_ptr(), stream=streams[0].cuda_stream)
+        ctxs[0].calibration_reads(main_work.codes.data_ptr(), total, stream=streams[0].cuda_stream)
         torch.cuda.synchronize(dev)
     if rank != 0:
-        ctx.close()
+        for c in ctxs:
+            c.close()
         if world > 1:
             dist.destroy_process_group()
         return
 
-    # ---- rank 0: kernel times (HIP events on each kernel's launch stream, mean over the timed steps) ----
-    ktimes = ctx.last_timings(min(args.steps * (npoints if args.naive_sweep else 1), 32))
+    # ---- rank 0 ----
     kern = {"k_vit": ktimes["vit"], "k_fwd": ktimes["fwd"], "k_win": ktimes["win"], "k_tracks": ktimes["tracks"]}
     if args.tracks:
         kern["k_bwd"] = ktimes["bwd"]
@@ -333,7 +416,7 @@ def main():
     achieved = path_bytes / (dom_ms * 1e-3) / 1e9
     # HBM traffic and executed instruction counts: PMC counters cannot be read from inside this process;
     # tools/pmc.sh collects them for this same workload and leaves the per-launch figures under profiles/
-    traffic, traffic_all, exec_ops, issue_instr, traffic_cal, traffic_all_cal, fetch_cal = (None,) * 7
+    traffic, traffic_all, exec_ops, issue_instr, traffic_cal, traffic_all_cal, fetch_cal, issue_classes = (None,) * 8
     import glob
     for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
         try:
@@ -355,9 +438,11 @@ def main():
                     fetch_cal = tj.get("fetch_calibration")
                 exec_ops = tj.get("fp64_ops_per_residue_executed")
                 issue_instr = tj.get("valu_lds_wave_instructions_per_step")
+                issue_classes = tj.get("issue_model")
         except (OSError, ValueError, KeyError):
             pass
     path_ms = ktimes["total"]
+    step_ms = dt / args.steps * 1e3
     algo_gops = ALGO_OPS_PER_RESIDUE * total / (path_ms * 1e-3) / 1e9
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -366,70 +451,101 @@ def main():
         "fetch_calibration": fetch_cal,
         "algorithmic_bytes": path_bytes, "measured_copy_GBps": copy_gbps,
         "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
-        "kernels_overlap": "k_vit, k_fwd, k_win, k_tracks run concurrently on 4 HIP streams; total = first launch -> join",
-        "path_achieved_GBps": round(path_bytes / (path_ms * 1e-3) / 1e9, 3),
-        "note": "fp64-VALU-bound path (SURVEY 8d M3): secondary roof below",
+        "kernels_overlap": "k_vit, k_fwd, k_win, k_tracks run concurrently on 4 HIP streams; total = first launch -> join"
+                           + ("; %d contexts alternate, consecutive steps overlap" % nctx if nctx > 1 else ""),
+        "path_achieved_GBps": round(path_bytes / (step_ms * 1e-3) / 1e9, 3),
+        "step_latency_ms": round(path_ms, 4),
+        "histogram_pass": None if hist_ms is None else {
+            "kernel": "k_hist", "ms": round(hist_ms, 4), "bytes": total + 8 * nprot,
+            "achieved_GBps": round((total + 8 * nprot) / (hist_ms * 1e-3) / 1e9, 1),
+            "frac_of_peak": round((total + 8 * nprot) / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "what": "background pass (countaas / isvalidprotein, plaac.java:1698-1739) over the resident batch, the one "
+                    "kernel of the path that IS HBM-bound; mean of 3 launches by HIP events"},
+        "note": "instruction-issue-bound path (SURVEY 8d M3): secondary roofs below",
         "valu_fp64": {
-            "algorithmic": {"ops_per_residue": ALGO_OPS_PER_RESIDUE, "achieved_Gops": round(algo_gops, 1),
-                            "frac": round(algo_gops / FP64_VALU_PEAK_GOPS, 4)},
+            "reference_equivalent": {"ops_per_residue": ALGO_OPS_PER_RESIDUE, "achieved_Gops": round(algo_gops, 1),
+                                     "what": "the reference's own fp64 operation count x this rate; NOT executed - the "
+                                             "filter tier decides from prefix sums"},
             "executed_pmc": None if not exec_ops else {
                 "ops_per_residue": exec_ops, "achieved_Gops": round(algo_gops * exec_ops / ALGO_OPS_PER_RESIDUE, 1),
                 "frac": round(algo_gops * exec_ops / ALGO_OPS_PER_RESIDUE / FP64_VALU_PEAK_GOPS, 4),
                 "source": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes over all kernels of a step, profiles/pmc_traffic.json"},
             "peak_Gops": FP64_VALU_PEAK_GOPS,
         },
-        # the roof that binds: every vector-ALU / LDS wave-instruction occupies its SIMD's issue port for 4 cycles
-        # (1024 SIMDs, 2.4 GHz peak clock); instruction counts from the PMC passes of tools/pmc.sh (same workload)
+        # the roof that binds: wave-instructions x measured issue cost per class (tools/issue_probe.hip on MI355X,
+        # profiles/r03_issue_probe.txt) on 1024 SIMDs at the 2.4 GHz peak clock; counts from the PMC passes of tools/pmc.sh
         "issue": None if not issue_instr else {
-            "valu_lds_wave_instructions_per_step": issue_instr,
-            "ms_at_peak_issue": round(issue_instr * 4 / 1024 / 2.4e9 * 1e3, 3),
-            "frac": round(issue_instr * 4 / 1024 / 2.4e9 * 1e3 / path_ms, 4),
-            "source": "SQ_INSTS_VALU + SQ_INSTS_LDS over all kernels of a step, profiles/pmc_traffic.json"},
+            "valu_lds_wave_instructions_per_step": issue_instr, "model": issue_classes,
+            "ms_at_peak_issue": None if not issue_classes else round(issue_classes["cycles_per_step"] / 1024 / 2.4e9 * 1e3, 3),
+            "frac": None if not issue_classes else round(issue_classes["cycles_per_step"] / 1024 / 2.4e9 * 1e3 / step_ms, 4),
+            "source": "SQ_INSTS_VALU (fp64 / other) + SQ_INSTS_LDS over all kernels of a step, profiles/pmc_traffic.json"},
     }
 
-    # ---- rank 0: CPU baseline = the oracle (a port, not the Java reference: no JVM on this box) ----
+    # ---- rank 0: CPU baseline = the oracle (a port, not the Java reference: no JVM on this box), and the parity check of
+    # this run's rows: slices spread over the WHOLE batch (strong scaling: over the gathered, re-ordered table)
     cpu, rc = None, 0
     if not args.no_cpu_baseline:
         from oracle import oracle_ctypes as oc
         nthreads = usable_cores()
-        n_s = min(nprot, 500000)
-        off_h = offsets[:n_s + 1].cpu().numpy().astype(np.uint64)
-        codes_h = codes[:int(off_h[-1])].cpu().numpy()
+        if strong:
+            chk_codes, chk_offs, chk_rows, chk_n = codes_full, offsets_full, bufs["final"].view(-1), nfull
+        else:
+            chk_codes, chk_offs, chk_rows, chk_n = main_work.codes, main_work.offsets, bufs["rows"], nprot
         if two_pass:  # same two-pass parameters as the GPU step (counts of the WHOLE input)
             Po = oc.build_params(alpha=alpha, bgcounts=cnt.cpu().numpy().astype(np.float64))
-        elif sweep_params:
-            Po = None
         else:
             Po = oc.build_params()
+
+        def host_slice(s, n):
+            o = chk_offs[s:s + n + 1].cpu().numpy().astype(np.int64)
+            return chk_codes[int(o[0]):int(o[-1])].cpu().numpy(), (o - o[0]).astype(np.uint64), int(o[-1])
+
+        slices = check_slices(chk_n)
+        codes_h, off_h, _ = host_slice(*slices[0])
+        n_s = slices[0][1]
         n_1 = min(n_s, 16000)
-        P1 = Po if Po is not None else oc.build_params()
-        oc.score_batch(P1, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)  # scratch warm-up
+        oc.score_batch(Po, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)  # scratch warm-up
         t1 = time.perf_counter()
-        oc.score_batch(P1, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)
+        oc.score_batch(Po, codes_h[:int(off_h[n_1])], off_h[:n_1 + 1], nthreads=1)
         dt1 = time.perf_counter() - t1
-        oc.score_batch(P1, codes_h, off_h, nthreads=nthreads)  # thread-pool and per-thread scratch warm-up
+        oc.score_batch(Po, codes_h, off_h, nthreads=nthreads)  # thread-pool and per-thread scratch warm-up
         t1 = time.perf_counter()
-        want = oc.score_batch(P1, codes_h, off_h, nthreads=nthreads)
+        want = oc.score_batch(Po, codes_h, off_h, nthreads=nthreads)
         dtn = time.perf_counter() - t1
+        checked, max_off, bad = 0, 0, []
         if sweep_params:  # every point of the sweep against the oracle run with that point's parameters
             n_c = min(n_s, 20000)
-            ok = True
             for k, (a, c) in enumerate((a, c) for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)):
                 Pk = oc.build_params(alpha=a, corelength=c, bgcounts=counts.astype(np.float64))
                 wk = oc.score_batch(Pk, codes_h[:int(off_h[n_c])], off_h[:n_c + 1], nthreads=nthreads)
-                gk = sweep_rows[k][:n_c * native.ROW_BYTES].cpu().numpy()
-                ok = ok and gk.tobytes() == wk.tobytes()
-            match = ok
+                gk = bufs["sweep_rows"][k][:n_c * RB].cpu().numpy()
+                if gk.tobytes() != wk.tobytes():
+                    bad.append(["sweep point", k])
+            checked = 9 * n_c
         else:
-            got = rows[:n_s * native.ROW_BYTES].cpu().numpy().view(native.ROW_DTYPE)
-            match = bool(got.tobytes() == want.tobytes())
+            for (s, n) in slices:
+                if s == 0:
+                    w = want
+                    max_off = max(max_off, int(off_h[-1]))
+                else:
+                    c_h, o_h, end = host_slice(s, n)
+                    w = oc.score_batch(Po, c_h, o_h, nthreads=nthreads)
+                    max_off = max(max_off, end)
+                got = chk_rows[s * RB:(s + n) * RB].cpu().numpy()
+                if got.tobytes() != w.tobytes():
+                    bad.append([s, n])
+                checked += n
+        match = not bad
         cpu = {
             "value": round(int(off_h[-1]) / dtn, 1), "unit": "residues/s", "cores": nthreads, "kind": "port",
-            "sample": "first %d sequences (%d residues) of rank 0's proteome on %d OpenMP threads, second of two runs; "
+            "sample": "first %d sequences (%d residues) of the proteome on %d OpenMP threads, second of two runs; "
                       "value_1core = first %d sequences on 1 thread; oracle/plaac_oracle.c restatement (not the Java "
                       "reference: no JVM on this box; its dead work omitted)" % (n_s, int(off_h[-1]), nthreads, n_1),
             "value_1core": round(int(off_h[n_1]) / dt1, 1),
             "gpu_rows_match_oracle": match,
+            "rows_checked": checked, "slices_checked": [list(x) for x in slices] if not sweep_params else None,
+            "max_residue_offset_checked": max_off, "mismatching_slices": bad,
+            "checked_table": "gathered rows of all ranks in input order" if strong else "rows of rank 0",
         }
         if not match:
             rc = 3
@@ -437,13 +553,13 @@ def main():
     # ---- rank 0, N = 1: end to end through the C++ host (FASTA bytes in -> TSV bytes out), SURVEY 8(d) M1 ----
     e2e = None
     if world == 1 and not args.no_e2e and not args.tracks and not args.sweep:
-        e2e = run_e2e(torch, codes, offsets, min(nprot, args.e2e_nprot or nprot))
+        e2e = run_e2e(torch, main_work.codes, main_work.offsets, min(nprot, args.e2e_nprot or nprot))
         # when the operator supplies the real reference (a JVM on PATH and
         # PLAAC_REF_JAR=/path/plaac.jar) time it too, single-threaded as it is, on a bounded sample
         if cpu is not None and os.environ.get("PLAAC_REF_JAR"):
             fa = os.path.join(os.environ.get("TMPDIR", "/tmp"), "plaac_bench_ref_%d.fa" % os.getpid())
             try:
-                _, nres_s = write_fasta(torch, codes, offsets, min(nprot, 8000), fa)
+                _, nres_s = write_fasta(torch, main_work.codes, main_work.offsets, min(nprot, 8000), fa)
                 cpu["reference_jar"] = time_reference_jar(fa, nres_s)
             finally:
                 if os.path.exists(fa):
@@ -456,8 +572,8 @@ def main():
           4: "cfg4 UniRef50-shaped, 10M sequences"}[args.config]
     if args.nprot:
         wl += "; --nprot %d sequences per GPU" % nprot
-    elif args.shard:
-        wl += "; ONE proteome sharded over %d GPU(s) (strong scaling)" % world
+    elif strong:
+        wl += "; ONE proteome cut by sequence over %d GPUs (strong scaling, equal residue counts)" % world
     elif world > 1:
         wl += "; one whole proteome PER GPU (weak scaling, %d x the config)" % world
     else:
@@ -466,8 +582,8 @@ def main():
     out = {
         "metric": "residues/sec", "value": round(job_res * npoints * args.steps / dt, 1), "unit": "residues/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "strong" if args.shard else "weak",
+        "ms_per_step": round(step_ms, 4), "higher_is_better": True,
+        "scaling": "weak" if (world > 1 and not strong) else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "proteins_per_sec": round(job_prot * npoints * args.steps / dt, 1),
         "config": {
@@ -476,17 +592,20 @@ def main():
                                                                   else ""), "sequences_per_gpu": nprot,
             "residues_per_gpu": total, "sequences_total": job_prot, "residues_total": job_res,
             "params": "c=60 ww=41 alpha=%.1f fg=prd_freq_scer_28%s" % (alpha, " bg=input counts" if two_pass else ""),
-            "sharding": "by sequence, %d rank(s)" % world,
+            "sharding": "by sequence, %d rank(s)" % world, "contexts_per_gpu": nctx,
             "exchange": ("%s gather of 160 B rows to rank 0" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
             if world > 1 else "none (1 GPU)",
-            "timed_region_s": round(dt, 3),
+            "timed_region_s": round(dt, 3), "exact_tier_fallbacks_rank0": fallbacks,
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
         "e2e": e2e,
     }
+    if weak:
+        out["weak"] = weak
     print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
     if rc:

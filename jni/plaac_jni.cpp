@@ -29,6 +29,10 @@ void *direct(JNIEnv *env, jobject buf, uint64_t need, const char *what) {
 
 plaac_node *node_of(jlong h) { return reinterpret_cast<plaac_node *>(static_cast<intptr_t>(h)); }
 
+// message of a failed node call; a null handle has no message of its own (plaac_node_last_error(nullptr) would hand back
+// the text of this thread's last failed plaac_node_create - another call's error)
+const char *node_error(jlong h) { return node_of(h) ? plaac_node_last_error(node_of(h)) : "null node handle"; }
+
 } // namespace
 
 extern "C" {
@@ -85,7 +89,7 @@ JNIEXPORT jlong JNICALL Java_PlaacNative_nodeCreate(JNIEnv *env, jclass, jobject
 
 JNIEXPORT void JNICALL Java_PlaacNative_nodeSetParams(JNIEnv *env, jclass, jlong node, jobject params) {
     const plaac_params *P = (const plaac_params *)direct(env, params, plaac_sizeof_params(), "params");
-    if (P && plaac_node_set_params(node_of(node), P) != PLAAC_OK) raise(env, plaac_node_last_error(node_of(node)));
+    if (P && plaac_node_set_params(node_of(node), P) != PLAAC_OK) raise(env, node_error(node));
 }
 
 JNIEXPORT void JNICALL Java_PlaacNative_nodeDestroy(JNIEnv *, jclass, jlong node) { plaac_node_destroy(node_of(node)); }
@@ -100,7 +104,7 @@ JNIEXPORT void JNICALL Java_PlaacNative_histogram(JNIEnv *env, jclass, jlong nod
     if (!c) return;
     int64_t counts[PLAAC_NAA];
     if (plaac_node_histogram(node_of(node), c, off, (uint32_t)nprot, counts) != PLAAC_OK)
-        return raise(env, plaac_node_last_error(node_of(node)));
+        return raise(env, node_error(node));
     jlong out[PLAAC_NAA];
     for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (jlong)counts[i];
     env->SetLongArrayRegion(counts22, 0, PLAAC_NAA, out);
@@ -128,7 +132,7 @@ JNIEXPORT void JNICALL Java_PlaacNative_score(JNIEnv *env, jclass, jlong node, j
         tp = &t;
     }
     if (plaac_node_score(node_of(node), c, off, (uint32_t)nprot, rows, tp) != PLAAC_OK)
-        raise(env, plaac_node_last_error(node_of(node)));
+        raise(env, node_error(node));
 }
 
 } // extern "C"

@@ -17,7 +17,10 @@
 //   PLAAC_BATCH_RECORDS / PLAAC_BATCH_BYTES   batch size (default 262144 records / 96 MiB of FASTA text)
 //   PLAAC_DEVICES=0,1,...                     devices to use, a device may be repeated (default: all, PLAAC_CTX_PER_DEVICE = 2 each)
 //   PLAAC_KEEP_BYTES                          the background pass keeps the parsed batches for the scoring pass up to this many
-//                                             bytes (default 4 GiB), beyond it the scoring pass reads the file again
+//                                             bytes (default: 4 GiB, at most a quarter of the memory the host / cgroup has
+//                                             free), beyond it the kept batches are released and the scoring pass reads the
+//                                             file again. Resident set of the default two-pass run: that budget + the batches
+//                                             in flight (4 x PLAAC_BATCH_BYTES of text, parsed) + 256 MiB of formatted output
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -29,6 +32,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include <unistd.h>
@@ -138,10 +142,72 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
     return v > 0 ? (uint64_t)v : dflt;
 }
 
+// Batches the background pass keeps for the scoring pass. Once the input turns out to be larger than the budget the
+// kept ones are of no use: those the pass is done with are released at once, the others as soon as their Batch goes.
+struct KeptState {
+    std::mutex m;
+    std::unordered_set<plaac_fasta *> done, freed; // kept batches whose Batch object is gone / that have been released
+    bool overflow = false, closed = false;
+    void batch_gone(plaac_fasta *f) {
+        std::lock_guard<std::mutex> l(m);
+        if (closed) return;
+        if (overflow) {
+            if (freed.insert(f).second) plaac_fasta_free(f);
+        } else {
+            done.insert(f);
+        }
+    }
+    void on_overflow() {
+        std::lock_guard<std::mutex> l(m);
+        overflow = true;
+        for (plaac_fasta *f : done)
+            if (freed.insert(f).second) plaac_fasta_free(f);
+        done.clear();
+    }
+    void release_rest(std::vector<plaac_fasta *> &keep) { // end of the pass: nothing of `keep` survives
+        std::lock_guard<std::mutex> l(m);
+        closed = true;
+        for (plaac_fasta *f : keep)
+            if (freed.insert(f).second) plaac_fasta_free(f);
+        keep.clear();
+    }
+};
+
+// default budget of the kept batches (PLAAC_KEEP_BYTES overrides): 4 GiB, but never more than a quarter of what the
+// host / the cgroup has free, so that a small-memory box re-reads the file instead of being OOM-killed
+uint64_t default_keep_bytes() {
+    uint64_t avail = UINT64_MAX;
+    if (FILE *fp = std::fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (std::fgets(line, sizeof line, fp)) {
+            unsigned long long kb = 0;
+            if (std::sscanf(line, "MemAvailable: %llu kB", &kb) == 1) avail = (uint64_t)kb << 10;
+        }
+        std::fclose(fp);
+    }
+    auto read_u64 = [](const char *path, uint64_t &v) {
+        FILE *fp = std::fopen(path, "r");
+        if (!fp) return false;
+        char buf[64] = {0};
+        const bool ok = std::fgets(buf, sizeof buf, fp) && buf[0] >= '0' && buf[0] <= '9';
+        std::fclose(fp);
+        if (ok) v = std::strtoull(buf, nullptr, 10);
+        return ok;
+    };
+    uint64_t lim = 0, cur = 0;
+    if (read_u64("/sys/fs/cgroup/memory.max", lim) && read_u64("/sys/fs/cgroup/memory.current", cur))
+        avail = std::min(avail, lim > cur ? lim - cur : 0);
+    else if (read_u64("/sys/fs/cgroup/memory/memory.limit_in_bytes", lim) &&
+             read_u64("/sys/fs/cgroup/memory/memory.usage_in_bytes", cur))
+        avail = std::min(avail, lim > cur ? lim - cur : 0);
+    return std::min<uint64_t>(4ull << 30, avail / 4);
+}
+
 struct Batch {
     uint64_t seq = 0;
     plaac_fasta *f = nullptr;
-    bool owned = true; // false: kept by the background pass, freed at exit
+    bool owned = true; // false: kept by the background pass (KeptState decides when it is released)
+    KeptState *kept = nullptr;
     std::vector<plaac_row> rows;
     // track mode: the selected records as their own batch
     std::vector<uint32_t> pick;
@@ -155,6 +221,7 @@ struct Batch {
     std::string err;
     ~Batch() {
         if (f && owned) plaac_fasta_free(f);
+        else if (f && kept) kept->batch_gone(f);
     }
 };
 using BatchPtr = std::unique_ptr<Batch>;
@@ -246,6 +313,7 @@ class Writer {
     std::vector<std::string> q;
     size_t bytes = 0;
     bool closed = false;
+    std::atomic<bool> bad{false}; // a short write or a stream error (ENOSPC, EIO, closed pipe): the table is incomplete
     std::thread th;
     static constexpr size_t CAP = 256u << 20; // text waiting to be written
 
@@ -262,10 +330,12 @@ class Writer {
                     bytes = 0;
                     cv_put.notify_all();
                 }
-                for (const std::string &s : take) std::fwrite(s.data(), 1, s.size(), stdout);
+                for (const std::string &s : take)
+                    if (!bad && std::fwrite(s.data(), 1, s.size(), stdout) != s.size()) bad = true;
             }
         });
     }
+    bool failed() const { return bad; }
     void write(std::string &&s) {
         if (s.empty()) return;
         std::unique_lock<std::mutex> l(m);
@@ -274,14 +344,15 @@ class Writer {
         q.push_back(std::move(s));
         cv_get.notify_one();
     }
-    void finish() { // everything handed over so far is in stdout's buffer when this returns
+    bool finish() { // everything handed over so far has been flushed when this returns; false: a write failed
         {
             std::lock_guard<std::mutex> l(m);
             closed = true;
             cv_get.notify_all();
         }
         if (th.joinable()) th.join();
-        std::fflush(stdout);
+        if (std::fflush(stdout) != 0 || std::ferror(stdout)) bad = true;
+        return !bad;
     }
     ~Writer() { finish(); }
 };
@@ -372,6 +443,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
     // A pass that keeps its parsed batches anyway (the background pass, up to keep_bytes) lets the reader run as far
     // ahead as it likes: it parses through the few hundred ms in which the GPU contexts come up instead of stopping
     // four batches in. A pass that does not keep them is bounded to four batches in flight.
+    KeptState ks; // (declared before the queues: batches still queued at a failure are destroyed before it)
     Queue q(keep ? (size_t)1 << 30 : 4);
     Reorder ro(4); // widened once the number of contexts is known
     std::atomic<bool> failed{false};
@@ -401,9 +473,11 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                     if (kept_bytes <= keep_bytes) {
                         keep->push_back(f);
                         b->owned = false;
-                    } else { // too large to keep: the later pass reads the file again (the batches kept so far may
-                        keeping = false; // still be in flight: they are released once the threads have been joined)
+                        b->kept = &ks;
+                    } else { // too large to keep: the later pass reads the file again; what this pass is done with is
+                        keeping = false; // released now, the kept batches still in flight when their Batch goes
                         keep_overflow = true;
+                        ks.on_overflow();
                         q.set_cap(4);
                     }
                 }
@@ -459,9 +533,10 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
     reader.join();
     for (auto &w : workers) w.join();
     if (fs) plaac_fasta_close(fs);
-    if (keep && (keep_overflow || !ok || failed)) {
-        for (plaac_fasta *k : *keep) plaac_fasta_free(k);
-        keep->clear();
+    if (keep && (keep_overflow || !ok || failed)) ks.release_rest(*keep);
+    else if (keep) { // the batches stay for the scoring pass: from now on nobody but `keep` refers to them
+        std::lock_guard<std::mutex> l(ks.m);
+        ks.closed = true;
     }
     return ok && !failed;
 }
@@ -610,7 +685,10 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             nrec += f->nrec;
             return true;
         });
-    writer.finish();
+    if (!writer.finish()) {
+        std::fprintf(stderr, "plaac: writing the table to stdout failed (disk full / closed pipe?): output is incomplete\n");
+        return false;
+    }
     g_timer.lap("scoring pass (read + H2D + GPU + D2H + format + write)", (double)nres, "residues");
     return ok;
 }
@@ -680,7 +758,10 @@ bool plot_some(Engine &eng, const plaac_params &P, const Options &o, const Strea
             }
             return true;
         });
-    std::fflush(stdout);
+    if (std::fflush(stdout) != 0 || std::ferror(stdout)) {
+        std::fprintf(stderr, "plaac: writing the tracks to stdout failed (disk full / closed pipe?): output is incomplete\n");
+        return false;
+    }
     g_timer.lap("track pass");
     return ok;
 }
@@ -731,7 +812,7 @@ int main(int argc, char **argv) {
     // track mode moves 82 bytes per residue through the host: smaller batches
     Stream sp{(uint32_t)env_u64("PLAAC_BATCH_RECORDS", 262144),
               env_u64("PLAAC_BATCH_BYTES", o.plotlist.empty() ? (96ull << 20) : (8ull << 20))};
-    const uint64_t keep_bytes = env_u64("PLAAC_KEEP_BYTES", 4ull << 30);
+    const uint64_t keep_bytes = env_u64("PLAAC_KEEP_BYTES", default_keep_bytes());
 
     // background counts (:377-384)
     double bgf[PLAAC_NAA] = {0}, fgf[PLAAC_NAA];

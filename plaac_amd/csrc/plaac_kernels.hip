@@ -303,6 +303,43 @@ const char *check_params(const plaac_params &P) {
     return nullptr;
 }
 
+// The window kernels divide by multiplying with a tabulated reciprocal and one correction step (SharedDiv), which is the
+// correctly rounded quotient if and only if the reciprocal itself is correctly rounded. Checked at every context
+// creation: the table k_build_divtab left on the device against the HOST's IEEE quotients, and the device-side count of
+// k_check_recip (the in-kernel constructor over every denominator it can meet, against the device's IEEE division).
+constexpr uint32_t RECIP_CHECK_MAX = 1u << 19;
+const char *check_divtab(plaac_ctx *ctx) {
+    static thread_local std::string msg;
+    std::vector<KbDivTab> h(1);
+    uint32_t bad = 0;
+    if (hipMemcpy(h.data(), ctx->d_divtab, sizeof(KbDivTab), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&bad, ctx->d_fbcount, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemset(ctx->d_fbcount, 0, sizeof(uint32_t)) != hipSuccess)
+        return "reciprocal table: device copy failed";
+    if (bad) {
+        msg = "SharedDiv: " + std::to_string(bad) + " in-kernel reciprocals differ from the IEEE quotient";
+        return msg.c_str();
+    }
+    constexpr int W = TW, M = 2 * W + 1;
+    auto off = [&](const double2 &e, double den, const char *what, int i) -> bool {
+        volatile double q = 1.0 / den; // IEEE division on the host
+        if (e.x == den && e.y == q) return false;
+        msg = std::string("reciprocal table entry ") + what + "[" + std::to_string(i) + "] is not the IEEE quotient 1/den";
+        return true;
+    };
+    for (int i = 0; i <= M; ++i)
+        if (off(h[0].first[i], (double)(i > 0 ? i : 1), "first", i)) return msg.c_str();
+    for (int i = 0; i < M * M; ++i) {
+        const int ml = i / M, mr = i % M;
+        const int den = M + (M * W - ((ml * (ml + 1)) >> 1)) + (M * W - ((mr * (mr + 1)) >> 1));
+        if (off(h[0].second[i], (double)den, "second", i)) return msg.c_str();
+    }
+    if (!(h[0].second[M * M].x == 1.0 && std::isnan(h[0].second[M * M].y)) ||
+        !(h[0].second[M * M + 1].x == 1.0 && h[0].second[M * M + 1].y == 1.0))
+        return "reciprocal table: sentinel entries are off";
+    return nullptr;
+}
+
 template <class Tp>
 plaac_status grow(plaac_ctx *ctx, Tp *&ptr, size_t &cap, size_t need) {
     if (need <= cap && ptr) return PLAAC_OK;
@@ -418,7 +455,14 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     if ((e = hipMemset(ctx->d_fbcount, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(fbcount)", e);
     hipLaunchKernelGGL(k_build_divtab, dim3(((2 * TW + 1) * (2 * TW + 1) + 256) / 256), dim3(256), 0, ctx->stream,
                        ctx->d_divtab);
+    hipLaunchKernelGGL(k_check_recip, dim3((RECIP_CHECK_MAX + 255u) / 256u), dim3(256), 0, ctx->stream, RECIP_CHECK_MAX,
+                       ctx->d_fbcount);
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail("k_build_divtab", e);
+    if (const char *why = check_divtab(ctx)) { // SharedDiv is correctly rounded only if every reciprocal is
+        g_create_err = why;
+        plaac_ctx_destroy(ctx);
+        return PLAAC_ERR_DEVICE;
+    }
     plaac_status st = plaac_ctx_set_params(ctx, params);
     if (st != PLAAC_OK) {
         g_create_err = ctx->err;
@@ -1092,8 +1136,8 @@ plaac_status plaac_histogram_device(plaac_ctx *ctx, const uint8_t *d_codes, cons
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     PL_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int64_t) * NAA, st));
     if (nprot) {
-        unsigned blocks = (nprot + 3u) / 4u;
-        if (blocks > 256u * 16u) blocks = 256u * 16u;
+        // one resident round of waves, each with an equal share of the residue stream (the kernel reads the total itself)
+        const unsigned blocks = (unsigned)ctx->num_cus * HIST_BLOCKS_PER_CU;
         hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(256), 0, st, d_codes, d_offsets, nprot,
                            (unsigned long long *)d_counts);
         PL_HIP(ctx, hipGetLastError());

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <thread>
@@ -41,28 +42,71 @@ std::vector<uint32_t> balanced_cuts(const uint64_t *offsets, uint32_t nprot, siz
     return cut;
 }
 
+// Runs body(k) for k = 0 .. parts-1, part 0 on the calling thread, the others on threads of their own. Nothing escapes:
+// an exception inside a part (std::bad_alloc of its offsets copy ...) or from std::thread's constructor becomes a status
+// in st[k], and every thread that was started is joined before this returns - the C ABI never unwinds into its caller
+// (under the JNI shim that would take the JVM down instead of raising IllegalStateException).
+template <class Body>
+void run_parts(size_t parts, std::vector<plaac_status> &st, std::vector<std::string> &why, Body &&body) {
+    auto guarded = [&](size_t k) {
+        try {
+            body(k);
+        } catch (const std::bad_alloc &) {
+            st[k] = PLAAC_ERR_NOMEM;
+            why[k] = "out of host memory";
+        } catch (const std::exception &e) {
+            st[k] = PLAAC_ERR_DEVICE;
+            why[k] = e.what();
+        } catch (...) {
+            st[k] = PLAAC_ERR_DEVICE;
+            why[k] = "unknown exception";
+        }
+    };
+    std::vector<std::thread> pool;
+    size_t started = 1;
+    try {
+        pool.reserve(parts);
+        for (; started < parts; ++started) pool.emplace_back(guarded, started);
+    } catch (...) { // thread creation failed: the parts that have no thread run here, one after the other
+        for (size_t k = started; k < parts; ++k) guarded(k);
+    }
+    guarded(0);
+    for (auto &t : pool) t.join();
+}
+
 template <class Fn>
 plaac_status for_each_part(plaac_node *node, const uint64_t *offsets, uint32_t nprot, Fn &&fn) {
     const size_t parts = node->ctx.size();
-    const std::vector<uint32_t> cut = balanced_cuts(offsets, nprot, parts);
-    std::vector<plaac_status> st(parts, PLAAC_OK);
-    std::vector<std::thread> pool;
-    auto work = [&](size_t k) {
+    std::vector<uint32_t> cut;
+    std::vector<plaac_status> st;
+    std::vector<std::string> why;
+    try {
+        cut = balanced_cuts(offsets, nprot, parts);
+        st.assign(parts, PLAAC_OK);
+        why.assign(parts, std::string());
+    } catch (...) {
+        node->err = "out of host memory";
+        return PLAAC_ERR_NOMEM;
+    }
+    run_parts(parts, st, why, [&](size_t k) {
         const uint32_t a = cut[k], b = cut[k + 1];
         if (a == b) return;
         std::vector<uint64_t> offs((size_t)(b - a) + 1); // the shard's own offsets, starting at 0
         for (uint32_t i = a; i <= b; ++i) offs[i - a] = offsets[i] - offsets[a];
         st[k] = fn(k, a, b, offs.data());
-    };
-    for (size_t k = 1; k < parts; ++k) pool.emplace_back(work, k);
-    work(0);
-    for (auto &t : pool) t.join();
+    });
     for (size_t k = 0; k < parts; ++k)
         if (st[k] != PLAAC_OK) {
-            node->err = std::string("device ") + std::to_string(node->device[k]) + ": " + plaac_last_error(node->ctx[k]);
+            node->err = std::string("device ") + std::to_string(node->device[k]) + ": " +
+                        (why[k].empty() ? plaac_last_error(node->ctx[k]) : why[k].c_str());
             return st[k];
         }
     return PLAAC_OK;
+}
+
+plaac_status node_fail(plaac_node *node, plaac_status st, const char *msg) {
+    if (node) node->err = msg;
+    return st;
 }
 
 } // namespace
@@ -76,34 +120,43 @@ plaac_status plaac_node_create(const plaac_params *params, const int *device_ids
     }
     *out = nullptr;
     std::vector<int> devs;
-    if (device_ids && ndev > 0) {
-        devs.assign(device_ids, device_ids + ndev);
-    } else {
-        const int n = plaac_device_count();
-        if (n <= 0) {
-            g_node_create_err = "no HIP device available";
-            return PLAAC_ERR_DEVICE;
+    try {
+        if (device_ids && ndev > 0) {
+            devs.assign(device_ids, device_ids + ndev);
+        } else {
+            const int n = plaac_device_count();
+            if (n <= 0) {
+                g_node_create_err = "no HIP device available";
+                return PLAAC_ERR_DEVICE;
+            }
+            for (int d = 0; d < n; ++d) devs.push_back(d);
         }
-        for (int d = 0; d < n; ++d) devs.push_back(d);
+    } catch (...) {
+        g_node_create_err = "out of host memory";
+        return PLAAC_ERR_NOMEM;
     }
     plaac_node *node = new (std::nothrow) plaac_node();
     if (!node) {
         g_node_create_err = "out of host memory";
         return PLAAC_ERR_NOMEM;
     }
-    node->device = devs;
-    node->ctx.assign(devs.size(), nullptr);
     // contexts are created side by side: HIP start-up and the per-context allocations dominate, not the tables
-    std::vector<plaac_status> st(devs.size(), PLAAC_OK);
-    std::vector<std::string> msg(devs.size());
-    std::vector<std::thread> pool;
-    auto make = [&](size_t k) {
+    std::vector<plaac_status> st;
+    std::vector<std::string> msg;
+    try {
+        node->device = devs;
+        node->ctx.assign(devs.size(), nullptr);
+        st.assign(devs.size(), PLAAC_OK);
+        msg.assign(devs.size(), std::string());
+    } catch (...) {
+        g_node_create_err = "out of host memory";
+        delete node;
+        return PLAAC_ERR_NOMEM;
+    }
+    run_parts(devs.size(), st, msg, [&](size_t k) {
         st[k] = plaac_ctx_create(params, devs[k], &node->ctx[k]);
         if (st[k] != PLAAC_OK) msg[k] = plaac_last_error(nullptr); // thread-local message of this thread
-    };
-    for (size_t k = 1; k < devs.size(); ++k) pool.emplace_back(make, k);
-    make(0);
-    for (auto &t : pool) t.join();
+    });
     for (size_t k = 0; k < devs.size(); ++k)
         if (st[k] != PLAAC_OK) {
             g_node_create_err = "device " + std::to_string(devs[k]) + ": " + msg[k];
@@ -133,7 +186,7 @@ const char *plaac_node_last_error(const plaac_node *node) {
 }
 
 plaac_status plaac_node_set_params(plaac_node *node, const plaac_params *params) {
-    if (!node || !params) return PLAAC_ERR_ARG;
+    if (!node || !params) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_set_params: null argument");
     for (size_t k = 0; k < node->ctx.size(); ++k) {
         const plaac_status st = plaac_ctx_set_params(node->ctx[k], params);
         if (st != PLAAC_OK) {
@@ -146,10 +199,15 @@ plaac_status plaac_node_set_params(plaac_node *node, const plaac_params *params)
 
 plaac_status plaac_node_histogram(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
                                   int64_t counts[PLAAC_NAA]) {
-    if (!node || !counts || (nprot && !offsets)) return PLAAC_ERR_ARG;
+    if (!node || !counts || (nprot && !offsets)) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_histogram: null argument");
     for (int i = 0; i < PLAAC_NAA; ++i) counts[i] = 0;
     if (nprot == 0) return PLAAC_OK;
-    std::vector<int64_t> part(node->ctx.size() * PLAAC_NAA, 0);
+    std::vector<int64_t> part;
+    try {
+        part.assign(node->ctx.size() * PLAAC_NAA, 0);
+    } catch (...) {
+        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+    }
     const plaac_status st = for_each_part(node, offsets, nprot, [&](size_t k, uint32_t a, uint32_t b, const uint64_t *offs) {
         return plaac_histogram(node->ctx[k], codes + offsets[a], offs, b - a, part.data() + k * PLAAC_NAA);
     });
@@ -161,7 +219,7 @@ plaac_status plaac_node_histogram(plaac_node *node, const uint8_t *codes, const 
 
 plaac_status plaac_node_score(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
                               plaac_row *rows, const plaac_tracks *tracks) {
-    if (!node || (nprot && (!offsets || !rows))) return PLAAC_ERR_ARG;
+    if (!node || (nprot && (!offsets || !rows))) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_score: null argument");
     if (nprot == 0) return PLAAC_OK;
     return for_each_part(node, offsets, nprot, [&](size_t k, uint32_t a, uint32_t b, const uint64_t *offs) {
         plaac_tracks t, *tp = nullptr;

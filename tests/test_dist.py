@@ -93,3 +93,23 @@ def test_single_process_gather_is_a_permutation():
     idx = np.array([3, 0, 4, 1, 2])
     out = pdist.gather_rows(rows, idx, 5).reshape(5, 160)
     assert np.array_equal(out[idx], rows)
+
+
+def test_torch_shard_plan_and_extract_equal_the_numpy_ones():
+    """bench.py cuts its HBM-resident proteome with the torch versions (strong scaling: ONE proteome over the ranks)"""
+    import torch
+    from plaac_amd import dist as pdist
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([rng.integers(0, 300, 3000), [36000, 36000, 11, 11, 11]])
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    codes = rng.integers(0, 22, int(offs[-1])).astype(np.uint8)
+    t_off, t_codes = torch.from_numpy(offs.astype(np.int64)), torch.from_numpy(codes)
+    for world in (1, 2, 3, 8):
+        plan = pdist.shard_plan(offs, world)
+        for rank in range(world):
+            idx = pdist.shard_plan_torch(t_off, world, rank)
+            assert np.array_equal(idx.numpy(), plan[rank])
+            c, o = pdist.extract_shard_torch(t_codes, t_off, idx)
+            c_np, o_np = pdist.extract_shard(codes, offs, plan[rank])
+            assert np.array_equal(c.numpy(), c_np) and np.array_equal(o.numpy().astype(np.uint64), o_np)

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT
+from conftest import GOLDEN, ROOT, read_fasta_simple
 
 pytestmark = pytest.mark.gpu
 
@@ -174,3 +174,46 @@ def test_background_dump_streams_and_missing_background_is_reported(native, tmp_
     assert run_env({"PLAAC_BATCH_RECORDS": 33, "PLAAC_DEVICES": "0,0"}, "-b", fa) == a
     out = run_env({}, "-b", "/nonexistent_bg.fa").decode()
     assert "# Couldn't open /nonexistent_bg.fa" in out and "0.000000 # A" in out
+
+
+def test_track_table_reads_like_the_R_consumer(io, tmp_path):
+    """The consumer of `-p` output is cli/R/plaac_plot_util.r: it drops every line that starts with '#'
+    (:371-372), reads the rest with read.table(header=TRUE, sep="\\t", quote="", comment.char="") (:373), keys
+    on column NAMES - ORDER (:401, :410), AA (:124), VIT / MAP (:186-187), the columns matching ^HMM (:115-117), the
+    tracks CHARGE HYDRO FI PLAAC PAPA FIx2 PLAACx2 PAPAx2 (:240-262) - and groups rows by ORDER. Parsed here the same way."""
+    lst = tmp_path / "list.txt"
+    lst.write_text("Rnq1p\tRNQ1 #1 display\nSup35p\n")  # a '#' inside a display name must survive (quote="", :369)
+    lines = run("-i", FA4, "-p", lst)
+    assert any(l.startswith("##") for l in lines)          # the parameter block is there and is dropped below
+    kept = [l for l in lines if l and not l.startswith("#")]  # datRaw[!grepl("^#", datRaw)]
+    header = kept[0].split("\t")
+    # read.table(header=TRUE) passes names through make.names: '-' becomes '.'
+    rnames = [h.replace("-", ".") for h in header]
+    for need in ("ORDER", "SEQid", "AANUM", "AA", "VIT", "MAP", "CHARGE", "HYDRO", "FI", "PLAAC", "PAPA", "FIx2",
+                 "PLAACx2", "PAPAx2"):
+        assert need in rnames, need
+    hmm = [h for h in rnames if h.startswith("HMM")]           # grep("^HMM", colnames(dat))
+    assert [h.replace("HMM.", "", 1) for h in hmm] == ["background", "PrD.like"]
+    rows = [l.split("\t") for l in kept[1:]]
+    assert all(len(r) == len(header) for r in rows)            # read.table refuses ragged lines
+    col = {h: [r[i] for r in rows] for i, h in enumerate(rnames)}
+
+    def rnum(x):  # type.convert: NaN / NA / Inf spellings R accepts
+        return float("nan") if x in ("NaN", "NA") else float(x)
+    for name in ("CHARGE", "HYDRO", "FI", "PLAAC", "PAPA", "FIx2", "PLAACx2", "PAPAx2") + tuple(hmm):
+        vals = np.array([rnum(x) for x in col[name]])          # every cell numeric -> the column is numeric in R
+        assert np.isfinite(vals).sum() > 0
+    assert set(col["VIT"]) <= {"0", "1"} and set(col["MAP"]) <= {"0", "1"}
+    order = [int(x) for x in col["ORDER"]]
+    groups = {}
+    for o_, nm, an, aa in zip(order, col["SEQid"], col["AANUM"], col["AA"]):
+        groups.setdefault(o_, []).append((nm, int(an), aa))
+    assert sorted(groups) == [1, 2]                            # sort(unique(datAll$ORDER)): plot order = list order
+    assert {g[0][0] for g in groups.values()} == {"RNQ1 #1 display", "Sup35p"}
+    seqs = dict(read_fasta_simple(FA4))
+    for o_, nm in ((1, "Rnq1p"), (2, "Sup35p")):
+        g = groups[o_]
+        assert [a for _, a, _ in g] == list(range(1, len(g) + 1))        # AANUM runs 1..n inside a group
+        assert "".join(aa for _, _, aa in g) == seqs[nm].rstrip("*")
+        post = np.array([[rnum(r[rnames.index(h)]) for h in hmm] for r in rows if int(r[0]) == o_])
+        assert np.all(np.abs(post.sum(axis=1) - 1.0) < 1e-3)          # posteriors of the two states

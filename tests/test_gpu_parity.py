@@ -185,6 +185,69 @@ def test_histogram_validity_rules(native, oracle, ctx):
     assert got.sum() > 0
 
 
+def _random_records(rng, nrec, bad_fraction, maxlen=600, x_rate=0.0, stop_fraction=0.3, empty_fraction=0.01):
+    """codes/offsets of random records; bad_fraction of them get an X or a stop at a random position (which may be a
+    position the rule exempts: 0, or the last one for a stop)"""
+    lens = rng.integers(1, maxlen, nrec)
+    lens[rng.random(nrec) < empty_fraction] = 0
+    offs = np.zeros(nrec + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    codes = rng.integers(1, 21, int(offs[-1])).astype(np.uint8)
+    if x_rate:
+        codes[rng.random(len(codes)) < x_rate] = 0
+    nz = np.nonzero(lens > 0)[0]
+    stops = nz[rng.random(len(nz)) < stop_fraction]
+    codes[(offs[1:][stops] - 1).astype(np.int64)] = 21
+    bad = nz[rng.random(len(nz)) < bad_fraction]
+    pos = (offs[:-1][bad] + rng.integers(0, 1 << 30, len(bad)) % lens[bad]).astype(np.int64)
+    codes[pos] = np.where(rng.random(len(bad)) < 0.5, 0, 21).astype(np.uint8)
+    return codes, offs
+
+
+def test_histogram_streaming_kernel_random_sets(native, oracle, ctx):
+    """k_hist streams the flat residue buffer (whole records per wave, flagged bytes decide validity, invalid records
+    subtracted): against countaas / isvalidprotein (plaac.java:1698-1739) on 1 M random records with 5 % invalid ones,
+    on X-rich text, on tiny / huge records and on every alignment of the buffer start."""
+    rng = np.random.default_rng(20261003)
+    codes, offs = _random_records(rng, 1_000_000, 0.05, maxlen=500)
+    assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs))
+    codes, offs = _random_records(rng, 20_000, 0.3, maxlen=300, x_rate=0.02)   # most records invalid, X everywhere
+    assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs))
+    codes, offs = _random_records(rng, 300_000, 0.2, maxlen=4, empty_fraction=0.3)  # 0..3-residue records
+    assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs))
+    codes, offs = _random_records(rng, 40, 0.5, maxlen=400_000)                 # records longer than a wave's share
+    assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs))
+    for seqs in (["X" * 5000], ["A" * 70000 + "X" + "A" * 3], ["*" * 40, "X", "AX", "XA", "A*", "*A", "AXA", "A*A", "A**"],
+                 ["A" * 17] * 1000 + ["AXA"] + ["C" * 15] * 1000, [""] * 100 + ["MKV"] + [""] * 100, [""], []):
+        codes, offs = native.pack(seqs)
+        assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs)), seqs[:3]
+
+
+def test_histogram_device_entry_any_alignment(native, oracle, ctx):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(7)
+    codes, offs = _random_records(rng, 5000, 0.1, maxlen=200)
+    dev = torch.device("cuda:0")
+    buf = torch.zeros(len(codes) + 64, dtype=torch.uint8, device=dev)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    cnt = torch.zeros(22, dtype=torch.int64, device=dev)
+    want = oracle.histogram(codes, offs)
+    for shift in (0, 1, 7, 15, 16, 33):
+        buf[shift:shift + len(codes)] = torch.from_numpy(codes).to(dev)
+        torch.cuda.synchronize()
+        ctx.histogram_device(buf.data_ptr() + shift, d_offs.data_ptr(), len(offs) - 1, cnt.data_ptr())
+        ctx.sync()
+        assert np.array_equal(cnt.cpu().numpy(), want), shift
+
+
+def test_reciprocal_selftest_passes_at_context_creation(native):
+    """plaac_ctx_create checks every tabulated reciprocal against the host's IEEE quotient and the in-kernel reciprocal
+    of every denominator up to 2^19 against the device's (SharedDiv is the correctly rounded quotient only then);
+    a context exists only if both passed"""
+    with native.Context(native.make_params()) as c:
+        assert c.score(*native.pack(["MKVLAAGQQNNQQ" * 10]))["prot_len"][0] == 130
+
+
 def test_results_independent_of_batch_split(native, ctx):
     from plaac_amd import synth
     ctx.set_params(native.make_params())
