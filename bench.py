@@ -162,8 +162,8 @@ def main():
                     "(per-GPU work fixed) instead of ONE proteome cut over the ranks")
     ap.add_argument("--shard", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--contexts", type=int, default=0, help="scoring contexts per GPU, used alternately so that "
-                    "consecutive steps overlap (the serial chain of one step's longest protein beside the next step's "
-                    "windows). 0 = 2 for batches below 5 M sequences per GPU, else 1")
+                    "consecutive steps overlap (measured on MI355X: no gain - the contexts' role streams share the four "
+                    "hardware queues of a priority class; default 1)")
     ap.add_argument("--tracks", action="store_true", help="per-residue track mode (82 B/residue written)")
     ap.add_argument("--sweep", action="store_true", help="BASELINE config 5: a step = the 9-point sweep "
                     "alpha in {0,0.5,1} x core length in {30,60,90} over the resident shard (value counts every "
@@ -235,7 +235,7 @@ def main():
         del mine
     else:
         main_work = Work(codes_full, offsets_full, None, nfull)
-    nctx = args.contexts or (2 if main_work.nprot < 5_000_000 and not args.tracks else 1)
+    nctx = args.contexts or 1
     ctxs = [native.Context(P, device=local_rank) for _ in range(nctx)]
     # real (non-null) HIP streams: the kernels are launched on them, the HIP events that time them are recorded on
     # them, and RCCL orders the row gather after them

@@ -65,7 +65,7 @@ struct plaac_ctx {
     std::vector<hipStream_t> gstreams; // side streams of the 2nd, 3rd ... group of a sweep (three each), high priority
     std::vector<hipStream_t> gstreams_n; // the same at normal priority (throughput-bound batches, see auxn)
     std::vector<hipEvent_t> gjev;      // their join events
-    hipEvent_t jev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
+    hipEvent_t jev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
     hipEvent_t fev[2] = {nullptr, nullptr};                            // k_finish waits for the forward / window streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
@@ -114,11 +114,28 @@ struct plaac_ctx {
     static constexpr int EV_PER = 15;  // start, planned, {begin,end} x {vit,fwd,win,tracks}, joined, {begin,end} x {pack,bwd}
     hipEvent_t ev[EV_SETS][EV_PER] = {};
     uint64_t ncalls = 0;
-    hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // high-priority side streams of the K-A roles
+    // Side streams, one per ROLE. The HIP runtime multiplexes the streams of a priority class onto FOUR hardware queues,
+    // and kernels of different streams that share a queue run strictly one after the other (tools/queue_probe.hip,
+    // profiles/r03_queue_probe.txt). Which roles share a queue therefore decides the step - measured on one box: the
+    // forward kernel sharing with the window-track kernels 27.7 ms per 10 M sequences, nobody sharing with them 22.3 ms -
+    // and which streams share one depends on everything the process has created and destroyed before (the probe shows
+    // 0-7 1-6 2-5-9 3-4-8 for ten fresh streams, 0-3 1-4 after others had been destroyed). So the context MEASURES which of
+    // its candidate streams collide with each other and with the caller's stream (assign_role_streams) and gives the
+    // roles that run together streams that do not. The window-track kernels (KB) run on the caller's stream.
+    enum Role { R_WIN = 0, R_VIT = 1, R_FWD = 2, R_KB = 3, R_BWD = 4, R_WIN2 = 5, NROLES = 6 };
+    static constexpr int NCAND = 8;
+    hipStream_t cand[2][NCAND] = {}; // [0] normal, [1] high priority: every side stream the context created
+    int ncand[2] = {0, 0};
+    bool cand_hit[2][NCAND][NCAND] = {}; // measured: the two candidates are serialised against each other
+    hipStream_t roles_for = nullptr;     // the caller's stream the normal-class roles were assigned for
+    bool roles_assigned = false;
+    long long *d_qprobe = nullptr;
+    int role_cost[2] = {-1, -1}; // weighted collisions left after the assignment (0: the roles that meet are all apart)
+    hipStream_t aux[NROLES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // high priority (chain-bound batches)
     // the same roles at normal priority, for throughput-bound batches: there the step is the sum of all kernels' issue
     // time, and high-priority chain kernels only keep the window kernel's waves out of the SIMDs until they are done
     // (chains, then windows, one after the other); at equal priority the two mix and hide each other's latencies
-    hipStream_t auxn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t auxn[NROLES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t vit_stop = 0; // DIAGNOSTIC, PLAAC_VIT_STOP=1|2: k_vit stops after that sweep (timing the sweeps; results are wrong)
     int latency_mode = -1; // PLAAC_LATENCY_MODE=0/1 forces the throughput / latency forms of the K-A kernels (-1: per batch)
     bool serial = false;                              // PLAAC_SERIAL_STREAMS=1: everything on one stream
@@ -340,6 +357,105 @@ const char *check_divtab(plaac_ctx *ctx) {
     return nullptr;
 }
 
+// Give every role a stream (see plaac_ctx::Role). Per priority class: start with as many candidate streams as the class
+// has roles, measure which of them are serialised against each other - and, in the normal class, against the caller's
+// stream `st`, which carries the window-track kernels - (a 100 us spin on one, a time stamp on the other; a collision is
+// confirmed by a second run, because a late submission of the second kernel looks like one), take the assignment with the
+// least weighted collision cost over the roles that run together, and add candidates (up to NCAND) while that cost is
+// above the least possible one. As few streams as possible: the HIP runtime's own per-call cost grows with the number of live streams
+// (measured: 17 streams per context 4.97 ms per 1.25 M-sequence step, 13 streams 4.06 ms). The high class is assigned
+// at context creation (st == nullptr), the normal class at the first scoring call on a given caller stream.
+// PLAAC_STREAM_PROBE=0: candidates in creation order, unmeasured.
+const char *assign_role_streams(plaac_ctx *ctx, int cls, hipStream_t st) {
+    constexpr int NMAX = plaac_ctx::NCAND;
+    const char *off = std::getenv("PLAAC_STREAM_PROBE");
+    const bool probe = !(off && off[0] == '0');
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    auto collide = [&](hipStream_t a, hipStream_t b, bool &out) -> bool { // false: HIP failure
+        out = true;
+        for (int rep = 0; rep < 2 && out; ++rep) {
+            hipLaunchKernelGGL(k_qprobe_spin, dim3(1), dim3(64), 0, a, 10000ll /* 100 us */, ctx->d_qprobe);
+            hipLaunchKernelGGL(k_qprobe_mark, dim3(1), dim3(64), 0, b, ctx->d_qprobe + 1);
+            long long t[2] = {0, 0};
+            if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
+                hipMemcpy(t, ctx->d_qprobe, sizeof t, hipMemcpyDeviceToHost) != hipSuccess)
+                return false;
+            out = t[1] >= t[0];
+        }
+        return true;
+    };
+    // roles of a class that get a stream of their own, and the cost of two of them sharing a queue (0: they never run
+    // together). Normal class: KB is the caller's stream. Measured per 10 M sequences (profiles/r03_role_sharing.txt): all
+    // apart 22.3 - 23.5 ms, the forward kernel with the window-track kernels 27.7, Viterbi with them 30.7, ...
+    static const int roles[2][4] = {{plaac_ctx::R_WIN, plaac_ctx::R_VIT, plaac_ctx::R_FWD, plaac_ctx::R_BWD},
+                                    {plaac_ctx::R_WIN, plaac_ctx::R_VIT, plaac_ctx::R_FWD, plaac_ctx::R_WIN2}};
+    static const int W[2][4][4] = {{{0, 4, 4, 3}, {4, 0, 8, 6}, {4, 8, 0, 8}, {3, 6, 8, 0}},   // normal: WIN VIT FWD BWD
+                                   {{0, 8, 8, 8}, {8, 0, 9, 8}, {8, 9, 0, 8}, {8, 8, 8, 0}}};  // high: WIN VIT FWD WIN2
+    static const int Wst[4] = {6, 9, 9, 9}; // normal class: sharing a queue with the window-track kernels
+    bool(&hit)[NMAX][NMAX] = ctx->cand_hit[cls];
+    bool hit_st[NMAX] = {};
+    int &n = ctx->ncand[cls];
+    if (probe && st)
+        for (int c = 0; c < n; ++c)
+            if (!collide(st, ctx->cand[cls][c], hit_st[c])) return "stream probe failed";
+    int best_cost = 1 << 30, best[4] = {0, 1, 2, 3};
+    for (;;) {
+        if (n >= 4) {
+            int cur[4];
+            best_cost = 1 << 30;
+            auto search = [&](auto &&self, int r, unsigned used, int cost) -> void {
+                if (r == 4) {
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        for (int i = 0; i < 4; ++i) best[i] = cur[i];
+                    }
+                    return;
+                }
+                for (int c = 0; c < n; ++c) {
+                    if (used & (1u << c)) continue;
+                    int add = (cls == 0 && hit_st[c]) ? Wst[r] : 0;
+                    for (int q = 0; q < r; ++q)
+                        if (hit[cur[q]][c]) add += W[cls][q][r];
+                    cur[r] = c;
+                    self(self, r + 1, used | (1u << c), cost + add);
+                }
+            };
+            search(search, 0, 0u, 0);
+            if (!probe || best_cost <= (cls == 0 && st ? 3 : 0) || n >= NMAX) break; // (normal: five parties on four queues)
+        }
+        // one more candidate, probed against the earlier ones (and the caller's stream)
+        if (hipStreamCreateWithPriority(&ctx->cand[cls][n], hipStreamNonBlocking, cls ? greatest : 0) != hipSuccess)
+            return "hipStreamCreateWithPriority failed";
+        for (int a = 0; probe && a < n; ++a) {
+            bool h = false;
+            if (!collide(ctx->cand[cls][a], ctx->cand[cls][n], h)) return "stream probe failed";
+            hit[a][n] = hit[n][a] = h;
+        }
+        if (probe && st && !collide(st, ctx->cand[cls][n], hit_st[n])) return "stream probe failed";
+        ++n;
+    }
+    hipStream_t *dst = cls ? ctx->aux : ctx->auxn;
+    for (int i = 0; i < 4; ++i) dst[roles[cls][i]] = ctx->cand[cls][best[i]];
+    // roles without a stream of their own: BWD (track mode) and WIN2 (latency forms, summary mode) never meet, so in the
+    // high class BWD takes WIN2's stream; in the normal class WIN2 only carries a join event
+    if (cls) ctx->aux[plaac_ctx::R_BWD] = ctx->aux[plaac_ctx::R_WIN2];
+    else ctx->auxn[plaac_ctx::R_WIN2] = ctx->auxn[plaac_ctx::R_WIN];
+    ctx->role_cost[cls] = probe ? best_cost : -1;
+    if (std::getenv("PLAAC_STREAM_DEBUG")) { // DIAGNOSTIC: the measured collisions and the assignment, on stderr
+        std::fprintf(stderr, "plaac: %s-priority streams, %d candidates, collisions:", cls ? "high" : "normal", n);
+        for (int a = 0; a < n; ++a)
+            for (int b = a + 1; b < n; ++b)
+                if (hit[a][b]) std::fprintf(stderr, " %d-%d", a, b);
+        for (int a = 0; a < n; ++a)
+            if (hit_st[a]) std::fprintf(stderr, " caller-%d", a);
+        std::fprintf(stderr, "; roles %s ->", cls ? "WIN VIT FWD WIN2" : "WIN VIT FWD BWD");
+        for (int i = 0; i < 4; ++i) std::fprintf(stderr, " %d", best[i]);
+        std::fprintf(stderr, "; cost %d\n", best_cost);
+    }
+    return nullptr;
+}
+
 template <class Tp>
 plaac_status grow(plaac_ctx *ctx, Tp *&ptr, size_t &cap, size_t need) {
     if (need <= cap && ptr) return PLAAC_OK;
@@ -404,17 +520,17 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         plaac_ctx_destroy(ctx);
         return PLAAC_ERR_DEVICE;
     }
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
-        return bail("hipStreamCreate", e);
     {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        for (auto &a : ctx->aux)
-            if ((e = hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest)) != hipSuccess)
-                return bail("hipStreamCreateWithPriority", e);
-        for (auto &a : ctx->auxn)
-            if ((e = hipStreamCreateWithPriority(&a, hipStreamNonBlocking, 0)) != hipSuccess)
-                return bail("hipStreamCreateWithPriority", e);
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail("hipStreamCreate", e);
+        if ((e = hipMalloc((void **)&ctx->d_qprobe, 2 * sizeof(long long))) != hipSuccess) return bail("hipMalloc(qprobe)", e);
+        if (const char *why = assign_role_streams(ctx, 1, nullptr)) {
+            g_create_err = why;
+            plaac_ctx_destroy(ctx);
+            return PLAAC_ERR_DEVICE;
+        }
         for (auto &je : ctx->jev)
             if ((e = hipEventCreateWithFlags(&je, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
@@ -523,16 +639,13 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     for (auto &set : ctx->ev)
         for (auto &ev : set)
             if (ev) (void)hipEventDestroy(ev);
-    for (auto &a : ctx->aux)
-        if (a) {
-            (void)hipStreamSynchronize(a);
-            (void)hipStreamDestroy(a);
-        }
-    for (auto &a : ctx->auxn)
-        if (a) {
-            (void)hipStreamSynchronize(a);
-            (void)hipStreamDestroy(a);
-        }
+    for (auto &cls : ctx->cand)
+        for (auto &a : cls)
+            if (a) {
+                (void)hipStreamSynchronize(a);
+                (void)hipStreamDestroy(a);
+            }
+    if (ctx->d_qprobe) (void)hipFree(ctx->d_qprobe);
     for (hipEvent_t e : ctx->gev)
         if (e) (void)hipEventDestroy(e);
     for (auto *gs : {&ctx->gstreams, &ctx->gstreams_n})
@@ -660,9 +773,18 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
 
     hipEvent_t *evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
     enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10, E_PACK = 11, E_BWD = 13 };
-    hipStream_t sv = ctx->serial ? st : ctx->aux[0], sf = ctx->serial ? st : ctx->aux[1],
-                sw = ctx->serial ? st : ctx->aux[2], sb = ctx->serial ? st : ctx->aux[3],
-                sw2 = ctx->serial ? st : ctx->aux[4];
+    if (!ctx->serial && (!ctx->roles_assigned || ctx->roles_for != st)) { // normal-class roles: apart from `st`, too
+        if (ctx->ncalls > 0) // (the probe kernels must not run beside a batch that is still being scored)
+            PL_HIP(ctx, hipEventSynchronize(ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
+        if (const char *why = assign_role_streams(ctx, 0, st)) return fail(ctx, PLAAC_ERR_DEVICE, why);
+        ctx->roles_for = st;
+        ctx->roles_assigned = true;
+    }
+    hipStream_t sv = ctx->serial ? st : ctx->aux[plaac_ctx::R_VIT], sf = ctx->serial ? st : ctx->aux[plaac_ctx::R_FWD],
+                sw = ctx->serial ? st : ctx->aux[plaac_ctx::R_WIN], sb = ctx->serial ? st : ctx->aux[plaac_ctx::R_BWD],
+                sw2 = ctx->serial ? st : ctx->aux[plaac_ctx::R_WIN2];
+    // the window-track kernels (K-B) run on the caller's stream, behind the planning kernels (no fork, no join)
+    const hipStream_t skb = st;
 
     // K-B base of a group: an earlier group whose window tracks differ only through the llr table (another alpha of
     // a sweep); such a group needs PAPAllr / PAPAllr2 at the known PAPA centre only (k_llr_at_centre)
@@ -691,15 +813,15 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // fields that do not depend on llr, then the llr track alone at the listed centres (nine proteins
                     // per wave), and the one-wave-per-protein kernel only for what the exact tier scored
                     const uint32_t *huge = ctx->d_hist + LEN_BINS;
-                    hipLaunchKernelGGL(k_copy_window_fields, dim3((nprot + 255u) / 256u), dim3(256), 0, st, src, dst, nprot);
+                    hipLaunchKernelGGL(k_copy_window_fields, dim3((nprot + 255u) / 256u), dim3(256), 0, skb, src, dst, nprot);
                     hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min((nprot + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)),
-                                       dim3(64), 0, st, d_codes, total_residues, gtab0 + g, ctx->d_divtab, dst, huge,
+                                       dim3(64), 0, skb, d_codes, total_residues, gtab0 + g, ctx->d_divtab, dst, huge,
                                        ctx->d_clist, ctx->d_crow, ctx->d_ccount);
-                    hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, st, d_codes,
+                    hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, skb, d_codes,
                                        d_offsets, ctx->d_neff, nprot, gtab0 + g, src, dst, ctx->d_order, ctx->d_fblist,
                                        ctx->d_fbcount, huge);
                 } else {
-                    hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 1u << 20)), dim3(256), 0, st, d_codes,
+                    hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 1u << 20)), dim3(256), 0, skb, d_codes,
                                        d_offsets, ctx->d_neff, nprot, gtab0 + g, src, dst);
                 }
                 return PLAAC_OK;
@@ -710,14 +832,14 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         plaac_row *rows = d_rows[groups[g].first];
         const int wmax = std::max(P.ww1 / 2, std::max(P.ww2 / 2, P.ww3 / 2));
         const bool fast20 = P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && !ctx->generic_tracks;
-        if (g == 0) PL_HIP(ctx, hipEventRecord(evs[E_TRK], st));
+        if (g == 0) PL_HIP(ctx, hipEventRecord(evs[E_TRK], skb));
 #define LAUNCH_KB(RING)                                                                                            \
     do {                                                                                                           \
         if (d_tracks)                                                                                              \
-            hipLaunchKernelGGL((k_tracks<RING, true>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,           \
+            hipLaunchKernelGGL((k_tracks<RING, true>), dim3(nprot), dim3(64), 0, skb, d_codes, d_offsets,           \
                                ctx->d_neff, ctx->d_order, nprot, tab, rows, tp);                                   \
         else                                                                                                       \
-            hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, st, d_codes, d_offsets,          \
+            hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, skb, d_codes, d_offsets,          \
                                ctx->d_neff, ctx->d_order, nprot, tab, rows, tp);                                   \
     } while (0)
         // the stream form keeps 32 proteins on one int32 position axis; a batch with a protein of >= 65535 residues is
@@ -729,44 +851,44 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             const uint32_t only_if_huge = ctx->per_protein_tracks ? 0u : 1u; // PLAAC_KB_PER_PROTEIN=1: always this form
             if (!ctx->per_protein_tracks) {
                 if (d_tracks) {
-                    hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                    hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
                                        total_residues, tab, ctx->d_divtab, rows, tp, huge);
                 } else if (ctx->kb_filter) {
                     // summary mode: decisions from error-bounded prefix sums, exact values at the chosen centre only,
                     // whatever the bounds cannot decide goes to the exact per-protein kernel through the fallback list
-                    PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), st));
-                    PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t), st));
+                    PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), skb));
+                    PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t), skb));
                     if (gfi[g] && ctx->fi_int_allowed)
-                        hipLaunchKernelGGL(k_tracks20f<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                        hipLaunchKernelGGL(k_tracks20f<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
                                            total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
                                            ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
                     else
-                        hipLaunchKernelGGL(k_tracks20f<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                        hipLaunchKernelGGL(k_tracks20f<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
                                            total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
                                            ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
                     filter_group = (long)g;
                     hipLaunchKernelGGL(k_refine_centres<false>, dim3(std::min((nprot + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)), dim3(64),
-                                       0, st, d_codes, total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist,
+                                       0, skb, d_codes, total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist,
                                        ctx->d_crow, ctx->d_ccount);
-                    hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, st, d_codes,
+                    hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
                                        d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
                                        0u, ctx->d_fblist, ctx->d_fbcount);
                 } else {
-                    hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, ctx->d_order, nprot,
+                    hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
                                        total_residues, tab, ctx->d_divtab, rows, tp, huge);
                 }
             }
             if (d_tracks)
-                hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
+                hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, ctx->d_neff,
                                    ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
             else
-                hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, st, d_codes, d_offsets, ctx->d_neff,
+                hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, ctx->d_neff,
                                    ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
         } else if (wmax <= 32) LAUNCH_KB(128);
         else if (wmax <= 96) LAUNCH_KB(256);
         else LAUNCH_KB(1024);
 #undef LAUNCH_KB
-        if (g == 0) PL_HIP(ctx, hipEventRecord(evs[E_TRK + 1], st));
+        if (g == 0) PL_HIP(ctx, hipEventRecord(evs[E_TRK + 1], skb));
         return PLAAC_OK;
     };
 
@@ -839,11 +961,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const std::vector<hipStream_t> &gs = chain_bound ? ctx->gstreams : ctx->gstreams_n;
     if (!ctx->serial) {
         if (!chain_bound) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn)
-            sv = ctx->auxn[0];
-            sf = ctx->auxn[1];
-            sw = ctx->auxn[2];
-            sb = ctx->auxn[3];
-            sw2 = ctx->auxn[4];
+            sv = ctx->auxn[plaac_ctx::R_VIT];
+            sf = ctx->auxn[plaac_ctx::R_FWD];
+            sw = ctx->auxn[plaac_ctx::R_WIN];
+            sb = ctx->auxn[plaac_ctx::R_BWD];
+            sw2 = ctx->auxn[plaac_ctx::R_WIN2];
             PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PACK + 1], 0));
         }
         for (hipStream_t a : {sf, sw, sb, sw2}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
@@ -1034,7 +1156,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[2], sw));
         PL_HIP(ctx, hipEventRecord(ctx->jev[3], sb));
         PL_HIP(ctx, hipEventRecord(ctx->jev[4], sw2));
-        for (hipEvent_t e : ctx->jev) PL_HIP(ctx, hipStreamWaitEvent(st, e, 0));
+        for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[k], 0));
         for (size_t k = 0; k < 3 * (ng - 1); ++k) {
             PL_HIP(ctx, hipEventRecord(ctx->gjev[k], gs[k]));
             PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
