@@ -1348,8 +1348,10 @@ static plaac_status stage_in(plaac_ctx *ctx, const uint8_t *codes, const uint64_
                              uint64_t *total_out) {
     if (!offsets) return fail(ctx, PLAAC_ERR_ARG, "null offsets");
     if (offsets[0] != 0) return fail(ctx, PLAAC_ERR_ARG, "offsets[0] must be 0");
-    for (uint32_t p = 0; p < nprot; ++p)
+    for (uint32_t p = 0; p < nprot; ++p) {
         if (offsets[p + 1] < offsets[p]) return fail(ctx, PLAAC_ERR_ARG, "offsets must be non-decreasing");
+        if (offsets[p + 1] - offsets[p] >= 0x7fffffffull) return fail(ctx, PLAAC_ERR_ARG, "a record of 2^31 residues or more");
+    }
     const uint64_t total = offsets[nprot];
     if (total && !codes) return fail(ctx, PLAAC_ERR_ARG, "null codes");
     plaac_status rc;
