@@ -22,6 +22,7 @@
 //                                   window size); k_llr_at_centre (sweeps)
 //   kernels_windows_filter.hip.inc  "K-B", summary mode: k_tracks20f (decisions from error-bounded prefix sums) and
 //                                   k_refine_centres (the reported values at the chosen centre in the reference's order)
+//   kernels_windows_lane.hip.inc    "K-B", summary mode, the filter tier with one lane per protein and sliding windows (k_tracksL)
 //   kernels_misc.hip.inc            k_hist (countaas / isvalidprotein :1698-1739), k_validate
 // Below them: the device half of the C ABI (contexts, streams, the scheduling of a scoring call).
 #include <hip/hip_runtime.h>
@@ -47,6 +48,7 @@ namespace {
 #include "kernels_chains.hip.inc"
 #include "kernels_windows_exact.hip.inc"
 #include "kernels_windows_filter.hip.inc"
+#include "kernels_windows_lane.hip.inc"
 #include "kernels_misc.hip.inc"
 
 } // namespace
@@ -93,6 +95,8 @@ struct plaac_ctx {
     void *d_corepart = nullptr; // their per-row best windows
     size_t cap_corep = 0, cap_corepart = 0;
     bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
+    bool kb_lane = true;   // PLAAC_KB_LANE=0: the filter tier in stream form (k_tracks20f) for every protein
+    bool kb_priority = true; // PLAAC_KB_PRIORITY=0: the lane-form window kernels stay on the caller's stream
     uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
     size_t cap_corelist = 0, cap_corecount = 0;
     bool core_list = true; // PLAAC_CORE_LIST=0: sweep 3 inside k_vit for every batch
@@ -546,6 +550,10 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         if (const char *rg = std::getenv("PLAAC_RF_GRID")) ctx->rf_grid = (unsigned)std::max(1, std::atoi(rg));
         const char *kbf = std::getenv("PLAAC_KB_FILTER");
         ctx->kb_filter = !(kbf && kbf[0] == '0');
+        const char *kbl = std::getenv("PLAAC_KB_LANE");
+        ctx->kb_lane = !(kbl && kbl[0] == '0');
+        const char *kbp = std::getenv("PLAAC_KB_PRIORITY");
+        ctx->kb_priority = !(kbp && kbp[0] == '0');
         const char *cp = std::getenv("PLAAC_CORE_PAR");
         ctx->core_par = !(cp && cp[0] == '0');
         const char *cl = std::getenv("PLAAC_CORE_LIST");
@@ -783,8 +791,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     hipStream_t sv = ctx->serial ? st : ctx->aux[plaac_ctx::R_VIT], sf = ctx->serial ? st : ctx->aux[plaac_ctx::R_FWD],
                 sw = ctx->serial ? st : ctx->aux[plaac_ctx::R_WIN], sb = ctx->serial ? st : ctx->aux[plaac_ctx::R_BWD],
                 sw2 = ctx->serial ? st : ctx->aux[plaac_ctx::R_WIN2];
-    // the window-track kernels (K-B) run on the caller's stream, behind the planning kernels (no fork, no join)
-    const hipStream_t skb = st;
+    // the window-track kernels (K-B) run on the caller's stream, behind the planning kernels (no fork, no join) - except
+    // in lane form in a throughput-bound batch (below): there they are the longest dependent chain of the step
+    // (packed copy -> filter -> refine -> exact tier) and take a high-priority stream of their own
+    hipStream_t skb = st;
+    bool kb_forked = false;
 
     // K-B base of a group: an earlier group whose window tracks differ only through the llr table (another alpha of
     // a sweep); such a group needs PAPAllr / PAPAllr2 at the known PAPA centre only (k_llr_at_centre)
@@ -800,6 +811,13 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                 return (long)h;
         }
         return -1;
+    };
+    // the lane-per-protein form of the filter tier (k_tracksL): summary mode, half windows of 20, FoldIndex in integers;
+    // it reads the packed rows, so its group's window kernels are enqueued after k_pack (PLAAC_KB_LANE=0: stream form)
+    auto lane_form = [&](size_t g) -> bool {
+        const plaac_params &P = points[groups[g].first];
+        return !d_tracks && ctx->kb_filter && ctx->kb_lane && !ctx->generic_tracks && !ctx->per_protein_tracks &&
+               P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && gfi[g] && ctx->fi_int_allowed && kb_base(g) < 0;
     };
     long filter_group = -1; // the group whose filter-tier lists (centres, fallbacks) the ctx buffers hold
     auto launch_tracks = [&](size_t g) -> plaac_status { // K-B: needs only the order, not the packed copy
@@ -858,7 +876,23 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // whatever the bounds cannot decide goes to the exact per-protein kernel through the fallback list
                     PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), skb));
                     PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t), skb));
-                    if (gfi[g] && ctx->fi_int_allowed)
+                    if (lane_form(g)) {
+                        // one lane per protein over the packed rows (k_tracksL); the long wave-groups (a prefix of the
+                        // descending-length plan) stay with the stream form. Called after the packed copy has been enqueued.
+                        const uint32_t lgroups = std::min<uint32_t>(ctx->h_pin[3], ngroups);
+                        const uint32_t nlong = std::min<uint64_t>((uint64_t)lgroups * 64u, nprot);
+                        if (nlong)
+                            hipLaunchKernelGGL(k_tracks20f<true>, dim3((nlong + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK),
+                                               dim3(64), 0, skb, d_codes, ctx->d_order, nlong, total_residues, tab,
+                                               ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount,
+                                               ctx->d_fblist, ctx->d_fbcount);
+                        if (!ctx->serial) PL_HIP(ctx, hipStreamWaitEvent(skb, evs[E_PACK + 1], 0));
+                        if (lgroups < ngroups)
+                            hipLaunchKernelGGL(k_tracksL, dim3((ngroups - lgroups + KL_THREADS / 64 - 1) / (KL_THREADS / 64)),
+                                               dim3(KL_THREADS), 0, skb, ctx->d_order, nprot, lgroups, tab, ctx->d_divtab,
+                                               ctx->d_packed, ctx->d_grow, rows, huge, ctx->d_clist, ctx->d_crow,
+                                               ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
+                    } else if (gfi[g] && ctx->fi_int_allowed)
                         hipLaunchKernelGGL(k_tracks20f<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
                                            total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
                                            ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
@@ -910,8 +944,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // The three K-A roles and K-B are independent given the plan: fork the K-A side onto high-priority streams
     // so the long serial chains (which set the wall time) overlap each other and the throughput-bound window
     // kernel. K-B starts right away on the caller's stream; the packing of the K-A input runs beside it.
+    const bool kb_after_pack = lane_form(0);
     if (!ctx->serial) {
-        if ((rc = launch_tracks(0)) != PLAAC_OK) return rc;
+        if (!kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
         PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PLAN], 0));
     }
     // group rows of the interleaved copy; their total is the one value the host needs back (buffer sizes)
@@ -958,6 +993,13 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     hipLaunchKernelGGL(k_pack, dim3((nprot + 15u) / 16u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
+    if (!ctx->serial && kb_after_pack) {
+        if (!chain_bound && ctx->kb_priority) { // (the high-priority class is idle in a throughput-bound batch)
+            skb = ctx->aux[plaac_ctx::R_WIN];
+            kb_forked = true;
+        }
+        if ((rc = launch_tracks(0)) != PLAAC_OK) return rc;
+    }
     const std::vector<hipStream_t> &gs = chain_bound ? ctx->gstreams : ctx->gstreams_n;
     if (!ctx->serial) {
         if (!chain_bound) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn)
@@ -1130,6 +1172,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             if (!ctx->serial) {
                 PL_HIP(ctx, hipEventRecord(ctx->gev[g], sf));
                 PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gev[g], 0));
+                if (kb_forked) { // the group's window-track fields
+                    PL_HIP(ctx, hipEventRecord(ctx->jev[5], skb));
+                    PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[5], 0));
+                }
             }
             for (size_t m0 = 1; m0 < G.members.size(); m0 += MAXC - 1) {
                 const int nd = (int)std::min<size_t>(MAXC - 1, G.members.size() - m0);
@@ -1157,6 +1203,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[3], sb));
         PL_HIP(ctx, hipEventRecord(ctx->jev[4], sw2));
         for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[k], 0));
+        if (kb_forked) {
+            PL_HIP(ctx, hipEventRecord(ctx->jev[5], skb));
+            PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[5], 0));
+        }
         for (size_t k = 0; k < 3 * (ng - 1); ++k) {
             PL_HIP(ctx, hipEventRecord(ctx->gjev[k], gs[k]));
             PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
