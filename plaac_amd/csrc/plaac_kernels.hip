@@ -96,7 +96,13 @@ struct plaac_ctx {
     size_t cap_corep = 0, cap_corepart = 0;
     bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
     bool kb_lane = true;   // PLAAC_KB_LANE=0: the filter tier in stream form (k_tracks20f) for every protein
-    bool kb_priority = true; // PLAAC_KB_PRIORITY=0: the lane-form window kernels stay on the caller's stream
+    static constexpr int KB_MAXSEG = 10;
+    // PLAAC_KB_CHUNKS (1..8): chunks of the lane-form filter, each refined on a second stream while the next is filtered.
+    // Measured at 10 M sequences: 1 chunk (filter, refine, exact tier in a row on the caller's stream) 21.0 ms, 4 chunks
+    // 21.1 ms, 8 chunks with a second hardware queue feeding the filter 20.5 ms - the step is bound by the sum of the
+    // kernels' issue time, not by their order - and the extra event hops cost the small batches 0.3 ms. Default 1.
+    uint32_t kb_chunks = 1;
+    hipEvent_t kbev[KB_MAXSEG] = {};
     uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
     size_t cap_corelist = 0, cap_corecount = 0;
     bool core_list = true; // PLAAC_CORE_LIST=0: sweep 3 inside k_vit for every batch
@@ -552,8 +558,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         ctx->kb_filter = !(kbf && kbf[0] == '0');
         const char *kbl = std::getenv("PLAAC_KB_LANE");
         ctx->kb_lane = !(kbl && kbl[0] == '0');
-        const char *kbp = std::getenv("PLAAC_KB_PRIORITY");
-        ctx->kb_priority = !(kbp && kbp[0] == '0');
+        if (const char *kc = std::getenv("PLAAC_KB_CHUNKS")) ctx->kb_chunks = (uint32_t)std::min(8, std::max(1, std::atoi(kc)));
+        for (auto &ke : ctx->kbev)
+            if ((e = hipEventCreateWithFlags(&ke, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         const char *cp = std::getenv("PLAAC_CORE_PAR");
         ctx->core_par = !(cp && cp[0] == '0');
         const char *cl = std::getenv("PLAAC_CORE_LIST");
@@ -666,6 +673,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->jev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->kbev)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->fev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->d_tabs) (void)hipFree(ctx->d_tabs);
@@ -740,7 +749,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
         if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, (size_t)nprot)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_crow, ctx->cap_crow, (size_t)nprot)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, ctx->d_ccount, ctx->cap_ccount, (size_t)1)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_ccount, ctx->cap_ccount, (size_t)plaac_ctx::KB_MAXSEG)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_fblist, ctx->cap_fblist, (size_t)nprot)) != PLAAC_OK) return rc;
     }
     // device tables: slot 0 keeps the ctx parameters (single-point calls), sweep groups use slots 1..ng
@@ -791,11 +800,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     hipStream_t sv = ctx->serial ? st : ctx->aux[plaac_ctx::R_VIT], sf = ctx->serial ? st : ctx->aux[plaac_ctx::R_FWD],
                 sw = ctx->serial ? st : ctx->aux[plaac_ctx::R_WIN], sb = ctx->serial ? st : ctx->aux[plaac_ctx::R_BWD],
                 sw2 = ctx->serial ? st : ctx->aux[plaac_ctx::R_WIN2];
-    // the window-track kernels (K-B) run on the caller's stream, behind the planning kernels (no fork, no join) - except
-    // in lane form in a throughput-bound batch (below): there they are the longest dependent chain of the step
-    // (packed copy -> filter -> refine -> exact tier) and take a high-priority stream of their own
-    hipStream_t skb = st;
-    bool kb_forked = false;
+    // the window-track kernels (K-B) run on the caller's stream, behind the planning kernels (no fork, no join)
+    const hipStream_t skb = st;
 
     // K-B base of a group: an earlier group whose window tracks differ only through the llr table (another alpha of
     // a sweep); such a group needs PAPAllr / PAPAllr2 at the known PAPA centre only (k_llr_at_centre)
@@ -814,12 +820,23 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     };
     // the lane-per-protein form of the filter tier (k_tracksL): summary mode, half windows of 20, FoldIndex in integers;
     // it reads the packed rows, so its group's window kernels are enqueued after k_pack (PLAAC_KB_LANE=0: stream form)
-    auto lane_form = [&](size_t g) -> bool {
+    // A lane walks its protein alone, so the form needs enough proteins to fill the chip: 4096 wave-groups = 16 waves on
+    // each of the 256 CUs (config 2, 92 groups: 0.69 ms in stream form, 1.27 ms in lane form; the 1.25 M-sequence share,
+    // 19.5 k groups: 4.14 against 3.74 ms); smaller batches keep the position-parallel stream form. Where the lane form is
+    // possible the window kernels of the first group are enqueued after the planning round trip, in either form.
+    auto lane_possible = [&](size_t g) -> bool {
         const plaac_params &P = points[groups[g].first];
         return !d_tracks && ctx->kb_filter && ctx->kb_lane && !ctx->generic_tracks && !ctx->per_protein_tracks &&
                P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && gfi[g] && ctx->fi_int_allowed && kb_base(g) < 0;
     };
+    bool kb_chain_bound = false; // (set once the batch's form is known)
+    auto lane_form = [&](size_t g) -> bool { return lane_possible(g) && ngroups >= 4096u; };
     long filter_group = -1; // the group whose filter-tier lists (centres, fallbacks) the ctx buffers hold
+    struct KbSeg {
+        uint32_t base, len; // a segment of the centre list: first slot, slots (its count is d_ccount[segment index])
+    };
+    std::vector<KbSeg> kb_segs; // of the filter group
+    bool kb_refine_pending = false;
     auto launch_tracks = [&](size_t g) -> plaac_status { // K-B: needs only the order, not the packed copy
         if (!d_tracks) {
             const long base = kb_base(g);
@@ -832,9 +849,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // per wave), and the one-wave-per-protein kernel only for what the exact tier scored
                     const uint32_t *huge = ctx->d_hist + LEN_BINS;
                     hipLaunchKernelGGL(k_copy_window_fields, dim3((nprot + 255u) / 256u), dim3(256), 0, skb, src, dst, nprot);
-                    hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min((nprot + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)),
-                                       dim3(64), 0, skb, d_codes, total_residues, gtab0 + g, ctx->d_divtab, dst, huge,
-                                       ctx->d_clist, ctx->d_crow, ctx->d_ccount);
+                    for (size_t sg = 0; sg < kb_segs.size(); ++sg) // (the base group's centre lists, segment by segment)
+                        hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min((kb_segs[sg].len + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)),
+                                           dim3(64), 0, skb, d_codes, total_residues, gtab0 + g, ctx->d_divtab, dst, huge,
+                                           ctx->d_clist + kb_segs[sg].base, ctx->d_crow + kb_segs[sg].base, ctx->d_ccount + sg);
                     hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, skb, d_codes,
                                        d_offsets, ctx->d_neff, nprot, gtab0 + g, src, dst, ctx->d_order, ctx->d_fblist,
                                        ctx->d_fbcount, huge);
@@ -875,23 +893,75 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // summary mode: decisions from error-bounded prefix sums, exact values at the chosen centre only,
                     // whatever the bounds cannot decide goes to the exact per-protein kernel through the fallback list
                     PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), skb));
-                    PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t), skb));
+                    PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t) * plaac_ctx::KB_MAXSEG, skb));
+                    kb_segs.clear();
+                    // the exact values at the chosen centres (k_refine_centres) of one list segment; in lane form on a
+                    // stream of its own, so that a chunk is refined while the filter kernel walks the next one
+                    // (a stream of the priority class the chain kernels do NOT use in this batch: its queues are free)
+                    const hipStream_t srf = (ctx->serial || !lane_form(g) || ctx->kb_chunks <= 1u) ? skb
+                                            : (kb_chain_bound ? ctx->auxn[plaac_ctx::R_BWD] : ctx->aux[plaac_ctx::R_WIN2]);
+                    auto refine_segment = [&](uint32_t base, uint32_t len, hipStream_t after) -> plaac_status {
+                        const size_t sg = kb_segs.size();
+                        kb_segs.push_back(KbSeg{base, len});
+                        if (srf != after) {
+                            PL_HIP(ctx, hipEventRecord(ctx->kbev[sg], after));
+                            PL_HIP(ctx, hipStreamWaitEvent(srf, ctx->kbev[sg], 0));
+                        }
+                        hipLaunchKernelGGL(k_refine_centres<false>, dim3(std::min((len + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)),
+                                           dim3(64), 0, srf, d_codes, total_residues, tab, ctx->d_divtab, rows, huge,
+                                           ctx->d_clist + base, ctx->d_crow + base, ctx->d_ccount + sg);
+                        return PLAAC_OK;
+                    };
                     if (lane_form(g)) {
                         // one lane per protein over the packed rows (k_tracksL); the long wave-groups (a prefix of the
                         // descending-length plan) stay with the stream form. Called after the packed copy has been enqueued.
                         const uint32_t lgroups = std::min<uint32_t>(ctx->h_pin[3], ngroups);
                         const uint32_t nlong = std::min<uint64_t>((uint64_t)lgroups * 64u, nprot);
-                        if (nlong)
+                        if (nlong) {
                             hipLaunchKernelGGL(k_tracks20f<true>, dim3((nlong + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK),
                                                dim3(64), 0, skb, d_codes, ctx->d_order, nlong, total_residues, tab,
                                                ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount,
                                                ctx->d_fblist, ctx->d_fbcount);
+                            if ((rc = refine_segment(0u, nlong, skb)) != PLAAC_OK) return rc;
+                        }
                         if (!ctx->serial) PL_HIP(ctx, hipStreamWaitEvent(skb, evs[E_PACK + 1], 0));
-                        if (lgroups < ngroups)
-                            hipLaunchKernelGGL(k_tracksL, dim3((ngroups - lgroups + KL_THREADS / 64 - 1) / (KL_THREADS / 64)),
-                                               dim3(KL_THREADS), 0, skb, ctx->d_order, nprot, lgroups, tab, ctx->d_divtab,
-                                               ctx->d_packed, ctx->d_grow, rows, huge, ctx->d_clist, ctx->d_crow,
-                                               ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
+                        // chunks of wave-groups (equal group counts: the filter's work per chunk falls with the lengths,
+                        // the refine kernel's is the same for all): chunk k+1 is filtered while chunk k is refined
+                        const uint32_t rest = ngroups - lgroups;
+                        const uint32_t nch = std::max(1u, std::min<uint32_t>(ctx->kb_chunks, (rest + 63u) / 64u));
+                        // EXPERIMENT PLAAC_KB_TWO_QUEUES=1: odd chunks on a second stream (a second hardware queue feeding the filter)
+                        static const bool two_q = std::getenv("PLAAC_KB_TWO_QUEUES") && std::getenv("PLAAC_KB_TWO_QUEUES")[0] == '1';
+                        const hipStream_t skb2 = (two_q && !ctx->serial && !kb_chain_bound) ? ctx->aux[plaac_ctx::R_VIT] : skb;
+                        if (skb2 != skb) PL_HIP(ctx, hipStreamWaitEvent(skb2, evs[E_PACK + 1], 0));
+                        for (uint32_t k = 0; k < nch && rest; ++k) {
+                            const hipStream_t sk = (k & 1u) ? skb2 : skb;
+                            const uint32_t g0 = lgroups + (uint32_t)((uint64_t)rest * k / nch);
+                            const uint32_t g1 = lgroups + (uint32_t)((uint64_t)rest * (k + 1) / nch);
+                            if (g1 == g0) continue;
+                            const size_t sg = kb_segs.size();
+                            const uint32_t base = g0 * 64u, len = std::min<uint64_t>((uint64_t)g1 * 64u, nprot) - base;
+                            hipLaunchKernelGGL(k_tracksL, dim3((g1 - g0 + KL_THREADS / 64 - 1) / (KL_THREADS / 64)),
+                                               dim3(KL_THREADS), 0, sk, ctx->d_order, nprot, g0, g1, tab, ctx->d_divtab,
+                                               ctx->d_packed, ctx->d_grow, rows, huge, ctx->d_clist + base, ctx->d_crow + base,
+                                               ctx->d_ccount + sg, ctx->d_fblist, ctx->d_fbcount);
+                            if ((rc = refine_segment(base, len, sk)) != PLAAC_OK) return rc;
+                        }
+                        if (skb2 != skb) { // the exact tier (caller's stream) needs every chunk's fallback entries
+                            PL_HIP(ctx, hipEventRecord(ctx->kbev[plaac_ctx::KB_MAXSEG - 1], skb2));
+                            PL_HIP(ctx, hipStreamWaitEvent(skb, ctx->kbev[plaac_ctx::KB_MAXSEG - 1], 0));
+                        }
+                        filter_group = (long)g;
+                        if (srf != skb) { // the caller's stream goes on (exact tier, later groups) and is joined here
+                            PL_HIP(ctx, hipEventRecord(ctx->jev[5], srf));
+                            kb_refine_pending = true;
+                        }
+                        hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
+                                           d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
+                                           0u, ctx->d_fblist, ctx->d_fbcount);
+                        if (kb_refine_pending) {
+                            PL_HIP(ctx, hipStreamWaitEvent(skb, ctx->jev[5], 0));
+                            kb_refine_pending = false;
+                        }
                     } else if (gfi[g] && ctx->fi_int_allowed)
                         hipLaunchKernelGGL(k_tracks20f<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
                                            total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
@@ -900,13 +970,13 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                         hipLaunchKernelGGL(k_tracks20f<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
                                            total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
                                            ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
-                    filter_group = (long)g;
-                    hipLaunchKernelGGL(k_refine_centres<false>, dim3(std::min((nprot + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)), dim3(64),
-                                       0, skb, d_codes, total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist,
-                                       ctx->d_crow, ctx->d_ccount);
-                    hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
-                                       d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
-                                       0u, ctx->d_fblist, ctx->d_fbcount);
+                    if (!lane_form(g)) {
+                        filter_group = (long)g;
+                        if ((rc = refine_segment(0u, nprot, skb)) != PLAAC_OK) return rc;
+                        hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
+                                           d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
+                                           0u, ctx->d_fblist, ctx->d_fbcount);
+                    }
                 } else {
                     hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
                                        total_residues, tab, ctx->d_divtab, rows, tp, huge);
@@ -966,6 +1036,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const bool chain_bound =
         ctx->latency_mode >= 0 ? ctx->latency_mode == 1 : (uint64_t)ctx->h_pin[2] * 384000ull > total_residues;
     const bool latency_mode = !ctx->serial && !d_tracks && npoints == 1 && chain_bound;
+    kb_chain_bound = chain_bound;
     const bool use_core_list = ctx->core_list && !latency_mode && !chain_bound; // (sweeps: one list per group)
     // the long wave-groups (proteins of >= 2048 residues) of a single-point call take the position-parallel core search
     // (PLAAC_CORE_LONG_LIST=1, EXPERIMENT: also in the list form of throughput-bound batches, where the listed long
@@ -993,13 +1064,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     hipLaunchKernelGGL(k_pack, dim3((nprot + 15u) / 16u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
                        ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
     PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
-    if (!ctx->serial && kb_after_pack) {
-        if (!chain_bound && ctx->kb_priority) { // (the high-priority class is idle in a throughput-bound batch)
-            skb = ctx->aux[plaac_ctx::R_WIN];
-            kb_forked = true;
-        }
-        if ((rc = launch_tracks(0)) != PLAAC_OK) return rc;
-    }
+    if (!ctx->serial && kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
     const std::vector<hipStream_t> &gs = chain_bound ? ctx->gstreams : ctx->gstreams_n;
     if (!ctx->serial) {
         if (!chain_bound) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn)
@@ -1172,10 +1237,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             if (!ctx->serial) {
                 PL_HIP(ctx, hipEventRecord(ctx->gev[g], sf));
                 PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gev[g], 0));
-                if (kb_forked) { // the group's window-track fields
-                    PL_HIP(ctx, hipEventRecord(ctx->jev[5], skb));
-                    PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[5], 0));
-                }
             }
             for (size_t m0 = 1; m0 < G.members.size(); m0 += MAXC - 1) {
                 const int nd = (int)std::min<size_t>(MAXC - 1, G.members.size() - m0);
@@ -1203,10 +1264,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[3], sb));
         PL_HIP(ctx, hipEventRecord(ctx->jev[4], sw2));
         for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[k], 0));
-        if (kb_forked) {
-            PL_HIP(ctx, hipEventRecord(ctx->jev[5], skb));
-            PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[5], 0));
-        }
+
         for (size_t k = 0; k < 3 * (ng - 1); ++k) {
             PL_HIP(ctx, hipEventRecord(ctx->gjev[k], gs[k]));
             PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
