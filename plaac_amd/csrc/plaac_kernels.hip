@@ -918,7 +918,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                         const uint32_t lgroups = std::min<uint32_t>(ctx->h_pin[3], ngroups);
                         const uint32_t nlong = std::min<uint64_t>((uint64_t)lgroups * 64u, nprot);
                         if (nlong) {
-                            hipLaunchKernelGGL(k_tracks20f<true>, dim3((nlong + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK),
+                            // (four proteins per block instead of 32: lane k of a block takes protein blockIdx + k * gridDim, so
+                            //  a larger grid leaves the lanes from 4 on without one - the long proteins spread over 8 x the waves)
+                            hipLaunchKernelGGL(k_tracks20f<true>, dim3((nlong + 3u) / 4u),
                                                dim3(64), 0, skb, d_codes, ctx->d_order, nlong, total_residues, tab,
                                                ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount,
                                                ctx->d_fblist, ctx->d_fbcount);
@@ -1217,6 +1219,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                 // MW window + means + hmm0's running sum as ONE kernel beside the LLR kernel. (As two kernels on two more
                 // streams they were measured back to back, not side by side: the runtime maps streams onto four hardware
                 // queues, the fifth and sixth stream share theirs, and 1.6 + 1.3 ms in a row outlast the forward chain.)
+                // (Round 3, with the streams' hardware queues measured: the MW window and the means + hmm0's sum as two
+                //  kernels, the fifth chain on a free queue of the normal class: 3.77 against 3.71 ms at the 1.25 M share -
+                //  the step is the forward / Viterbi chain by then.)
                 LAUNCH_WIN(1, 3, sw2);
             } else {
                 switch (nc) {

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""tools/issue_model.py [build/plaac_kernels.s] [profiles/r03_issue_probe.txt] -> profiles/r03_issue_classes.json
+
+The instruction-issue roof of the path with MEASURED per-class costs ("4 cycles for every VALU and
+LDS wave-instruction" was an assumption).
+
+1. tools/issue_probe.hip (run on MI355X, output committed as profiles/r03_issue_probe.txt) gives SIMD cycles per
+   wave-instruction per class at 1..4 waves per SIMD. The chip does not hold its 2.4 GHz under these streams (v_add_f64,
+   a documented quarter-rate = 4-cycle instruction, reads 4.3 .. 5.5 "2.4 GHz cycles" from box to box and with the
+   number of waves), so the costs are taken RELATIVE to v_add_f64 at the same occupancy and scaled to 4.0:
+       simple 32-bit VOP1/VOP2 (add, sub, and, or, xor, mov, cndmask by vcc, f32 add)     ~2.6   ("fast")
+       shifts, mul24, max/min, every VOP3-only op (mad, bfe, lshl_add, add3, alignbit, perm, sad, or3), DPP, SDWA,
+       cndmask by an SGPR pair, 64-bit shifts / adds, every fp64 op                         4.0
+       v_cmp*, v_readlane, v_readfirstlane                                                  ~4.5
+       v_rcp_f64                                                                            ~15
+   SALU instructions issue beside the VALU stream of other waves (v_add_f64 : s_add_u32 = 1 : 1 costs 3.5 per
+   instruction against 5.5 for the fp64 half alone) and are not charged.
+2. The `make asm` listing gives, per kernel, which share of the non-fp64 VALU instructions of its loops (basic blocks
+   of >= 60 instructions) is "fast".
+3. tools/pmc_summary.py combines that share with the DYNAMIC counts of the PMC passes (SQ_INSTS_VALU, SQ_INSTS_VALU_*_F64,
+   SQ_INSTS_LDS per kernel and step): cycles = 4 f64 + (VALU - f64) (fast_share c_fast + (1 - fast_share) c_other) + 4 LDS,
+   summed over the kernels of a step, / 1024 SIMDs / clock. bench.py prints it as roofline.issue.
+"""
+import collections
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32", "v_not_b32",
+        "v_add_f32", "v_sub_f32", "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_subrev_co_u32",
+        "v_xnor_b32", "v_accvgpr")
+SLOW45 = ("v_cmp", "v_readlane", "v_readfirstlane")
+KERNELS = ("k_tracksL", "k_tracks20f", "k_refine_centres", "k_fwd_pair", "k_fwd", "k_win", "k_vit", "k_core_list", "k_pack",
+           "k_finish", "k_tracks20s", "k_tracks20", "k_bwd", "k_post", "k_hist", "k_core_par", "k_core_eval", "k_core_reduce",
+           "k_core_chain", "k_llr_at_centre", "k_plan_lengths", "k_plan_scatter")
+
+
+def probe_costs(path):
+    """cycles per wave-instruction relative to v_add_f64 (= 4.0) at 3-4 waves per SIMD, per probe row"""
+    rows = collections.OrderedDict()
+    for line in open(path):
+        m = re.match(r"(.*?)\s+chains\s+(\d+)\s+waves/SIMD (\d)\s+([\d.]+) ms\s+([\d.]+) cycles", line)
+        if m:
+            rows.setdefault(m.group(1).strip(), {})[(int(m.group(2)), int(m.group(3)))] = float(m.group(5))
+    ref = rows["v_add_f64"]
+    out = {}
+    for name, v in rows.items():
+        rel = [v[(8, w)] / ref[(8, w)] * 4.0 for w in (3, 4) if (8, w) in v and (8, w) in ref]
+        if rel:
+            out[name] = round(sum(rel) / len(rel), 2)
+    clock = {w: round(2.4 * 4.0 / ref[(8, w)], 2) for w in (1, 2, 3, 4)}
+    return out, clock
+
+
+def classify(op, text):
+    base = op.replace("_e32", "").replace("_e64", "")
+    if op.startswith("v_") and "_f64" in op:
+        return "rcp64" if op.startswith(("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")) else "f64"
+    if not op.startswith("v_"):
+        return None
+    if op.startswith(SLOW45):
+        return "slow"
+    if "dpp" in op or "sdwa" in op or " row_" in text or "quad_perm" in text:
+        return "other"
+    if base == "v_cndmask_b32":
+        return "fast" if text.rstrip().endswith("vcc") else "other"
+    if base.startswith(FAST):
+        return "fast"
+    return "other"
+
+
+def kernel_mix(asm_path):
+    lines = open(asm_path).read().split("\n")
+    mix = {}
+    i = 0
+    while i < len(lines):
+        l = lines[i]
+        if l.startswith("_ZN") and not l.startswith("\t") and ":" in l:
+            name = l.split(":")[0]
+            end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+            key = next((k for k in KERNELS if ("%d%s" % (len(k), k)) in name), None)
+            if key:
+                blocks, cur = [], []
+                for t in lines[i + 1:end]:
+                    t = t.strip()
+                    if not t or t.startswith((";", ".", "//")) and not t.startswith(".LBB"):
+                        continue
+                    if t.startswith(".LBB") and t.endswith(":") or re.match(r"^\.LBB\d+_\d+:", t):
+                        blocks.append(cur)
+                        cur = []
+                    else:
+                        cur.append(t)
+                blocks.append(cur)
+                c = collections.Counter()
+                for b in blocks:
+                    if len(b) < 60:
+                        continue
+                    for t in b:
+                        cls = classify(t.split()[0], t)
+                        if cls:
+                            c[cls] += 1
+                        elif t.startswith("ds_"):
+                            c["lds"] += 1
+                        elif t.startswith("s_") and not t.startswith("s_waitcnt"):
+                            c["salu"] += 1
+                if sum(c.values()):
+                    agg = mix.setdefault(key, collections.Counter())
+                    agg.update(c)
+            i = end
+        i += 1
+    out = {}
+    for k, c in mix.items():
+        nonf = c["fast"] + c["other"] + c["slow"]
+        out[k] = {"static_loop_instructions": dict(c),
+                  "fast_share_of_non_fp64_valu": round(c["fast"] / nonf, 3) if nonf else 0.0,
+                  "slow_share_of_non_fp64_valu": round(c["slow"] / nonf, 3) if nonf else 0.0}
+    return out
+
+
+def main():
+    asm = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "build", "plaac_kernels.s")
+    probe = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03_issue_probe.txt")
+    costs, clock = probe_costs(probe)
+    fast = [costs[k] for k in costs if k.startswith(("v_add_u32 (VOP2)", "v_mov_b32 (VOP1)", "v_and_b32", "v_add_f32 (VOP2)",
+                                                      "v_cndmask vcc : v_add_u32"))]
+    other = [costs[k] for k in costs if k.startswith(("v_lshlrev_b32 (VOP2)", "v_mul_u32_u24", "v_max_u32", "v_add3_u32", "v_lshl_add_u32",
+                                                       "v_bfe_u32", "v_mad_i32_i24", "v_alignbit", "v_or3", "v_sad_u32", "v_perm",
+                                                       "v_mov_b32 dpp", "v_add_u32 sdwa", "v_cndmask_b32_e64"))]
+    slow = [costs[k] for k in costs if k.startswith(("v_cmp_gt_u32 vcc (VOPC)", "v_cmp_gt_f64 vcc (VOPC)", "v_readlane", "v_readfirstlane"))]
+    model = {
+        "cost_cycles": {"f64": 4.0, "fast": round(sum(fast) / len(fast), 2), "other": round(sum(other) / len(other), 2),
+                        "slow": round(sum(slow) / len(slow), 2), "rcp64": costs.get("v_rcp_f64 (transcendental)", 15.0),
+                        "lds_issue": 4.0},
+        "probe_rows_relative_to_add_f64": costs,
+        "clock_GHz_if_add_f64_is_4_cycles": clock,
+        "kernels": kernel_mix(asm),
+        "source": "tools/issue_model.py: profiles/r03_issue_probe.txt (MI355X) + the `make asm` listing of this tree",
+    }
+    out = os.path.join(ROOT, "profiles", "r03_issue_classes.json")
+    with open(out, "w") as fh:
+        json.dump(model, fh, indent=1, sort_keys=True)
+        fh.write("\n")
+    print(json.dumps({k: v for k, v in model.items() if k != "probe_rows_relative_to_add_f64"}, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()

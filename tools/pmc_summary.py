@@ -4,8 +4,9 @@
 FETCH_SIZE / WRITE_SIZE are in KB. MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the
 bytes of a wide coalesced streaming read and other access widths are uncalibrated, so the summary carries
  (a) the raw figure, (b) the guide's x2-corrected figure (used as `traffic`), and (c) a calibration on this
-repo's own narrow-read pattern: k_hist reads every residue byte exactly twice (validity pass + count pass),
-so its expected fetch is known."""
+repo's own access shapes (plaac_calibration_reads: three streaming reads of known size).
+The instruction-issue roof (`issue_model`) combines the dynamic instruction counts of the PMC passes with the measured
+per-class issue costs and the static class shares of profiles/r03_issue_classes.json (tools/issue_model.py)."""
 import collections
 import csv
 import glob
@@ -13,7 +14,7 @@ import json
 import os
 import sys
 
-KEYS = ("k_calib_read<16, 0>", "k_calib_read<4, 0>", "k_calib_read<4, 1>", "k_tracks20f", "k_refine_centres", "k_core_list", "k_core_chain", "k_core_eval", "k_core_reduce", "k_fwd_pair", "k_finish", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
+KEYS = ("k_calib_read<16, 0>", "k_calib_read<4, 0>", "k_calib_read<4, 1>", "k_tracksL", "k_tracks20f", "k_refine_centres", "k_core_list", "k_core_chain", "k_core_eval", "k_core_reduce", "k_fwd_pair", "k_finish", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
         "k_plan_scatter", "k_pack", "k_group_rows", "k_scan_u32")
 
 
@@ -65,7 +66,7 @@ def main(root):
             calib[name] = {"fetch_raw_bytes": traffic[key]["fetch_raw_bytes"], "bytes_read": R,
                            "bytes_per_reported_byte": R / traffic[key]["fetch_raw_bytes"]}
     summary["fetch_calibration_reads"] = calib
-    NARROW = ("k_tracks20f", "k_refine_centres", "k_tracks20s", "k_tracks20", "k_tracks", "k_hist", "k_plan_lengths",
+    NARROW = ("k_tracks20f", "k_refine_centres", "k_tracks20s", "k_tracks20", "k_tracks", "k_plan_lengths",
               "k_llr_at_centre")  # residues read as (unaligned) dwords / bytes; every other kernel reads 16 bytes per lane
     if "wide16" in calib and "dword_unaligned" in calib:
         for k, t in traffic.items():
@@ -73,11 +74,33 @@ def main(root):
             t["fetch_factor_calibrated"] = f
             t["hbm_bytes_calibrated"] = f * t["fetch_raw_bytes"] + t["write_bytes"]
     summary["traffic"] = traffic
-    if R and "k_hist" in traffic:
-        expect = 2 * R + 8 * P
-        summary["fetch_calibration_k_hist"] = {
-            "expected_read_bytes": expect, "fetch_raw_bytes": traffic["k_hist"]["fetch_raw_bytes"],
-            "raw_over_expected": traffic["k_hist"]["fetch_raw_bytes"] / expect}
+    # instruction-issue roof with measured per-class costs
+    issue = None
+    try:
+        cls = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                                          "r03_issue_classes.json")))
+        cost = cls["cost_cycles"]
+        per, tot = {}, 0.0
+        for k, c in mean.items():
+            if k == "k_hist" or k.startswith("k_calib") or "SQ_INSTS_VALU" not in c:
+                continue
+            f64 = c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_FMA_F64", 0)
+            rest = max(0.0, c["SQ_INSTS_VALU"] - f64 - c.get("SQ_INSTS_VALU_TRANS_F64", 0))
+            mix = cls["kernels"].get(k, {})
+            fs, ss = mix.get("fast_share_of_non_fp64_valu", 0.3), mix.get("slow_share_of_non_fp64_valu", 0.05)
+            cyc = (f64 * cost["f64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0) * cost["rcp64"] +
+                   rest * (fs * cost["fast"] + ss * cost["slow"] + (1 - fs - ss) * cost["other"]) +
+                   c.get("SQ_INSTS_LDS", 0) * cost["lds_issue"])
+            per[k] = {"cycles": round(cyc), "valu": round(c["SQ_INSTS_VALU"]), "fp64": round(f64), "lds": round(c.get("SQ_INSTS_LDS", 0)),
+                      "fast_share": fs}
+            tot += cyc
+        issue = {"cycles_per_step": round(tot), "cost_cycles": cost, "per_kernel": per,
+                 "ms_at_2.4GHz": round(tot / 1024 / 2.4e9 * 1e3, 3),
+                 "what": "sum over the kernels of a step of wave-instructions x measured issue cost of their class "
+                         "(tools/issue_probe.hip, tools/issue_model.py); / 1024 SIMDs / clock"}
+    except (OSError, ValueError, KeyError) as e:
+        issue = {"error": str(e)}
+    summary["issue_model"] = issue
     json.dump(summary, open(os.path.join(root, "summary.json"), "w"), indent=1, sort_keys=True)
     # fp64 operations the kernels EXECUTED (wave instructions x 64 lanes), per residue, over one step
     f64 = sum(c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_FMA_F64", 0)
@@ -98,6 +121,7 @@ def main(root):
                                                           if k != "k_hist" and not k.startswith("k_calib"))) or None,
                    "fetch_calibration": {k: round(v["bytes_per_reported_byte"], 3) for k, v in calib.items()},
                    "fp64_ops_per_residue_executed": round(f64 * 64 / R, 1) if f64 else None,
+                   "issue_model": issue,
                    # what actually bounds the path: vector-ALU and LDS wave-instructions issued per step (SQ_INSTS_VALU +
                    # SQ_INSTS_LDS over all kernels of a step); a SIMD issues one per 4 cycles at best
                    "valu_lds_wave_instructions_per_step": round(sum(
@@ -109,8 +133,7 @@ def main(root):
         ser = durations.get("trace_serial", {}).get(k, {})
         print("%-16s serial %.3f ms  fetch_raw %.1f MB  write %.1f MB" % (
             k, ser.get("mean_ms", float("nan")), t.get("fetch_raw_bytes", 0) / 1e6, t.get("write_bytes", 0) / 1e6))
-    if "fetch_calibration_k_hist" in summary:
-        print("calibration k_hist:", summary["fetch_calibration_k_hist"])
+    print("issue model:", json.dumps(issue)[:600])
 
 
 if __name__ == "__main__":
