@@ -1,5 +1,6 @@
-"""-m gpu: the multi-GPU path with the HIP scorer. Two ranks (one process each, both on cuda:0 because the GPU box
-has one device; the exchange runs over gloo there, RCCL needs one device per rank) shard a proteome by sequence
+"""-m gpu: the multi-GPU path with the HIP scorer. Two ranks, one process each. With two or more visible devices every
+rank takes its own GPU and the exchanges run over RCCL (backend "nccl": rows stay in HBM and travel over xGMI); on a
+one-GPU box both ranks share cuda:0 and the exchanges run over gloo (RCCL needs one device per rank). They shard a proteome by sequence
 (plaac_amd.dist.shard_plan), all-reduce the background histogram, score their shards through the C ABI on their own
 HIP contexts and gather the 160-byte rows to rank 0 in input order. Rank 0 compares with a single-context run over
 the whole proteome and with the oracle (reference loop: cli/src/plaac.java:755, output in file order)."""
@@ -25,24 +26,28 @@ def _free_port():
 
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
-    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+    import torch
+    rccl = torch.cuda.device_count() >= world  # (device_count does not initialise the GPU)
+    dev_index = rank if rccl else 0
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(dev_index), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     from plaac_amd import dist as pdist
     from plaac_amd import native, synth
-    r, _, w = pdist.init_process_group("gloo")
+    r, _, w = pdist.init_process_group("nccl" if rccl else "gloo")
     assert (r, w) == (rank, world)
+    xdev = torch.device("cuda", dev_index) if rccl else None  # where the exchanged tensors live
     P0 = native.make_params()
     codes, offs = synth.make_batch(3, nprot=2500, seed=77, fg=np.array(P0.fg), bg=np.array(P0.bg), stop_fraction=0.1)
     plan = pdist.shard_plan(offs, world)
     c_s, o_s = pdist.extract_shard(codes, offs, plan[rank])
-    with native.Context(P0, device=0) as ctx:
+    with native.Context(P0, device=dev_index) as ctx:
         with ctx.upload(c_s, o_s) as batch:  # one upload for the background pass and the scoring pass
-            counts = pdist.allreduce_counts(batch.histogram())  # exchange (i)
+            counts = pdist.allreduce_counts(batch.histogram(), device=xdev)  # exchange (i)
             P2 = native.make_params(alpha=0.5, bgcounts=counts.astype(np.float64))
             ctx.set_params(P2)
             rows_s = batch.score()  # data path: HIP kernels, no collective
-        out = pdist.gather_rows(rows_s, plan[rank], len(offs) - 1)  # exchange (ii)
+        out = pdist.gather_rows(rows_s, plan[rank], len(offs) - 1, device=xdev)  # exchange (ii)
         if rank == 0:
             assert np.array_equal(counts, ctx.histogram(codes, offs))
             whole = ctx.score(codes, offs)
@@ -50,7 +55,7 @@ def _worker(rank, world, port, tmp):
             from oracle import oracle_ctypes as oc
             want = oc.score_batch(oc.build_params(alpha=0.5, bgcounts=counts.astype(np.float64)), codes, offs, nthreads=4)
             assert out.tobytes() == want.tobytes(), "gathered rows differ from the oracle"
-            open(os.path.join(tmp, "ok"), "w").write("ok %d rows" % (len(offs) - 1))
+            open(os.path.join(tmp, "ok"), "w").write("ok %d rows over %s" % (len(offs) - 1, "nccl (RCCL)" if rccl else "gloo"))
         else:
             assert out is None
     dist.barrier()
@@ -94,3 +99,25 @@ def test_node_over_two_contexts_equals_one_context():
         assert len(node.score(np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
     with pytest.raises(native.PlaacError):
         native.Node(P, [99])
+
+
+def test_bench_two_ranks_strong_scaling_line(tmp_path):
+    """bench.py at N = 2 (its default at N > 1: ONE proteome cut by plaac_amd.dist.shard_plan over the ranks, rows
+    gathered to rank 0 and put back into input order, the gathered table checked against the oracle): RCCL with two
+    devices, gloo with both ranks on the box's one device."""
+    import json
+    import subprocess
+    import torch
+    two = torch.cuda.device_count() >= 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "2", "--steps", "3",
+           "--warmup", "1", "--no-e2e"] + ([] if two else ["--one-device", "--backend", "gloo"])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["sequences_total"] == 5880 and line["config"]["sequences_per_gpu"] in (2940, 2941)
+    assert line["cpu_baseline"]["gpu_rows_match_oracle"] is True
+    assert line["cpu_baseline"]["checked_table"].startswith("gathered rows of all ranks")
+    assert line["weak"]["scaling"] == "weak" and line["weak"]["value"] > 0
