@@ -99,8 +99,10 @@ struct plaac_ctx {
     static constexpr int KB_MAXSEG = 10;
     // PLAAC_KB_CHUNKS (1..8): chunks of the lane-form filter, each refined on a second stream while the next is filtered.
     // Measured at 10 M sequences: 1 chunk (filter, refine, exact tier in a row on the caller's stream) 21.0 ms, 4 chunks
-    // 21.1 ms, 8 chunks with a second hardware queue feeding the filter 20.5 ms - the step is bound by the sum of the
-    // kernels' issue time, not by their order - and the extra event hops cost the small batches 0.3 ms. Default 1.
+    // 21.1 ms, 8 chunks with a second hardware queue feeding the filter 20.5 ms; holding the chain kernels back until
+    // the filter is through (so that the refine kernel does not end the step alone) 20.5 - 22.6 against 20.4 ms: the
+    // step is bound by the sum of the kernels' issue time, not by their order, and the extra event hops cost the small
+    // batches 0.3 ms. Default 1.
     uint32_t kb_chunks = 1;
     hipEvent_t kbev[KB_MAXSEG] = {};
     uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
@@ -931,12 +933,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                         // the refine kernel's is the same for all): chunk k+1 is filtered while chunk k is refined
                         const uint32_t rest = ngroups - lgroups;
                         const uint32_t nch = std::max(1u, std::min<uint32_t>(ctx->kb_chunks, (rest + 63u) / 64u));
-                        // EXPERIMENT PLAAC_KB_TWO_QUEUES=1: odd chunks on a second stream (a second hardware queue feeding the filter)
-                        static const bool two_q = std::getenv("PLAAC_KB_TWO_QUEUES") && std::getenv("PLAAC_KB_TWO_QUEUES")[0] == '1';
-                        const hipStream_t skb2 = (two_q && !ctx->serial && !kb_chain_bound) ? ctx->aux[plaac_ctx::R_VIT] : skb;
-                        if (skb2 != skb) PL_HIP(ctx, hipStreamWaitEvent(skb2, evs[E_PACK + 1], 0));
                         for (uint32_t k = 0; k < nch && rest; ++k) {
-                            const hipStream_t sk = (k & 1u) ? skb2 : skb;
+                            const hipStream_t sk = skb;
                             const uint32_t g0 = lgroups + (uint32_t)((uint64_t)rest * k / nch);
                             const uint32_t g1 = lgroups + (uint32_t)((uint64_t)rest * (k + 1) / nch);
                             if (g1 == g0) continue;
@@ -947,10 +945,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                                                ctx->d_packed, ctx->d_grow, rows, huge, ctx->d_clist + base, ctx->d_crow + base,
                                                ctx->d_ccount + sg, ctx->d_fblist, ctx->d_fbcount);
                             if ((rc = refine_segment(base, len, sk)) != PLAAC_OK) return rc;
-                        }
-                        if (skb2 != skb) { // the exact tier (caller's stream) needs every chunk's fallback entries
-                            PL_HIP(ctx, hipEventRecord(ctx->kbev[plaac_ctx::KB_MAXSEG - 1], skb2));
-                            PL_HIP(ctx, hipStreamWaitEvent(skb, ctx->kbev[plaac_ctx::KB_MAXSEG - 1], 0));
                         }
                         filter_group = (long)g;
                         if (srf != skb) { // the caller's stream goes on (exact tier, later groups) and is joined here
