@@ -6,7 +6,7 @@ run() { # label, env..., -- bench args
 import json;d=json.loads(open('$O/kb.json').read().strip().splitlines()[-1]);print('$1', d['ms_per_step'], d['roofline']['kernel_ms'], d['config'].get('exact_tier_fallbacks_rank0'), (d.get('cpu_baseline') or {}).get('gpu_rows_match_oracle'))"
 }
 B="python3 bench.py --no-e2e --steps 20 --no-cpu-baseline"
-run "10M" $B
-run "10M first1" PLAAC_KB_FIRST=1 $B
-run "10M first2" PLAAC_KB_FIRST=2 $B
-run "10M first3" PLAAC_KB_FIRST=3 $B
+run "10M ctx1" $B
+run "10M ctx2" $B --contexts 2
+run "10M ctx3" $B --contexts 3
+run "1250k ctx2" $B --nprot 1250000 --contexts 2
