@@ -96,6 +96,7 @@ struct plaac_ctx {
     size_t cap_corep = 0, cap_corepart = 0;
     bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
     bool kb_lane = true;   // PLAAC_KB_LANE=0: the filter tier in stream form (k_tracks20f) for every protein
+    uint32_t kb_lane_min_groups = 4096; // PLAAC_KB_LANE_MIN_GROUPS (tests: 1 = lane form for any batch)
     static constexpr int KB_MAXSEG = 10;
     // PLAAC_KB_CHUNKS (1..8): chunks of the lane-form filter, each refined on a second stream while the next is filtered.
     // Measured at 10 M sequences: 1 chunk (filter, refine, exact tier in a row on the caller's stream) 21.0 ms, 4 chunks
@@ -560,6 +561,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         ctx->kb_filter = !(kbf && kbf[0] == '0');
         const char *kbl = std::getenv("PLAAC_KB_LANE");
         ctx->kb_lane = !(kbl && kbl[0] == '0');
+        if (const char *mg = std::getenv("PLAAC_KB_LANE_MIN_GROUPS")) ctx->kb_lane_min_groups = (uint32_t)std::max(1, std::atoi(mg));
         if (const char *kc = std::getenv("PLAAC_KB_CHUNKS")) ctx->kb_chunks = (uint32_t)std::min(8, std::max(1, std::atoi(kc)));
         for (auto &ke : ctx->kbev)
             if ((e = hipEventCreateWithFlags(&ke, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -832,7 +834,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && gfi[g] && ctx->fi_int_allowed && kb_base(g) < 0;
     };
     bool kb_chain_bound = false; // (set once the batch's form is known)
-    auto lane_form = [&](size_t g) -> bool { return lane_possible(g) && ngroups >= 4096u; };
+    auto lane_form = [&](size_t g) -> bool { return lane_possible(g) && ngroups >= ctx->kb_lane_min_groups; };
     long filter_group = -1; // the group whose filter-tier lists (centres, fallbacks) the ctx buffers hold
     struct KbSeg {
         uint32_t base, len; // a segment of the centre list: first slot, slots (its count is d_ccount[segment index])

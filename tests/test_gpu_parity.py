@@ -618,6 +618,94 @@ def test_filter_and_exact_window_kernels_agree(native, monkeypatch):
     assert r1.tobytes() == e1.tobytes() and r2.tobytes() == e2.tobytes()
 
 
+# ---- the filter tier in LANE form (k_tracksL: one lane per protein, sliding windows). The library takes it for batches of
+#      >= 4096 wave-groups only; PLAAC_KB_LANE_MIN_GROUPS=1 makes every batch take it. ----
+@pytest.fixture()
+def lane_ctx(native, monkeypatch):
+    monkeypatch.setenv("PLAAC_KB_LANE_MIN_GROUPS", "1")
+    c = native.Context(native.make_params())
+    yield c
+    c.close()
+
+
+def _uniform_length_batch(native, rng, lengths, per=64):
+    """waves whose 64 proteins have the same length (the lane kernel's scalar-predicate and predicate-free blocks), with
+    X, stops, proline runs and prion-like stretches in them"""
+    aas = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    seqs = []
+    for n in lengths:
+        for k in range(per):
+            a = rng.choice(aas, n)
+            if n > 60 and k % 3 == 0:
+                s0 = int(rng.integers(0, n - 50))
+                a[s0:s0 + 50] = rng.choice(np.array(list("QNQNGSY")), 50)
+            if k % 5 == 0:
+                a[rng.integers(0, n, max(1, n // 40))] = "P"
+            if k % 7 == 0:
+                a[int(rng.integers(0, n))] = "X"
+            seqs.append("".join(a))
+    return native.pack(seqs)
+
+
+def test_lane_form_filter_on_every_kind_of_wave(native, oracle, lane_ctx):
+    rng = np.random.default_rng(31)
+    # same-length waves at the lengths where the block kinds change (41: first candidate; 79/80/81: both-ends reciprocal
+    # table; 85/86/101/102: first predicate-free block), and long enough for many of them
+    codes, offs = _uniform_length_batch(native, rng, [1, 2, 20, 40, 41, 42, 64, 79, 80, 81, 85, 86, 101, 102, 117, 118,
+                                                        285, 300, 1000, 2047])
+    for kw in ({}, {"ww1": 40, "ww2": 40}, {"adjustprolines": False}, {"alpha": 0.3, "corelength": 25,
+                                                                     "bgcounts": np.arange(22.0) + 5}):
+        check_batch(native, oracle, lane_ctx, codes, offs, tracks=False, what="uniform waves %s" % kw, **kw)
+    # mixed lengths within a wave (per-lane predicates), adversarial sequences (ties -> exact tier), skipped records
+    codes, offs = _adversarial_batch(native)
+    for kw in ({}, {"ww1": 40, "ww2": 40}, {"adjustprolines": False}):
+        check_batch(native, oracle, lane_ctx, codes, offs, tracks=False, what="adversarial, lane form %s" % kw, **kw)
+    lane_ctx.set_params(native.make_params())
+    lane_ctx.score(codes, offs)
+    assert lane_ctx.last_exact_fallbacks() > 0
+    codes, offs = native.pack(["", "*", "Q" * 100, "", "MKV", "QN" * 60 + "*", ""])
+    check_batch(native, oracle, lane_ctx, codes, offs, tracks=False, what="skipped records, lane form")
+
+
+def test_lane_form_with_long_proteins_in_the_stream_form_prefix(native, oracle, lane_ctx):
+    """proteins of >= 2048 residues (the long wave-groups, a prefix of the descending-length plan) stay with the stream
+    form; the rest of the batch takes the lane form; both feed one refine list (in segments) and one fallback list"""
+    from plaac_amd import synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(3, nprot=2500, seed=17, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+    lens = np.diff(offs.astype(np.int64))
+    assert (lens >= 2048).sum() >= 2 and (lens < 2048).sum() > 2000
+    check_batch(native, oracle, lane_ctx, codes, offs, tracks=False, what="long prefix + lane form")
+    check_batch(native, oracle, lane_ctx, codes, offs, tracks=False, what="long prefix + lane form, two-pass",
+                alpha=0.5, bgcounts=oracle.histogram(codes, offs).astype(np.float64))
+
+
+def test_lane_form_equals_stream_form_on_a_large_batch(native, oracle, monkeypatch):
+    """300 k UniRef50-shaped proteins (above the library's own 4096-group threshold: the lane form without the test knob)
+    against the stream form and, on a slice, the oracle; sweeps take the lane form for their first group too"""
+    from plaac_amd import synth
+    P, O = both_params(native, oracle)
+    codes, offs = synth.make_batch(4, nprot=300_000, seed=5, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.02)
+    with native.Context(P) as c:
+        lane = c.score(codes, offs)
+        nfb = c.last_exact_fallbacks()
+        with c.upload(codes, offs) as batch:
+            sets = [native.make_params(alpha=a, corelength=cl) for a in (1.0, 0.5) for cl in (60, 30)]
+            swept = batch.sweep(sets)
+    monkeypatch.setenv("PLAAC_KB_LANE", "0")
+    with native.Context(P) as c:
+        stream = c.score(codes, offs)
+    assert lane.tobytes() == stream.tobytes()
+    assert nfb <= 300
+    n_s = 20000
+    want = oracle.score_batch(O, codes[:int(offs[n_s])], offs[:n_s + 1], nthreads=8)
+    assert_rows_equal(lane[:n_s], want, "lane form, 300 k batch")
+    assert swept[0].tobytes() == lane.tobytes()
+    for k, (a, cl) in enumerate((a, cl) for a in (1.0, 0.5) for cl in (60, 30)):
+        wk = oracle.score_batch(oracle.build_params(alpha=a, corelength=cl), codes[:int(offs[n_s])], offs[:n_s + 1], nthreads=8)
+        assert_rows_equal(swept[k][:n_s], wk, "sweep point %d over the lane-form batch" % k)
+
+
 def _with_tables(native, oracle, hydro2=None, cc=None, **kw):
     Pn, Po = both_params(native, oracle, **kw)
     for P in (Pn, Po):

@@ -70,9 +70,12 @@ def test_scer_survey_c4_anchors(oracle, io):
 # GPU: every record of both files, summary + tracks, defaults and the two-pass -a 0.5 run, bit for bit
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["library default (stream-form filter at this size)", "lane-form filter"])
 @pytest.mark.parametrize("path", [SCER, TAIR])
-def test_hip_scores_the_real_proteome_like_the_oracle(native, oracle, io, path):
+def test_hip_scores_the_real_proteome_like_the_oracle(native, oracle, io, path, form, monkeypatch):
     from test_gpu_parity import assert_rows_equal, assert_tracks_equal
+    if form.startswith("lane"):  # k_tracksL (taken by itself for batches of >= 4096 wave-groups only)
+        monkeypatch.setenv("PLAAC_KB_LANE_MIN_GROUPS", "1")
     names, codes, offs = io.read_fasta(path)
     A = ANCHORS[os.path.basename(path)]
     with native.Context(native.make_params()) as ctx:
@@ -87,7 +90,7 @@ def test_hip_scores_the_real_proteome_like_the_oracle(native, oracle, io, path):
             nfb = ctx.last_exact_fallbacks()
             assert_rows_equal(summ, want, tag + " (summary mode)")
             assert hashlib.sha256(summ.tobytes()).hexdigest() == A[tag]["rows_sha256"]
-            print("%s %s: %d of %d proteins took the exact tier" % (os.path.basename(path), tag, nfb, len(names)))
+            print("%s %s [%s]: %d of %d proteins took the exact tier" % (os.path.basename(path), tag, form, nfb, len(names)))
             assert nfb <= len(names) // 20
             assert prd_runs(got, gtr, offs) == (A[tag]["prd_runs"], A[tag]["prd_residues"])
 
