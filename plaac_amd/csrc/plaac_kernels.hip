@@ -1272,8 +1272,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         }
     }
     if (d_tracks && total_rows) // posteriors, MAP, Viterbi bytes: needs k_fwd, k_bwd and the path bits (k_vit)
-        hipLaunchKernelGGL(k_post, dim3((unsigned)total_rows), dim3(64), 0, st, d_offsets, ctx->d_neff, ctx->d_order,
-                           nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp);
+        hipLaunchKernelGGL(k_post, dim3((unsigned)((total_rows + POST_ROWS - 1) / POST_ROWS)), dim3(64), 0, st, d_offsets,
+                           ctx->d_neff, ctx->d_order, nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits,
+                           tp, (uint32_t)total_rows);
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->ncalls++;
