@@ -1257,6 +1257,21 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         }
         hipLaunchKernelGGL(k_finish, dim3(pb), dim3(256), 0, sv, d_rows[0], ctx->d_lat, ctx->d_lat + nprot, nprot);
     }
+    // posteriors, MAP, Viterbi bytes (track mode): k_post needs k_fwd, k_bwd and the path bits (k_vit) - not the window
+    // tracks, so it goes on the backward stream behind the forward and the Viterbi kernels and runs beside the window-
+    // track kernel of the caller's stream instead of after it
+    auto launch_post = [&](hipStream_t s) {
+        hipLaunchKernelGGL(k_post, dim3((unsigned)((total_rows + POST_ROWS - 1) / POST_ROWS)), dim3(64), 0, s, d_offsets,
+                           ctx->d_neff, ctx->d_order, nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits,
+                           tp, (uint32_t)total_rows);
+    };
+    if (d_tracks && total_rows && !ctx->serial) {
+        PL_HIP(ctx, hipEventRecord(ctx->kbev[0], sf));
+        PL_HIP(ctx, hipEventRecord(ctx->kbev[1], sv));
+        PL_HIP(ctx, hipStreamWaitEvent(sb, ctx->kbev[0], 0));
+        PL_HIP(ctx, hipStreamWaitEvent(sb, ctx->kbev[1], 0));
+        launch_post(sb);
+    }
     if (!ctx->serial) {
         // join: everything enqueued on the side streams so far
         PL_HIP(ctx, hipEventRecord(ctx->jev[0], sv));
@@ -1271,10 +1286,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
         }
     }
-    if (d_tracks && total_rows) // posteriors, MAP, Viterbi bytes: needs k_fwd, k_bwd and the path bits (k_vit)
-        hipLaunchKernelGGL(k_post, dim3((unsigned)((total_rows + POST_ROWS - 1) / POST_ROWS)), dim3(64), 0, st, d_offsets,
-                           ctx->d_neff, ctx->d_order, nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits,
-                           tp, (uint32_t)total_rows);
+    if (d_tracks && total_rows && ctx->serial) launch_post(st);
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->ncalls++;
