@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 
 #include <cmath>
@@ -44,6 +45,11 @@
 
 namespace {
 
+static inline void cpu_relax() {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+    __asm__ __volatile__("pause");
+#endif
+}
 #include "kernels_tables_plan.hip.inc"
 #include "kernels_chains.hip.inc"
 #include "kernels_windows_exact.hip.inc"
@@ -75,7 +81,10 @@ struct plaac_ctx {
     uint4 *d_order = nullptr; // the sorted plan: {offset lo, offset hi, effective length, protein index}
     uint4 *d_packed = nullptr;
     double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
-    uint32_t *h_pin = nullptr; // pinned words: [0] total packed rows of a call, [1] upload validation flag
+    uint32_t *h_pin = nullptr; // pinned words: [0] total packed rows of a call, [1] upload validation flag, [2..5] see score_points
+    uint32_t *d_hpin = nullptr; // the same words as the device sees them
+    bool poll_ok = true;        // the host polls h_pin[5] for the plan words (false: stream synchronisation)
+    unsigned long polled = 0, synced = 0; // DIAGNOSTIC (PLAAC_STREAM_DEBUG): calls served either way
     // pinned staging for the host-buffer entry points (pageable memcpy runs at a tenth of the link rate)
     static constexpr size_t STAGE_BYTES = 16u << 20;
     uint8_t *h_stage[2] = {nullptr, nullptr};
@@ -106,6 +115,9 @@ struct plaac_ctx {
     // batches 0.3 ms. Default 1.
     uint32_t kb_chunks = 1;
     hipEvent_t kbev[KB_MAXSEG] = {};
+    static constexpr int TRK_MAXSEG = 8;  // track mode: runs of wave-groups (k_post of one run beside the chains of the next)
+    hipEvent_t tfev[TRK_MAXSEG] = {}, tbev[TRK_MAXSEG] = {}, tpev = nullptr; // forward / backward of a run done; posteriors done
+    int track_segments = 4; // PLAAC_TRACK_SEGMENTS (1.25 M-sequence share: 21.4 ms with 1, 20.9 with 4, same box)
     uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
     size_t cap_corelist = 0, cap_corecount = 0;
     bool core_list = true; // PLAAC_CORE_LIST=0: sweep 3 inside k_vit for every batch
@@ -563,6 +575,12 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         ctx->kb_lane = !(kbl && kbl[0] == '0');
         if (const char *mg = std::getenv("PLAAC_KB_LANE_MIN_GROUPS")) ctx->kb_lane_min_groups = (uint32_t)std::max(1, std::atoi(mg));
         if (const char *kc = std::getenv("PLAAC_KB_CHUNKS")) ctx->kb_chunks = (uint32_t)std::min(8, std::max(1, std::atoi(kc)));
+        for (auto *arr : {ctx->tfev, ctx->tbev})
+            for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
+                if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&ctx->tpev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if (const char *ts = std::getenv("PLAAC_TRACK_SEGMENTS"))
+            ctx->track_segments = std::max(1, std::min((int)plaac_ctx::TRK_MAXSEG, std::atoi(ts)));
         for (auto &ke : ctx->kbev)
             if ((e = hipEventCreateWithFlags(&ke, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         const char *cp = std::getenv("PLAAC_CORE_PAR");
@@ -583,8 +601,12 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         return bail("hipMalloc(hist)", e);
     if ((e = hipMalloc((void **)&ctx->d_counts, sizeof(unsigned long long) * NAA)) != hipSuccess)
         return bail("hipMalloc(counts)", e);
-    if ((e = hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
         return bail("hipHostMalloc", e);
+    std::memset(ctx->h_pin, 0, 64);
+    if ((e = hipHostGetDevicePointer((void **)&ctx->d_hpin, ctx->h_pin, 0)) != hipSuccess)
+        return bail("hipHostGetDevicePointer", e);
+    if (const char *pl = std::getenv("PLAAC_POLL_PLAN")) ctx->poll_ok = pl[0] != '0';
     if ((e = hipMalloc((void **)&ctx->d_divtab, sizeof(KbDivTab))) != hipSuccess) return bail("hipMalloc(divtab)", e);
     if ((e = hipMalloc((void **)&ctx->d_fbcount, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(fbcount)", e);
     if ((e = hipMemset(ctx->d_fbcount, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(fbcount)", e);
@@ -639,6 +661,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (std::getenv("PLAAC_STREAM_DEBUG"))
+        std::fprintf(stderr, "plaac: plan words polled in %lu calls, stream-synchronised in %lu\n", ctx->polled, ctx->synced);
     if (ctx->d_bwd) (void)hipFree(ctx->d_bwd);
     void *bufs[] = {ctx->d_tab,  ctx->d_neff,    ctx->d_order, ctx->d_hist, ctx->d_bits,  ctx->d_fwd,   ctx->d_codes,
                     ctx->d_offsets, ctx->d_rows, ctx->d_trk8,  ctx->d_trk64, ctx->d_counts, ctx->d_grow, ctx->d_packed};
@@ -677,6 +701,11 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->jev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->tfev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->tbev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->tpev) (void)hipEventDestroy(ctx->tpev);
     for (hipEvent_t e : ctx->kbev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->fev)
@@ -1021,19 +1050,48 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     PL_HIP(ctx, hipEventRecord(evs[E_PACK], sv));
     hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, sv, ctx->d_neff, ctx->d_order, nprot,
                        ngroups, ctx->d_grow);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(256), 0, sv, ctx->d_grow, ngroups, CORE_LONG_ROWS, CORE_MAX_GROUPS);
-    PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_grow + ngroups, sizeof(uint32_t), hipMemcpyDeviceToHost, sv));
-    PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 2, ctx->d_grow + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, sv));
-    PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 3, ctx->d_grow + ngroups + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                               sv)); // [3] the long wave-groups the k_core_* kernels serve (a prefix of the plan), [4] their rows
-    PL_HIP(ctx, hipStreamSynchronize(sv));
+    // the scan writes the four words the host needs (h_pin[0] total rows, [2] rows of the first wave-group, [3] the long
+    // wave-groups the k_core_* kernels serve - a prefix of the plan -, [4] their rows) into pinned host memory and then
+    // this call's sequence number into h_pin[5]: the host polls that word (no copy kernels, no interrupt-driven
+    // synchronisation: ~40 us per call, 6 % of a config-2 step). If the word does not arrive (memory not coherent on
+    // this system, a failed launch) the stream is synchronised as before and polling is switched off for the context.
+    const uint32_t seq = (uint32_t)(ctx->ncalls + 1) | 0x80000000u;
+    for (int k = 6; k < 6 + SCAN_SEGS - 1; ++k) ctx->h_pin[k] = 0xffffffffu; // (no rows: the scan leaves them alone)
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(SCAN_THREADS), 0, sv, ctx->d_grow, ngroups, CORE_LONG_ROWS, CORE_MAX_GROUPS,
+                       ctx->d_hpin, seq);
+    PL_HIP(ctx, hipGetLastError());
+    {
+        volatile uint32_t *hp = ctx->h_pin;
+        bool arrived = false;
+        if (ctx->poll_ok) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0;; ++spins) {
+                if (__atomic_load_n(&ctx->h_pin[5], __ATOMIC_ACQUIRE) == seq) {
+                    arrived = true;
+                    ++ctx->polled;
+                    break;
+                }
+                if ((spins & 1023u) == 1023u &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50 + (long)(nprot >> 16)))
+                    break;
+                cpu_relax();
+            }
+        }
+        if (!arrived) {
+            PL_HIP(ctx, hipStreamSynchronize(sv));
+            ++ctx->synced;
+            if (ctx->poll_ok && hp[5] != seq) return fail(ctx, PLAAC_ERR_DEVICE, "plan words did not reach the host");
+            ctx->poll_ok = false;
+        }
+    }
     const size_t total_rows = ctx->h_pin[0];
     // Is this batch bound by the serial chain of its longest protein (16-residue rows of the first wave-group x ~150 ns
     // per residue) rather than by throughput (~12 ps per residue)? Then the lane-per-protein kernels take the forms
     // that shorten one wave's chain (k_win as two kernels) at the price of a few more instructions in total.
     const bool chain_bound =
         ctx->latency_mode >= 0 ? ctx->latency_mode == 1 : (uint64_t)ctx->h_pin[2] * 384000ull > total_residues;
-    const bool latency_mode = !ctx->serial && !d_tracks && npoints == 1 && chain_bound;
+    // (track mode too, since round 3: k_fwd_pair<true> / k_bwd_pair store the forward / backward pairs k_post combines)
+    const bool latency_mode = !ctx->serial && npoints == 1 && chain_bound;
     kb_chain_bound = chain_bound;
     const bool use_core_list = ctx->core_list && !latency_mode && !chain_bound; // (sweeps: one list per group)
     // the long wave-groups (proteins of >= 2048 residues) of a single-point call take the position-parallel core search
@@ -1076,12 +1134,35 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         for (hipStream_t a : {sf, sw, sb, sw2}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
         for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(gs[k], evs[E_PACK + 1], 0));
     }
-    const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS, fb = (nprot + KF_THREADS - 1) / KF_THREADS;
+    const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
+    // Track mode: the wave-groups are cut into runs of about equal row counts (the scan left the groups that hold the
+    // rows k/8 of the total in h_pin[6..12]); the forward and backward kernels are launched per run, and k_post of a run
+    // (HBM-bound: 50 bytes per residue) runs beside the chains of the next runs (instruction-issue-bound) instead of
+    // after everything. The longest proteins - the chains that bound small batches - are all in the first run.
+    std::vector<uint32_t> segb{0u};
+    if (d_tracks && !ctx->serial) {
+        const int nseg = total_rows >= 32768u ? ctx->track_segments : 1; // (small batches: nothing to hide, launches to pay)
+        for (int k = 1; k < nseg; ++k) {
+            const uint32_t g = ctx->h_pin[6 + SCAN_SEGS * k / nseg - 1];
+            if (g != 0xffffffffu && g > segb.back() && g < ngroups) segb.push_back(g);
+        }
+    }
+    segb.push_back(ngroups);
+    const size_t ntseg = segb.size() - 1;
+    auto seg_first = [&](size_t k) { return segb[k] * 64u; };
+    auto seg_count = [&](size_t k) { return (uint32_t)(std::min<uint64_t>((uint64_t)segb[k + 1] * 64u, nprot) - seg_first(k)); };
     // track mode: the backward recurrence is a chain of its own, beside the forward one
     PL_HIP(ctx, hipEventRecord(evs[E_BWD], sb));
-    if (d_tracks)
-        hipLaunchKernelGGL(k_bwd, dim3(fb), dim3(KF_THREADS), 0, sb, d_offsets, ctx->d_neff, ctx->d_order, nprot, gtab0,
-                           ctx->d_packed, ctx->d_grow, ctx->d_bwd);
+    for (size_t k = 0; d_tracks && k < ntseg; ++k) {
+        const uint32_t first = seg_first(k), cnt = seg_count(k);
+        if (latency_mode)
+            hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, sb,
+                               ctx->d_order + first, cnt, gtab0, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_bwd);
+        else
+            hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sb, d_offsets, ctx->d_neff,
+                               ctx->d_order + first, cnt, gtab0, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_bwd);
+        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tbev[k], sb));
+    }
     PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
 
     // masked core window of the long wave-groups (single-point calls): prefix sums position-parallel on the chain's
@@ -1121,23 +1202,33 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             sw = gs[3 * (g - 1) + 2];
         }
         uint32_t *gbits = ctx->d_bits + bits_stride * g;
+        const hipStream_t win3_stream = d_tracks ? sw : sw2;
         // K-B of this group (group 0 was launched before the host round trip; serialised mode launches it last)
         if (g > 0 && !ctx->serial) {
             if ((rc = launch_tracks(g)) != PLAAC_OK) return rc;
         }
         // forward pass: once per group
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
-#define LAUNCH_FWD(TRK, EXTF)                                                                                      \
-    hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3(fb), dim3(KF_THREADS), 0, sf, d_codes, d_offsets, ctx->d_neff,     \
-                       ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, \
-                       ctx->d_lat)
-        if (latency_mode)
-            hipLaunchKernelGGL(k_fwd_pair, dim3((nprot + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, sf,
-                               ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_lat);
-        else if (d_tracks && single) LAUNCH_FWD(true, true);
-        else if (d_tracks) LAUNCH_FWD(true, false);
-        else if (single) LAUNCH_FWD(false, true);
-        else LAUNCH_FWD(false, false);
+#define LAUNCH_FWD(TRK, EXTF, FIRST, CNT, G0)                                                                      \
+    hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3(((CNT) + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sf, d_codes, \
+                       d_offsets, ctx->d_neff, ctx->d_order + (FIRST), (CNT), tab, ctx->d_packed, ctx->d_grow + (G0),  \
+                       rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, ctx->d_lat, nprot)
+        if (d_tracks) { // per run of wave-groups (see segb)
+            for (size_t k = 0; k < ntseg; ++k) {
+                const uint32_t first = seg_first(k), cnt = seg_count(k);
+                if (latency_mode)
+                    hipLaunchKernelGGL(k_fwd_pair<true>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS),
+                                       0, sf, ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_lat,
+                                       ctx->d_fwd);
+                else if (single) LAUNCH_FWD(true, true, first, cnt, segb[k]);
+                else LAUNCH_FWD(true, false, first, cnt, segb[k]);
+                if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tfev[k], sf));
+            }
+        } else if (latency_mode)
+            hipLaunchKernelGGL(k_fwd_pair<false>, dim3((nprot + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
+                               sf, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_lat, (double2 *)nullptr);
+        else if (single) LAUNCH_FWD(false, true, 0u, nprot, 0u);
+        else LAUNCH_FWD(false, false, 0u, nprot, 0u);
 #undef LAUNCH_FWD
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
         // Viterbi / windows: up to MAXC core lengths per launch
@@ -1218,7 +1309,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                 // (Round 3, with the streams' hardware queues measured: the MW window and the means + hmm0's sum as two
                 //  kernels, the fifth chain on a free queue of the normal class: 3.77 against 3.71 ms at the 1.25 M share -
                 //  the step is the forward / Viterbi chain by then.)
-                LAUNCH_WIN(1, 3, sw2);
+                // (track mode: the backward chain has the stream of the second window kernel - the priority class has four
+                //  hardware queues - so both window kernels go on the first one's, 5.8 + 2.7 ms in a row beside 13 ms chains)
+                LAUNCH_WIN(1, 3, win3_stream);
             } else {
                 switch (nc) {
                 case 1: LAUNCH_WIN(1, 0, sw); break;
@@ -1251,26 +1344,30 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                   // behind the kernels that produced the other two terms, so that it runs beside the window kernel
         if (!ctx->serial) {
             PL_HIP(ctx, hipEventRecord(ctx->fev[0], sf));
-            PL_HIP(ctx, hipEventRecord(ctx->fev[1], latency_mode ? sw2 : sb)); // latency mode: hmm0's total comes from k_win<1,3>
+            PL_HIP(ctx, hipEventRecord(ctx->fev[1], latency_mode ? (d_tracks ? sw : sw2) : sb)); // latency mode: hmm0's total comes from k_win<1,3>
             PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[0], 0));
             PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[1], 0));
         }
         hipLaunchKernelGGL(k_finish, dim3(pb), dim3(256), 0, sv, d_rows[0], ctx->d_lat, ctx->d_lat + nprot, nprot);
     }
-    // posteriors, MAP, Viterbi bytes (track mode): k_post needs k_fwd, k_bwd and the path bits (k_vit) - not the window
-    // tracks, so it goes on the backward stream behind the forward and the Viterbi kernels and runs beside the window-
-    // track kernel of the caller's stream instead of after it
-    auto launch_post = [&](hipStream_t s) {
-        hipLaunchKernelGGL(k_post, dim3((unsigned)((total_rows + POST_ROWS - 1) / POST_ROWS)), dim3(64), 0, s, d_offsets,
-                           ctx->d_neff, ctx->d_order, nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits,
-                           tp, (uint32_t)total_rows);
-    };
+    // posteriors + MAP bytes (track mode): k_post<true, false> of a run needs the run's k_fwd and k_bwd; it goes on the
+    // window kernels' stream (they are the first chains to finish) and runs beside the chains of the later runs and the
+    // window-track kernel. (On a stream of the other priority class - a sixth hardware queue - its first launch was
+    // not served before one of the five busy queues ran empty: measured, 14.6 ms into the step.) Viterbi bytes:
+    // k_post<false, true> behind k_vit on its stream.
+    const unsigned post_grid = (unsigned)((total_rows + POST_ROWS - 1) / POST_ROWS);
     if (d_tracks && total_rows && !ctx->serial) {
-        PL_HIP(ctx, hipEventRecord(ctx->kbev[0], sf));
-        PL_HIP(ctx, hipEventRecord(ctx->kbev[1], sv));
-        PL_HIP(ctx, hipStreamWaitEvent(sb, ctx->kbev[0], 0));
-        PL_HIP(ctx, hipStreamWaitEvent(sb, ctx->kbev[1], 0));
-        launch_post(sb);
+        const hipStream_t sp = sw;
+        for (size_t k = 0; k < ntseg; ++k) {
+            PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->tfev[k], 0));
+            PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->tbev[k], 0));
+            hipLaunchKernelGGL((k_post<true, false>), dim3(post_grid), dim3(64), 0, sp, d_offsets, ctx->d_neff, ctx->d_order,
+                               nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, segb[k], segb[k + 1]);
+        }
+        PL_HIP(ctx, hipEventRecord(ctx->tpev, sp));
+        PL_HIP(ctx, hipStreamWaitEvent(st, ctx->tpev, 0));
+        hipLaunchKernelGGL((k_post<false, true>), dim3(post_grid), dim3(64), 0, sv, d_offsets, ctx->d_neff, ctx->d_order, nprot,
+                           ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, 0u, ngroups);
     }
     if (!ctx->serial) {
         // join: everything enqueued on the side streams so far
@@ -1286,7 +1383,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
         }
     }
-    if (d_tracks && total_rows && ctx->serial) launch_post(st);
+    if (d_tracks && total_rows && ctx->serial)
+        hipLaunchKernelGGL((k_post<true, true>), dim3(post_grid), dim3(64), 0, st, d_offsets, ctx->d_neff, ctx->d_order, nprot,
+                           ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, 0u, ngroups);
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->ncalls++;

@@ -764,4 +764,9 @@ def test_throughput_and_latency_forms_of_the_chain_kernels(native, oracle, monke
         Pn, Po = both_params(native, oracle, **kw)
         with native.Context(Pn) as c:
             got = c.score(codes, offs)
-        assert_rows_equal(got, oracle.score_batch(Po, codes, offs, nthreads=8), what="mode %s %s" % (mode, kw))
+            trows, tr = c.score(codes, offs, tracks=True) if kw.get("corelength", 60) in (60, 100) else (None, None)
+        want, wtr = oracle.score_batch(Po, codes, offs, tracks=True, nthreads=8)
+        assert_rows_equal(got, want, what="mode %s %s" % (mode, kw))
+        if tr is not None:  # track mode in both forms: paired-lane forward AND backward chains feed k_post (mode 1)
+            assert_rows_equal(trows, want, what="track mode, mode %s %s" % (mode, kw))
+            assert_tracks_equal(tr, wtr, codes, offs, "mode %s %s" % (mode, kw))

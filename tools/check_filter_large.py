@@ -50,12 +50,17 @@ with native.Context(P) as ctx:
         got = ctx.score(codes, offs)
         tg = time.time() - t
         nfb = ctx.last_exact_fallbacks()
+        with ctx.upload(codes, offs) as resident:  # device time of the scoring pass alone, residues resident
+            for _ in range(3):
+                resident.score()
+            dev = ctx.last_timings(3)
         t = time.time()
         want = oc.score_batch(Po, codes, offs, nthreads=os.cpu_count() or 8)
         tc = time.time() - t
         same = got.tobytes() == want.tobytes()
-        msg = "%-14s %8d proteins %11d residues: rows identical to the oracle: %s; exact tier took %d (%.4f %%); gpu %.2f s, oracle %.1f s" % (
-            model, n_per, int(offs[-1]), same, nfb, 100.0 * nfb / n_per, tg, tc)
+        msg = ("%-14s %8d proteins %11d residues: rows identical to the oracle: %s; exact tier took %d (%.4f %%); device %.2f ms "
+               "per pass (window kernels incl. exact tier %.2f ms); with upload %.2f s, oracle %.1f s") % (
+            model, n_per, int(offs[-1]), same, nfb, 100.0 * nfb / n_per, dev["total"], dev["tracks"], tg, tc)
         print(msg, flush=True)
         out.append(msg)
         if not same:

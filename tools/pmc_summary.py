@@ -49,11 +49,18 @@ def main(root):
         except Exception as e:  # noqa: BLE001
             bench[mode] = {"error": str(e)}
     mean = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in counters.items()}
-    summary = {"counters_mean_per_launch": mean, "kernel_durations": durations, "bench_lines": bench}
+    # launches per step (k_pack runs once per step): k_refine_centres and k_tracks20 run twice, every figure "per step"
+    # below is the mean per launch times this
+    per_step = {}
+    for k, d in counters.items():
+        n = [len(v) / len(counters["k_pack"][c]) for c, v in d.items() if counters.get("k_pack", {}).get(c)]
+        per_step[k] = round(sum(n) / len(n), 3) if n and k != "k_hist" and not k.startswith("k_calib") else 1.0
+    step = {k: {c: v * per_step[k] for c, v in d.items()} for k, d in mean.items()}
+    summary = {"counters_mean_per_launch": mean, "launches_per_step": per_step, "kernel_durations": durations, "bench_lines": bench}
     cfg = bench.get("trace_serial", {}).get("config", {})
     R, P = cfg.get("residues_per_gpu"), cfg.get("sequences_per_gpu")
     traffic = {}
-    for k, c in mean.items():
+    for k, c in step.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             traffic[k] = {"fetch_raw_bytes": c["FETCH_SIZE"] * 1024, "write_bytes": c["WRITE_SIZE"] * 1024,
                           "hbm_bytes_gfx950_corrected": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024}
@@ -81,7 +88,7 @@ def main(root):
                                           "r03_issue_classes.json")))
         cost = cls["cost_cycles"]
         per, tot = {}, 0.0
-        for k, c in mean.items():
+        for k, c in step.items():
             if k == "k_hist" or k.startswith("k_calib") or "SQ_INSTS_VALU" not in c:
                 continue
             f64 = c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_FMA_F64", 0)
@@ -104,7 +111,7 @@ def main(root):
     json.dump(summary, open(os.path.join(root, "summary.json"), "w"), indent=1, sort_keys=True)
     # fp64 operations the kernels EXECUTED (wave instructions x 64 lanes), per residue, over one step
     f64 = sum(c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_FMA_F64", 0)
-              for k, c in mean.items() if k != "k_hist" and not k.startswith("k_calib"))
+              for k, c in step.items() if k != "k_hist" and not k.startswith("k_calib"))
     if R:
         mode = cfg.get("mode") == "tracks"
         wl = {"cfg2": 2, "cfg3": 3, "cfg4": 4}.get(cfg.get("workload", "")[:4], 4)
@@ -125,7 +132,7 @@ def main(root):
                    # what actually bounds the path: vector-ALU and LDS wave-instructions issued per step (SQ_INSTS_VALU +
                    # SQ_INSTS_LDS over all kernels of a step); a SIMD issues one per 4 cycles at best
                    "valu_lds_wave_instructions_per_step": round(sum(
-                       c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_LDS", 0) for k, c in mean.items()
+                       c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_LDS", 0) for k, c in step.items()
                        if k != "k_hist" and not k.startswith("k_calib")))},
                   open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     for k in sorted(mean):
