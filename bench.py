@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' + --one-device lets two ranks share one GPU for a plumbing check")
     ap.add_argument("--one-device", action="store_true", help="TEST ONLY: every rank uses cuda:0")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the shader-clock measurement (extra untimed steps)")
     ap.add_argument("--calibrate", action="store_true", help="after the timed region run the histogram kernel once "
                     "(it reads exactly R bytes): calibration of FETCH_SIZE for tools/pmc.sh")
     args = ap.parse_args()
@@ -391,6 +392,31 @@ def main():
             ev[1].record(st)
         st.synchronize()
         hist_ms = ev[0].elapsed_time(ev[1]) / 3
+    # the shader clock the chip holds under this load (untimed extra steps; a sleeping wave beside the scoring kernels):
+    # the issue roof below is priced in cycles
+    clock = None
+    if rank == 0 and world == 1 and not args.no_clock_probe:
+        import threading
+        try:
+            idle = ctxs[0].clock_probe(5000)
+            seen, stop = [], threading.Event()
+
+            def prober():
+                while not stop.is_set():
+                    seen.append(ctxs[0].clock_probe(4000))
+
+            th = threading.Thread(target=prober)
+            th.start()
+            run_region(main_work, max(5, min(args.steps, 20)), 1, args.tracks)
+            stop.set()
+            th.join()
+            if seen:
+                clock = {"idle_MHz": round(idle, 1), "under_load_MHz_mean": round(sum(seen) / len(seen), 1),
+                         "under_load_MHz_min": round(min(seen), 1), "samples": len(seen),
+                         "what": "plaac_clock_probe: s_sleep steps of a lone wave per 100 MHz tick, 4 ms windows during "
+                                 "extra untimed steps of this workload"}
+        except native.PlaacError as e:
+            clock = {"error": str(e)}
     if args.calibrate:
         ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt.data_ptr(), stream=streams[0].cuda_stream)
         ctxs[0].calibration_reads(main_work.codes.data_ptr(), total, stream=streams[0].cuda_stream)
@@ -478,7 +504,11 @@ def main():
             "valu_lds_wave_instructions_per_step": issue_instr, "model": issue_classes,
             "ms_at_peak_issue": None if not issue_classes else round(issue_classes["cycles_per_step"] / 1024 / 2.4e9 * 1e3, 3),
             "frac": None if not issue_classes else round(issue_classes["cycles_per_step"] / 1024 / 2.4e9 * 1e3 / step_ms, 4),
+            "shader_clock": clock,
+            "frac_at_measured_clock": None if not (issue_classes and clock and clock.get("under_load_MHz_mean")) else round(
+                issue_classes["cycles_per_step"] / 1024 / (clock["under_load_MHz_mean"] * 1e6) * 1e3 / step_ms, 4),
             "source": "SQ_INSTS_VALU (fp64 / other) + SQ_INSTS_LDS over all kernels of a step, profiles/pmc_traffic.json"},
+        "shader_clock": clock,
     }
 
     # ---- rank 0: CPU baseline = the oracle (a port, not the Java reference: no JVM on this box), and the parity check of

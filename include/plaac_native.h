@@ -239,6 +239,13 @@ plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count);
  * anything but wide streaming reads). Asynchronous on `stream` (NULL = the ctx's own). No result. */
 plaac_status plaac_calibration_reads(plaac_ctx *ctx, const uint8_t *d_codes, uint64_t total_residues, void *stream);
 
+/* DIAGNOSTIC (bench.py --clock-probe): the shader clock the chip actually holds while the scoring kernels run. One wave
+ * on a stream of its own sleeps in s_sleep 127 steps (64 x 127 shader cycles each) for `micros` microseconds of the
+ * constant 100 MHz counter; *mhz = slept cycles / elapsed time. The instruction-issue roof of the path is priced in
+ * cycles, so its fraction depends on this clock (nominal 2.4 GHz; under the fp64 + LDS load of this path the chip runs
+ * lower). Blocks the calling thread (not the scoring streams) until the wave has finished. */
+plaac_status plaac_clock_probe(plaac_ctx *ctx, uint32_t micros, double *mhz);
+
 /* The filter tier needs the SIGN of FoldIndex (plaac.java:4885, :5020-5058) and of its second smoothing (:4903, :4944)
  * at every position. When hydro2[] and cc[] are rationals with small denominators - the reference's own tables are:
  * aahydro / 9 + 0.5 with one-decimal aahydro (:90), cc = {2.785, -1, -1.151} - m * FoldIndex is an integer over the

@@ -117,6 +117,13 @@ struct plaac_ctx {
     hipEvent_t kbev[KB_MAXSEG] = {};
     static constexpr int TRK_MAXSEG = 8;  // track mode: runs of wave-groups (k_post of one run beside the chains of the next)
     hipEvent_t tfev[TRK_MAXSEG] = {}, tbev[TRK_MAXSEG] = {}, tpev = nullptr; // forward / backward of a run done; posteriors done
+    hipEvent_t pkev[TRK_MAXSEG] = {}; // packed copy of a run done
+    int pipe_segments = 1; // PLAAC_PIPE_SEGMENTS: runs of a pipelined single-point call in summary mode. Measured at 10 M
+                           // sequences, same box: 20.04 / 20.29 / 19.84 / 20.13 ms with 1 / 2 / 4 / 8 runs - the 2.4 ms of
+                           // planning and packing at the head of the step are filled, and the scoring kernels then share
+                           // the chip with the copy and take that much longer (the step is bound by its total work). In a
+                           // chain-bound batch the runs behind the first wait for its longest chain (3.8 -> 4.9 ms at the
+                           // 1.25 M share): never pipelined.
     int track_segments = 4; // PLAAC_TRACK_SEGMENTS (1.25 M-sequence share: 21.4 ms with 1, 20.9 with 4, same box)
     uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
     size_t cap_corelist = 0, cap_corecount = 0;
@@ -575,10 +582,12 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         ctx->kb_lane = !(kbl && kbl[0] == '0');
         if (const char *mg = std::getenv("PLAAC_KB_LANE_MIN_GROUPS")) ctx->kb_lane_min_groups = (uint32_t)std::max(1, std::atoi(mg));
         if (const char *kc = std::getenv("PLAAC_KB_CHUNKS")) ctx->kb_chunks = (uint32_t)std::min(8, std::max(1, std::atoi(kc)));
-        for (auto *arr : {ctx->tfev, ctx->tbev})
+        for (auto *arr : {ctx->tfev, ctx->tbev, ctx->pkev})
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&ctx->tpev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if (const char *ps = std::getenv("PLAAC_PIPE_SEGMENTS"))
+            ctx->pipe_segments = std::max(1, std::min((int)plaac_ctx::TRK_MAXSEG, std::atoi(ps)));
         if (const char *ts = std::getenv("PLAAC_TRACK_SEGMENTS"))
             ctx->track_segments = std::max(1, std::min((int)plaac_ctx::TRK_MAXSEG, std::atoi(ts)));
         for (auto &ke : ctx->kbev)
@@ -704,6 +713,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     for (hipEvent_t e : ctx->tfev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->tbev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->pkev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->tpev) (void)hipEventDestroy(ctx->tpev);
     for (hipEvent_t e : ctx->kbev)
@@ -862,7 +873,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         return !d_tracks && ctx->kb_filter && ctx->kb_lane && !ctx->generic_tracks && !ctx->per_protein_tracks &&
                P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && gfi[g] && ctx->fi_int_allowed && kb_base(g) < 0;
     };
-    bool kb_chain_bound = false; // (set once the batch's form is known)
+    const hipEvent_t *pack_events = nullptr;     // lane form: the packed copy is made in runs of wave-groups (set with the
+    const std::vector<uint32_t> *kb_runs = nullptr; // plan words); run k = groups [(*kb_runs)[k], (*kb_runs)[k+1])
     auto lane_form = [&](size_t g) -> bool { return lane_possible(g) && ngroups >= ctx->kb_lane_min_groups; };
     long filter_group = -1; // the group whose filter-tier lists (centres, fallbacks) the ctx buffers hold
     struct KbSeg {
@@ -931,8 +943,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // the exact values at the chosen centres (k_refine_centres) of one list segment; in lane form on a
                     // stream of its own, so that a chunk is refined while the filter kernel walks the next one
                     // (a stream of the priority class the chain kernels do NOT use in this batch: its queues are free)
-                    const hipStream_t srf = (ctx->serial || !lane_form(g) || ctx->kb_chunks <= 1u) ? skb
-                                            : (kb_chain_bound ? ctx->auxn[plaac_ctx::R_BWD] : ctx->aux[plaac_ctx::R_WIN2]);
+                    const hipStream_t srf = skb;
                     auto refine_segment = [&](uint32_t base, uint32_t len, hipStream_t after) -> plaac_status {
                         const size_t sg = kb_segs.size();
                         kb_segs.push_back(KbSeg{base, len});
@@ -959,16 +970,13 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                                                ctx->d_fblist, ctx->d_fbcount);
                             if ((rc = refine_segment(0u, nlong, skb)) != PLAAC_OK) return rc;
                         }
-                        if (!ctx->serial) PL_HIP(ctx, hipStreamWaitEvent(skb, evs[E_PACK + 1], 0));
-                        // chunks of wave-groups (equal group counts: the filter's work per chunk falls with the lengths,
-                        // the refine kernel's is the same for all): chunk k+1 is filtered while chunk k is refined
-                        const uint32_t rest = ngroups - lgroups;
-                        const uint32_t nch = std::max(1u, std::min<uint32_t>(ctx->kb_chunks, (rest + 63u) / 64u));
-                        for (uint32_t k = 0; k < nch && rest; ++k) {
+                        // one launch per run of the packed copy, behind the run's copy
+                        const std::vector<uint32_t> &runs = *kb_runs;
+                        for (size_t k = 0; k + 1 < runs.size(); ++k) {
                             const hipStream_t sk = skb;
-                            const uint32_t g0 = lgroups + (uint32_t)((uint64_t)rest * k / nch);
-                            const uint32_t g1 = lgroups + (uint32_t)((uint64_t)rest * (k + 1) / nch);
-                            if (g1 == g0) continue;
+                            const uint32_t g0 = std::max(runs[k], lgroups), g1 = runs[k + 1];
+                            if (!ctx->serial) PL_HIP(ctx, hipStreamWaitEvent(skb, pack_events[k], 0));
+                            if (g1 <= g0) continue;
                             const size_t sg = kb_segs.size();
                             const uint32_t base = g0 * 64u, len = std::min<uint64_t>((uint64_t)g1 * 64u, nprot) - base;
                             hipLaunchKernelGGL(k_tracksL, dim3((g1 - g0 + KL_THREADS / 64 - 1) / (KL_THREADS / 64)),
@@ -1092,7 +1100,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         ctx->latency_mode >= 0 ? ctx->latency_mode == 1 : (uint64_t)ctx->h_pin[2] * 384000ull > total_residues;
     // (track mode too, since round 3: k_fwd_pair<true> / k_bwd_pair store the forward / backward pairs k_post combines)
     const bool latency_mode = !ctx->serial && npoints == 1 && chain_bound;
-    kb_chain_bound = chain_bound;
     const bool use_core_list = ctx->core_list && !latency_mode && !chain_bound; // (sweeps: one list per group)
     // the long wave-groups (proteins of >= 2048 residues) of a single-point call take the position-parallel core search
     // (PLAAC_CORE_LONG_LIST=1, EXPERIMENT: also in the list form of throughput-bound batches, where the listed long
@@ -1117,31 +1124,16 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_bwd, ctx->cap_bwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
     }
-    hipLaunchKernelGGL(k_pack, dim3((nprot + 15u) / 16u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
-                       ctx->d_order, nprot, total_residues, ctx->d_grow, ctx->d_packed);
-    PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
-    if (!ctx->serial && kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
-    const std::vector<hipStream_t> &gs = chain_bound ? ctx->gstreams : ctx->gstreams_n;
-    if (!ctx->serial) {
-        if (!chain_bound) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn)
-            sv = ctx->auxn[plaac_ctx::R_VIT];
-            sf = ctx->auxn[plaac_ctx::R_FWD];
-            sw = ctx->auxn[plaac_ctx::R_WIN];
-            sb = ctx->auxn[plaac_ctx::R_BWD];
-            sw2 = ctx->auxn[plaac_ctx::R_WIN2];
-            PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PACK + 1], 0));
-        }
-        for (hipStream_t a : {sf, sw, sb, sw2}) PL_HIP(ctx, hipStreamWaitEvent(a, evs[E_PACK + 1], 0));
-        for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(gs[k], evs[E_PACK + 1], 0));
-    }
-    const unsigned ab = (nprot + KA_THREADS - 1) / KA_THREADS;
-    // Track mode: the wave-groups are cut into runs of about equal row counts (the scan left the groups that hold the
-    // rows k/8 of the total in h_pin[6..12]); the forward and backward kernels are launched per run, and k_post of a run
-    // (HBM-bound: 50 bytes per residue) runs beside the chains of the next runs (instruction-issue-bound) instead of
-    // after everything. The longest proteins - the chains that bound small batches - are all in the first run.
+    // Single-point calls on large batches are PIPELINED over runs of wave-groups of about equal row counts (the scan left
+    // the groups that hold the rows k/8 of the total in h_pin[6..12]): the packed copy is made run by run and every
+    // lane-per-protein kernel is launched per run (`order`, `grow`, `nprot` of the run), behind the run's copy. The copy is
+    // HBM-bound, the kernels are bound by instruction issue: the second run is packed while the first is scored (the
+    // 10 M-sequence step began with 2.4 ms of planning and packing during which no scoring kernel could start). In track
+    // mode k_post of a run (HBM-bound too: 50 bytes per residue) likewise runs beside the chains of the later runs. The
+    // longest proteins - the chains that bound small batches - are all in the first run.
     std::vector<uint32_t> segb{0u};
-    if (d_tracks && !ctx->serial) {
-        const int nseg = total_rows >= 32768u ? ctx->track_segments : 1; // (small batches: nothing to hide, launches to pay)
+    if (single && !ctx->serial && total_rows >= 32768u) { // (small batches: nothing to hide, launches to pay)
+        const int nseg = d_tracks ? ctx->track_segments : (chain_bound ? 1 : ctx->pipe_segments);
         for (int k = 1; k < nseg; ++k) {
             const uint32_t g = ctx->h_pin[6 + SCAN_SEGS * k / nseg - 1];
             if (g != 0xffffffffu && g > segb.back() && g < ngroups) segb.push_back(g);
@@ -1151,10 +1143,37 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const size_t ntseg = segb.size() - 1;
     auto seg_first = [&](size_t k) { return segb[k] * 64u; };
     auto seg_count = [&](size_t k) { return (uint32_t)(std::min<uint64_t>((uint64_t)segb[k + 1] * 64u, nprot) - seg_first(k)); };
+    for (size_t k = 0; k < ntseg; ++k) {
+        const uint32_t first = seg_first(k), cnt = seg_count(k);
+        hipLaunchKernelGGL(k_pack, dim3((cnt + 15u) / 16u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
+                           ctx->d_order + first, cnt, total_residues, ctx->d_grow + segb[k], ctx->d_packed);
+        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->pkev[k], sv));
+    }
+    PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
+    pack_events = &ctx->pkev[0];
+    kb_runs = &segb;
+    if (!ctx->serial && kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
+    const std::vector<hipStream_t> &gs = chain_bound ? ctx->gstreams : ctx->gstreams_n;
+    if (!ctx->serial) {
+        if (!chain_bound) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn)
+            sv = ctx->auxn[plaac_ctx::R_VIT];
+            sf = ctx->auxn[plaac_ctx::R_FWD];
+            sw = ctx->auxn[plaac_ctx::R_WIN];
+            sb = ctx->auxn[plaac_ctx::R_BWD];
+            sw2 = ctx->auxn[plaac_ctx::R_WIN2];
+        }
+        // (the role streams wait for the packed copy run by run, see wait_run; the streams of further sweep groups for all)
+        for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(gs[k], evs[E_PACK + 1], 0));
+    }
+    auto wait_run = [&](hipStream_t s, size_t k) -> plaac_status { // stream s may touch run k of the packed copy
+        if (!ctx->serial) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->pkev[k], 0));
+        return PLAAC_OK;
+    };
     // track mode: the backward recurrence is a chain of its own, beside the forward one
     PL_HIP(ctx, hipEventRecord(evs[E_BWD], sb));
     for (size_t k = 0; d_tracks && k < ntseg; ++k) {
         const uint32_t first = seg_first(k), cnt = seg_count(k);
+        if ((rc = wait_run(sb, k)) != PLAAC_OK) return rc;
         if (latency_mode)
             hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, sb,
                                ctx->d_order + first, cnt, gtab0, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_bwd);
@@ -1207,28 +1226,32 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if (g > 0 && !ctx->serial) {
             if ((rc = launch_tracks(g)) != PLAAC_OK) return rc;
         }
+        // every lane-per-protein kernel below is launched per run of wave-groups (one run unless the call is pipelined,
+        // see segb): the run's slice of the plan (`order + first`, its count, `grow + first group`), behind the run's
+        // packed copy; sweep groups beyond the first have waited for the whole copy on their own streams
         // forward pass: once per group
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
 #define LAUNCH_FWD(TRK, EXTF, FIRST, CNT, G0)                                                                      \
     hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3(((CNT) + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sf, d_codes, \
                        d_offsets, ctx->d_neff, ctx->d_order + (FIRST), (CNT), tab, ctx->d_packed, ctx->d_grow + (G0),  \
                        rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, ctx->d_lat, nprot)
-        if (d_tracks) { // per run of wave-groups (see segb)
-            for (size_t k = 0; k < ntseg; ++k) {
-                const uint32_t first = seg_first(k), cnt = seg_count(k);
-                if (latency_mode)
-                    hipLaunchKernelGGL(k_fwd_pair<true>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS),
-                                       0, sf, ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_lat,
-                                       ctx->d_fwd);
-                else if (single) LAUNCH_FWD(true, true, first, cnt, segb[k]);
-                else LAUNCH_FWD(true, false, first, cnt, segb[k]);
-                if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tfev[k], sf));
-            }
-        } else if (latency_mode)
-            hipLaunchKernelGGL(k_fwd_pair<false>, dim3((nprot + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
-                               sf, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, ctx->d_lat, (double2 *)nullptr);
-        else if (single) LAUNCH_FWD(false, true, 0u, nprot, 0u);
-        else LAUNCH_FWD(false, false, 0u, nprot, 0u);
+        for (size_t k = 0; k < ntseg; ++k) {
+            const uint32_t first = seg_first(k), cnt = seg_count(k);
+            if (g == 0 && (rc = wait_run(sf, k)) != PLAAC_OK) return rc;
+            if (latency_mode && d_tracks)
+                hipLaunchKernelGGL(k_fwd_pair<true>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
+                                   sf, ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_lat,
+                                   ctx->d_fwd);
+            else if (latency_mode)
+                hipLaunchKernelGGL(k_fwd_pair<false>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
+                                   sf, ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_lat,
+                                   (double2 *)nullptr);
+            else if (d_tracks && single) LAUNCH_FWD(true, true, first, cnt, segb[k]);
+            else if (d_tracks) LAUNCH_FWD(true, false, first, cnt, segb[k]);
+            else if (single) LAUNCH_FWD(false, true, first, cnt, segb[k]);
+            else LAUNCH_FWD(false, false, first, cnt, segb[k]);
+            if (d_tracks && !ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tfev[k], sf));
+        }
 #undef LAUNCH_FWD
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
         // Viterbi / windows: up to MAXC core lengths per launch
@@ -1244,83 +1267,95 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             tg.stop_after = ctx->vit_stop;
             tg.long_groups_elsewhere = core_long ? 1u : 0u;
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
-#define LAUNCH_VIT(NC)                                                                                             \
-    hipLaunchKernelGGL((k_vit<NC>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff, ctx->d_order, \
-                       nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg)
-            if (latency_mode) {
-                hipLaunchKernelGGL((k_vit<1, true, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg);
-                if (tg.stop_after == 0u && core_long) { // some group is long: its core window
-                    if ((rc = launch_core_long(tab, gbits, tg, sv, G.first)) != PLAAC_OK) return rc;
-                }
-            } else if (single && use_core_list) { // throughput-bound: sweep 3 only for proteins that can have a core
-                PL_HIP(ctx, hipMemsetAsync(ctx->d_corecount, 0, sizeof(uint32_t), sv));
-                hipLaunchKernelGGL((k_vit<1, false, true, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,
-                                   ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg,
-                                   ctx->d_corelist, ctx->d_corecount);
-                if (tg.stop_after == 0u) {
-                    // the long wave-groups first: the chain of a 36,000-residue protein on the list would be the tail of
-                    // the whole step
-                    if (core_long && (rc = launch_core_long(tab, gbits, tg, sv, G.first)) != PLAAC_OK) return rc;
-                    hipLaunchKernelGGL(k_core_list<1>, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes,
-                                       total_residues, ctx->d_order, tab, ctx->d_packed, ctx->d_grow, gbits, tg,
-                                       ctx->d_corelist, ctx->d_corecount);
-                }
-            } else if (use_core_list) { // sweep groups: the group's own list, reused by its launches (same stream)
-                uint32_t *gl = ctx->d_corelist + (size_t)nprot * g, *gc = ctx->d_corecount + g;
-                PL_HIP(ctx, hipMemsetAsync(gc, 0, sizeof(uint32_t), sv));
-#define LAUNCH_VIT_LIST(NC)                                                                                        \
-    do {                                                                                                           \
-        hipLaunchKernelGGL((k_vit<NC, false, false, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets, \
-                           ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg, gl, gc);   \
-        if (tg.stop_after == 0u)                                                                                   \
-            hipLaunchKernelGGL(k_core_list<NC>, dim3(std::min(ab, 2048u)), dim3(KA_THREADS), 0, sv, d_codes,        \
-                               total_residues, ctx->d_order, tab, ctx->d_packed, ctx->d_grow, gbits, tg, gl, gc);   \
-    } while (0)
-                switch (nc) {
-                case 1: LAUNCH_VIT_LIST(1); break;
-                case 2: LAUNCH_VIT_LIST(2); break;
-                case 3: LAUNCH_VIT_LIST(3); break;
-                default: LAUNCH_VIT_LIST(4); break;
-                }
+            // the core list of this launch: the call's (single point), or the sweep group's own, reused by its launches
+            uint32_t *gl = single ? ctx->d_corelist : ctx->d_corelist + (size_t)nprot * g;
+            uint32_t *gc = single ? ctx->d_corecount : ctx->d_corecount + g;
+            if (use_core_list) PL_HIP(ctx, hipMemsetAsync(gc, 0, sizeof(uint32_t), sv));
+            for (size_t k = 0; k < ntseg; ++k) {
+                const uint32_t first = seg_first(k), cnt = seg_count(k);
+                const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
+                if (g == 0 && (rc = wait_run(sv, k)) != PLAAC_OK) return rc;
+                tg.first = first;
+#define VIT_ARGS d_codes, d_offsets, ctx->d_neff, ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], gbits, tg
+#define LAUNCH_VIT(NC) hipLaunchKernelGGL((k_vit<NC>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS)
+#define LAUNCH_VIT_LIST(NC) hipLaunchKernelGGL((k_vit<NC, false, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, gl, gc)
+                if (latency_mode)
+                    hipLaunchKernelGGL((k_vit<1, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS);
+                else if (single && use_core_list) // throughput-bound: sweep 3 only for proteins that can have a core
+                    hipLaunchKernelGGL((k_vit<1, false, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, gl, gc);
+                else if (use_core_list) { // sweep groups
+                    switch (nc) {
+                    case 1: LAUNCH_VIT_LIST(1); break;
+                    case 2: LAUNCH_VIT_LIST(2); break;
+                    case 3: LAUNCH_VIT_LIST(3); break;
+                    default: LAUNCH_VIT_LIST(4); break;
+                    }
+                } else if (single) // hmm0's running sum is k_fwd's (k_finish)
+                    hipLaunchKernelGGL((k_vit<1, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS);
+                else
+                    switch (nc) {
+                    case 1: LAUNCH_VIT(1); break;
+                    case 2: LAUNCH_VIT(2); break;
+                    case 3: LAUNCH_VIT(3); break;
+                    default: LAUNCH_VIT(4); break;
+                    }
 #undef LAUNCH_VIT_LIST
-            } else if (single) { // hmm0's running sum is k_fwd's (k_finish)
-                hipLaunchKernelGGL((k_vit<1, false, true>), dim3(ab), dim3(KA_THREADS), 0, sv, d_codes, d_offsets,
-                                   ctx->d_neff, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, gbits, tg);
-            } else
-            switch (nc) {
-            case 1: LAUNCH_VIT(1); break;
-            case 2: LAUNCH_VIT(2); break;
-            case 3: LAUNCH_VIT(3); break;
-            default: LAUNCH_VIT(4); break;
-            }
 #undef LAUNCH_VIT
+#undef VIT_ARGS
+            }
+            tg.first = 0u;
+            // after the runs: the core window of the long wave-groups, then sweep 3 for the listed proteins
+            if (tg.stop_after == 0u) {
+                // (the long wave-groups first: the chain of a 36,000-residue protein on the list would be the tail of the step)
+                if (core_long && (latency_mode || (single && use_core_list)) &&
+                    (rc = launch_core_long(tab, gbits, tg, sv, G.first)) != PLAAC_OK)
+                    return rc;
+                if (use_core_list) {
+                    const unsigned lgrid = std::min((nprot + KA_THREADS - 1) / KA_THREADS, 2048u);
+#define LAUNCH_CORE_LIST(NC)                                                                                       \
+    hipLaunchKernelGGL(k_core_list<NC>, dim3(lgrid), dim3(KA_THREADS), 0, sv, d_codes, total_residues, ctx->d_order, tab, \
+                       ctx->d_packed, ctx->d_grow, gbits, tg, gl, gc)
+                    switch (single ? 1 : nc) {
+                    case 1: LAUNCH_CORE_LIST(1); break;
+                    case 2: LAUNCH_CORE_LIST(2); break;
+                    case 3: LAUNCH_CORE_LIST(3); break;
+                    default: LAUNCH_CORE_LIST(4); break;
+                    }
+#undef LAUNCH_CORE_LIST
+                }
+            }
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT + 1], sv));
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_WIN], sw));
+            for (size_t k = 0; k < ntseg; ++k) {
+                const uint32_t first = seg_first(k), cnt = seg_count(k);
+                const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
+                if (g == 0 && (rc = wait_run(sw, k)) != PLAAC_OK) return rc;
+                if (g == 0 && latency_mode && win3_stream != sw && (rc = wait_run(win3_stream, k)) != PLAAC_OK) return rc;
 #define LAUNCH_WIN(NC, ROLE, STREAM)                                                                               \
-    hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(ab), dim3(KA_THREADS), 0, STREAM, d_codes, d_offsets, ctx->d_neff,  \
-                       ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow, tg,                                   \
+    hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, STREAM, d_codes, d_offsets, ctx->d_neff, \
+                       ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], tg,                   \
                        ctx->d_lat ? ctx->d_lat + nprot : (double *)nullptr)
-            if (latency_mode) { // three thirds side by side (LLR window | MW window | means + hmm0's running sum)
-                LAUNCH_WIN(1, 2, sw);
-                // MW window + means + hmm0's running sum as ONE kernel beside the LLR kernel. (As two kernels on two more
-                // streams they were measured back to back, not side by side: the runtime maps streams onto four hardware
-                // queues, the fifth and sixth stream share theirs, and 1.6 + 1.3 ms in a row outlast the forward chain.)
-                // (Round 3, with the streams' hardware queues measured: the MW window and the means + hmm0's sum as two
-                //  kernels, the fifth chain on a free queue of the normal class: 3.77 against 3.71 ms at the 1.25 M share -
-                //  the step is the forward / Viterbi chain by then.)
-                // (track mode: the backward chain has the stream of the second window kernel - the priority class has four
-                //  hardware queues - so both window kernels go on the first one's, 5.8 + 2.7 ms in a row beside 13 ms chains)
-                LAUNCH_WIN(1, 3, win3_stream);
-            } else {
-                switch (nc) {
-                case 1: LAUNCH_WIN(1, 0, sw); break;
-                case 2: LAUNCH_WIN(2, 0, sw); break;
-                case 3: LAUNCH_WIN(3, 0, sw); break;
-                default: LAUNCH_WIN(4, 0, sw); break;
+                if (latency_mode) { // two halves side by side (LLR window | MW window + means + hmm0's running sum)
+                    LAUNCH_WIN(1, 2, sw);
+                    // MW window + means + hmm0's running sum as ONE kernel beside the LLR kernel. (As two kernels on two more
+                    // streams they were measured back to back, not side by side: the runtime maps streams onto four hardware
+                    // queues, the fifth and sixth stream share theirs, and 1.6 + 1.3 ms in a row outlast the forward chain.)
+                    // (Round 3, with the streams' hardware queues measured: the MW window and the means + hmm0's sum as two
+                    //  kernels, the fifth chain on a free queue of the normal class: 3.77 against 3.71 ms at the 1.25 M share -
+                    //  the step is the forward / Viterbi chain by then.)
+                    // (track mode: the backward chain has the stream of the second window kernel - the priority class has four
+                    //  hardware queues - so both window kernels go on the first one's, 5.8 + 2.7 ms in a row beside 13 ms chains)
+                    LAUNCH_WIN(1, 3, win3_stream);
+                } else {
+                    switch (nc) {
+                    case 1: LAUNCH_WIN(1, 0, sw); break;
+                    case 2: LAUNCH_WIN(2, 0, sw); break;
+                    case 3: LAUNCH_WIN(3, 0, sw); break;
+                    default: LAUNCH_WIN(4, 0, sw); break;
+                    }
                 }
-            }
 #undef LAUNCH_WIN
+            }
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_WIN + 1], sw));
         }
         if (ctx->serial) {
@@ -1430,6 +1465,28 @@ plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
 }
 
 plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]) { return plaac_timings_mean(ctx, 1, ms); }
+
+plaac_status plaac_clock_probe(plaac_ctx *ctx, uint32_t micros, double *mhz) {
+    if (!ctx || !mhz || micros == 0 || micros > 2000000u) return PLAAC_ERR_ARG;
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    // a stream and a result buffer of the probe's own: the scoring streams are not touched (the probe runs beside them)
+    hipStream_t s = nullptr;
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    PL_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipError_t e = hipMalloc((void **)&d, sizeof h);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, (unsigned long long)micros * 100ull, d);
+        e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (d) (void)hipFree(d);
+    (void)hipStreamDestroy(s);
+    if (e != hipSuccess) return fail(ctx, PLAAC_ERR_DEVICE, hipGetErrorString(e));
+    if (h[0] == 0) return fail(ctx, PLAAC_ERR_DEVICE, "clock probe returned nothing");
+    // s_sleep n waits 64 n cycles (plus up to 64): 127 -> 8,128 .. 8,192; the midpoint prices a step
+    *mhz = (double)h[1] * 8160.0 / ((double)h[0] / 100.0);
+    return PLAAC_OK;
+}
 
 plaac_status plaac_calibration_reads(plaac_ctx *ctx, const uint8_t *d_codes, uint64_t total_residues, void *stream_) {
     if (!ctx || !d_codes) return PLAAC_ERR_ARG;

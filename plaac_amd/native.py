@@ -70,7 +70,7 @@ EXPORTS = (
     "plaac_histogram", "plaac_score", "plaac_score_device", "plaac_histogram_device", "plaac_ctx_sync",
     "plaac_last_timings", "plaac_timings_mean", "plaac_batch_upload", "plaac_batch_histogram", "plaac_batch_score",
     "plaac_batch_free", "plaac_batch_sweep", "plaac_score_sweep_device", "plaac_last_exact_fallbacks",
-    "plaac_fi_integer_form", "plaac_calibration_reads",
+    "plaac_fi_integer_form", "plaac_calibration_reads", "plaac_clock_probe",
     "plaac_device_count", "plaac_node_create", "plaac_node_destroy", "plaac_node_size", "plaac_node_ctx",
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
 )
@@ -124,6 +124,7 @@ def load():
     L.plaac_timings_mean.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.plaac_last_exact_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_calibration_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.plaac_clock_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.plaac_fi_integer_form.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_fi_integer_form.restype = C.c_int
     L.plaac_device_count.restype = C.c_int
@@ -292,6 +293,12 @@ class Context:
         """diagnostic: three known-size streaming reads of the residue buffer (FETCH_SIZE calibration, tools/pmc.sh)"""
         self._check(self._L.plaac_calibration_reads(self._h, int(d_codes), int(total_residues),
                                                     None if stream is None else int(stream)))
+
+    def clock_probe(self, micros=20000):
+        """diagnostic: shader clock (MHz) held over the next `micros` microseconds (a sleeping wave beside whatever runs)"""
+        mhz = C.c_double(0.0)
+        self._check(self._L.plaac_clock_probe(self._h, int(micros), C.addressof(mhz)))
+        return float(mhz.value)
 
     def sync(self):
         self._check(self._L.plaac_ctx_sync(self._h))
