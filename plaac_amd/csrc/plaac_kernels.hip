@@ -81,6 +81,7 @@ struct plaac_ctx {
     uint4 *d_order = nullptr; // the sorted plan: {offset lo, offset hi, effective length, protein index}
     uint4 *d_packed = nullptr;
     double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
+    bool core_long_list = false; // PLAAC_CORE_LONG_LIST=1 (experiment, read at creation like every other knob)
     uint32_t *h_pin = nullptr; // pinned words: [0] total packed rows of a call, [1] upload validation flag, [2..5] see score_points
     uint32_t *d_hpin = nullptr; // the same words as the device sees them
     bool poll_ok = true;        // the host polls h_pin[5] for the plan words (false: stream synchronisation)
@@ -586,6 +587,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&ctx->tpev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if (const char *cl = std::getenv("PLAAC_CORE_LONG_LIST")) ctx->core_long_list = cl[0] == '1';
         if (const char *ps = std::getenv("PLAAC_PIPE_SEGMENTS"))
             ctx->pipe_segments = std::max(1, std::min((int)plaac_ctx::TRK_MAXSEG, std::atoi(ps)));
         if (const char *ts = std::getenv("PLAAC_TRACK_SEGMENTS"))
@@ -1105,7 +1107,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // (PLAAC_CORE_LONG_LIST=1, EXPERIMENT: also in the list form of throughput-bound batches, where the listed long
     // proteins are k_core_list's tail. Measured at 10 M sequences: 23.0 against 22.2 ms - the tail was hidden, the extra
     // kernels are not.)
-    static const bool long_in_list = std::getenv("PLAAC_CORE_LONG_LIST") && std::getenv("PLAAC_CORE_LONG_LIST")[0] == '1';
+    const bool long_in_list = ctx->core_long_list;
     const bool core_long = single && (latency_mode || (use_core_list && long_in_list)) && ctx->h_pin[2] >= CORE_LONG_ROWS;
     if (core_long) { // scratch of k_core_*: the rows of the first CORE_MAX_GROUPS wave-groups
         const size_t lrows = ctx->h_pin[4];
