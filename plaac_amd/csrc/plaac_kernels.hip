@@ -114,7 +114,6 @@ struct plaac_ctx {
     // the filter is through (so that the refine kernel does not end the step alone) 20.5 - 22.6 against 20.4 ms: the
     // step is bound by the sum of the kernels' issue time, not by their order, and the extra event hops cost the small
     // batches 0.3 ms. Default 1.
-    uint32_t kb_chunks = 1;
     hipEvent_t kbev[KB_MAXSEG] = {};
     static constexpr int TRK_MAXSEG = 8;  // track mode: runs of wave-groups (k_post of one run beside the chains of the next)
     hipEvent_t tfev[TRK_MAXSEG] = {}, tbev[TRK_MAXSEG] = {}, tpev = nullptr; // forward / backward of a run done; posteriors done
@@ -125,6 +124,7 @@ struct plaac_ctx {
                            // the chip with the copy and take that much longer (the step is bound by its total work). In a
                            // chain-bound batch the runs behind the first wait for its longest chain (3.8 -> 4.9 ms at the
                            // 1.25 M share): never pipelined.
+    uint32_t segment_min_rows = 32768u; // PLAAC_SEGMENT_MIN_ROWS: packed rows from which a call is cut into runs (tests lower it)
     int track_segments = 4; // PLAAC_TRACK_SEGMENTS (1.25 M-sequence share: 21.4 ms with 1, 20.9 with 4, same box)
     uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
     size_t cap_corelist = 0, cap_corecount = 0;
@@ -582,7 +582,6 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         const char *kbl = std::getenv("PLAAC_KB_LANE");
         ctx->kb_lane = !(kbl && kbl[0] == '0');
         if (const char *mg = std::getenv("PLAAC_KB_LANE_MIN_GROUPS")) ctx->kb_lane_min_groups = (uint32_t)std::max(1, std::atoi(mg));
-        if (const char *kc = std::getenv("PLAAC_KB_CHUNKS")) ctx->kb_chunks = (uint32_t)std::min(8, std::max(1, std::atoi(kc)));
         for (auto *arr : {ctx->tfev, ctx->tbev, ctx->pkev})
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -590,6 +589,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         if (const char *cl = std::getenv("PLAAC_CORE_LONG_LIST")) ctx->core_long_list = cl[0] == '1';
         if (const char *ps = std::getenv("PLAAC_PIPE_SEGMENTS"))
             ctx->pipe_segments = std::max(1, std::min((int)plaac_ctx::TRK_MAXSEG, std::atoi(ps)));
+        if (const char *mr = std::getenv("PLAAC_SEGMENT_MIN_ROWS")) ctx->segment_min_rows = (uint32_t)std::max(1, std::atoi(mr));
         if (const char *ts = std::getenv("PLAAC_TRACK_SEGMENTS"))
             ctx->track_segments = std::max(1, std::min((int)plaac_ctx::TRK_MAXSEG, std::atoi(ts)));
         for (auto &ke : ctx->kbev)
@@ -1134,7 +1134,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // mode k_post of a run (HBM-bound too: 50 bytes per residue) likewise runs beside the chains of the later runs. The
     // longest proteins - the chains that bound small batches - are all in the first run.
     std::vector<uint32_t> segb{0u};
-    if (single && !ctx->serial && total_rows >= 32768u) { // (small batches: nothing to hide, launches to pay)
+    if (single && !ctx->serial && total_rows >= ctx->segment_min_rows) { // (small batches: nothing to hide, launches to pay)
         const int nseg = d_tracks ? ctx->track_segments : (chain_bound ? 1 : ctx->pipe_segments);
         for (int k = 1; k < nseg; ++k) {
             const uint32_t g = ctx->h_pin[6 + SCAN_SEGS * k / nseg - 1];

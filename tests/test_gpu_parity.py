@@ -770,3 +770,42 @@ def test_throughput_and_latency_forms_of_the_chain_kernels(native, oracle, monke
         if tr is not None:  # track mode in both forms: paired-lane forward AND backward chains feed k_post (mode 1)
             assert_rows_equal(trows, want, what="track mode, mode %s %s" % (mode, kw))
             assert_tracks_equal(tr, wtr, codes, offs, "mode %s %s" % (mode, kw))
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("nseg", ["2", "3", "8"])
+def test_calls_cut_into_runs_of_wave_groups(native, oracle, monkeypatch, mode, nseg):
+    """Large single-point calls are pipelined over runs of wave-groups of about equal row counts (the planner's scan leaves
+    the run boundaries with the plan words): the packed copy, every lane-per-protein kernel and, in track mode, k_post are
+    launched per run with the run's slice of the plan. The threshold is lowered so that small batches take the path, in
+    both forms of the chain kernels, summary and track mode, the lane form of the filter tier included; group counts that
+    are not multiples of the run count, runs that hold a single long protein's group, an empty batch."""
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_SEGMENT_MIN_ROWS", "1")
+    monkeypatch.setenv("PLAAC_TRACK_SEGMENTS", nseg)
+    monkeypatch.setenv("PLAAC_PIPE_SEGMENTS", nseg)
+    monkeypatch.setenv("PLAAC_LATENCY_MODE", mode)
+    monkeypatch.setenv("PLAAC_KB_LANE_MIN_GROUPS", "1")
+    P0 = native.make_params()
+    rng = np.random.default_rng(int(nseg) * 10 + int(mode))
+    for lens in (np.concatenate([[9000, 2100, 1], rng.integers(1, 600, 700)]), rng.integers(20, 120, 130),
+                 np.array([40000, 3, 70]), np.array([77])):
+        rng.shuffle(lens)
+        codes, offs = synth.residues(lens, np.array(P0.fg), np.array(P0.bg), rng, stop_fraction=0.1)
+        want, wtr = oracle.score_batch(oracle.build_params(), codes, offs, tracks=True, nthreads=8)
+        with native.Context(P0) as c:
+            got = c.score(codes, offs)
+            trows, tr = c.score(codes, offs, tracks=True)
+        what = "runs %s mode %s, %d proteins" % (nseg, mode, len(lens))
+        assert_rows_equal(got, want, what)
+        assert_rows_equal(trows, want, what + " (track mode)")
+        assert_tracks_equal(tr, wtr, codes, offs, what)
+    with native.Context(P0) as c:
+        assert len(c.score(np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
+
+
+def test_clock_probe_reports_the_shader_clock(native):
+    """plaac_clock_probe (bench.py's roofline.shader_clock): an idle MI355X holds about 2.4 GHz"""
+    with native.Context(native.make_params()) as c:
+        mhz = c.clock_probe(3000)
+    assert 800.0 < mhz < 3000.0, mhz

@@ -49,11 +49,11 @@ def main(root):
         except Exception as e:  # noqa: BLE001
             bench[mode] = {"error": str(e)}
     mean = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in counters.items()}
-    # launches per step (k_pack runs once per step): k_refine_centres and k_tracks20 run twice, every figure "per step"
-    # below is the mean per launch times this
+    # launches per step (k_plan_lengths runs once per step): k_refine_centres and k_tracks20 run twice, the kernels of a
+    # call cut into runs of wave-groups once per run; every figure "per step" below is the mean per launch times this
     per_step = {}
     for k, d in counters.items():
-        n = [len(v) / len(counters["k_pack"][c]) for c, v in d.items() if counters.get("k_pack", {}).get(c)]
+        n = [len(v) / len(counters["k_plan_lengths"][c]) for c, v in d.items() if counters.get("k_plan_lengths", {}).get(c)]
         per_step[k] = round(sum(n) / len(n), 3) if n and k != "k_hist" and not k.startswith("k_calib") else 1.0
     step = {k: {c: v * per_step[k] for c, v in d.items()} for k, d in mean.items()}
     summary = {"counters_mean_per_launch": mean, "launches_per_step": per_step, "kernel_durations": durations, "bench_lines": bench}
