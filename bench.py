@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' + --one-device lets two ranks share one GPU for a plumbing check")
     ap.add_argument("--one-device", action="store_true", help="TEST ONLY: every rank uses cuda:0")
+    ap.add_argument("--no-overlap", action="store_true", help="every step is ordered behind the whole previous step (default: "
+                    "plaac_ctx_set_overlap - the planning and packing of a step run beside the last window kernels of the "
+                    "step before it)")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the shader-clock measurement (extra untimed steps)")
     ap.add_argument("--calibrate", action="store_true", help="after the timed region run the histogram kernel once "
                     "(it reads exactly R bytes): calibration of FETCH_SIZE for tools/pmc.sh")
@@ -238,6 +241,12 @@ def main():
         main_work = Work(codes_full, offsets_full, None, nfull)
     nctx = args.contexts or 1
     ctxs = [native.Context(P, device=local_rank) for _ in range(nctx)]
+    # consecutive steps on the resident batch may overlap (plaac_ctx_set_overlap: the planning + packing of step k+1 beside
+    # the last window kernels of step k; the batch is complete before the first step, the rows of a step are not read
+    # before the next one is enqueued - at N > 1 two row buffers alternate); --no-overlap: every step behind the previous
+    overlap = not args.no_overlap
+    for c in ctxs:
+        c.set_overlap(overlap)
     # real (non-null) HIP streams: the kernels are launched on them, the HIP events that time them are recorded on
     # them, and RCCL orders the row gather after them
     streams = [torch.cuda.Stream(dev) for _ in range(nctx)]
@@ -623,6 +632,7 @@ def main():
             "residues_per_gpu": total, "sequences_total": job_prot, "residues_total": job_res,
             "params": "c=60 ww=41 alpha=%.1f fg=prd_freq_scer_28%s" % (alpha, " bg=input counts" if two_pass else ""),
             "sharding": "by sequence, %d rank(s)" % world, "contexts_per_gpu": nctx,
+            "consecutive_steps_overlap": bool(overlap) and not args.tracks and not args.sweep,
             "exchange": ("%s gather of 160 B rows to rank 0" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
             if world > 1 else "none (1 GPU)",
             "timed_region_s": round(dt, 3), "exact_tier_fallbacks_rank0": fallbacks,

@@ -239,6 +239,17 @@ plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count);
  * anything but wide streaming reads). Asynchronous on `stream` (NULL = the ctx's own). No result. */
 plaac_status plaac_calibration_reads(plaac_ctx *ctx, const uint8_t *d_codes, uint64_t total_residues, void *stream);
 
+/* Pipelines of batches: let consecutive scoring calls of this context OVERLAP (default off = every call is ordered behind
+ * everything enqueued on its stream before it). With overlap on, the planning and packing kernels of a single-point
+ * summary-mode call - which read `d_codes` / `d_offsets` and write context scratch only - start as soon as the previous
+ * call's kernels that use that scratch have finished, i.e. beside the previous call's last window kernels (the exact values
+ * at the PAPA centres, the exact tier), instead of after them; everything that writes `d_rows` of the new call is still
+ * ordered as before. The caller guarantees: (1) `d_codes` / `d_offsets` of a call are complete when the call is made (not
+ * produced by work that is still pending on the stream); (2) `d_rows` of consecutive calls are different buffers, or are
+ * not read between the calls. Results are unchanged; a lone call is unchanged. (bench.py switches it on: its steps
+ * are back to back on one resident batch. Measured: DESIGN.md 4.7.) */
+plaac_status plaac_ctx_set_overlap(plaac_ctx *ctx, int on);
+
 /* DIAGNOSTIC (bench.py --clock-probe): the shader clock the chip actually holds while the scoring kernels run. One wave
  * on a stream of its own sleeps in s_sleep 127 steps (64 x 127 shader cycles each) for `micros` microseconds of the
  * constant 100 MHz counter; *mhz = slept cycles / elapsed time. The instruction-issue roof of the path is priced in

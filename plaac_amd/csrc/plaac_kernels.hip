@@ -97,7 +97,8 @@ struct plaac_ctx {
     uint32_t *d_crow = nullptr;
     size_t cap_crow = 0;
     unsigned rf_grid = 256u * 8u; // blocks of k_refine_centres (it strides over the list)
-    uint32_t *d_ccount = nullptr, *d_fblist = nullptr, *d_fbcount = nullptr;
+    uint32_t *d_ccount = nullptr, *d_fbcount = nullptr;
+    uint4 *d_fblist = nullptr; // plan items of the proteins the filter tier hands to the exact tier
     size_t cap_clist = 0, cap_ccount = 0, cap_fblist = 0;
     double *d_lat = nullptr; // latency forms: [0, nprot) lmarginalprob of hmm1, [nprot, 2 nprot) total of hmm0
     size_t cap_lat = 0;
@@ -118,6 +119,13 @@ struct plaac_ctx {
     static constexpr int TRK_MAXSEG = 8;  // track mode: runs of wave-groups (k_post of one run beside the chains of the next)
     hipEvent_t tfev[TRK_MAXSEG] = {}, tbev[TRK_MAXSEG] = {}, tpev = nullptr; // forward / backward of a run done; posteriors done
     hipEvent_t pkev[TRK_MAXSEG] = {}; // packed copy of a run done
+    // Consecutive calls may overlap (plaac_ctx_set_overlap): the planning and packing of a call - HBM-bound, they touch the
+    // plan buffers only - run beside the "tail" of the previous call, the exact values at the PAPA centres and the exact
+    // tier (k_refine_centres, k_tracks20 over the fallback list: instruction-bound, alone on the chip otherwise), which read
+    // their own lists and this call's copy of the "huge" word only. tail_ev: recorded on the caller's stream before the tail.
+    bool overlap = false, tail_open = false;
+    hipEvent_t tail_ev = nullptr;
+    uint32_t *d_huge = nullptr; // two words, used by alternate calls
     int pipe_segments = 1; // PLAAC_PIPE_SEGMENTS: runs of a pipelined single-point call in summary mode. Measured at 10 M
                            // sequences, same box: 20.04 / 20.29 / 19.84 / 20.13 ms with 1 / 2 / 4 / 8 runs - the 2.4 ms of
                            // planning and packing at the head of the step are filled, and the scoring kernels then share
@@ -586,6 +594,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&ctx->tpev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipMalloc((void **)&ctx->d_huge, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(huge)", e);
+        if (const char *ov = std::getenv("PLAAC_OVERLAP")) ctx->overlap = ov[0] == '1';
         if (const char *cl = std::getenv("PLAAC_CORE_LONG_LIST")) ctx->core_long_list = cl[0] == '1';
         if (const char *ps = std::getenv("PLAAC_PIPE_SEGMENTS"))
             ctx->pipe_segments = std::max(1, std::min((int)plaac_ctx::TRK_MAXSEG, std::atoi(ps)));
@@ -719,6 +730,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     for (hipEvent_t e : ctx->pkev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->tpev) (void)hipEventDestroy(ctx->tpev);
+    if (ctx->tail_ev) (void)hipEventDestroy(ctx->tail_ev);
+    if (ctx->d_huge) (void)hipFree(ctx->d_huge);
     for (hipEvent_t e : ctx->kbev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->fev)
@@ -875,6 +888,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         return !d_tracks && ctx->kb_filter && ctx->kb_lane && !ctx->generic_tracks && !ctx->per_protein_tracks &&
                P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && gfi[g] && ctx->fi_int_allowed && kb_base(g) < 0;
     };
+    // the kernels after the filter kernel of a single-point summary call read no plan buffer: the next call may plan beside them
+    const bool tail_allowed = ctx->overlap && !ctx->serial && npoints == 1 && !d_tracks;
     const hipEvent_t *pack_events = nullptr;     // lane form: the packed copy is made in runs of wave-groups (set with the
     const std::vector<uint32_t> *kb_runs = nullptr; // plan words); run k = groups [(*kb_runs)[k], (*kb_runs)[k+1])
     auto lane_form = [&](size_t g) -> bool { return lane_possible(g) && ngroups >= ctx->kb_lane_min_groups; };
@@ -894,14 +909,14 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // the base group went through the filter tier: its list of centres is still in place. Copy the
                     // fields that do not depend on llr, then the llr track alone at the listed centres (nine proteins
                     // per wave), and the one-wave-per-protein kernel only for what the exact tier scored
-                    const uint32_t *huge = ctx->d_hist + LEN_BINS;
+                    const uint32_t *huge = ctx->d_huge + (ctx->ncalls & 1u);
                     hipLaunchKernelGGL(k_copy_window_fields, dim3((nprot + 255u) / 256u), dim3(256), 0, skb, src, dst, nprot);
                     for (size_t sg = 0; sg < kb_segs.size(); ++sg) // (the base group's centre lists, segment by segment)
                         hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min((kb_segs[sg].len + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)),
                                            dim3(64), 0, skb, d_codes, total_residues, gtab0 + g, ctx->d_divtab, dst, huge,
                                            ctx->d_clist + kb_segs[sg].base, ctx->d_crow + kb_segs[sg].base, ctx->d_ccount + sg);
                     hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, skb, d_codes,
-                                       d_offsets, ctx->d_neff, nprot, gtab0 + g, src, dst, ctx->d_order, ctx->d_fblist,
+                                       d_offsets, ctx->d_neff, nprot, gtab0 + g, src, dst, ctx->d_fblist,
                                        ctx->d_fbcount, huge);
                 } else {
                     hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 1u << 20)), dim3(256), 0, skb, d_codes,
@@ -930,8 +945,17 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         // enqueued: the one the flag rules out returns at once (no host round trip before the window kernel starts).
         if (fast20) {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
-            const uint32_t *huge = ctx->d_hist + LEN_BINS;
+            const uint32_t *huge = ctx->d_huge + (ctx->ncalls & 1u);
             const uint32_t only_if_huge = ctx->per_protein_tracks ? 0u : 1u; // PLAAC_KB_PER_PROTEIN=1: always this form
+            // the one-protein-at-a-time kernel over the WHOLE plan (it returns at once unless the batch has a protein too
+            // long for the stream kernels). It reads the plan, so with overlapping calls it goes before the tail.
+            bool whole_plan_launched = false;
+            auto whole_plan = [&]() {
+                hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, ctx->d_neff,
+                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint4 *)nullptr,
+                                   (const uint32_t *)nullptr);
+                whole_plan_launched = true;
+            };
             if (!ctx->per_protein_tracks) {
                 if (d_tracks) {
                     hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
@@ -953,7 +977,12 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                             PL_HIP(ctx, hipEventRecord(ctx->kbev[sg], after));
                             PL_HIP(ctx, hipStreamWaitEvent(srf, ctx->kbev[sg], 0));
                         }
-                        hipLaunchKernelGGL(k_refine_centres<false>, dim3(std::min((len + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)),
+                        // a resident grid that strides over the list: 8 one-wave blocks of 20 KB per CU hold the LDS of every
+                        // CU until the list is through - 7 per CU when the next call may plan beside this kernel (its
+                        // planning kernels take 8 / 16 KB per block; with 32 KB they waited for this kernel's end: 3.3 ms)
+                        const unsigned rounds = (len + RF_SLOTS - 1) / RF_SLOTS;
+                        const unsigned rgrid = std::min(rounds, tail_allowed ? ctx->rf_grid / 8u * 7u : ctx->rf_grid);
+                        hipLaunchKernelGGL(k_refine_centres<false>, dim3(rgrid),
                                            dim3(64), 0, srf, d_codes, total_residues, tab, ctx->d_divtab, rows, huge,
                                            ctx->d_clist + base, ctx->d_crow + base, ctx->d_ccount + sg);
                         return PLAAC_OK;
@@ -974,6 +1003,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                         }
                         // one launch per run of the packed copy, behind the run's copy
                         const std::vector<uint32_t> &runs = *kb_runs;
+                        size_t last_run = 0; // the last run this kernel has groups in
+                        for (size_t k = 0; k + 1 < runs.size(); ++k)
+                            if (runs[k + 1] > std::max(runs[k], lgroups)) last_run = k;
                         for (size_t k = 0; k + 1 < runs.size(); ++k) {
                             const hipStream_t sk = skb;
                             const uint32_t g0 = std::max(runs[k], lgroups), g1 = runs[k + 1];
@@ -985,6 +1017,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                                                dim3(KL_THREADS), 0, sk, ctx->d_order, nprot, g0, g1, tab, ctx->d_divtab,
                                                ctx->d_packed, ctx->d_grow, rows, huge, ctx->d_clist + base, ctx->d_crow + base,
                                                ctx->d_ccount + sg, ctx->d_fblist, ctx->d_fbcount);
+                            if (k == last_run && tail_allowed) { // nothing after this point reads the plan or the packed copy
+                                whole_plan();
+                                PL_HIP(ctx, hipEventRecord(ctx->tail_ev, skb));
+                                ctx->tail_open = true;
+                            }
                             if ((rc = refine_segment(base, len, sk)) != PLAAC_OK) return rc;
                         }
                         filter_group = (long)g;
@@ -1009,6 +1046,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                                            ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
                     if (!lane_form(g)) {
                         filter_group = (long)g;
+                        if (tail_allowed) {
+                            whole_plan();
+                            PL_HIP(ctx, hipEventRecord(ctx->tail_ev, skb));
+                            ctx->tail_open = true;
+                        }
                         if ((rc = refine_segment(0u, nprot, skb)) != PLAAC_OK) return rc;
                         hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
                                            d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
@@ -1021,10 +1063,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             }
             if (d_tracks)
                 hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-            else
-                hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint4 *)nullptr, (const uint32_t *)nullptr);
+            else if (!whole_plan_launched)
+                whole_plan();
         } else if (wmax <= 32) LAUNCH_KB(128);
         else if (wmax <= 96) LAUNCH_KB(256);
         else LAUNCH_KB(1024);
@@ -1035,26 +1076,37 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
 
     // the ctx's plan / scratch buffers are shared by consecutive calls: order this call after the previous one even
     // when the caller hands in a different stream
+    const bool prev_tail = ctx->tail_open; // the previous call left a tail on its stream that reads no plan buffer
+    ctx->tail_open = false;
     if (ctx->ncalls > 0)
         PL_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][E_JOIN], 0));
-    PL_HIP(ctx, hipEventRecord(evs[E_START], st));
+    // overlapped calls: the head (planning, packed copy) goes on the Viterbi stream, behind everything of the previous call
+    // that touches the plan buffers - its side streams and its window kernels up to the tail - but NOT behind the tail
+    const bool head_aside = ctx->overlap && !ctx->serial && ctx->ncalls > 0 && prev_tail;
+    const hipStream_t sh = head_aside ? sv : st;
+    if (head_aside) {
+        PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->tail_ev, 0));
+        for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->jev[k], 0));
+    }
+    PL_HIP(ctx, hipEventRecord(evs[E_START], sh));
     PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), st)); // plaac_last_exact_fallbacks: this call's count
-    PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * (LEN_BINS + 1), st));
+    PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * (LEN_BINS + 1), sh));
     const unsigned pb = (nprot + 255u) / 256u;
     const unsigned plb = (nprot + PLAN_THREADS * PLAN_ITEMS - 1) / (PLAN_THREADS * PLAN_ITEMS);
-    hipLaunchKernelGGL(k_plan_lengths, dim3(plb), dim3(PLAN_THREADS), 0, st, d_codes, d_offsets, nprot, ctx->d_neff,
+    hipLaunchKernelGGL(k_plan_lengths, dim3(plb), dim3(PLAN_THREADS), 0, sh, d_codes, d_offsets, nprot, ctx->d_neff,
                        ctx->d_hist);
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ctx->d_hist);
-    hipLaunchKernelGGL(k_plan_scatter, dim3(plb), dim3(PLAN_THREADS), 0, st, ctx->d_neff, nprot, ctx->d_hist,
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, sh, ctx->d_hist, ctx->d_huge + (ctx->ncalls & 1u));
+    hipLaunchKernelGGL(k_plan_scatter, dim3(plb), dim3(PLAN_THREADS), 0, sh, ctx->d_neff, nprot, ctx->d_hist,
                        d_offsets, ctx->d_order);
-    PL_HIP(ctx, hipEventRecord(evs[E_PLAN], st));
+    PL_HIP(ctx, hipEventRecord(evs[E_PLAN], sh));
+    if (head_aside) PL_HIP(ctx, hipStreamWaitEvent(st, evs[E_PLAN], 0)); // the window kernels read the plan
     // The three K-A roles and K-B are independent given the plan: fork the K-A side onto high-priority streams
     // so the long serial chains (which set the wall time) overlap each other and the throughput-bound window
     // kernel. K-B starts right away on the caller's stream; the packing of the K-A input runs beside it.
     const bool kb_after_pack = lane_form(0);
     if (!ctx->serial) {
         if (!kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
-        PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PLAN], 0));
+        if (!head_aside) PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PLAN], 0));
     }
     // group rows of the interleaved copy; their total is the one value the host needs back (buffer sizes)
     PL_HIP(ctx, hipEventRecord(evs[E_PACK], sv));
@@ -1467,6 +1519,12 @@ plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
 }
 
 plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]) { return plaac_timings_mean(ctx, 1, ms); }
+
+plaac_status plaac_ctx_set_overlap(plaac_ctx *ctx, int on) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    ctx->overlap = on != 0;
+    return PLAAC_OK;
+}
 
 plaac_status plaac_clock_probe(plaac_ctx *ctx, uint32_t micros, double *mhz) {
     if (!ctx || !mhz || micros == 0 || micros > 2000000u) return PLAAC_ERR_ARG;

@@ -70,7 +70,7 @@ EXPORTS = (
     "plaac_histogram", "plaac_score", "plaac_score_device", "plaac_histogram_device", "plaac_ctx_sync",
     "plaac_last_timings", "plaac_timings_mean", "plaac_batch_upload", "plaac_batch_histogram", "plaac_batch_score",
     "plaac_batch_free", "plaac_batch_sweep", "plaac_score_sweep_device", "plaac_last_exact_fallbacks",
-    "plaac_fi_integer_form", "plaac_calibration_reads", "plaac_clock_probe",
+    "plaac_fi_integer_form", "plaac_calibration_reads", "plaac_clock_probe", "plaac_ctx_set_overlap",
     "plaac_device_count", "plaac_node_create", "plaac_node_destroy", "plaac_node_size", "plaac_node_ctx",
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
 )
@@ -125,6 +125,7 @@ def load():
     L.plaac_last_exact_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_calibration_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.plaac_clock_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.plaac_ctx_set_overlap.argtypes = [C.c_void_p, C.c_int]
     L.plaac_fi_integer_form.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_fi_integer_form.restype = C.c_int
     L.plaac_device_count.restype = C.c_int
@@ -293,6 +294,11 @@ class Context:
         """diagnostic: three known-size streaming reads of the residue buffer (FETCH_SIZE calibration, tools/pmc.sh)"""
         self._check(self._L.plaac_calibration_reads(self._h, int(d_codes), int(total_residues),
                                                     None if stream is None else int(stream)))
+
+    def set_overlap(self, on=True):
+        """consecutive calls may overlap (the next call plans beside the last window kernels of this one); see the header
+        for what the caller then guarantees about its buffers"""
+        self._check(self._L.plaac_ctx_set_overlap(self._h, 1 if on else 0))
 
     def clock_probe(self, micros=20000):
         """diagnostic: shader clock (MHz) held over the next `micros` microseconds (a sleeping wave beside whatever runs)"""

@@ -809,3 +809,41 @@ def test_clock_probe_reports_the_shader_clock(native):
     with native.Context(native.make_params()) as c:
         mhz = c.clock_probe(3000)
     assert 800.0 < mhz < 3000.0, mhz
+
+
+@pytest.mark.parametrize("lane", ["1", "4096"])
+def test_overlapped_consecutive_calls_give_the_same_rows(native, oracle, monkeypatch, lane):
+    """plaac_ctx_set_overlap: the planning and packing of a call run beside the last window kernels (refine, exact tier) of
+    the call before it. Batches of different sizes and contents back to back on one context WITHOUT a wait in between
+    (device-resident entry point), each into its own row buffer; afterwards every buffer must hold its batch's rows - also
+    for a batch with exact-tier fallbacks followed by a batch with a protein of >= 65,535 residues (the `huge` word of the
+    next call must not reach the previous call's tail) and by an empty one. Lane form and stream form of the filter tier."""
+    import torch
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_KB_LANE_MIN_GROUPS", lane)
+    P0 = native.make_params()
+    rng = np.random.default_rng(31)
+    a_codes, a_offs = _adversarial_batch(native)
+    batches = [synth.make_batch(4, nprot=9000, seed=5, fg=np.array(P0.fg), bg=np.array(P0.bg), stop_fraction=0.05),
+               (a_codes, a_offs),
+               synth.residues(np.array([70000, 300, 20]), np.array(P0.fg), np.array(P0.bg), rng),
+               synth.make_batch(4, nprot=700, seed=6, fg=np.array(P0.fg), bg=np.array(P0.bg)),
+               synth.make_batch(4, nprot=12000, seed=7, fg=np.array(P0.fg), bg=np.array(P0.bg), stop_fraction=0.05)]
+    want = [oracle.score_batch(oracle.build_params(), c, o, nthreads=8) for c, o in batches]
+    dev = torch.device("cuda", 0)
+    with native.Context(P0) as ctx:
+        ctx.set_overlap(True)
+        st = torch.cuda.Stream(dev)
+        dc = [torch.from_numpy(np.ascontiguousarray(c)).to(dev) for c, _ in batches]
+        do = [torch.from_numpy(np.ascontiguousarray(o).view(np.int64)).to(dev) for _, o in batches]
+        rows = [torch.zeros(len(o) - 1, native.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _, o in batches]
+        torch.cuda.synchronize(dev)
+        for rep in range(3):  # (the third round starts behind the tail of the second)
+            for k, (c, o) in enumerate(batches):
+                ctx.score_device(dc[k].data_ptr(), do[k].data_ptr(), len(o) - 1, int(o[-1]), rows[k].data_ptr(), None,
+                                 stream=st.cuda_stream)
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        for k in range(len(batches)):
+            got = rows[k].cpu().numpy().view(native.ROW_DTYPE).reshape(-1)
+            assert_rows_equal(got, want[k], "batch %d (filter tier from %s wave-groups in lane form)" % (k, lane))
