@@ -478,7 +478,8 @@ def main():
             pass
     path_ms = ktimes["total"]
     step_ms = dt / args.steps * 1e3
-    algo_gops = ALGO_OPS_PER_RESIDUE * total / (path_ms * 1e-3) / 1e9
+    # (rates are per timed step; with overlapping steps a call's own latency - first planning kernel to join - is longer)
+    algo_gops = ALGO_OPS_PER_RESIDUE * total / (min(path_ms, step_ms) * 1e-3) / 1e9
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_all_kernels": traffic_all,
@@ -487,6 +488,9 @@ def main():
         "algorithmic_bytes": path_bytes, "measured_copy_GBps": copy_gbps,
         "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
         "kernels_overlap": "k_vit, k_fwd, k_win, k_tracks run concurrently on 4 HIP streams; total = first launch -> join"
+                           + ("; consecutive steps overlap (plaac_ctx_set_overlap): the planning and packing of a step run "
+                              "beside the last window kernels of the step before, so total (a call's latency) exceeds "
+                              "ms_per_step" if (overlap and not args.tracks and not args.sweep) else "")
                            + ("; %d contexts alternate, consecutive steps overlap" % nctx if nctx > 1 else ""),
         "path_achieved_GBps": round(path_bytes / (step_ms * 1e-3) / 1e9, 3),
         "step_latency_ms": round(path_ms, 4),

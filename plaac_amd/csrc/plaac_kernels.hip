@@ -133,7 +133,7 @@ struct plaac_ctx {
                            // chain-bound batch the runs behind the first wait for its longest chain (3.8 -> 4.9 ms at the
                            // 1.25 M share): never pipelined.
     uint32_t segment_min_rows = 32768u; // PLAAC_SEGMENT_MIN_ROWS: packed rows from which a call is cut into runs (tests lower it)
-    int track_segments = 4; // PLAAC_TRACK_SEGMENTS (1.25 M-sequence share: 21.4 ms with 1, 20.9 with 4, same box)
+    int track_segments = 2; // PLAAC_TRACK_SEGMENTS (1.25 M-sequence share, same-box A/Bs on two boxes: 1 run 21.3 / 21.4 ms, 2 runs 21.2, 4 runs 20.9 / 21.8)
     uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
     size_t cap_corelist = 0, cap_corecount = 0;
     bool core_list = true; // PLAAC_CORE_LIST=0: sweep 3 inside k_vit for every batch
