@@ -242,8 +242,9 @@ def main():
     nctx = args.contexts or 1
     ctxs = [native.Context(P, device=local_rank) for _ in range(nctx)]
     # consecutive steps on the resident batch may overlap (plaac_ctx_set_overlap: the planning + packing of step k+1 beside
-    # the last window kernels of step k; the batch is complete before the first step, the rows of a step are not read
-    # before the next one is enqueued - at N > 1 two row buffers alternate); --no-overlap: every step behind the previous
+    # the scoring kernels of step k; the batch is complete before the first step, and at N > 1 - two row buffers alternate,
+    # the gather reads one while the next step writes the other - the host waits for the gather that last read a buffer
+    # before the buffer is handed to a step again); --no-overlap: every step behind the previous
     overlap = not args.no_overlap
     for c in ctxs:
         c.set_overlap(overlap)
@@ -301,6 +302,8 @@ def main():
             step_no[0] += 1
             with torch.cuda.stream(stream):
                 if world > 1 and step_no[0] > nslots:
+                    if overlap:  # (two steps back: done long ago - the library's kernels do not follow stream-side waits here)
+                        gathered[b].synchronize()
                     stream.wait_event(gathered[b])  # the gather that last read this buffer has finished
                 if sweep_params and not args.naive_sweep:  # one planned pass, shared per-alpha work
                     ctx.score_sweep_device(W.codes.data_ptr(), W.offsets.data_ptr(), W.nprot, W.total, sweep_params,

@@ -240,14 +240,17 @@ plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count);
 plaac_status plaac_calibration_reads(plaac_ctx *ctx, const uint8_t *d_codes, uint64_t total_residues, void *stream);
 
 /* Pipelines of batches: let consecutive scoring calls of this context OVERLAP (default off = every call is ordered behind
- * everything enqueued on its stream before it). With overlap on, the planning and packing kernels of a single-point
- * summary-mode call - which read `d_codes` / `d_offsets` and write context scratch only - start as soon as the previous
- * call's kernels that use that scratch have finished, i.e. beside the previous call's last window kernels (the exact values
- * at the PAPA centres, the exact tier), instead of after them; everything that writes `d_rows` of the new call is still
- * ordered as before. The caller guarantees: (1) `d_codes` / `d_offsets` of a call are complete when the call is made (not
- * produced by work that is still pending on the stream); (2) `d_rows` of consecutive calls are different buffers, or are
- * not read between the calls. Results are unchanged; a lone call is unchanged. (bench.py switches it on: its steps
- * are back to back on one resident batch. Measured: DESIGN.md 4.7.) */
+ * everything enqueued on its stream before it). With overlap on, the planning and packing kernels of a call - which read
+ * `d_codes` / `d_offsets` and write context scratch only (the plan and the packed copy exist twice, used by alternate
+ * calls) - run on a stream of their own as soon as the call BEFORE the previous one has let go of that scratch, i.e. beside
+ * the previous call's scoring kernels; the lane-per-protein kernels of the call follow as soon as those of the previous
+ * call are through; its window kernels stay on the caller's stream. The caller guarantees: (1) `d_codes` / `d_offsets` of
+ * a call are complete when the call is made (not produced by work still pending on a stream) and stay unchanged until it
+ * has completed; (2) `d_rows` (and the tracks) of a call are not in use by anything ELSE that is still pending when the
+ * call is made - consecutive calls may write the same buffer, but a consumer of an earlier call's rows on another stream
+ * has to be waited for on the host (an event synchronisation, plaac_ctx_sync), not by a stream-side wait on the caller's
+ * stream. Results are unchanged; a lone call is unchanged. (bench.py switches it on: its steps are back to back on one
+ * resident batch. Measured: DESIGN.md 4.9.) */
 plaac_status plaac_ctx_set_overlap(plaac_ctx *ctx, int on);
 
 /* DIAGNOSTIC (bench.py --clock-probe): the shader clock the chip actually holds while the scoring kernels run. One wave

@@ -77,9 +77,16 @@ struct plaac_ctx {
     hipEvent_t fev[2] = {nullptr, nullptr};                            // k_finish waits for the forward / window streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
-    uint32_t *d_neff = nullptr, *d_hist = nullptr, *d_bits = nullptr, *d_grow = nullptr;
-    uint4 *d_order = nullptr; // the sorted plan: {offset lo, offset hi, effective length, protein index}
-    uint4 *d_packed = nullptr;
+    uint32_t *d_bits = nullptr;
+    // The plan of a call - effective lengths, length histogram, the sorted plan {offset lo, offset hi, effective length,
+    // protein index}, row offsets of the wave-groups, the packed copy - exists TWICE, used by alternate calls: with
+    // overlapping calls (plaac_ctx_set_overlap) the planning and packing of call k+1 then depend on call k-1 only and run
+    // beside the whole of call k.
+    struct PlanBufs {
+        uint32_t *neff = nullptr, *hist = nullptr, *grow = nullptr;
+        uint4 *order = nullptr, *packed = nullptr;
+        size_t cap_prot = 0, cap_order = 0, cap_grow = 0, cap_packed = 0;
+    } pl[2];
     double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
     bool core_long_list = false; // PLAAC_CORE_LONG_LIST=1 (experiment, read at creation like every other knob)
     uint32_t *h_pin = nullptr; // pinned words: [0] total packed rows of a call, [1] upload validation flag, [2..5] see score_points
@@ -123,9 +130,12 @@ struct plaac_ctx {
     // plan buffers only - run beside the "tail" of the previous call, the exact values at the PAPA centres and the exact
     // tier (k_refine_centres, k_tracks20 over the fallback list: instruction-bound, alone on the chip otherwise), which read
     // their own lists and this call's copy of the "huge" word only. tail_ev: recorded on the caller's stream before the tail.
-    bool overlap = false, tail_open = false;
-    hipEvent_t tail_ev = nullptr;
-    uint32_t *d_huge = nullptr; // two words, used by alternate calls
+    // With the plan double-buffered the head of call k+1 depends on call k-1 only (same buffers): on tail_ev2[p] (recorded on
+    // the caller's stream before the tail of the call that used buffers p; tail_open2[p]: that call recorded one) and
+    // ka_done[p] (its side streams joined). The chain kernels of call k+1 wait for ka_done of call k (shared scratch).
+    bool overlap = false, tail_open2[2] = {false, false}, last_chain_bound = false;
+    hipEvent_t tail_ev2[2] = {nullptr, nullptr}, ka_done[2] = {nullptr, nullptr};
+    uint32_t *d_huge = nullptr; // four words, used in turn: the tail of call k reads its word while call k+2 already plans
     int pipe_segments = 1; // PLAAC_PIPE_SEGMENTS: runs of a pipelined single-point call in summary mode. Measured at 10 M
                            // sequences, same box: 20.04 / 20.29 / 19.84 / 20.13 ms with 1 / 2 / 4 / 8 runs - the 2.4 ms of
                            // planning and packing at the head of the step are filled, and the scoring kernels then share
@@ -142,7 +152,7 @@ struct plaac_ctx {
     bool core_par_ok = false; // the tables in d_tab pass core_par_tables_ok
     bool fi_int = false;   // the tables in d_tab qualify for FoldIndex in integers (derive_fi_int)
     bool fi_int_allowed = true; // PLAAC_FI_INT=0: always the fp64 form of the filter kernel
-    size_t cap_prot = 0, cap_order = 0, cap_bits = 0, cap_fwd = 0, cap_bwd = 0, cap_grow = 0, cap_packed = 0;
+    size_t cap_bits = 0, cap_fwd = 0, cap_bwd = 0;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
     uint64_t *d_offsets = nullptr;
@@ -594,8 +604,10 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&ctx->tpev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipMalloc((void **)&ctx->d_huge, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(huge)", e);
+        for (auto *arr : {ctx->tail_ev2, ctx->ka_done})
+            for (int k = 0; k < 2; ++k)
+                if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipMalloc((void **)&ctx->d_huge, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(huge)", e);
         if (const char *ov = std::getenv("PLAAC_OVERLAP")) ctx->overlap = ov[0] == '1';
         if (const char *cl = std::getenv("PLAAC_CORE_LONG_LIST")) ctx->core_long_list = cl[0] == '1';
         if (const char *ps = std::getenv("PLAAC_PIPE_SEGMENTS"))
@@ -619,8 +631,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         for (auto &ev : set)
             if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void **)&ctx->d_tab, sizeof(DevTables))) != hipSuccess) return bail("hipMalloc(tables)", e);
-    if ((e = hipMalloc((void **)&ctx->d_hist, sizeof(uint32_t) * (LEN_BINS + 1))) != hipSuccess)
-        return bail("hipMalloc(hist)", e);
+    for (auto &pb : ctx->pl)
+        if ((e = hipMalloc((void **)&pb.hist, sizeof(uint32_t) * (LEN_BINS + 1))) != hipSuccess)
+            return bail("hipMalloc(hist)", e);
     if ((e = hipMalloc((void **)&ctx->d_counts, sizeof(unsigned long long) * NAA)) != hipSuccess)
         return bail("hipMalloc(counts)", e);
     if ((e = hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
@@ -686,8 +699,10 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (std::getenv("PLAAC_STREAM_DEBUG"))
         std::fprintf(stderr, "plaac: plan words polled in %lu calls, stream-synchronised in %lu\n", ctx->polled, ctx->synced);
     if (ctx->d_bwd) (void)hipFree(ctx->d_bwd);
-    void *bufs[] = {ctx->d_tab,  ctx->d_neff,    ctx->d_order, ctx->d_hist, ctx->d_bits,  ctx->d_fwd,   ctx->d_codes,
-                    ctx->d_offsets, ctx->d_rows, ctx->d_trk8,  ctx->d_trk64, ctx->d_counts, ctx->d_grow, ctx->d_packed};
+    void *bufs[] = {ctx->d_tab,        ctx->d_bits,        ctx->d_fwd,         ctx->d_codes,      ctx->d_offsets,
+                    ctx->d_rows,       ctx->d_trk8,        ctx->d_trk64,       ctx->d_counts,     ctx->pl[0].neff,
+                    ctx->pl[0].order,  ctx->pl[0].hist,    ctx->pl[0].grow,    ctx->pl[0].packed, ctx->pl[1].neff,
+                    ctx->pl[1].order,  ctx->pl[1].hist,    ctx->pl[1].grow,    ctx->pl[1].packed};
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (int i = 0; i < 2; ++i) {
         if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
@@ -730,7 +745,9 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     for (hipEvent_t e : ctx->pkev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->tpev) (void)hipEventDestroy(ctx->tpev);
-    if (ctx->tail_ev) (void)hipEventDestroy(ctx->tail_ev);
+    for (auto *arr : {ctx->tail_ev2, ctx->ka_done})
+        for (int k = 0; k < 2; ++k)
+            if (arr[k]) (void)hipEventDestroy(arr[k]);
     if (ctx->d_huge) (void)hipFree(ctx->d_huge);
     for (hipEvent_t e : ctx->kbev)
         if (e) (void)hipEventDestroy(e);
@@ -799,10 +816,12 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const size_t ng = groups.size();
 
     plaac_status rc;
-    if ((rc = grow(ctx, ctx->d_neff, ctx->cap_prot, (size_t)nprot)) != PLAAC_OK) return rc;
-    if ((rc = grow(ctx, ctx->d_order, ctx->cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
+    const unsigned par = (unsigned)(ctx->ncalls & 1u); // this call's plan buffers, `huge` word and body events
+    plaac_ctx::PlanBufs &PL = ctx->pl[par];
+    if ((rc = grow(ctx, PL.neff, PL.cap_prot, (size_t)nprot)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, PL.order, PL.cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
     const uint32_t ngroups = (nprot + 63u) / 64u;
-    if ((rc = grow(ctx, ctx->d_grow, ctx->cap_grow, (size_t)ngroups + 3)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, PL.grow, PL.cap_grow, (size_t)ngroups + 3)) != PLAAC_OK) return rc;
     const bool single = npoints == 1; // one parameter point: hmm0's running sum is computed once (k_fwd / k_win), k_finish
     if (single && (rc = grow(ctx, ctx->d_lat, ctx->cap_lat, 2 * (size_t)nprot)) != PLAAC_OK) return rc;
     if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
@@ -909,18 +928,18 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // the base group went through the filter tier: its list of centres is still in place. Copy the
                     // fields that do not depend on llr, then the llr track alone at the listed centres (nine proteins
                     // per wave), and the one-wave-per-protein kernel only for what the exact tier scored
-                    const uint32_t *huge = ctx->d_huge + (ctx->ncalls & 1u);
+                    const uint32_t *huge = ctx->d_huge + (ctx->ncalls & 3u);
                     hipLaunchKernelGGL(k_copy_window_fields, dim3((nprot + 255u) / 256u), dim3(256), 0, skb, src, dst, nprot);
                     for (size_t sg = 0; sg < kb_segs.size(); ++sg) // (the base group's centre lists, segment by segment)
                         hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min((kb_segs[sg].len + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)),
                                            dim3(64), 0, skb, d_codes, total_residues, gtab0 + g, ctx->d_divtab, dst, huge,
                                            ctx->d_clist + kb_segs[sg].base, ctx->d_crow + kb_segs[sg].base, ctx->d_ccount + sg);
                     hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, skb, d_codes,
-                                       d_offsets, ctx->d_neff, nprot, gtab0 + g, src, dst, ctx->d_fblist,
+                                       d_offsets, PL.neff, nprot, gtab0 + g, src, dst, ctx->d_fblist,
                                        ctx->d_fbcount, huge);
                 } else {
                     hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 1u << 20)), dim3(256), 0, skb, d_codes,
-                                       d_offsets, ctx->d_neff, nprot, gtab0 + g, src, dst);
+                                       d_offsets, PL.neff, nprot, gtab0 + g, src, dst);
                 }
                 return PLAAC_OK;
             }
@@ -935,30 +954,30 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     do {                                                                                                           \
         if (d_tracks)                                                                                              \
             hipLaunchKernelGGL((k_tracks<RING, true>), dim3(nprot), dim3(64), 0, skb, d_codes, d_offsets,           \
-                               ctx->d_neff, ctx->d_order, nprot, tab, rows, tp);                                   \
+                               PL.neff, PL.order, nprot, tab, rows, tp);                                   \
         else                                                                                                       \
             hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, skb, d_codes, d_offsets,          \
-                               ctx->d_neff, ctx->d_order, nprot, tab, rows, tp);                                   \
+                               PL.neff, PL.order, nprot, tab, rows, tp);                                   \
     } while (0)
         // the stream form keeps 32 proteins on one int32 position axis; a batch with a protein of >= 65535 residues is
         // left to the one-protein-at-a-time form. The planner raises a device flag for such a batch and both kernels are
         // enqueued: the one the flag rules out returns at once (no host round trip before the window kernel starts).
         if (fast20) {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
-            const uint32_t *huge = ctx->d_huge + (ctx->ncalls & 1u);
+            const uint32_t *huge = ctx->d_huge + (ctx->ncalls & 3u);
             const uint32_t only_if_huge = ctx->per_protein_tracks ? 0u : 1u; // PLAAC_KB_PER_PROTEIN=1: always this form
             // the one-protein-at-a-time kernel over the WHOLE plan (it returns at once unless the batch has a protein too
             // long for the stream kernels). It reads the plan, so with overlapping calls it goes before the tail.
             bool whole_plan_launched = false;
             auto whole_plan = [&]() {
-                hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint4 *)nullptr,
+                hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, PL.neff,
+                                   PL.order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint4 *)nullptr,
                                    (const uint32_t *)nullptr);
                 whole_plan_launched = true;
             };
             if (!ctx->per_protein_tracks) {
                 if (d_tracks) {
-                    hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
+                    hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, PL.order, nprot,
                                        total_residues, tab, ctx->d_divtab, rows, tp, huge);
                 } else if (ctx->kb_filter) {
                     // summary mode: decisions from error-bounded prefix sums, exact values at the chosen centre only,
@@ -996,7 +1015,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                             // (four proteins per block instead of 32: lane k of a block takes protein blockIdx + k * gridDim, so
                             //  a larger grid leaves the lanes from 4 on without one - the long proteins spread over 8 x the waves)
                             hipLaunchKernelGGL(k_tracks20f<true>, dim3((nlong + 3u) / 4u),
-                                               dim3(64), 0, skb, d_codes, ctx->d_order, nlong, total_residues, tab,
+                                               dim3(64), 0, skb, d_codes, PL.order, nlong, total_residues, tab,
                                                ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount,
                                                ctx->d_fblist, ctx->d_fbcount);
                             if ((rc = refine_segment(0u, nlong, skb)) != PLAAC_OK) return rc;
@@ -1014,13 +1033,13 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                             const size_t sg = kb_segs.size();
                             const uint32_t base = g0 * 64u, len = std::min<uint64_t>((uint64_t)g1 * 64u, nprot) - base;
                             hipLaunchKernelGGL(k_tracksL, dim3((g1 - g0 + KL_THREADS / 64 - 1) / (KL_THREADS / 64)),
-                                               dim3(KL_THREADS), 0, sk, ctx->d_order, nprot, g0, g1, tab, ctx->d_divtab,
-                                               ctx->d_packed, ctx->d_grow, rows, huge, ctx->d_clist + base, ctx->d_crow + base,
+                                               dim3(KL_THREADS), 0, sk, PL.order, nprot, g0, g1, tab, ctx->d_divtab,
+                                               PL.packed, PL.grow, rows, huge, ctx->d_clist + base, ctx->d_crow + base,
                                                ctx->d_ccount + sg, ctx->d_fblist, ctx->d_fbcount);
                             if (k == last_run && tail_allowed) { // nothing after this point reads the plan or the packed copy
                                 whole_plan();
-                                PL_HIP(ctx, hipEventRecord(ctx->tail_ev, skb));
-                                ctx->tail_open = true;
+                                PL_HIP(ctx, hipEventRecord(ctx->tail_ev2[par], skb));
+                                ctx->tail_open2[par] = true;
                             }
                             if ((rc = refine_segment(base, len, sk)) != PLAAC_OK) return rc;
                         }
@@ -1030,40 +1049,40 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                             kb_refine_pending = true;
                         }
                         hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
-                                           d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
+                                           d_offsets, PL.neff, PL.order, nprot, total_residues, tab, rows, tp, huge,
                                            0u, ctx->d_fblist, ctx->d_fbcount);
                         if (kb_refine_pending) {
                             PL_HIP(ctx, hipStreamWaitEvent(skb, ctx->jev[5], 0));
                             kb_refine_pending = false;
                         }
                     } else if (gfi[g] && ctx->fi_int_allowed)
-                        hipLaunchKernelGGL(k_tracks20f<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
+                        hipLaunchKernelGGL(k_tracks20f<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, PL.order, nprot,
                                            total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
                                            ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
                     else
-                        hipLaunchKernelGGL(k_tracks20f<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
+                        hipLaunchKernelGGL(k_tracks20f<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, PL.order, nprot,
                                            total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
                                            ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
                     if (!lane_form(g)) {
                         filter_group = (long)g;
                         if (tail_allowed) {
                             whole_plan();
-                            PL_HIP(ctx, hipEventRecord(ctx->tail_ev, skb));
-                            ctx->tail_open = true;
+                            PL_HIP(ctx, hipEventRecord(ctx->tail_ev2[par], skb));
+                            ctx->tail_open2[par] = true;
                         }
                         if ((rc = refine_segment(0u, nprot, skb)) != PLAAC_OK) return rc;
                         hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
-                                           d_offsets, ctx->d_neff, ctx->d_order, nprot, total_residues, tab, rows, tp, huge,
+                                           d_offsets, PL.neff, PL.order, nprot, total_residues, tab, rows, tp, huge,
                                            0u, ctx->d_fblist, ctx->d_fbcount);
                     }
                 } else {
-                    hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, ctx->d_order, nprot,
+                    hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, PL.order, nprot,
                                        total_residues, tab, ctx->d_divtab, rows, tp, huge);
                 }
             }
             if (d_tracks)
-                hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, ctx->d_neff,
-                                   ctx->d_order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint4 *)nullptr, (const uint32_t *)nullptr);
+                hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, PL.neff,
+                                   PL.order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint4 *)nullptr, (const uint32_t *)nullptr);
             else if (!whole_plan_launched)
                 whole_plan();
         } else if (wmax <= 32) LAUNCH_KB(128);
@@ -1076,28 +1095,38 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
 
     // the ctx's plan / scratch buffers are shared by consecutive calls: order this call after the previous one even
     // when the caller hands in a different stream
-    const bool prev_tail = ctx->tail_open; // the previous call left a tail on its stream that reads no plan buffer
-    ctx->tail_open = false;
+    // the call before the previous one used THESE plan buffers; did it leave a tail event (summary mode, single point)?
+    const bool old_tail = ctx->tail_open2[par];
+    ctx->tail_open2[par] = false;
     if (ctx->ncalls > 0)
         PL_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][E_JOIN], 0));
-    // overlapped calls: the head (planning, packed copy) goes on the Viterbi stream, behind everything of the previous call
-    // that touches the plan buffers - its side streams and its window kernels up to the tail - but NOT behind the tail
-    const bool head_aside = ctx->overlap && !ctx->serial && ctx->ncalls > 0 && prev_tail;
-    const hipStream_t sh = head_aside ? sv : st;
-    if (head_aside) {
-        PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->tail_ev, 0));
-        for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->jev[k], 0));
+    // Overlapping calls: the head (planning, packed copy) goes on a stream of its own - the Viterbi stream of the priority
+    // class the previous call's chain kernels did NOT use: an idle hardware queue - and waits only for the call before the
+    // previous one, which read the buffers it writes: that call's side streams, and its window kernels up to its tail.
+    const bool head_aside = ctx->overlap && !ctx->serial && ctx->ncalls > 0;
+    const hipStream_t sh = !head_aside ? st : (ctx->last_chain_bound ? ctx->auxn[plaac_ctx::R_VIT] : ctx->aux[plaac_ctx::R_VIT]);
+    // (Measured and dropped: the chain kernels - they write the rows - additionally waiting for the caller's stream as it
+    //  stands at the entry of the call, which would let the caller order consumers of the row buffers on that stream: the
+    //  chains of call k+1 then start behind the whole of call k, 17.8 -> 19.1 ms per 10 M-sequence step, config 2 0.57 ->
+    //  0.77 ms. The header asks for row buffers that are free when the call is made instead.)
+    if (head_aside && ctx->ncalls > 1) {
+        if (old_tail) {
+            PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->tail_ev2[par], 0));
+            PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->ka_done[par], 0));
+        } else {
+            PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->ev[(ctx->ncalls - 2) % plaac_ctx::EV_SETS][E_JOIN], 0));
+        }
     }
     PL_HIP(ctx, hipEventRecord(evs[E_START], sh));
     PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), st)); // plaac_last_exact_fallbacks: this call's count
-    PL_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(uint32_t) * (LEN_BINS + 1), sh));
+    PL_HIP(ctx, hipMemsetAsync(PL.hist, 0, sizeof(uint32_t) * (LEN_BINS + 1), sh));
     const unsigned pb = (nprot + 255u) / 256u;
     const unsigned plb = (nprot + PLAN_THREADS * PLAN_ITEMS - 1) / (PLAN_THREADS * PLAN_ITEMS);
-    hipLaunchKernelGGL(k_plan_lengths, dim3(plb), dim3(PLAN_THREADS), 0, sh, d_codes, d_offsets, nprot, ctx->d_neff,
-                       ctx->d_hist);
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, sh, ctx->d_hist, ctx->d_huge + (ctx->ncalls & 1u));
-    hipLaunchKernelGGL(k_plan_scatter, dim3(plb), dim3(PLAN_THREADS), 0, sh, ctx->d_neff, nprot, ctx->d_hist,
-                       d_offsets, ctx->d_order);
+    hipLaunchKernelGGL(k_plan_lengths, dim3(plb), dim3(PLAN_THREADS), 0, sh, d_codes, d_offsets, nprot, PL.neff,
+                       PL.hist);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, sh, PL.hist, ctx->d_huge + (ctx->ncalls & 3u));
+    hipLaunchKernelGGL(k_plan_scatter, dim3(plb), dim3(PLAN_THREADS), 0, sh, PL.neff, nprot, PL.hist,
+                       d_offsets, PL.order);
     PL_HIP(ctx, hipEventRecord(evs[E_PLAN], sh));
     if (head_aside) PL_HIP(ctx, hipStreamWaitEvent(st, evs[E_PLAN], 0)); // the window kernels read the plan
     // The three K-A roles and K-B are independent given the plan: fork the K-A side onto high-priority streams
@@ -1108,10 +1137,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if (!kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
         if (!head_aside) PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PLAN], 0));
     }
+    const hipStream_t spk = head_aside ? sh : sv; // the packed copy follows the plan on the head's stream
     // group rows of the interleaved copy; their total is the one value the host needs back (buffer sizes)
-    PL_HIP(ctx, hipEventRecord(evs[E_PACK], sv));
-    hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, sv, ctx->d_neff, ctx->d_order, nprot,
-                       ngroups, ctx->d_grow);
+    PL_HIP(ctx, hipEventRecord(evs[E_PACK], spk));
+    hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, spk, PL.neff, PL.order, nprot,
+                       ngroups, PL.grow);
     // the scan writes the four words the host needs (h_pin[0] total rows, [2] rows of the first wave-group, [3] the long
     // wave-groups the k_core_* kernels serve - a prefix of the plan -, [4] their rows) into pinned host memory and then
     // this call's sequence number into h_pin[5]: the host polls that word (no copy kernels, no interrupt-driven
@@ -1119,7 +1149,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // this system, a failed launch) the stream is synchronised as before and polling is switched off for the context.
     const uint32_t seq = (uint32_t)(ctx->ncalls + 1) | 0x80000000u;
     for (int k = 6; k < 6 + SCAN_SEGS - 1; ++k) ctx->h_pin[k] = 0xffffffffu; // (no rows: the scan leaves them alone)
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(SCAN_THREADS), 0, sv, ctx->d_grow, ngroups, CORE_LONG_ROWS, CORE_MAX_GROUPS,
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(SCAN_THREADS), 0, spk, PL.grow, ngroups, CORE_LONG_ROWS, CORE_MAX_GROUPS,
                        ctx->d_hpin, seq);
     PL_HIP(ctx, hipGetLastError());
     {
@@ -1140,7 +1170,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             }
         }
         if (!arrived) {
-            PL_HIP(ctx, hipStreamSynchronize(sv));
+            PL_HIP(ctx, hipStreamSynchronize(spk));
             ++ctx->synced;
             if (ctx->poll_ok && hp[5] != seq) return fail(ctx, PLAAC_ERR_DEVICE, "plan words did not reach the host");
             ctx->poll_ok = false;
@@ -1171,7 +1201,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if ((rc = grow(ctx, ctx->d_corelist, ctx->cap_corelist, (size_t)nprot * ng)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_corecount, ctx->cap_corecount, ng)) != PLAAC_OK) return rc;
     }
-    if ((rc = grow(ctx, ctx->d_packed, ctx->cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, PL.packed, PL.cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
     const size_t bits_stride = total_rows * 64u + 64u; // one traceback-bit buffer per group
     if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, bits_stride * ng)) != PLAAC_OK) return rc;
     if (d_tracks) {
@@ -1199,11 +1229,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     auto seg_count = [&](size_t k) { return (uint32_t)(std::min<uint64_t>((uint64_t)segb[k + 1] * 64u, nprot) - seg_first(k)); };
     for (size_t k = 0; k < ntseg; ++k) {
         const uint32_t first = seg_first(k), cnt = seg_count(k);
-        hipLaunchKernelGGL(k_pack, dim3((cnt + 15u) / 16u), dim3(256), 0, sv, d_codes, d_offsets, ctx->d_neff,
-                           ctx->d_order + first, cnt, total_residues, ctx->d_grow + segb[k], ctx->d_packed);
-        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->pkev[k], sv));
+        hipLaunchKernelGGL(k_pack, dim3((cnt + 15u) / 16u), dim3(256), 0, spk, d_codes, d_offsets, PL.neff,
+                           PL.order + first, cnt, total_residues, PL.grow + segb[k], PL.packed);
+        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->pkev[k], spk));
     }
-    PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], sv));
+    PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], spk));
     pack_events = &ctx->pkev[0];
     kb_runs = &segb;
     if (!ctx->serial && kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
@@ -1217,10 +1247,16 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             sw2 = ctx->auxn[plaac_ctx::R_WIN2];
         }
         // (the role streams wait for the packed copy run by run, see wait_run; the streams of further sweep groups for all)
-        for (size_t k = 0; k < 3 * (ng - 1); ++k) PL_HIP(ctx, hipStreamWaitEvent(gs[k], evs[E_PACK + 1], 0));
+        for (size_t k = 0; k < 3 * (ng - 1); ++k) {
+            PL_HIP(ctx, hipStreamWaitEvent(gs[k], evs[E_PACK + 1], 0));
+            if (head_aside) PL_HIP(ctx, hipStreamWaitEvent(gs[k], ctx->ka_done[par ^ 1u], 0));
+        }
     }
     auto wait_run = [&](hipStream_t s, size_t k) -> plaac_status { // stream s may touch run k of the packed copy
         if (!ctx->serial) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->pkev[k], 0));
+        // ... and, with overlapping calls, the chain kernels' scratch (path bits, core lists, latency-form words, forward /
+        // backward pairs) only when the previous call's side streams are through with it
+        if (head_aside && k == 0) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->ka_done[par ^ 1u], 0));
         return PLAAC_OK;
     };
     // track mode: the backward recurrence is a chain of its own, beside the forward one
@@ -1230,10 +1266,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if ((rc = wait_run(sb, k)) != PLAAC_OK) return rc;
         if (latency_mode)
             hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, sb,
-                               ctx->d_order + first, cnt, gtab0, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_bwd);
+                               PL.order + first, cnt, gtab0, PL.packed, PL.grow + segb[k], ctx->d_bwd);
         else
-            hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sb, d_offsets, ctx->d_neff,
-                               ctx->d_order + first, cnt, gtab0, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_bwd);
+            hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sb, d_offsets, PL.neff,
+                               PL.order + first, cnt, gtab0, PL.packed, PL.grow + segb[k], ctx->d_bwd);
         if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tbev[k], sb));
     }
     PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
@@ -1250,14 +1286,14 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             if (!ctx->d_coreflags)
                 PL_HIP(ctx, hipMalloc((void **)&ctx->d_coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
             PL_HIP(ctx, hipMemsetAsync(ctx->d_coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, s));
-            hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, s, d_codes, ctx->d_order, nprot, tab,
-                               ctx->d_grow, gbits, ctx->d_corep, ctx->d_coreflags);
+            hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, s, d_codes, PL.order, nprot, tab,
+                               PL.grow, gbits, ctx->d_corep, ctx->d_coreflags);
         }
-        hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, s, ctx->d_order, nprot, tab, ctx->d_packed, ctx->d_grow,
+        hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, s, PL.order, nprot, tab, PL.packed, PL.grow,
                            gbits, ctx->d_corep, par ? ctx->d_coreflags : (const uint32_t *)nullptr);
-        hipLaunchKernelGGL(k_core_eval, dim3(ctx->h_pin[4]), dim3(64), 0, s, ctx->d_order, nprot, ngroups, ctx->d_grow,
+        hipLaunchKernelGGL(k_core_eval, dim3(ctx->h_pin[4]), dim3(64), 0, s, PL.order, nprot, ngroups, PL.grow,
                            ctx->d_corep, (CorePart *)ctx->d_corepart, tg.c[0]);
-        hipLaunchKernelGGL(k_core_reduce, dim3(lg * 64u), dim3(64), 0, s, d_codes, ctx->d_order, nprot, tab, ctx->d_grow,
+        hipLaunchKernelGGL(k_core_reduce, dim3(lg * 64u), dim3(64), 0, s, d_codes, PL.order, nprot, tab, PL.grow,
                            gbits, (const CorePart *)ctx->d_corepart, tg.rows[0], tg.c[0]);
         return PLAAC_OK;
     };
@@ -1287,18 +1323,18 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
 #define LAUNCH_FWD(TRK, EXTF, FIRST, CNT, G0)                                                                      \
     hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3(((CNT) + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sf, d_codes, \
-                       d_offsets, ctx->d_neff, ctx->d_order + (FIRST), (CNT), tab, ctx->d_packed, ctx->d_grow + (G0),  \
+                       d_offsets, PL.neff, PL.order + (FIRST), (CNT), tab, PL.packed, PL.grow + (G0),  \
                        rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, ctx->d_lat, nprot)
         for (size_t k = 0; k < ntseg; ++k) {
             const uint32_t first = seg_first(k), cnt = seg_count(k);
             if (g == 0 && (rc = wait_run(sf, k)) != PLAAC_OK) return rc;
             if (latency_mode && d_tracks)
                 hipLaunchKernelGGL(k_fwd_pair<true>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
-                                   sf, ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_lat,
+                                   sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], ctx->d_lat,
                                    ctx->d_fwd);
             else if (latency_mode)
                 hipLaunchKernelGGL(k_fwd_pair<false>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
-                                   sf, ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], ctx->d_lat,
+                                   sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], ctx->d_lat,
                                    (double2 *)nullptr);
             else if (d_tracks && single) LAUNCH_FWD(true, true, first, cnt, segb[k]);
             else if (d_tracks) LAUNCH_FWD(true, false, first, cnt, segb[k]);
@@ -1324,13 +1360,14 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             // the core list of this launch: the call's (single point), or the sweep group's own, reused by its launches
             uint32_t *gl = single ? ctx->d_corelist : ctx->d_corelist + (size_t)nprot * g;
             uint32_t *gc = single ? ctx->d_corecount : ctx->d_corecount + g;
+            if (g == 0 && (rc = wait_run(sv, 0)) != PLAAC_OK) return rc; // (the list is scratch of the chain kernels)
             if (use_core_list) PL_HIP(ctx, hipMemsetAsync(gc, 0, sizeof(uint32_t), sv));
             for (size_t k = 0; k < ntseg; ++k) {
                 const uint32_t first = seg_first(k), cnt = seg_count(k);
                 const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
                 if (g == 0 && (rc = wait_run(sv, k)) != PLAAC_OK) return rc;
                 tg.first = first;
-#define VIT_ARGS d_codes, d_offsets, ctx->d_neff, ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], gbits, tg
+#define VIT_ARGS d_codes, d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], gbits, tg
 #define LAUNCH_VIT(NC) hipLaunchKernelGGL((k_vit<NC>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS)
 #define LAUNCH_VIT_LIST(NC) hipLaunchKernelGGL((k_vit<NC, false, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, gl, gc)
                 if (latency_mode)
@@ -1367,8 +1404,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                 if (use_core_list) {
                     const unsigned lgrid = std::min((nprot + KA_THREADS - 1) / KA_THREADS, 2048u);
 #define LAUNCH_CORE_LIST(NC)                                                                                       \
-    hipLaunchKernelGGL(k_core_list<NC>, dim3(lgrid), dim3(KA_THREADS), 0, sv, d_codes, total_residues, ctx->d_order, tab, \
-                       ctx->d_packed, ctx->d_grow, gbits, tg, gl, gc)
+    hipLaunchKernelGGL(k_core_list<NC>, dim3(lgrid), dim3(KA_THREADS), 0, sv, d_codes, total_residues, PL.order, tab, \
+                       PL.packed, PL.grow, gbits, tg, gl, gc)
                     switch (single ? 1 : nc) {
                     case 1: LAUNCH_CORE_LIST(1); break;
                     case 2: LAUNCH_CORE_LIST(2); break;
@@ -1386,8 +1423,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                 if (g == 0 && (rc = wait_run(sw, k)) != PLAAC_OK) return rc;
                 if (g == 0 && latency_mode && win3_stream != sw && (rc = wait_run(win3_stream, k)) != PLAAC_OK) return rc;
 #define LAUNCH_WIN(NC, ROLE, STREAM)                                                                               \
-    hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, STREAM, d_codes, d_offsets, ctx->d_neff, \
-                       ctx->d_order + first, cnt, tab, ctx->d_packed, ctx->d_grow + segb[k], tg,                   \
+    hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, STREAM, d_codes, d_offsets, PL.neff, \
+                       PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], tg,                   \
                        ctx->d_lat ? ctx->d_lat + nprot : (double *)nullptr)
                 if (latency_mode) { // two halves side by side (LLR window | MW window + means + hmm0's running sum)
                     LAUNCH_WIN(1, 2, sw);
@@ -1450,13 +1487,13 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         for (size_t k = 0; k < ntseg; ++k) {
             PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->tfev[k], 0));
             PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->tbev[k], 0));
-            hipLaunchKernelGGL((k_post<true, false>), dim3(post_grid), dim3(64), 0, sp, d_offsets, ctx->d_neff, ctx->d_order,
-                               nprot, ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, segb[k], segb[k + 1]);
+            hipLaunchKernelGGL((k_post<true, false>), dim3(post_grid), dim3(64), 0, sp, d_offsets, PL.neff, PL.order,
+                               nprot, ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, segb[k], segb[k + 1]);
         }
         PL_HIP(ctx, hipEventRecord(ctx->tpev, sp));
         PL_HIP(ctx, hipStreamWaitEvent(st, ctx->tpev, 0));
-        hipLaunchKernelGGL((k_post<false, true>), dim3(post_grid), dim3(64), 0, sv, d_offsets, ctx->d_neff, ctx->d_order, nprot,
-                           ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, 0u, ngroups);
+        hipLaunchKernelGGL((k_post<false, true>), dim3(post_grid), dim3(64), 0, sv, d_offsets, PL.neff, PL.order, nprot,
+                           ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, 0u, ngroups);
     }
     if (!ctx->serial) {
         // join: everything enqueued on the side streams so far
@@ -1471,12 +1508,21 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             PL_HIP(ctx, hipEventRecord(ctx->gjev[k], gs[k]));
             PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
         }
+        // "the side streams of this call are through" as ONE event (overlapping calls wait for it): on the Viterbi stream
+        // behind the other four - or, for sweeps (streams per group), on the caller's stream behind everything
+        if (single) {
+            for (int k = 1; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->jev[k], 0));
+            PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], sv));
+        } else {
+            PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], st));
+        }
     }
     if (d_tracks && total_rows && ctx->serial)
-        hipLaunchKernelGGL((k_post<true, true>), dim3(post_grid), dim3(64), 0, st, d_offsets, ctx->d_neff, ctx->d_order, nprot,
-                           ngroups, ctx->d_grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, 0u, ngroups);
+        hipLaunchKernelGGL((k_post<true, true>), dim3(post_grid), dim3(64), 0, st, d_offsets, PL.neff, PL.order, nprot,
+                           ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, 0u, ngroups);
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
+    ctx->last_chain_bound = chain_bound;
     ctx->ncalls++;
     return PLAAC_OK;
 }

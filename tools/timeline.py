@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/timeline.py <kernel_trace.csv> [step]: the kernels of one scoring step (the step-th k_plan_lengths from the end
+"""tools/timeline.py <kernel_trace.csv> [step] [nsteps]: the kernels of one scoring step (the step-th k_plan_lengths from the end
 of a rocprofv3 --kernel-trace run) as a timeline: start / end in ms from the step's first kernel, hardware queue and
 stream ids as rocprofv3 reports them."""
 import csv
@@ -14,8 +14,9 @@ def main():
     starts = [i for i, r in enumerate(rows) if "k_plan_lengths" in r["Kernel_Name"]]
     if len(starts) < back:
         sys.exit("fewer than %d steps in the trace" % back)
+    nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # steps to print (overlapping calls: a step's kernels interleave)
     a = starts[-back]
-    b = starts[-back + 1] if back > 1 else len(rows)
+    b = starts[-back + nsteps] if back > nsteps else len(rows)
     t0 = int(rows[a]["Start_Timestamp"])
     for r in rows[a:b]:
         name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
