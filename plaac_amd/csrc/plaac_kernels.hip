@@ -85,7 +85,10 @@ struct plaac_ctx {
     struct PlanBufs {
         uint32_t *neff = nullptr, *hist = nullptr, *grow = nullptr;
         uint4 *order = nullptr, *packed = nullptr;
-        size_t cap_prot = 0, cap_order = 0, cap_grow = 0, cap_packed = 0;
+        // [0, nprot) lmarginalprob of hmm1, [nprot, 2 nprot) total of hmm0 (single-point calls: k_finish combines them). Per
+        // call too: the forward / window kernels of the next call write theirs while k_finish of this one still reads.
+        double *lat = nullptr;
+        size_t cap_prot = 0, cap_order = 0, cap_grow = 0, cap_packed = 0, cap_lat = 0;
     } pl[2];
     double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
     bool core_long_list = false; // PLAAC_CORE_LONG_LIST=1 (experiment, read at creation like every other knob)
@@ -107,8 +110,6 @@ struct plaac_ctx {
     uint32_t *d_ccount = nullptr, *d_fbcount = nullptr;
     uint4 *d_fblist = nullptr; // plan items of the proteins the filter tier hands to the exact tier
     size_t cap_clist = 0, cap_ccount = 0, cap_fblist = 0;
-    double *d_lat = nullptr; // latency forms: [0, nprot) lmarginalprob of hmm1, [nprot, 2 nprot) total of hmm0
-    size_t cap_lat = 0;
     double *d_corep = nullptr; // latency forms: masked prefix sums of the long wave-groups, packed row numbering
     void *d_corepart = nullptr; // their per-row best windows
     size_t cap_corep = 0, cap_corepart = 0;
@@ -133,7 +134,7 @@ struct plaac_ctx {
     // With the plan double-buffered the head of call k+1 depends on call k-1 only (same buffers): on tail_ev2[p] (recorded on
     // the caller's stream before the tail of the call that used buffers p; tail_open2[p]: that call recorded one) and
     // ka_done[p] (its side streams joined). The chain kernels of call k+1 wait for ka_done of call k (shared scratch).
-    bool overlap = false, tail_open2[2] = {false, false}, last_chain_bound = false;
+    bool overlap = false, tail_open2[2] = {false, false}, last_chain_bound = false, last_single_summary = false;
     hipEvent_t tail_ev2[2] = {nullptr, nullptr}, ka_done[2] = {nullptr, nullptr};
     uint32_t *d_huge = nullptr; // four words, used in turn: the tail of call k reads its word while call k+2 already plans
     int pipe_segments = 1; // PLAAC_PIPE_SEGMENTS: runs of a pipelined single-point call in summary mode. Measured at 10 M
@@ -712,7 +713,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
     for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_crow, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount,
                     (void *)ctx->d_corelist, (void *)ctx->d_corecount, (void *)ctx->d_coreflags,
-                    (void *)ctx->d_lat, (void *)ctx->d_corep, ctx->d_corepart})
+                    (void *)ctx->pl[0].lat, (void *)ctx->pl[1].lat, (void *)ctx->d_corep, ctx->d_corepart})
         if (b) (void)hipFree(b);
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -823,7 +824,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const uint32_t ngroups = (nprot + 63u) / 64u;
     if ((rc = grow(ctx, PL.grow, PL.cap_grow, (size_t)ngroups + 3)) != PLAAC_OK) return rc;
     const bool single = npoints == 1; // one parameter point: hmm0's running sum is computed once (k_fwd / k_win), k_finish
-    if (single && (rc = grow(ctx, ctx->d_lat, ctx->cap_lat, 2 * (size_t)nprot)) != PLAAC_OK) return rc;
+    if (single && (rc = grow(ctx, PL.lat, PL.cap_lat, 2 * (size_t)nprot)) != PLAAC_OK) return rc;
     if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
         if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, (size_t)nprot)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_crow, ctx->cap_crow, (size_t)nprot)) != PLAAC_OK) return rc;
@@ -1252,11 +1253,15 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             if (head_aside) PL_HIP(ctx, hipStreamWaitEvent(gs[k], ctx->ka_done[par ^ 1u], 0));
         }
     }
+    const bool ka_wait = d_tracks || !single || !ctx->last_single_summary || chain_bound != ctx->last_chain_bound;
     auto wait_run = [&](hipStream_t s, size_t k) -> plaac_status { // stream s may touch run k of the packed copy
         if (!ctx->serial) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->pkev[k], 0));
         // ... and, with overlapping calls, the chain kernels' scratch (path bits, core lists, latency-form words, forward /
         // backward pairs) only when the previous call's side streams are through with it
-        if (head_aside && k == 0) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->ka_done[par ^ 1u], 0));
+        // (not a single-point summary call that takes the same forms as the previous call: every role then runs on the
+        //  stream it had in that call, in order behind its own kernels; what crosses streams - lmarginalprob and hmm0's
+        //  total for k_finish - exists per call, and the path bits / core scratch stay on the Viterbi stream)
+        if (head_aside && k == 0 && ka_wait) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->ka_done[par ^ 1u], 0));
         return PLAAC_OK;
     };
     // track mode: the backward recurrence is a chain of its own, beside the forward one
@@ -1324,17 +1329,17 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
 #define LAUNCH_FWD(TRK, EXTF, FIRST, CNT, G0)                                                                      \
     hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3(((CNT) + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sf, d_codes, \
                        d_offsets, PL.neff, PL.order + (FIRST), (CNT), tab, PL.packed, PL.grow + (G0),  \
-                       rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, ctx->d_lat, nprot)
+                       rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, PL.lat, nprot)
         for (size_t k = 0; k < ntseg; ++k) {
             const uint32_t first = seg_first(k), cnt = seg_count(k);
             if (g == 0 && (rc = wait_run(sf, k)) != PLAAC_OK) return rc;
             if (latency_mode && d_tracks)
                 hipLaunchKernelGGL(k_fwd_pair<true>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
-                                   sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], ctx->d_lat,
+                                   sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], PL.lat,
                                    ctx->d_fwd);
             else if (latency_mode)
                 hipLaunchKernelGGL(k_fwd_pair<false>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
-                                   sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], ctx->d_lat,
+                                   sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], PL.lat,
                                    (double2 *)nullptr);
             else if (d_tracks && single) LAUNCH_FWD(true, true, first, cnt, segb[k]);
             else if (d_tracks) LAUNCH_FWD(true, false, first, cnt, segb[k]);
@@ -1425,7 +1430,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
 #define LAUNCH_WIN(NC, ROLE, STREAM)                                                                               \
     hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, STREAM, d_codes, d_offsets, PL.neff, \
                        PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], tg,                   \
-                       ctx->d_lat ? ctx->d_lat + nprot : (double *)nullptr)
+                       PL.lat ? PL.lat + nprot : (double *)nullptr)
                 if (latency_mode) { // two halves side by side (LLR window | MW window + means + hmm0's running sum)
                     LAUNCH_WIN(1, 2, sw);
                     // MW window + means + hmm0's running sum as ONE kernel beside the LLR kernel. (As two kernels on two more
@@ -1474,7 +1479,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[0], 0));
             PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[1], 0));
         }
-        hipLaunchKernelGGL(k_finish, dim3(pb), dim3(256), 0, sv, d_rows[0], ctx->d_lat, ctx->d_lat + nprot, nprot);
+        hipLaunchKernelGGL(k_finish, dim3(pb), dim3(256), 0, sv, d_rows[0], PL.lat, PL.lat + nprot, nprot);
     }
     // posteriors + MAP bytes (track mode): k_post<true, false> of a run needs the run's k_fwd and k_bwd; it goes on the
     // window kernels' stream (they are the first chains to finish) and runs beside the chains of the later runs and the
@@ -1523,6 +1528,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->last_chain_bound = chain_bound;
+    ctx->last_single_summary = single && !d_tracks;
     ctx->ncalls++;
     return PLAAC_OK;
 }
