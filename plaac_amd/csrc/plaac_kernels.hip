@@ -1104,7 +1104,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // Overlapping calls: the head (planning, packed copy) goes on a stream of its own - the Viterbi stream of the priority
     // class the previous call's chain kernels did NOT use: an idle hardware queue - and waits only for the call before the
     // previous one, which read the buffers it writes: that call's side streams, and its window kernels up to its tail.
-    const bool head_aside = ctx->overlap && !ctx->serial && ctx->ncalls > 0;
+    // (single-point summary calls: measured neutral for track mode and sweeps, whose steps are not bound by their two ends)
+    const bool head_aside = ctx->overlap && !ctx->serial && ctx->ncalls > 0 && npoints == 1 && !d_tracks;
     const hipStream_t sh = !head_aside ? st : (ctx->last_chain_bound ? ctx->auxn[plaac_ctx::R_VIT] : ctx->aux[plaac_ctx::R_VIT]);
     // (Measured and dropped: the chain kernels - they write the rows - additionally waiting for the caller's stream as it
     //  stands at the entry of the call, which would let the caller order consumers of the row buffers on that stream: the
