@@ -847,3 +847,65 @@ def test_overlapped_consecutive_calls_give_the_same_rows(native, oracle, monkeyp
         for k in range(len(batches)):
             got = rows[k].cpu().numpy().view(native.ROW_DTYPE).reshape(-1)
             assert_rows_equal(got, want[k], "batch %d (filter tier from %s wave-groups in lane form)" % (k, lane))
+
+
+def test_overlapping_calls_of_every_kind_in_any_order(native, oracle):
+    """plaac_ctx_set_overlap with the kinds of call mixed on one context, back to back without a wait: summary calls that are
+    throughput-bound and chain-bound (the kernel forms and the streams change between calls), a track-mode call, a sweep -
+    every transition between a call whose head runs aside and one whose head does not, and the re-use of each of the two sets
+    of plan buffers by a call of another kind. Every call writes its own buffers; all are checked at the end."""
+    import torch
+    from plaac_amd import synth
+    P0 = native.make_params()
+    rng = np.random.default_rng(77)
+    fg, bg = np.array(P0.fg), np.array(P0.bg)
+    wide = synth.make_batch(4, nprot=7000, seed=11, fg=fg, bg=bg, stop_fraction=0.05)            # throughput-bound
+    deep = synth.residues(np.concatenate([[30000, 2500], rng.integers(20, 300, 400)]), fg, bg, rng)  # chain-bound
+    small = synth.make_batch(4, nprot=300, seed=12, fg=fg, bg=bg)
+    sweep_pts = [native.make_params(alpha=a, corelength=c) for a in (1.0, 0.5) for c in (30, 60)]
+    plan = [("sum", wide), ("sum", deep), ("trk", small), ("sum", wide), ("swp", small), ("sum", deep), ("sum", small),
+            ("trk", deep), ("sum", wide), ("sum", wide), ("swp", wide), ("sum", deep)]
+    dev = torch.device("cuda", 0)
+    up = {}
+    for _, (c, o) in plan:
+        if id(c) not in up:
+            up[id(c)] = (torch.from_numpy(np.ascontiguousarray(c)).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(o).view(np.int64)).to(dev))
+    outs = []
+    with native.Context(P0) as ctx:
+        ctx.set_overlap(True)
+        st = torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        for kind, (c, o) in plan:
+            dc, do = up[id(c)]
+            n, tot = len(o) - 1, int(o[-1])
+            if kind == "swp":
+                rws = [torch.zeros(n, native.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in sweep_pts]
+                ctx.score_sweep_device(dc.data_ptr(), do.data_ptr(), n, tot, sweep_pts, [r.data_ptr() for r in rws],
+                                       stream=st.cuda_stream)
+                outs.append((kind, c, o, rws, None))
+                continue
+            rws = torch.zeros(n, native.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            trk = None
+            if kind == "trk":
+                trk = {k: torch.zeros(tot, dtype=torch.uint8, device=dev) for k in native.TRACK_U8}
+                trk.update({k: torch.full((tot,), float("nan"), dtype=torch.float64, device=dev) for k in native.TRACK_F64})
+            ctx.score_device(dc.data_ptr(), do.data_ptr(), n, tot, rws.data_ptr(),
+                             None if trk is None else {k: v.data_ptr() for k, v in trk.items()}, stream=st.cuda_stream)
+            outs.append((kind, c, o, rws, trk))
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+    want_cache = {}
+    for i, (kind, c, o, rws, trk) in enumerate(outs):
+        what = "call %d (%s, %d proteins)" % (i, kind, len(o) - 1)
+        if kind == "swp":
+            for P, r in zip(sweep_pts, rws):
+                want = oracle.score_batch(oracle.build_params(alpha=P.alpha, corelength=P.corelength), c, o, nthreads=8)
+                assert_rows_equal(r.cpu().numpy().view(native.ROW_DTYPE).reshape(-1), want, what)
+            continue
+        if id(c) not in want_cache:
+            want_cache[id(c)] = oracle.score_batch(oracle.build_params(), c, o, tracks=True, nthreads=8)
+        want, wtr = want_cache[id(c)]
+        assert_rows_equal(rws.cpu().numpy().view(native.ROW_DTYPE).reshape(-1), want, what)
+        if trk is not None:
+            assert_tracks_equal({k: v.cpu().numpy() for k, v in trk.items()}, wtr, c, o, what)
