@@ -8,7 +8,7 @@ cp gpurun_out/pmc/summary.json $O/pmc_summary_cfg4_full.json; cp gpurun_out/pmc/
 cp gpurun_out/pmc/pmc_traffic.json profiles/pmc_traffic.json   # the bench lines below quote THESE counters
 cp $(find gpurun_out/pmc/trace_concurrent -name "*kernel_stats.csv" | head -1) $O/kernel_stats_concurrent_cfg4_full.csv
 cp $(find gpurun_out/pmc/trace_serial -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial_cfg4_full.csv
-python3 tools/timeline.py $(find gpurun_out/pmc/trace_concurrent -name "*kernel_trace.csv" | head -1) 2 > $O/timeline_concurrent_cfg4_full.txt
+python3 tools/timeline.py $(find gpurun_out/pmc/trace_concurrent -name "*kernel_trace.csv" | head -1) 3 2 > $O/timeline_concurrent_cfg4_full.txt
 rm -rf gpurun_out/pmc
 # track mode (1.25 M-sequence share): the same passes
 bash tools/pmc.sh --tracks > $O/pmc_tracks_1250k.log 2>&1
@@ -18,6 +18,7 @@ cp $(find gpurun_out/pmc/trace_serial -name "*kernel_stats.csv" | head -1) $O/ke
 python3 tools/timeline.py $(find gpurun_out/pmc/trace_concurrent -name "*kernel_trace.csv" | head -1) 2 > $O/timeline_concurrent_tracks_1250k.txt
 rm -rf gpurun_out/pmc
 python3 bench.py > $O/bench_cfg4_full.json 2> $O/bench_cfg4_full.err
+python3 bench.py --no-overlap --no-e2e --no-cpu-baseline > $O/bench_cfg4_full_no_overlap.json 2>/dev/null
 python3 bench.py --config 2 --steps 200 --no-e2e > $O/bench_cfg2.json 2>/dev/null
 python3 bench.py --config 3 --steps 100 --no-e2e > $O/bench_cfg3_two_pass.json 2>/dev/null
 python3 bench.py --nprot 1250000 --no-e2e > $O/bench_cfg4_shard_1250k.json 2>/dev/null
