@@ -404,6 +404,23 @@ def main():
             ev[1].record(st)
         st.synchronize()
         hist_ms = ev[0].elapsed_time(ev[1]) / 3
+    # PCIe-inclusive rate (never `value`): the host-buffer entry point plaac_score on a bounded sample - residues and
+    # offsets from host memory in, rows to host memory out, through the library's pinned staging
+    host_io = None
+    if rank == 0 and world == 1 and not args.tracks and not args.sweep:
+        ns = min(nprot, 1250000)
+        o_h = main_work.offsets[:ns + 1].cpu().numpy().astype(np.uint64)
+        c_h = main_work.codes[:int(o_h[-1])].cpu().numpy()
+        ctxs[0].sync()
+        ctxs[0].score(c_h, o_h)
+        t0h = time.perf_counter()
+        ctxs[0].score(c_h, o_h)
+        dth = time.perf_counter() - t0h
+        host_io = {"value": round(int(o_h[-1]) / dth, 1), "unit": "residues/s", "sequences": ns, "residues": int(o_h[-1]),
+                   "seconds": round(dth, 4), "bytes_in": int(o_h[-1]) + 8 * (ns + 1), "bytes_out": 160 * ns,
+                   "what": "plaac_score (host buffers in, host rows out, pinned staging + PCIe + kernels), second of two "
+                           "calls on the first %d sequences; PCIe-inclusive, never reported as `value`" % ns}
+        del c_h, o_h
     # the shader clock the chip holds under this load (untimed extra steps; a sleeping wave beside the scoring kernels):
     # the issue roof below is priced in cycles
     clock = None
@@ -525,6 +542,7 @@ def main():
                 issue_classes["cycles_per_step"] / 1024 / (clock["under_load_MHz_mean"] * 1e6) * 1e3 / step_ms, 4),
             "source": "SQ_INSTS_VALU (fp64 / other) + SQ_INSTS_LDS over all kernels of a step, profiles/pmc_traffic.json"},
         "shader_clock": clock,
+        "host_buffers_pcie_inclusive": host_io,
     }
 
     # ---- rank 0: CPU baseline = the oracle (a port, not the Java reference: no JVM on this box), and the parity check of
