@@ -404,6 +404,17 @@ def main():
             ev[1].record(st)
         st.synchronize()
         hist_ms = ev[0].elapsed_time(ev[1]) / 3
+    # the same step with every call ordered behind the whole previous one (plaac_ctx_set_overlap off): untimed extra steps
+    by_itself = None
+    if overlap and world == 1 and not args.tracks and not args.sweep:
+        for c in ctxs:
+            c.set_overlap(False)
+        ndt, nb = run_region(main_work, max(3, min(args.steps, 10)), 1, False)
+        del nb
+        by_itself = {"ms_per_step": round(ndt / max(3, min(args.steps, 10)) * 1e3, 4),
+                     "what": "plaac_ctx_set_overlap off: every step behind the whole previous step (extra untimed steps)"}
+        for c in ctxs:
+            c.set_overlap(True)
     # PCIe-inclusive rate (never `value`): the host-buffer entry point plaac_score on a bounded sample - residues and
     # offsets from host memory in, rows to host memory out, through the library's pinned staging
     host_io = None
@@ -658,6 +669,7 @@ def main():
             "params": "c=60 ww=41 alpha=%.1f fg=prd_freq_scer_28%s" % (alpha, " bg=input counts" if two_pass else ""),
             "sharding": "by sequence, %d rank(s)" % world, "contexts_per_gpu": nctx,
             "consecutive_steps_overlap": bool(overlap) and not args.tracks and not args.sweep,
+            "step_by_itself": by_itself,
             "exchange": ("%s gather of 160 B rows to rank 0" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
             if world > 1 else "none (1 GPU)",
             "timed_region_s": round(dt, 3), "exact_tier_fallbacks_rank0": fallbacks,
