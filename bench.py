@@ -334,6 +334,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
+        torch.cuda.synchronize(dev)  # (the buffers above were filled on torch's stream, the steps run on others)
         for _ in range(nwarm):
             step()
         fence()

@@ -871,25 +871,32 @@ def test_overlapping_calls_of_every_kind_in_any_order(native, oracle):
         if id(c) not in up:
             up[id(c)] = (torch.from_numpy(np.ascontiguousarray(c)).to(dev),
                          torch.from_numpy(np.ascontiguousarray(o).view(np.int64)).to(dev))
+    # the outputs exist (and torch's fill of them has completed) before the first call: a buffer handed to an overlapping call
+    # must not be in use by other pending work
+    pre = []
+    for kind, (c, o) in plan:
+        n, tot = len(o) - 1, int(o[-1])
+        if kind == "swp":
+            pre.append(([torch.zeros(n, native.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in sweep_pts], None))
+            continue
+        trk = None
+        if kind == "trk":
+            trk = {k: torch.zeros(tot, dtype=torch.uint8, device=dev) for k in native.TRACK_U8}
+            trk.update({k: torch.full((tot,), float("nan"), dtype=torch.float64, device=dev) for k in native.TRACK_F64})
+        pre.append((torch.zeros(n, native.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev), trk))
     outs = []
     with native.Context(P0) as ctx:
         ctx.set_overlap(True)
         st = torch.cuda.Stream(dev)
         torch.cuda.synchronize(dev)
-        for kind, (c, o) in plan:
+        for (kind, (c, o)), (rws, trk) in zip(plan, pre):
             dc, do = up[id(c)]
             n, tot = len(o) - 1, int(o[-1])
             if kind == "swp":
-                rws = [torch.zeros(n, native.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in sweep_pts]
                 ctx.score_sweep_device(dc.data_ptr(), do.data_ptr(), n, tot, sweep_pts, [r.data_ptr() for r in rws],
                                        stream=st.cuda_stream)
                 outs.append((kind, c, o, rws, None))
                 continue
-            rws = torch.zeros(n, native.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            trk = None
-            if kind == "trk":
-                trk = {k: torch.zeros(tot, dtype=torch.uint8, device=dev) for k in native.TRACK_U8}
-                trk.update({k: torch.full((tot,), float("nan"), dtype=torch.float64, device=dev) for k in native.TRACK_F64})
             ctx.score_device(dc.data_ptr(), do.data_ptr(), n, tot, rws.data_ptr(),
                              None if trk is None else {k: v.data_ptr() for k, v in trk.items()}, stream=st.cuda_stream)
             outs.append((kind, c, o, rws, trk))

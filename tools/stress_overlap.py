@@ -61,20 +61,28 @@ with native.Context(P0) as ctx:
             dc = torch.from_numpy(np.ascontiguousarray(c)).to(dev) if len(c) else torch.zeros(16, dtype=torch.uint8, device=dev)
             do = torch.from_numpy(np.ascontiguousarray(o).view(np.int64)).to(dev)
             held.append((dc, do))
-        torch.cuda.synchronize(dev)
-        outs = []
-        for (k, c, o), (dc, do) in zip(calls, held):
+        # ... and so are the outputs: torch fills a new tensor on ITS current stream, and a buffer handed to an overlapping
+        # call must not be in use by other pending work (the fill arriving after the scoring kernels' writes was the one
+        # "mismatch" this tool ever found - in itself)
+        pre = []
+        for k, c, o in calls:
             n, tot = len(o) - 1, int(o[-1])
             if k == "swp":
-                rws = [torch.zeros(max(n, 1), RB, dtype=torch.uint8, device=dev) for _ in sweep_pts]
-                ctx.score_sweep_device(dc.data_ptr(), do.data_ptr(), n, tot, sweep_pts, [x.data_ptr() for x in rws], stream=st.cuda_stream)
-                outs.append((rws, None))
+                pre.append(([torch.zeros(max(n, 1), RB, dtype=torch.uint8, device=dev) for _ in sweep_pts], None))
                 continue
-            rws = torch.zeros(max(n, 1), RB, dtype=torch.uint8, device=dev)
             trk = None
             if k == "trk":
                 trk = {t: torch.zeros(max(tot, 1), dtype=torch.uint8, device=dev) for t in native.TRACK_U8}
                 trk.update({t: torch.full((max(tot, 1),), float("nan"), dtype=torch.float64, device=dev) for t in native.TRACK_F64})
+            pre.append((torch.zeros(max(n, 1), RB, dtype=torch.uint8, device=dev), trk))
+        torch.cuda.synchronize(dev)
+        outs = []
+        for (k, c, o), (dc, do), (rws, trk) in zip(calls, held, pre):
+            n, tot = len(o) - 1, int(o[-1])
+            if k == "swp":
+                ctx.score_sweep_device(dc.data_ptr(), do.data_ptr(), n, tot, sweep_pts, [x.data_ptr() for x in rws], stream=st.cuda_stream)
+                outs.append((rws, None))
+                continue
             ctx.score_device(dc.data_ptr(), do.data_ptr(), n, tot, rws.data_ptr(),
                              None if trk is None else {t: v.data_ptr() for t, v in trk.items()}, stream=st.cuda_stream)
             outs.append((rws, trk))
