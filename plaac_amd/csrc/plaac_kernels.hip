@@ -114,6 +114,7 @@ struct plaac_ctx {
     void *d_corepart = nullptr; // their per-row best windows
     size_t cap_corep = 0, cap_corepart = 0;
     bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
+    bool sweep_spread = true; // PLAAC_SWEEP_SPREAD=0: every further group of a chain-bound sweep on extra high-class streams
     bool kb_lane = true;   // PLAAC_KB_LANE=0: the filter tier in stream form (k_tracks20f) for every protein
     uint32_t kb_lane_min_groups = 4096; // PLAAC_KB_LANE_MIN_GROUPS (tests: 1 = lane form for any batch)
     static constexpr int KB_MAXSEG = 10;
@@ -596,6 +597,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         const char *ppt = std::getenv("PLAAC_KB_PER_PROTEIN");
         ctx->per_protein_tracks = ppt && ppt[0] == '1';
         if (const char *rg = std::getenv("PLAAC_RF_GRID")) ctx->rf_grid = (unsigned)std::max(1, std::atoi(rg));
+        if (const char *ss = std::getenv("PLAAC_SWEEP_SPREAD")) ctx->sweep_spread = ss[0] != '0';
         const char *kbf = std::getenv("PLAAC_KB_FILTER");
         ctx->kb_filter = !(kbf && kbf[0] == '0');
         const char *kbl = std::getenv("PLAAC_KB_LANE");
@@ -1239,7 +1241,23 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     pack_events = &ctx->pkev[0];
     kb_runs = &segb;
     if (!ctx->serial && kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
-    const std::vector<hipStream_t> &gs = chain_bound ? ctx->gstreams : ctx->gstreams_n;
+    // Streams of the sweep groups after the first. Chain-bound sweeps: the Viterbi and forward chains of the longest
+    // protein bound the call once per GROUP, and streams map onto four hardware queues per priority class - with every
+    // group's streams in the high class (ten streams on four queues) the chains of different groups queued up behind each
+    // other (three Viterbi chains in a row: 12.6 of 20.2 ms for nine points over the 1.25 M share). The second and third
+    // group therefore take the role streams a summary sweep leaves idle: their Viterbi chains (10 ms alone for three core
+    // lengths) the normal class's Viterbi stream and the high class's second-window stream - every Viterbi chain a queue
+    // of its own -, their window chains (7 ms) the normal class's forward and window streams (measured apart from each
+    // other and from the caller's stream), their forward chains (5 ms) behind the first group's forward and window chains.
+    // Further groups take the extra streams as before.
+    std::vector<hipStream_t> gs_spread;
+    if (chain_bound && ng > 1 && !d_tracks && ctx->sweep_spread && !ctx->serial) {
+        gs_spread = ctx->gstreams;
+        const hipStream_t pick[6] = {ctx->auxn[plaac_ctx::R_VIT], ctx->aux[plaac_ctx::R_FWD], ctx->auxn[plaac_ctx::R_FWD],
+                                     ctx->aux[plaac_ctx::R_WIN2], ctx->aux[plaac_ctx::R_WIN], ctx->auxn[plaac_ctx::R_WIN]};
+        for (size_t k = 0; k < 6 && k < gs_spread.size(); ++k) gs_spread[k] = pick[k];
+    }
+    const std::vector<hipStream_t> &gs = !gs_spread.empty() ? gs_spread : (chain_bound ? ctx->gstreams : ctx->gstreams_n);
     if (!ctx->serial) {
         if (!chain_bound) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn)
             sv = ctx->auxn[plaac_ctx::R_VIT];
