@@ -1250,12 +1250,17 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // of its own -, their window chains (7 ms) the normal class's forward and window streams (measured apart from each
     // other and from the caller's stream), their forward chains (5 ms) behind the first group's forward and window chains.
     // Further groups take the extra streams as before.
+    // Throughput-bound sweeps: the first group has the normal class (see auxn), the other groups' nine streams shared its
+    // four queues (and the caller's, behind the window kernels) while the high class stood idle: the second group takes
+    // the high class's role streams, the third its second-window stream and places behind the second group's chains.
     std::vector<hipStream_t> gs_spread;
-    if (chain_bound && ng > 1 && !d_tracks && ctx->sweep_spread && !ctx->serial) {
-        gs_spread = ctx->gstreams;
-        const hipStream_t pick[6] = {ctx->auxn[plaac_ctx::R_VIT], ctx->aux[plaac_ctx::R_FWD], ctx->auxn[plaac_ctx::R_FWD],
-                                     ctx->aux[plaac_ctx::R_WIN2], ctx->aux[plaac_ctx::R_WIN], ctx->auxn[plaac_ctx::R_WIN]};
-        for (size_t k = 0; k < 6 && k < gs_spread.size(); ++k) gs_spread[k] = pick[k];
+    if (ng > 1 && !d_tracks && ctx->sweep_spread && !ctx->serial) {
+        gs_spread = chain_bound ? ctx->gstreams : ctx->gstreams_n;
+        const hipStream_t pick_c[6] = {ctx->auxn[plaac_ctx::R_VIT], ctx->aux[plaac_ctx::R_FWD], ctx->auxn[plaac_ctx::R_FWD],
+                                       ctx->aux[plaac_ctx::R_WIN2], ctx->aux[plaac_ctx::R_WIN], ctx->auxn[plaac_ctx::R_WIN]};
+        const hipStream_t pick_t[6] = {ctx->aux[plaac_ctx::R_VIT], ctx->aux[plaac_ctx::R_FWD], ctx->aux[plaac_ctx::R_WIN],
+                                       ctx->aux[plaac_ctx::R_WIN2], ctx->aux[plaac_ctx::R_FWD], ctx->aux[plaac_ctx::R_WIN]};
+        for (size_t k = 0; k < 6 && k < gs_spread.size(); ++k) gs_spread[k] = chain_bound ? pick_c[k] : pick_t[k];
     }
     const std::vector<hipStream_t> &gs = !gs_spread.empty() ? gs_spread : (chain_bound ? ctx->gstreams : ctx->gstreams_n);
     if (!ctx->serial) {
