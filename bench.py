@@ -182,6 +182,8 @@ def main():
                     "plaac_ctx_set_overlap - the planning and packing of a step run beside the last window kernels of the "
                     "step before it)")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the shader-clock measurement (extra untimed steps)")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive plaac_score calls on a 1.25 M-sequence "
+                    "sample (counter passes: their launches would be averaged into the per-launch means)")
     ap.add_argument("--calibrate", action="store_true", help="after the timed region run the histogram kernel once "
                     "(it reads exactly R bytes): calibration of FETCH_SIZE for tools/pmc.sh")
     args = ap.parse_args()
@@ -419,7 +421,7 @@ def main():
     # PCIe-inclusive rate (never `value`): the host-buffer entry point plaac_score on a bounded sample - residues and
     # offsets from host memory in, rows to host memory out, through the library's pinned staging
     host_io = None
-    if rank == 0 and world == 1 and not args.tracks and not args.sweep:
+    if rank == 0 and world == 1 and not args.tracks and not args.sweep and not args.no_host_leg:
         ns = min(nprot, 1250000)
         o_h = main_work.offsets[:ns + 1].cpu().numpy().astype(np.uint64)
         c_h = main_work.codes[:int(o_h[-1])].cpu().numpy()
