@@ -349,13 +349,16 @@ def test_resident_batch_histogram_score_and_sweep(native, oracle, ctx):
         assert_tracks_equal(tr, wtr, codes, offs)
 
 
+@pytest.mark.parametrize("spread", ["1", "0"])
 @pytest.mark.parametrize("mode", ["0", "1"])
-def test_sweep_on_adversarial_sequences_in_both_scheduling_modes(native, oracle, monkeypatch, mode):
+def test_sweep_on_adversarial_sequences_in_both_scheduling_modes(native, oracle, monkeypatch, mode, spread):
     """a sweep whose dependent alpha groups take plaacllr / plaacllrx2 from the llr-only refine kernel (listed centres)
     and from the one-wave-per-protein kernel (what the exact tier scored: the adversarial set is full of those), with
-    the core lists of the throughput-bound schedule (mode 0) and the in-kernel core sweep of the chain-bound one (1)"""
+    the core lists of the throughput-bound schedule (mode 0) and the in-kernel core sweep of the chain-bound one (1);
+    the second and third group on the idle role streams of both priority classes (spread 1) or on streams of their own"""
     from plaac_amd import synth
     monkeypatch.setenv("PLAAC_LATENCY_MODE", mode)
+    monkeypatch.setenv("PLAAC_SWEEP_SPREAD", spread)
     P = native.make_params()
     c1, o1 = _adversarial_batch(native)
     c2, o2 = synth.make_batch(4, nprot=3000, seed=77, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.05)
