@@ -115,6 +115,7 @@ struct plaac_ctx {
     size_t cap_corep = 0, cap_corepart = 0;
     bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
     bool sweep_spread = true; // PLAAC_SWEEP_SPREAD=0: every further group of a chain-bound sweep on extra high-class streams
+    bool sweep_latency = true; // PLAAC_SWEEP_LATENCY=0: chain-bound sweeps keep the throughput form of k_vit for every wave-group
     bool kb_lane = true;   // PLAAC_KB_LANE=0: the filter tier in stream form (k_tracks20f) for every protein
     uint32_t kb_lane_min_groups = 4096; // PLAAC_KB_LANE_MIN_GROUPS (tests: 1 = lane form for any batch)
     static constexpr int KB_MAXSEG = 10;
@@ -598,6 +599,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         ctx->per_protein_tracks = ppt && ppt[0] == '1';
         if (const char *rg = std::getenv("PLAAC_RF_GRID")) ctx->rf_grid = (unsigned)std::max(1, std::atoi(rg));
         if (const char *ss = std::getenv("PLAAC_SWEEP_SPREAD")) ctx->sweep_spread = ss[0] != '0';
+        if (const char *sl = std::getenv("PLAAC_SWEEP_LATENCY")) ctx->sweep_latency = sl[0] != '0';
         const char *kbf = std::getenv("PLAAC_KB_FILTER");
         ctx->kb_filter = !(kbf && kbf[0] == '0');
         const char *kbl = std::getenv("PLAAC_KB_LANE");
@@ -1194,12 +1196,21 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // proteins are k_core_list's tail. Measured at 10 M sequences: 23.0 against 22.2 ms - the tail was hidden, the extra
     // kernels are not.)
     const bool long_in_list = ctx->core_long_list;
-    const bool core_long = single && (latency_mode || (use_core_list && long_in_list)) && ctx->h_pin[2] >= CORE_LONG_ROWS;
+    // Chain-bound SWEEPS (round 3): the long wave-groups (proteins of >= 2048 residues) are a run of their own and take the
+    // latency form of the Viterbi kernel - unpinned steps, and their core windows (one trailing chain per core length in
+    // the throughput form: 10.3 ms for three core lengths with a 36,000-residue protein) from k_core_chain / _eval /
+    // _reduce: one prefix chain per group, the windows per core length. Every other wave-group keeps the throughput form
+    // (the unpinned form takes 180 registers: as the form of the whole batch its 4,800 blocks waited for register space).
+    const bool sweep_lat = !single && chain_bound && !ctx->serial && !d_tracks && ctx->sweep_latency &&
+                           ctx->h_pin[2] >= CORE_LONG_ROWS && ctx->h_pin[3] > 0u && ctx->h_pin[3] < CORE_MAX_GROUPS;
+    const bool core_long = sweep_lat || (single && (latency_mode || (use_core_list && long_in_list)) &&
+                                         ctx->h_pin[2] >= CORE_LONG_ROWS);
+    const size_t core_lrows = core_long ? (size_t)ctx->h_pin[4] : 0;
+    const size_t core_copies = sweep_lat ? ng : 1; // (the groups of a sweep run side by side: scratch per group)
     if (core_long) { // scratch of k_core_*: the rows of the first CORE_MAX_GROUPS wave-groups
-        const size_t lrows = ctx->h_pin[4];
-        if ((rc = grow(ctx, ctx->d_corep, ctx->cap_corep, lrows * 1024u)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_corep, ctx->cap_corep, core_lrows * 1024u * core_copies)) != PLAAC_OK) return rc;
         char *&cp = reinterpret_cast<char *&>(ctx->d_corepart);
-        if ((rc = grow(ctx, cp, ctx->cap_corepart, lrows * 64u * sizeof(CorePart))) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, cp, ctx->cap_corepart, core_lrows * 64u * sizeof(CorePart) * core_copies)) != PLAAC_OK) return rc;
     }
     if (use_core_list) {
         if ((rc = grow(ctx, ctx->d_corelist, ctx->cap_corelist, (size_t)nprot * ng)) != PLAAC_OK) return rc;
@@ -1229,6 +1240,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     }
     segb.push_back(ngroups);
     const size_t ntseg = segb.size() - 1;
+    // the Viterbi kernel's own runs (chain-bound sweeps: the long wave-groups apart, see sweep_lat; the forward and window
+    // kernels of a sweep stay one launch each: as two they only queue up behind each other)
+    std::vector<uint32_t> vsegb = segb;
+    if (sweep_lat && ctx->h_pin[3] < ngroups) vsegb = {0u, ctx->h_pin[3], ngroups};
     auto seg_first = [&](size_t k) { return segb[k] * 64u; };
     auto seg_count = [&](size_t k) { return (uint32_t)(std::min<uint64_t>((uint64_t)segb[k + 1] * 64u, nprot) - seg_first(k)); };
     for (size_t k = 0; k < ntseg; ++k) {
@@ -1306,24 +1321,30 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // masked core window of the long wave-groups (single-point calls): prefix sums position-parallel on the chain's
     // rounding grid where the tables and the protein allow it (k_core_par), the serial chain for whatever it flags, then
     // every window per packed row and the ordered reduction
-    auto launch_core_long = [&](const DevTables *tab, uint32_t *gbits, const SweepTargets &tg, hipStream_t s,
-                                uint32_t point) -> plaac_status {
+    // `copy`: which scratch copy (the sweep group; 0 for single-point calls); `prefix`: compute the masked prefix sums (they
+    // do not depend on the core length: once per group); then the windows of ONE core length into `rows`
+    auto launch_core_long = [&](const DevTables *tab, uint32_t *gbits, uint32_t c, plaac_row *rows, hipStream_t s,
+                                uint32_t point, size_t copy, bool prefix) -> plaac_status {
         const unsigned lg = ctx->h_pin[3]; // (the kernels re-check every group: lengths >= 65535 are not ordered)
-        const bool par = ctx->core_par && ctx->core_par_ok &&
-                         std::memcmp(&points[point], &ctx->params, sizeof(plaac_params)) == 0;
-        if (par) {
-            if (!ctx->d_coreflags)
-                PL_HIP(ctx, hipMalloc((void **)&ctx->d_coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
-            PL_HIP(ctx, hipMemsetAsync(ctx->d_coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, s));
-            hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, s, d_codes, PL.order, nprot, tab,
-                               PL.grow, gbits, ctx->d_corep, ctx->d_coreflags);
+        double *corep = ctx->d_corep + core_lrows * 1024u * copy;
+        CorePart *corepart = (CorePart *)ctx->d_corepart + core_lrows * 64u * copy;
+        if (prefix) {
+            const bool par = copy == 0 && single && ctx->core_par && ctx->core_par_ok &&
+                             std::memcmp(&points[point], &ctx->params, sizeof(plaac_params)) == 0;
+            if (par) {
+                if (!ctx->d_coreflags)
+                    PL_HIP(ctx, hipMalloc((void **)&ctx->d_coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
+                PL_HIP(ctx, hipMemsetAsync(ctx->d_coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, s));
+                hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, s, d_codes, PL.order, nprot, tab,
+                                   PL.grow, gbits, corep, ctx->d_coreflags);
+            }
+            hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, s, PL.order, nprot, tab, PL.packed, PL.grow,
+                               gbits, corep, par ? ctx->d_coreflags : (const uint32_t *)nullptr);
         }
-        hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, s, PL.order, nprot, tab, PL.packed, PL.grow,
-                           gbits, ctx->d_corep, par ? ctx->d_coreflags : (const uint32_t *)nullptr);
         hipLaunchKernelGGL(k_core_eval, dim3(ctx->h_pin[4]), dim3(64), 0, s, PL.order, nprot, ngroups, PL.grow,
-                           ctx->d_corep, (CorePart *)ctx->d_corepart, tg.c[0]);
+                           corep, corepart, c);
         hipLaunchKernelGGL(k_core_reduce, dim3(lg * 64u), dim3(64), 0, s, d_codes, PL.order, nprot, tab, PL.grow,
-                           gbits, (const CorePart *)ctx->d_corepart, tg.rows[0], tg.c[0]);
+                           gbits, (const CorePart *)corepart, rows, c);
         return PLAAC_OK;
     };
     const hipStream_t sv0 = sv, sf0 = sf, sw0 = sw;
@@ -1391,16 +1412,24 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             uint32_t *gc = single ? ctx->d_corecount : ctx->d_corecount + g;
             if (g == 0 && (rc = wait_run(sv, 0)) != PLAAC_OK) return rc; // (the list is scratch of the chain kernels)
             if (use_core_list) PL_HIP(ctx, hipMemsetAsync(gc, 0, sizeof(uint32_t), sv));
-            for (size_t k = 0; k < ntseg; ++k) {
-                const uint32_t first = seg_first(k), cnt = seg_count(k);
+            for (size_t k = 0; k + 1 < vsegb.size(); ++k) {
+                const uint32_t first = vsegb[k] * 64u;
+                const uint32_t cnt = (uint32_t)(std::min<uint64_t>((uint64_t)vsegb[k + 1] * 64u, nprot) - first);
                 const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
-                if (g == 0 && (rc = wait_run(sv, k)) != PLAAC_OK) return rc;
+                if (g == 0 && (rc = wait_run(sv, std::min(k, ntseg - 1))) != PLAAC_OK) return rc;
                 tg.first = first;
-#define VIT_ARGS d_codes, d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], gbits, tg
+#define VIT_ARGS d_codes, d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + vsegb[k], gbits, tg
 #define LAUNCH_VIT(NC) hipLaunchKernelGGL((k_vit<NC>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS)
 #define LAUNCH_VIT_LIST(NC) hipLaunchKernelGGL((k_vit<NC, false, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, gl, gc)
                 if (latency_mode)
                     hipLaunchKernelGGL((k_vit<1, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS);
+                else if (sweep_lat && vsegb[k + 1] <= ctx->h_pin[3]) // the run of the long wave-groups
+                    switch (nc) {
+                    case 1: hipLaunchKernelGGL((k_vit<1, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
+                    case 2: hipLaunchKernelGGL((k_vit<2, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
+                    case 3: hipLaunchKernelGGL((k_vit<3, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
+                    default: hipLaunchKernelGGL((k_vit<4, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
+                    }
                 else if (single && use_core_list) // throughput-bound: sweep 3 only for proteins that can have a core
                     hipLaunchKernelGGL((k_vit<1, false, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, gl, gc);
                 else if (use_core_list) { // sweep groups
@@ -1428,8 +1457,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             if (tg.stop_after == 0u) {
                 // (the long wave-groups first: the chain of a 36,000-residue protein on the list would be the tail of the step)
                 if (core_long && (latency_mode || (single && use_core_list)) &&
-                    (rc = launch_core_long(tab, gbits, tg, sv, G.first)) != PLAAC_OK)
+                    (rc = launch_core_long(tab, gbits, tg.c[0], tg.rows[0], sv, G.first, 0, true)) != PLAAC_OK)
                     return rc;
+                for (int k = 0; sweep_lat && k < nc; ++k) // (the path bits of the group: the same for every launch)
+                    if ((rc = launch_core_long(tab, gbits, tg.c[k], tg.rows[k], sv, G.first, g, m0 == 0 && k == 0)) != PLAAC_OK)
+                        return rc;
                 if (use_core_list) {
                     const unsigned lgrid = std::min((nprot + KA_THREADS - 1) / KA_THREADS, 2048u);
 #define LAUNCH_CORE_LIST(NC)                                                                                       \

@@ -460,6 +460,38 @@ def test_stream_and_per_protein_window_kernels_agree(native, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["1", "0"])
+def test_chain_bound_sweep_with_long_proteins_in_both_viterbi_forms(native, oracle, monkeypatch, form):
+    """a chain-bound sweep over a batch whose first wave-groups hold proteins of >= 2048 residues: those groups are a run of
+    their own in the latency form of k_vit, their core windows come from k_core_chain / _eval / _reduce per core length
+    with scratch per sweep group (form 1); form 0 keeps the throughput form for every wave-group. Five core lengths per
+    alpha: two launches per group. Prion-like long proteins, so that the long groups do have cores."""
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_LATENCY_MODE", "1")
+    monkeypatch.setenv("PLAAC_SWEEP_LATENCY", form)
+    P = native.make_params()
+    rng = np.random.default_rng(31)
+    aas = "ACDEFGHIKLMNPQRSTVWY"
+    longs = ["".join(rng.choice(list("QNGSYQNQ"), 700)) + "".join(rng.choice(list(aas), n)) + "QN" * 150
+             for n in (1200, 2100, 4000, 9000)] + ["".join(rng.choice(list(aas), 2048)), "".join(rng.choice(list(aas), 2047))]
+    c1, o1 = native.pack(longs)
+    c2, o2 = synth.make_batch(4, nprot=9000, seed=78, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.05)
+    codes = np.concatenate([c1, c2])
+    offs = np.concatenate([o1, o2[1:] + o1[-1]]).astype(np.uint64)
+    points = [(a, c) for a in (1.0, 0.0, 0.5) for c in (30, 60, 90, 20, 45)]
+    with native.Context(P) as c:
+        with c.upload(codes, offs) as batch:
+            bg = batch.histogram().astype(np.float64)
+            got = batch.sweep([native.make_params(alpha=a, corelength=cl, bgcounts=bg) for a, cl in points])
+    ncores = 0
+    for (a, cl), rows in zip(points, got):
+        want = oracle.score_batch(oracle.build_params(alpha=a, corelength=cl, bgcounts=bg), codes, offs, nthreads=8)
+        assert_rows_equal(rows, want, "alpha=%s c=%d viterbi form %s" % (a, cl, form))
+        ncores += int((want["core_start"][:4] >= 0).sum())
+    assert ncores > 0  # the long proteins do have core windows
+
+
 @pytest.mark.parametrize("ww", [dict(ww1=31, ww2=21), dict(ww1=41, ww2=41, ww3=21), dict(ww1=41, ww2=21, ww3=61)])
 def test_sweep_over_alpha_with_other_windows(native, oracle, ctx, ww):
     """The further alphas of a sweep take the PAPA centre from the first alpha's window kernel and recompute only the two
