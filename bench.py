@@ -187,6 +187,11 @@ def main():
     ap.add_argument("--calibrate", action="store_true", help="after the timed region run the histogram kernel once "
                     "(it reads exactly R bytes): calibration of FETCH_SIZE for tools/pmc.sh")
     args = ap.parse_args()
+    # Sweeps run nine chains (three per alpha group) beside the window kernels: with the HIP runtime's default of four
+    # hardware queues per priority class they share queues; INTEGRATION.md recommends twelve for sweep-heavy hosts (the
+    # library then gives every group streams of its own). Must be set before the runtime initialises; the host's choice.
+    if args.sweep:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
     import torch
     import torch.distributed as dist
@@ -672,6 +677,7 @@ def main():
             "params": "c=60 ww=41 alpha=%.1f fg=prd_freq_scer_28%s" % (alpha, " bg=input counts" if two_pass else ""),
             "sharding": "by sequence, %d rank(s)" % world, "contexts_per_gpu": nctx,
             "consecutive_steps_overlap": bool(overlap) and not args.tracks and not args.sweep,
+            "hip_hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4 per priority class)"),
             "step_by_itself": by_itself,
             "exchange": ("%s gather of 160 B rows to rank 0" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
             if world > 1 else "none (1 GPU)",

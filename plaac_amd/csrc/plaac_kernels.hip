@@ -598,6 +598,10 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         const char *ppt = std::getenv("PLAAC_KB_PER_PROTEIN");
         ctx->per_protein_tracks = ppt && ppt[0] == '1';
         if (const char *rg = std::getenv("PLAAC_RF_GRID")) ctx->rf_grid = (unsigned)std::max(1, std::atoi(rg));
+        // (a host that raised the runtime's hardware queues - GPU_MAX_HW_QUEUES >= 12, before HIP initialised - has a queue
+        //  for every chain of a three-group sweep: every group then keeps streams of its own. Measured, 9 points over the
+        //  1.25 M share: 4 queues 14.4 / 18.0 ms spread / own streams, 8 queues 14.4 / 16.7, 12 queues 14.4 / 12.6)
+        if (const char *hq = std::getenv("GPU_MAX_HW_QUEUES")) ctx->sweep_spread = std::atoi(hq) < 12;
         if (const char *ss = std::getenv("PLAAC_SWEEP_SPREAD")) ctx->sweep_spread = ss[0] != '0';
         if (const char *sl = std::getenv("PLAAC_SWEEP_LATENCY")) ctx->sweep_latency = sl[0] != '0';
         const char *kbf = std::getenv("PLAAC_KB_FILTER");
