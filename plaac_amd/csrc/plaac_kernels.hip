@@ -218,6 +218,26 @@ plaac_status fail(plaac_ctx *ctx, plaac_status st, const char *msg) {
 
 void derive_fi_int(const plaac_params &P, DevTables &D, int32_t *info = nullptr);
 
+// May the forward / backward kernels take lse_lut<CLAMPED> (kernels_chains.hip.inc) for these tables? Its argument: the larger
+// operand of every log-sum-exp of the recurrences is a sum of transition / initial / final log-probabilities (all <= 0
+// here) and at least one emission log-probability (all <= -0.125 here), so it is <= -0.125, and the table's last entry
+// (the most a difference in [40, 40.01) can add) is below half the spacing of the doubles there, 2^-57.
+// PLAAC_LSE_CLAMP=0: never.
+bool lse_clamp_ok(const plaac_params &P) {
+    if (const char *e = std::getenv("PLAAC_LSE_CLAMP")) // (read whenever tables are built: the tests switch it)
+        if (e[0] == '0') return false;
+    auto nonpos = [](double v) { return v <= 0.0; }; // (false for NaN)
+    for (int i = 0; i < 2; ++i) {
+        if (!nonpos(P.hmm1.li[i]) || !nonpos(P.hmm1.lf[i])) return false;
+        for (int j = 0; j < 2; ++j)
+            if (!nonpos(P.hmm1.lt[i][j])) return false;
+        for (int k = 0; k < NAA; ++k)
+            if (!(P.hmm1.le[i][k] <= -0.125)) return false;
+    }
+    const double last = P.loglut[LUTLEN - 1];
+    return last >= 0.0 && last < 0x1p-57;
+}
+
 void fill_tables(const plaac_params &P, DevTables &D) {
     std::memset(&D, 0, sizeof D);
     for (int k = 0; k < NAA; ++k) {
@@ -247,6 +267,7 @@ void fill_tables(const plaac_params &P, DevTables &D) {
     D.ww3 = P.ww3;
     D.adjustprolines = P.adjustprolines;
     std::memcpy(D.loglut, P.loglut, sizeof P.loglut); // D.loglut[LUTLEN], [LUTLEN + 1] stay 0.0
+    D.lse_clamp = lse_clamp_ok(P) ? 1 : 0;
     derive_fi_int(P, D);
 }
 

@@ -461,6 +461,26 @@ def test_stream_and_per_protein_window_kernels_agree(native, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.gpu
+@pytest.mark.parametrize("clamp", ["1", "0"])
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_log_sum_exp_with_and_without_its_in_range_select(native, oracle, monkeypatch, clamp, mode):
+    """the forward / backward kernels leave out the in-range select of the LUT log-sum-exp when the tables allow it
+    (lse_clamp_ok: every emission log-probability <= -0.125, the table's last entry below 2^-57); PLAAC_LSE_CLAMP=0 keeps
+    the select. Both must give the oracle's rows and posteriors, in the throughput and the latency forms - also for
+    tables that do NOT qualify (a background of nearly one residue: an emission log-probability close to zero)."""
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_LSE_CLAMP", clamp)
+    monkeypatch.setenv("PLAAC_LATENCY_MODE", mode)
+    P = native.make_params()
+    codes, offs = synth.make_batch(2, nprot=700, seed=5, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.05)
+    lopsided = np.full(22, 1e-4)
+    lopsided[13] = 1.0  # background almost all proline: log(freq) ~ -0.002 > -0.125
+    for kw in ({}, {"alpha": 0.0, "bgcounts": lopsided}):
+        with native.Context(native.make_params(**kw)) as c:
+            check_batch(native, oracle, c, codes, offs, tracks=True, what="lse clamp %s mode %s %s" % (clamp, mode, kw), **kw)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["1", "0"])
 def test_chain_bound_sweep_with_long_proteins_in_both_viterbi_forms(native, oracle, monkeypatch, form):
     """a chain-bound sweep over a batch whose first wave-groups hold proteins of >= 2048 residues: those groups are a run of
