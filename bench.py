@@ -239,9 +239,11 @@ def main():
             self.nmax = nmax    # rows per gathered block (dist.gather wants equal blocks)
 
     if strong:
-        mine = pdist.shard_plan_torch(offsets_full, world, rank)
+        all_plans = pdist.shard_plan_torch(offsets_full, world)  # the C partitioner (plaac_shard_plan), every rank the same
+        mine = all_plans[rank]
         c_s, o_s = pdist.extract_shard_torch(codes_full, offsets_full, mine)
-        plans = [pdist.shard_plan_torch(offsets_full, world, r) for r in range(world)] if rank == 0 else None
+        plans = all_plans if rank == 0 else None
+        del all_plans
         main_work = Work(c_s, o_s, plans, (nfull + world - 1) // world)
         del mine
     else:

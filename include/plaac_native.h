@@ -197,7 +197,8 @@ plaac_status plaac_ctx_sync(plaac_ctx *ctx);
  * [2] k_vit (Viterbi / traceback / core), [3] k_fwd (forward recurrence),
  * [4] k_win (MW / LLR windows, means), [5] k_tracks (FoldIndex / PAPA window tracks),
  * [6] group-interleaved packing of the residues for [2..4] (incl. the host round trip for its size),
- * [7] k_bwd (backward recurrence; track mode only, else 0).
+ * [7] k_bwd (backward recurrence) in track mode; in summary mode the long run of a chain-bound call (k_long: the latency
+ *     forms of the long wave-groups + their core search; [2..4] are the throughput-form runs then), else 0.
  * The four scoring kernels run concurrently on separate streams (PLAAC_SERIAL_STREAMS=1 in the
  * environment at ctx creation serialises them for profiling), so [2..5] overlap and do not add up to [0].
  * Blocks until the batch has completed. */
@@ -226,6 +227,33 @@ plaac_status plaac_node_score(plaac_node *node, const uint8_t *codes, const uint
                               plaac_row *rows, const plaac_tracks *tracks);
 /* message of the last failing call on this node (node == NULL: last failing plaac_node_create on this thread) */
 const char *plaac_node_last_error(const plaac_node *node);
+/* plaac_ctx_set_overlap on every context of the node (for hosts that feed the contexts' device entry points themselves) */
+plaac_status plaac_node_set_overlap(plaac_node *node, int on);
+
+/* THE partitioner of every multi-GPU layer (plaac_node_*, plaac_amd/dist.py, bench.py): SURVEY.md 8(e) G1's "sort by
+ * length, deal". The records are sorted by length (descending, stable) and dealt to `parts` shards boustrophedon
+ * (0 .. parts-1, parts-1 .. 0, ...): equal residue counts, and every shard gets the same share of the long proteins whose
+ * serial chains bound a step (plaac.java:3360-3368). index_out[part_start[k] .. part_start[k+1]) = the records of shard k
+ * in ascending input order; part_start has parts + 1 entries. Host-only: needs no device. */
+plaac_status plaac_shard_plan(const uint64_t *offsets, uint32_t nprot, uint32_t parts, uint32_t *index_out,
+                              uint32_t *part_start);
+
+/* Resident batches on all devices of a node: the batch is cut with plaac_shard_plan, every shard is uploaded ONCE to its
+ * device and stays there for the background pass (plaac.java:377-384), the scoring pass (:755) - the reference's two
+ * passes over one input - and for parameter sweeps, which the reference runs as one `main` invocation per point
+ * (plaac.java:337-353, web/lib/server.rb:152-155: nine uploads of the same proteome). Rows (and tracks) come back in
+ * INPUT order. plaac_node_score / plaac_node_histogram are upload + use + free of such a batch. */
+typedef struct plaac_node_batch plaac_node_batch;
+plaac_status plaac_node_batch_upload(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                                     plaac_node_batch **out);
+plaac_status plaac_node_batch_histogram(plaac_node_batch *b, int64_t counts[PLAAC_NAA]);
+/* scores with the node's CURRENT parameters (plaac_node_set_params between calls: the two-pass run on one upload) */
+plaac_status plaac_node_batch_score(plaac_node_batch *b, plaac_row *rows, const plaac_tracks *tracks);
+/* BASELINE config 5 on all devices: rows[i] = host array of nprot rows for points[i]; every device runs the sweep-aware
+ * schedule of plaac_score_sweep_device over its resident shard. The node's own parameters are not changed. */
+plaac_status plaac_node_batch_sweep(plaac_node_batch *b, const plaac_params *points, uint32_t npoints,
+                                    plaac_row *const *rows);
+void plaac_node_batch_free(plaac_node_batch *b);
 
 /* Summary mode scores the FoldIndex / PAPA window tracks in two tiers: a filter that decides from error-bounded
  * prefix sums, and the exact fixed-order kernel for every protein the bounds cannot decide (results are identical
@@ -247,9 +275,11 @@ plaac_status plaac_calibration_reads(plaac_ctx *ctx, const uint8_t *d_codes, uin
  * call are through; its window kernels stay on the caller's stream. The caller guarantees: (1) `d_codes` / `d_offsets` of
  * a call are complete when the call is made (not produced by work still pending on a stream) and stay unchanged until it
  * has completed; (2) `d_rows` (and the tracks) of a call are not in use by anything ELSE that is still pending when the
- * call is made - consecutive calls may write the same buffer, but a consumer of an earlier call's rows on another stream
- * has to be waited for on the host (an event synchronisation, plaac_ctx_sync), not by a stream-side wait on the caller's
- * stream. Results are unchanged; a lone call is unchanged. (bench.py switches it on: its steps are back to back on one
+ * call is made - a consumer of an earlier call's rows on another stream has to be waited for on the host (an event
+ * synchronisation, plaac_ctx_sync), not by a stream-side wait on the caller's stream; consecutive calls may write the
+ * same buffer only when they score the same batch with the same parameters (every row field is written once per call,
+ * with its final value; the long runs of consecutive chain-bound calls run side by side, so the LATER call is not
+ * always the last writer). Results are unchanged; a lone call is unchanged. (bench.py switches it on: its steps are back to back on one
  * resident batch. Measured: DESIGN.md 4.9.) */
 plaac_status plaac_ctx_set_overlap(plaac_ctx *ctx, int on);
 

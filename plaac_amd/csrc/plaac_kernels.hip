@@ -77,7 +77,6 @@ struct plaac_ctx {
     hipEvent_t fev[2] = {nullptr, nullptr};                            // k_finish waits for the forward / window streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
-    uint32_t *d_bits = nullptr;
     // The plan of a call - effective lengths, length histogram, the sorted plan {offset lo, offset hi, effective length,
     // protein index}, row offsets of the wave-groups, the packed copy - exists TWICE, used by alternate calls: with
     // overlapping calls (plaac_ctx_set_overlap) the planning and packing of call k+1 then depend on call k-1 only and run
@@ -87,8 +86,17 @@ struct plaac_ctx {
         uint4 *order = nullptr, *packed = nullptr;
         // [0, nprot) lmarginalprob of hmm1, [nprot, 2 nprot) total of hmm0 (single-point calls: k_finish combines them). Per
         // call too: the forward / window kernels of the next call write theirs while k_finish of this one still reads.
+        // [2 nprot, 3 nprot) end score of the Viterbi path (k_vit<.., EXT>; k_finish writes HMMvit).
         double *lat = nullptr;
         size_t cap_prot = 0, cap_order = 0, cap_grow = 0, cap_packed = 0, cap_lat = 0;
+        // Everything else the lane-per-protein kernels of a call write besides the rows (round 4: per call parity as well,
+        // so that the chain kernels of call k+1 need nothing from call k and the long runs of consecutive calls - k_long on
+        // alternating streams - run side by side): traceback / path bit words, core list and its count (k_vit<.., LIST> ->
+        // k_core_list), scratch of the position-parallel core search of the long wave-groups (k_core_*).
+        uint32_t *bits = nullptr, *corelist = nullptr, *corecount = nullptr, *coreflags = nullptr;
+        double *corep = nullptr; // latency forms: masked prefix sums of the long wave-groups, packed row numbering
+        void *corepart = nullptr; // their per-row best windows
+        size_t cap_bits = 0, cap_corelist = 0, cap_corecount = 0, cap_corep = 0, cap_corepart = 0;
     } pl[2];
     double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
     bool core_long_list = false; // PLAAC_CORE_LONG_LIST=1 (experiment, read at creation like every other knob)
@@ -110,9 +118,6 @@ struct plaac_ctx {
     uint32_t *d_ccount = nullptr, *d_fbcount = nullptr;
     uint4 *d_fblist = nullptr; // plan items of the proteins the filter tier hands to the exact tier
     size_t cap_clist = 0, cap_ccount = 0, cap_fblist = 0;
-    double *d_corep = nullptr; // latency forms: masked prefix sums of the long wave-groups, packed row numbering
-    void *d_corepart = nullptr; // their per-row best windows
-    size_t cap_corep = 0, cap_corepart = 0;
     bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
     bool sweep_spread = true; // PLAAC_SWEEP_SPREAD=0: every further group of a chain-bound sweep on extra high-class streams
     bool sweep_latency = true; // PLAAC_SWEEP_LATENCY=0: chain-bound sweeps keep the throughput form of k_vit for every wave-group
@@ -147,15 +152,19 @@ struct plaac_ctx {
                            // 1.25 M share): never pipelined.
     uint32_t segment_min_rows = 32768u; // PLAAC_SEGMENT_MIN_ROWS: packed rows from which a call is cut into runs (tests lower it)
     int track_segments = 2; // PLAAC_TRACK_SEGMENTS (1.25 M-sequence share, same-box A/Bs on two boxes: 1 run 21.3 / 21.4 ms, 2 runs 21.2, 4 runs 20.9 / 21.8)
-    uint32_t *d_corelist = nullptr, *d_corecount = nullptr; // k_vit<.., LIST> -> k_core_list
-    size_t cap_corelist = 0, cap_corecount = 0;
     bool core_list = true; // PLAAC_CORE_LIST=0: sweep 3 inside k_vit for every batch
-    uint32_t *d_coreflags = nullptr; // k_core_par -> k_core_chain: proteins of the long groups left to the serial chain
+    // Chain-bound single-point summary calls in MIXED FORMS (round 4, PLAAC_MIXED=0: latency forms for every wave-group as
+    // in round 3): the long wave-groups as one grid (k_long) on a stream of its own - long_stream[call parity], two streams
+    // of the high class -, every other wave-group in the throughput forms on the normal class's role streams.
+    bool mixed = true;
+    uint32_t mixed_groups = 0; // PLAAC_MIXED_GROUPS (tests): the long run takes at least this many wave-groups
+    bool last_mixed = false;
+    hipEvent_t lev[2] = {nullptr, nullptr}; // long run of a call done (per parity)
     bool core_par = true;  // PLAAC_CORE_PAR=0: always the serial masked prefix chain (k_core_chain) in the latency form
     bool core_par_ok = false; // the tables in d_tab pass core_par_tables_ok
     bool fi_int = false;   // the tables in d_tab qualify for FoldIndex in integers (derive_fi_int)
     bool fi_int_allowed = true; // PLAAC_FI_INT=0: always the fp64 form of the filter kernel
-    size_t cap_bits = 0, cap_fwd = 0, cap_bwd = 0;
+    size_t cap_fwd = 0, cap_bwd = 0;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
     uint64_t *d_offsets = nullptr;
@@ -634,9 +643,11 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&ctx->tpev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        for (auto *arr : {ctx->tail_ev2, ctx->ka_done})
+        for (auto *arr : {ctx->tail_ev2, ctx->ka_done, ctx->lev})
             for (int k = 0; k < 2; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if (const char *mx = std::getenv("PLAAC_MIXED")) ctx->mixed = mx[0] != '0';
+        if (const char *mg = std::getenv("PLAAC_MIXED_GROUPS")) ctx->mixed_groups = (uint32_t)std::max(0, std::atoi(mg));
         if ((e = hipMalloc((void **)&ctx->d_huge, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(huge)", e);
         if (const char *ov = std::getenv("PLAAC_OVERLAP")) ctx->overlap = ov[0] == '1';
         if (const char *cl = std::getenv("PLAAC_CORE_LONG_LIST")) ctx->core_long_list = cl[0] == '1';
@@ -729,7 +740,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (std::getenv("PLAAC_STREAM_DEBUG"))
         std::fprintf(stderr, "plaac: plan words polled in %lu calls, stream-synchronised in %lu\n", ctx->polled, ctx->synced);
     if (ctx->d_bwd) (void)hipFree(ctx->d_bwd);
-    void *bufs[] = {ctx->d_tab,        ctx->d_bits,        ctx->d_fwd,         ctx->d_codes,      ctx->d_offsets,
+    void *bufs[] = {ctx->d_tab,        ctx->d_fwd,         ctx->d_codes,      ctx->d_offsets,
                     ctx->d_rows,       ctx->d_trk8,        ctx->d_trk64,       ctx->d_counts,     ctx->pl[0].neff,
                     ctx->pl[0].order,  ctx->pl[0].hist,    ctx->pl[0].grow,    ctx->pl[0].packed, ctx->pl[1].neff,
                     ctx->pl[1].order,  ctx->pl[1].hist,    ctx->pl[1].grow,    ctx->pl[1].packed};
@@ -741,9 +752,14 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
     for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_crow, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount,
-                    (void *)ctx->d_corelist, (void *)ctx->d_corecount, (void *)ctx->d_coreflags,
-                    (void *)ctx->pl[0].lat, (void *)ctx->pl[1].lat, (void *)ctx->d_corep, ctx->d_corepart})
+                    (void *)ctx->pl[0].lat, (void *)ctx->pl[1].lat})
         if (b) (void)hipFree(b);
+    for (auto &pb : ctx->pl)
+        for (void *b : {(void *)pb.bits, (void *)pb.corelist, (void *)pb.corecount, (void *)pb.coreflags, (void *)pb.corep,
+                        pb.corepart})
+            if (b) (void)hipFree(b);
+    for (hipEvent_t e : ctx->lev)
+        if (e) (void)hipEventDestroy(e);
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &set : ctx->ev)
@@ -853,7 +869,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const uint32_t ngroups = (nprot + 63u) / 64u;
     if ((rc = grow(ctx, PL.grow, PL.cap_grow, (size_t)ngroups + 3)) != PLAAC_OK) return rc;
     const bool single = npoints == 1; // one parameter point: hmm0's running sum is computed once (k_fwd / k_win), k_finish
-    if (single && (rc = grow(ctx, PL.lat, PL.cap_lat, 2 * (size_t)nprot)) != PLAAC_OK) return rc;
+    if (single && (rc = grow(ctx, PL.lat, PL.cap_lat, 3 * (size_t)nprot)) != PLAAC_OK) return rc;
     if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
         if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, (size_t)nprot)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_crow, ctx->cap_crow, (size_t)nprot)) != PLAAC_OK) return rc;
@@ -1135,7 +1151,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // previous one, which read the buffers it writes: that call's side streams, and its window kernels up to its tail.
     // (single-point summary calls: measured neutral for track mode and sweeps, whose steps are not bound by their two ends)
     const bool head_aside = ctx->overlap && !ctx->serial && ctx->ncalls > 0 && npoints == 1 && !d_tracks;
-    const hipStream_t sh = !head_aside ? st : (ctx->last_chain_bound ? ctx->auxn[plaac_ctx::R_VIT] : ctx->aux[plaac_ctx::R_VIT]);
+    // (after a call in mixed forms - long run on the high class's Viterbi / forward stream, the other runs on the normal
+    //  class's role streams -: the high class's window stream)
+    const hipStream_t sh = !head_aside ? st
+                           : ctx->last_mixed ? ctx->aux[plaac_ctx::R_WIN]
+                                             : (ctx->last_chain_bound ? ctx->auxn[plaac_ctx::R_VIT] : ctx->aux[plaac_ctx::R_VIT]);
     // (Measured and dropped: the chain kernels - they write the rows - additionally waiting for the caller's stream as it
     //  stands at the entry of the call, which would let the caller order consumers of the row buffers on that stream: the
     //  chains of call k+1 then start behind the whole of call k, 17.8 -> 19.1 ms per 10 M-sequence step, config 2 0.57 ->
@@ -1215,7 +1235,22 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         ctx->latency_mode >= 0 ? ctx->latency_mode == 1 : (uint64_t)ctx->h_pin[2] * 384000ull > total_residues;
     // (track mode too, since round 3: k_fwd_pair<true> / k_bwd_pair store the forward / backward pairs k_post combines)
     const bool latency_mode = !ctx->serial && npoints == 1 && chain_bound;
-    const bool use_core_list = ctx->core_list && !latency_mode && !chain_bound; // (sweeps: one list per group)
+    // MIXED FORMS (round 4; summary mode): only the long wave-groups - the prefix of the plan whose proteins have >= 2048
+    // residues, h_pin[3] groups - take the latency forms, as ONE grid (k_long) on a stream of its own; every other
+    // wave-group takes the throughput forms (fewer instructions in total: one lane per protein in the forward pass, one
+    // window kernel, the pinned Viterbi step, the core list). gl = wave-groups of the long run: all of them when the batch
+    // has no long group or more than the core kernels serve (then the call is the latency form of round 3 in one grid), and
+    // under PLAAC_LATENCY_MODE=1 (the tests force the latency forms on small batches that way); PLAAC_MIXED_GROUPS=n (tests):
+    // at least n groups in the long run.
+    const bool mixed = latency_mode && !d_tracks && ctx->mixed;
+    uint32_t gl = 0u;
+    if (mixed) {
+        const uint32_t lgw = ctx->h_pin[3];
+        gl = (ctx->latency_mode != 1 && lgw > 0u && lgw < CORE_MAX_GROUPS) ? std::min(lgw, ngroups) : ngroups;
+        if (ctx->mixed_groups > 0u && ctx->latency_mode != 1) gl = std::min(std::max(ctx->h_pin[3] < CORE_MAX_GROUPS ? ctx->h_pin[3] : ngroups, ctx->mixed_groups), ngroups);
+    }
+    const bool lat_all = latency_mode && !mixed; // the latency forms as kernels of their own for every wave-group (track mode; PLAAC_MIXED=0)
+    const bool use_core_list = ctx->core_list && ((!latency_mode && !chain_bound) || (mixed && gl < ngroups)); // (sweeps: one list per group)
     // the long wave-groups (proteins of >= 2048 residues) of a single-point call take the position-parallel core search
     // (PLAAC_CORE_LONG_LIST=1, EXPERIMENT: also in the list form of throughput-bound batches, where the listed long
     // proteins are k_core_list's tail. Measured at 10 M sequences: 23.0 against 22.2 ms - the tail was hidden, the extra
@@ -1233,17 +1268,17 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const size_t core_lrows = core_long ? (size_t)ctx->h_pin[4] : 0;
     const size_t core_copies = sweep_lat ? ng : 1; // (the groups of a sweep run side by side: scratch per group)
     if (core_long) { // scratch of k_core_*: the rows of the first CORE_MAX_GROUPS wave-groups
-        if ((rc = grow(ctx, ctx->d_corep, ctx->cap_corep, core_lrows * 1024u * core_copies)) != PLAAC_OK) return rc;
-        char *&cp = reinterpret_cast<char *&>(ctx->d_corepart);
-        if ((rc = grow(ctx, cp, ctx->cap_corepart, core_lrows * 64u * sizeof(CorePart) * core_copies)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, PL.corep, PL.cap_corep, core_lrows * 1024u * core_copies)) != PLAAC_OK) return rc;
+        char *&cp = reinterpret_cast<char *&>(PL.corepart);
+        if ((rc = grow(ctx, cp, PL.cap_corepart, core_lrows * 64u * sizeof(CorePart) * core_copies)) != PLAAC_OK) return rc;
     }
     if (use_core_list) {
-        if ((rc = grow(ctx, ctx->d_corelist, ctx->cap_corelist, (size_t)nprot * ng)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, ctx->d_corecount, ctx->cap_corecount, ng)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, PL.corelist, PL.cap_corelist, (size_t)nprot * ng)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, PL.corecount, PL.cap_corecount, ng)) != PLAAC_OK) return rc;
     }
     if ((rc = grow(ctx, PL.packed, PL.cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
     const size_t bits_stride = total_rows * 64u + 64u; // one traceback-bit buffer per group
-    if ((rc = grow(ctx, ctx->d_bits, ctx->cap_bits, bits_stride * ng)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, PL.bits, PL.cap_bits, bits_stride * ng)) != PLAAC_OK) return rc;
     if (d_tracks) {
         if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_bwd, ctx->cap_bwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
@@ -1263,8 +1298,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             if (g != 0xffffffffu && g > segb.back() && g < ngroups) segb.push_back(g);
         }
     }
+    if (mixed && gl > 0u && gl < ngroups) segb.push_back(gl); // mixed forms: the long run and the rest (packed separately: the
+                                                              // long run starts behind its own few rows)
     segb.push_back(ngroups);
     const size_t ntseg = segb.size() - 1;
+    auto run_is_long = [&](size_t k) { return mixed && segb[k + 1] <= gl; };
     // the Viterbi kernel's own runs (chain-bound sweeps: the long wave-groups apart, see sweep_lat; the forward and window
     // kernels of a sweep stay one launch each: as two they only queue up behind each other)
     std::vector<uint32_t> vsegb = segb;
@@ -1304,7 +1342,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     }
     const std::vector<hipStream_t> &gs = !gs_spread.empty() ? gs_spread : (chain_bound ? ctx->gstreams : ctx->gstreams_n);
     if (!ctx->serial) {
-        if (!chain_bound) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn)
+        if (!chain_bound || mixed) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn);
+                                     // mixed forms: the throughput-form runs likewise, the long run on `hl` below
             sv = ctx->auxn[plaac_ctx::R_VIT];
             sf = ctx->auxn[plaac_ctx::R_FWD];
             sw = ctx->auxn[plaac_ctx::R_WIN];
@@ -1328,8 +1367,12 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if (head_aside && k == 0 && ka_wait) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->ka_done[par ^ 1u], 0));
         return PLAAC_OK;
     };
+    // the stream of the long run (mixed forms): two streams of the high class in turn, so that the long runs of consecutive
+    // overlapping calls run side by side (their scratch exists per call parity)
+    const hipStream_t hl = ctx->aux[par ? plaac_ctx::R_FWD : plaac_ctx::R_VIT];
     // track mode: the backward recurrence is a chain of its own, beside the forward one
-    PL_HIP(ctx, hipEventRecord(evs[E_BWD], sb));
+    // (E_BWD .. E_BWD + 1 time the backward kernels in track mode and the long run in mixed forms)
+    PL_HIP(ctx, hipEventRecord(evs[E_BWD], mixed ? hl : sb));
     for (size_t k = 0; d_tracks && k < ntseg; ++k) {
         const uint32_t first = seg_first(k), cnt = seg_count(k);
         if ((rc = wait_run(sb, k)) != PLAAC_OK) return rc;
@@ -1341,7 +1384,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                                PL.order + first, cnt, gtab0, PL.packed, PL.grow + segb[k], ctx->d_bwd);
         if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tbev[k], sb));
     }
-    PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
+    if (!mixed) PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
 
     // masked core window of the long wave-groups (single-point calls): prefix sums position-parallel on the chain's
     // rounding grid where the tables and the protein allow it (k_core_par), the serial chain for whatever it flags, then
@@ -1351,20 +1394,20 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     auto launch_core_long = [&](const DevTables *tab, uint32_t *gbits, uint32_t c, plaac_row *rows, hipStream_t s,
                                 uint32_t point, size_t copy, bool prefix) -> plaac_status {
         const unsigned lg = ctx->h_pin[3]; // (the kernels re-check every group: lengths >= 65535 are not ordered)
-        double *corep = ctx->d_corep + core_lrows * 1024u * copy;
-        CorePart *corepart = (CorePart *)ctx->d_corepart + core_lrows * 64u * copy;
+        double *corep = PL.corep + core_lrows * 1024u * copy;
+        CorePart *corepart = (CorePart *)PL.corepart + core_lrows * 64u * copy;
         if (prefix) {
             const bool par = copy == 0 && single && ctx->core_par && ctx->core_par_ok &&
                              std::memcmp(&points[point], &ctx->params, sizeof(plaac_params)) == 0;
             if (par) {
-                if (!ctx->d_coreflags)
-                    PL_HIP(ctx, hipMalloc((void **)&ctx->d_coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
-                PL_HIP(ctx, hipMemsetAsync(ctx->d_coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, s));
+                if (!PL.coreflags)
+                    PL_HIP(ctx, hipMalloc((void **)&PL.coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
+                PL_HIP(ctx, hipMemsetAsync(PL.coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, s));
                 hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, s, d_codes, PL.order, nprot, tab,
-                                   PL.grow, gbits, corep, ctx->d_coreflags);
+                                   PL.grow, gbits, corep, PL.coreflags);
             }
             hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, s, PL.order, nprot, tab, PL.packed, PL.grow,
-                               gbits, corep, par ? ctx->d_coreflags : (const uint32_t *)nullptr);
+                               gbits, corep, par ? PL.coreflags : (const uint32_t *)nullptr);
         }
         hipLaunchKernelGGL(k_core_eval, dim3(ctx->h_pin[4]), dim3(64), 0, s, PL.order, nprot, ngroups, PL.grow,
                            corep, corepart, c);
@@ -1385,7 +1428,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             sf = gs[3 * (g - 1) + 1];
             sw = gs[3 * (g - 1) + 2];
         }
-        uint32_t *gbits = ctx->d_bits + bits_stride * g;
+        uint32_t *gbits = PL.bits + bits_stride * g;
         const hipStream_t win3_stream = d_tracks ? sw : sw2;
         // K-B of this group (group 0 was launched before the host round trip; serialised mode launches it last)
         if (g > 0 && !ctx->serial) {
@@ -1394,6 +1437,30 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         // every lane-per-protein kernel below is launched per run of wave-groups (one run unless the call is pipelined,
         // see segb): the run's slice of the plan (`order + first`, its count, `grow + first group`), behind the run's
         // packed copy; sweep groups beyond the first have waited for the whole copy on their own streams
+        // mixed forms: the long run first - forward pairs, Viterbi, the two window roles of the long wave-groups as one grid,
+        // then their core search and their HMMall / HMMvit, all on the long stream (nothing crosses streams)
+        if (mixed) {
+            const uint32_t lcnt = (uint32_t)std::min<uint64_t>((uint64_t)gl * 64u, nprot);
+            SweepTargets tl{};
+            for (int k = 0; k < MAXC; ++k) {
+                tl.c[k] = (uint32_t)points[G.first].corelength;
+                tl.rows[k] = rows0;
+            }
+            tl.stop_after = ctx->vit_stop;
+            tl.long_groups_elsewhere = core_long ? 1u : 0u;
+            tl.first = 0u;
+            if ((rc = wait_run(hl, 0)) != PLAAC_OK) return rc;
+            hipLaunchKernelGGL(k_long, dim3(5u * ((lcnt + KA_THREADS - 1) / KA_THREADS)), dim3(KA_THREADS), 0, hl, d_codes,
+                               d_offsets, PL.neff, PL.order, lcnt, tab, PL.packed, PL.grow, gbits, tl, PL.lat, PL.lat + nprot,
+                               PL.lat + 2 * (size_t)nprot);
+            if (core_long && tl.stop_after == 0u &&
+                (rc = launch_core_long(tab, gbits, tl.c[0], rows0, hl, G.first, 0, true)) != PLAAC_OK)
+                return rc;
+            hipLaunchKernelGGL(k_finish, dim3((lcnt + 255u) / 256u), dim3(256), 0, hl, PL.order, lcnt, rows0, PL.lat,
+                               PL.lat + nprot, PL.lat + 2 * (size_t)nprot);
+            PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], hl));
+            PL_HIP(ctx, hipEventRecord(ctx->lev[par], hl));
+        }
         // forward pass: once per group
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
 #define LAUNCH_FWD(TRK, EXTF, FIRST, CNT, G0)                                                                      \
@@ -1402,12 +1469,13 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                        rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, PL.lat, nprot)
         for (size_t k = 0; k < ntseg; ++k) {
             const uint32_t first = seg_first(k), cnt = seg_count(k);
+            if (run_is_long(k)) continue; // (k_long)
             if (g == 0 && (rc = wait_run(sf, k)) != PLAAC_OK) return rc;
-            if (latency_mode && d_tracks)
+            if (lat_all && d_tracks)
                 hipLaunchKernelGGL(k_fwd_pair<true>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
                                    sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], PL.lat,
                                    ctx->d_fwd);
-            else if (latency_mode)
+            else if (lat_all)
                 hipLaunchKernelGGL(k_fwd_pair<false>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
                                    sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], PL.lat,
                                    (double2 *)nullptr);
@@ -1430,24 +1498,27 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             }
             const bool t0 = timed && m0 == 0;
             tg.stop_after = ctx->vit_stop;
-            tg.long_groups_elsewhere = core_long ? 1u : 0u;
+            tg.long_groups_elsewhere = (core_long && !mixed) ? 1u : 0u; // (mixed forms: the long wave-groups are k_long's)
             if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
             // the core list of this launch: the call's (single point), or the sweep group's own, reused by its launches
-            uint32_t *gl = single ? ctx->d_corelist : ctx->d_corelist + (size_t)nprot * g;
-            uint32_t *gc = single ? ctx->d_corecount : ctx->d_corecount + g;
+            uint32_t *cl_list = single ? PL.corelist : PL.corelist + (size_t)nprot * g;
+            uint32_t *cl_count = single ? PL.corecount : PL.corecount + g;
             if (g == 0 && (rc = wait_run(sv, 0)) != PLAAC_OK) return rc; // (the list is scratch of the chain kernels)
-            if (use_core_list) PL_HIP(ctx, hipMemsetAsync(gc, 0, sizeof(uint32_t), sv));
+            if (use_core_list) PL_HIP(ctx, hipMemsetAsync(cl_count, 0, sizeof(uint32_t), sv));
             for (size_t k = 0; k + 1 < vsegb.size(); ++k) {
                 const uint32_t first = vsegb[k] * 64u;
                 const uint32_t cnt = (uint32_t)(std::min<uint64_t>((uint64_t)vsegb[k + 1] * 64u, nprot) - first);
                 const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
+                if (mixed && run_is_long(k)) continue; // (k_long; vsegb == segb in single-point calls)
                 if (g == 0 && (rc = wait_run(sv, std::min(k, ntseg - 1))) != PLAAC_OK) return rc;
                 tg.first = first;
 #define VIT_ARGS d_codes, d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + vsegb[k], gbits, tg
 #define LAUNCH_VIT(NC) hipLaunchKernelGGL((k_vit<NC>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS)
-#define LAUNCH_VIT_LIST(NC) hipLaunchKernelGGL((k_vit<NC, false, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, gl, gc)
-                if (latency_mode)
-                    hipLaunchKernelGGL((k_vit<1, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS);
+#define LAUNCH_VIT_LIST(NC) hipLaunchKernelGGL((k_vit<NC, false, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, cl_list, cl_count)
+                double *const vend = PL.lat ? PL.lat + 2 * (size_t)nprot : nullptr; // (EXT forms: single-point calls)
+                if (lat_all)
+                    hipLaunchKernelGGL((k_vit<1, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, (uint32_t *)nullptr,
+                                       (uint32_t *)nullptr, vend);
                 else if (sweep_lat && vsegb[k + 1] <= ctx->h_pin[3]) // the run of the long wave-groups
                     switch (nc) {
                     case 1: hipLaunchKernelGGL((k_vit<1, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
@@ -1456,7 +1527,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     default: hipLaunchKernelGGL((k_vit<4, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
                     }
                 else if (single && use_core_list) // throughput-bound: sweep 3 only for proteins that can have a core
-                    hipLaunchKernelGGL((k_vit<1, false, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, gl, gc);
+                    hipLaunchKernelGGL((k_vit<1, false, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, cl_list, cl_count,
+                                       vend);
                 else if (use_core_list) { // sweep groups
                     switch (nc) {
                     case 1: LAUNCH_VIT_LIST(1); break;
@@ -1465,7 +1537,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     default: LAUNCH_VIT_LIST(4); break;
                     }
                 } else if (single) // hmm0's running sum is k_fwd's (k_finish)
-                    hipLaunchKernelGGL((k_vit<1, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS);
+                    hipLaunchKernelGGL((k_vit<1, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, (uint32_t *)nullptr,
+                                       (uint32_t *)nullptr, vend);
                 else
                     switch (nc) {
                     case 1: LAUNCH_VIT(1); break;
@@ -1481,7 +1554,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             // after the runs: the core window of the long wave-groups, then sweep 3 for the listed proteins
             if (tg.stop_after == 0u) {
                 // (the long wave-groups first: the chain of a 36,000-residue protein on the list would be the tail of the step)
-                if (core_long && (latency_mode || (single && use_core_list)) &&
+                if (core_long && !mixed && (latency_mode || (single && use_core_list)) &&
                     (rc = launch_core_long(tab, gbits, tg.c[0], tg.rows[0], sv, G.first, 0, true)) != PLAAC_OK)
                     return rc;
                 for (int k = 0; sweep_lat && k < nc; ++k) // (the path bits of the group: the same for every launch)
@@ -1491,7 +1564,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     const unsigned lgrid = std::min((nprot + KA_THREADS - 1) / KA_THREADS, 2048u);
 #define LAUNCH_CORE_LIST(NC)                                                                                       \
     hipLaunchKernelGGL(k_core_list<NC>, dim3(lgrid), dim3(KA_THREADS), 0, sv, d_codes, total_residues, PL.order, tab, \
-                       PL.packed, PL.grow, gbits, tg, gl, gc)
+                       PL.packed, PL.grow, gbits, tg, cl_list, cl_count)
                     switch (single ? 1 : nc) {
                     case 1: LAUNCH_CORE_LIST(1); break;
                     case 2: LAUNCH_CORE_LIST(2); break;
@@ -1506,13 +1579,14 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             for (size_t k = 0; k < ntseg; ++k) {
                 const uint32_t first = seg_first(k), cnt = seg_count(k);
                 const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
+                if (run_is_long(k)) continue; // (k_long)
                 if (g == 0 && (rc = wait_run(sw, k)) != PLAAC_OK) return rc;
-                if (g == 0 && latency_mode && win3_stream != sw && (rc = wait_run(win3_stream, k)) != PLAAC_OK) return rc;
+                if (g == 0 && lat_all && win3_stream != sw && (rc = wait_run(win3_stream, k)) != PLAAC_OK) return rc;
 #define LAUNCH_WIN(NC, ROLE, STREAM)                                                                               \
     hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, STREAM, d_codes, d_offsets, PL.neff, \
                        PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], tg,                   \
                        PL.lat ? PL.lat + nprot : (double *)nullptr)
-                if (latency_mode) { // two halves side by side (LLR window | MW window + means + hmm0's running sum)
+                if (lat_all) { // two halves side by side (LLR window | MW window + means + hmm0's running sum)
                     LAUNCH_WIN(1, 2, sw);
                     // MW window + means + hmm0's running sum as ONE kernel beside the LLR kernel. (As two kernels on two more
                     // streams they were measured back to back, not side by side: the runtime maps streams onto four hardware
@@ -1556,11 +1630,15 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                   // behind the kernels that produced the other two terms, so that it runs beside the window kernel
         if (!ctx->serial) {
             PL_HIP(ctx, hipEventRecord(ctx->fev[0], sf));
-            PL_HIP(ctx, hipEventRecord(ctx->fev[1], latency_mode ? (d_tracks ? sw : sw2) : sb)); // latency mode: hmm0's total comes from k_win<1,3>
+            PL_HIP(ctx, hipEventRecord(ctx->fev[1], lat_all ? (d_tracks ? sw : sw2) : sb)); // latency forms: hmm0's total comes from k_win<1,3>
             PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[0], 0));
             PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[1], 0));
         }
-        hipLaunchKernelGGL(k_finish, dim3(pb), dim3(256), 0, sv, d_rows[0], PL.lat, PL.lat + nprot, nprot);
+        // (mixed forms: the long run has formed its own on the long stream; here the throughput-form runs)
+        const uint32_t f0 = mixed ? (uint32_t)std::min<uint64_t>((uint64_t)gl * 64u, nprot) : 0u;
+        if (nprot > f0)
+            hipLaunchKernelGGL(k_finish, dim3((nprot - f0 + 255u) / 256u), dim3(256), 0, sv, PL.order + f0, nprot - f0, d_rows[0],
+                               PL.lat, PL.lat + nprot, PL.lat + 2 * (size_t)nprot);
     }
     // posteriors + MAP bytes (track mode): k_post<true, false> of a run needs the run's k_fwd and k_bwd; it goes on the
     // window kernels' stream (they are the first chains to finish) and runs beside the chains of the later runs and the
@@ -1574,12 +1652,12 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->tfev[k], 0));
             PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->tbev[k], 0));
             hipLaunchKernelGGL((k_post<true, false>), dim3(post_grid), dim3(64), 0, sp, d_offsets, PL.neff, PL.order,
-                               nprot, ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, segb[k], segb[k + 1]);
+                               nprot, ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, PL.bits, tp, segb[k], segb[k + 1]);
         }
         PL_HIP(ctx, hipEventRecord(ctx->tpev, sp));
         PL_HIP(ctx, hipStreamWaitEvent(st, ctx->tpev, 0));
         hipLaunchKernelGGL((k_post<false, true>), dim3(post_grid), dim3(64), 0, sv, d_offsets, PL.neff, PL.order, nprot,
-                           ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, 0u, ngroups);
+                           ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, PL.bits, tp, 0u, ngroups);
     }
     if (!ctx->serial) {
         // join: everything enqueued on the side streams so far
@@ -1589,6 +1667,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[3], sb));
         PL_HIP(ctx, hipEventRecord(ctx->jev[4], sw2));
         for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[k], 0));
+        if (mixed) PL_HIP(ctx, hipStreamWaitEvent(st, ctx->lev[par], 0));
 
         for (size_t k = 0; k < 3 * (ng - 1); ++k) {
             PL_HIP(ctx, hipEventRecord(ctx->gjev[k], gs[k]));
@@ -1598,6 +1677,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         // behind the other four - or, for sweeps (streams per group), on the caller's stream behind everything
         if (single) {
             for (int k = 1; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->jev[k], 0));
+            if (mixed) PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->lev[par], 0));
             PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], sv));
         } else {
             PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], st));
@@ -1605,10 +1685,11 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     }
     if (d_tracks && total_rows && ctx->serial)
         hipLaunchKernelGGL((k_post<true, true>), dim3(post_grid), dim3(64), 0, st, d_offsets, PL.neff, PL.order, nprot,
-                           ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, ctx->d_bits, tp, 0u, ngroups);
+                           ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, PL.bits, tp, 0u, ngroups);
     PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
     PL_HIP(ctx, hipGetLastError());
     ctx->last_chain_bound = chain_bound;
+    ctx->last_mixed = mixed;
     ctx->last_single_summary = single && !d_tracks;
     ctx->ncalls++;
     return PLAAC_OK;

@@ -2,10 +2,15 @@
 //
 // The reference scores a proteome in one serial loop (cli/src/plaac.java:755 summary, :610 tracks). Proteins are
 // independent given the parameter tables, so a node shards a batch BY SEQUENCE: one scoring context (plaac_ctx: its own
-// device, streams and work buffers) per listed device, one host thread per context, contiguous ranges of records with
-// about equal residue counts, rows written straight to their place in the caller's array (input order is restored
-// for free), no data-path collective. The only reduction is the 22 x int64 background histogram, summed on the host.
-// Pure host code on top of the single-device C ABI.
+// device, streams and work buffers) per listed device, one host thread per context, no data-path collective. The only
+// reduction is the 22 x int64 background histogram, summed on the host.
+// ONE partitioner for every multi-GPU layer (plaac_shard_plan; plaac_amd/dist.py and bench.py call it through ctypes):
+// records sorted by length, dealt to the shards in turn - SURVEY 8(e) G1's "sort by length, deal" - so that every shard
+// gets the same residue count AND the same share of the long proteins whose serial chains bound a step. A shard's records
+// are gathered into one contiguous batch (they are not contiguous in the input), its rows and tracks are scattered back
+// to their places in the caller's arrays: input order is restored on the host.
+// A plaac_node_batch keeps every shard resident on its device (upload once; histogram, scoring, the two-pass run and
+// parameter sweeps reuse it). Pure host code on top of the single-device C ABI.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -23,24 +28,22 @@ struct plaac_node {
     std::string err;
 };
 
+// a batch whose shards are resident on the devices of a node
+struct plaac_node_batch {
+    plaac_node *node = nullptr;
+    uint32_t nprot = 0;
+    struct Part {
+        plaac_batch *b = nullptr;
+        std::vector<uint32_t> idx;      // records of this shard, ascending input order
+        std::vector<uint64_t> src_off;  // idx.size() + 1: offsets of those records in the CALLER'S residue numbering ...
+        std::vector<uint64_t> offs;     // ... and in the shard's own (starting at 0)
+    };
+    std::vector<Part> part;
+};
+
 namespace {
 
 thread_local std::string g_node_create_err;
-
-// record ranges [cut[k], cut[k+1]) of about equal residue counts
-std::vector<uint32_t> balanced_cuts(const uint64_t *offsets, uint32_t nprot, size_t parts) {
-    std::vector<uint32_t> cut(parts + 1, nprot);
-    cut[0] = 0;
-    const uint64_t total = offsets[nprot] - offsets[0];
-    for (size_t k = 1; k < parts; ++k) {
-        const uint64_t target = offsets[0] + total / parts * k;
-        const uint64_t *it = std::lower_bound(offsets, offsets + nprot + 1, target);
-        uint32_t r = (uint32_t)(it - offsets);
-        if (r > nprot) r = nprot;
-        cut[k] = std::max(r, cut[k - 1]);
-    }
-    return cut;
-}
 
 // Runs body(k) for k = 0 .. parts-1, part 0 on the calling thread, the others on threads of their own. Nothing escapes:
 // an exception inside a part (std::bad_alloc of its offsets copy ...) or from std::thread's constructor becomes a status
@@ -74,28 +77,9 @@ void run_parts(size_t parts, std::vector<plaac_status> &st, std::vector<std::str
     for (auto &t : pool) t.join();
 }
 
-template <class Fn>
-plaac_status for_each_part(plaac_node *node, const uint64_t *offsets, uint32_t nprot, Fn &&fn) {
-    const size_t parts = node->ctx.size();
-    std::vector<uint32_t> cut;
-    std::vector<plaac_status> st;
-    std::vector<std::string> why;
-    try {
-        cut = balanced_cuts(offsets, nprot, parts);
-        st.assign(parts, PLAAC_OK);
-        why.assign(parts, std::string());
-    } catch (...) {
-        node->err = "out of host memory";
-        return PLAAC_ERR_NOMEM;
-    }
-    run_parts(parts, st, why, [&](size_t k) {
-        const uint32_t a = cut[k], b = cut[k + 1];
-        if (a == b) return;
-        std::vector<uint64_t> offs((size_t)(b - a) + 1); // the shard's own offsets, starting at 0
-        for (uint32_t i = a; i <= b; ++i) offs[i - a] = offsets[i] - offsets[a];
-        st[k] = fn(k, a, b, offs.data());
-    });
-    for (size_t k = 0; k < parts; ++k)
+// first failing part -> node->err and its status
+plaac_status parts_status(plaac_node *node, const std::vector<plaac_status> &st, const std::vector<std::string> &why) {
+    for (size_t k = 0; k < st.size(); ++k)
         if (st[k] != PLAAC_OK) {
             node->err = std::string("device ") + std::to_string(node->device[k]) + ": " +
                         (why[k].empty() ? plaac_last_error(node->ctx[k]) : why[k].c_str());
@@ -197,41 +181,261 @@ plaac_status plaac_node_set_params(plaac_node *node, const plaac_params *params)
     return PLAAC_OK;
 }
 
+plaac_status plaac_node_set_overlap(plaac_node *node, int on) {
+    if (!node) return PLAAC_ERR_ARG;
+    for (size_t k = 0; k < node->ctx.size(); ++k) {
+        const plaac_status st = plaac_ctx_set_overlap(node->ctx[k], on);
+        if (st != PLAAC_OK) return node_fail(node, st, "plaac_ctx_set_overlap failed");
+    }
+    return PLAAC_OK;
+}
+
+// ---- the one partitioner -------------------------------------------------------------------------------------------
+plaac_status plaac_shard_plan(const uint64_t *offsets, uint32_t nprot, uint32_t parts, uint32_t *index_out,
+                              uint32_t *part_start) {
+    if (!part_start || parts == 0 || (nprot && (!offsets || !index_out))) return PLAAC_ERR_ARG;
+    try {
+        // stable sort by descending length: LSD radix sort on ~length (four 8-bit passes, stable by construction)
+        std::vector<uint32_t> key(nprot), idx(nprot), key2(nprot), idx2(nprot);
+        for (uint32_t i = 0; i < nprot; ++i) {
+            if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0xfffffffeull) return PLAAC_ERR_ARG;
+            key[i] = ~(uint32_t)(offsets[i + 1] - offsets[i]);
+            idx[i] = i;
+        }
+        for (int pass = 0; pass < 4; ++pass) {
+            const int sh = 8 * pass;
+            size_t cnt[257] = {0};
+            for (uint32_t i = 0; i < nprot; ++i) ++cnt[((key[i] >> sh) & 255u) + 1];
+            bool trivial = false;
+            for (int b = 0; b < 256; ++b) {
+                if (cnt[b + 1] == nprot) trivial = true; // every key has the same digit: nothing moves
+                cnt[b + 1] += cnt[b];
+            }
+            if (trivial) continue;
+            for (uint32_t i = 0; i < nprot; ++i) {
+                const size_t d = cnt[(key[i] >> sh) & 255u]++;
+                key2[d] = key[i];
+                idx2[d] = idx[i];
+            }
+            key.swap(key2);
+            idx.swap(idx2);
+        }
+        // deal: position pos of the sorted order goes to shard (lap even ? col : parts - 1 - col), lap = pos / parts
+        std::vector<uint32_t> &owner = key; // (reused)
+        std::vector<size_t> count(parts, 0);
+        for (uint32_t pos = 0; pos < nprot; ++pos) {
+            const uint32_t lap = pos / parts, col = pos % parts;
+            const uint32_t o = (lap & 1u) ? parts - 1u - col : col;
+            owner[idx[pos]] = o;
+            ++count[o];
+        }
+        part_start[0] = 0;
+        for (uint32_t k = 0; k < parts; ++k) part_start[k + 1] = part_start[k] + (uint32_t)count[k];
+        std::vector<uint32_t> fill(part_start, part_start + parts);
+        for (uint32_t i = 0; i < nprot; ++i) index_out[fill[owner[i]]++] = i; // ascending input order inside a shard
+    } catch (...) {
+        return PLAAC_ERR_NOMEM;
+    }
+    return PLAAC_OK;
+}
+
+// ---- resident batches ----------------------------------------------------------------------------------------------
+plaac_status plaac_node_batch_upload(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                                     plaac_node_batch **out) {
+    if (!node || !out || (nprot && !offsets)) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_batch_upload: null argument");
+    *out = nullptr;
+    if (nprot && offsets[nprot] && !codes) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_batch_upload: null codes");
+    const size_t parts = node->ctx.size();
+    plaac_node_batch *nb = nullptr;
+    std::vector<uint32_t> index, start;
+    std::vector<plaac_status> st;
+    std::vector<std::string> why;
+    try {
+        nb = new plaac_node_batch();
+        nb->node = node;
+        nb->nprot = nprot;
+        nb->part.resize(parts);
+        index.resize(nprot);
+        start.resize(parts + 1);
+        st.assign(parts, PLAAC_OK);
+        why.assign(parts, std::string());
+    } catch (...) {
+        delete nb;
+        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+    }
+    const plaac_status ps = plaac_shard_plan(offsets, nprot, (uint32_t)parts, index.data(), start.data());
+    if (ps != PLAAC_OK) {
+        delete nb;
+        return node_fail(node, ps, ps == PLAAC_ERR_NOMEM ? "out of host memory" : "offsets must be non-decreasing, records below 2^32 residues");
+    }
+    run_parts(parts, st, why, [&](size_t k) {
+        plaac_node_batch::Part &P = nb->part[k];
+        const uint32_t n = start[k + 1] - start[k];
+        P.idx.assign(index.begin() + start[k], index.begin() + start[k + 1]);
+        P.src_off.resize((size_t)n + 1);
+        P.offs.resize((size_t)n + 1);
+        P.offs[0] = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t r = P.idx[i];
+            P.src_off[i] = offsets[r];
+            P.offs[i + 1] = P.offs[i] + (offsets[r + 1] - offsets[r]);
+        }
+        P.src_off[n] = 0;
+        if (n == 0) return;
+        // the shard's records as one contiguous batch (runs of neighbouring records are copied in one piece)
+        std::vector<uint8_t> shard((size_t)P.offs[n]);
+        for (uint32_t i = 0; i < n;) {
+            uint32_t j = i + 1;
+            while (j < n && P.idx[j] == P.idx[j - 1] + 1u) ++j;
+            std::memcpy(shard.data() + P.offs[i], codes + offsets[P.idx[i]], (size_t)(P.offs[j] - P.offs[i]));
+            i = j;
+        }
+        st[k] = plaac_batch_upload(node->ctx[k], shard.data(), P.offs.data(), n, &P.b);
+    });
+    const plaac_status bad = parts_status(node, st, why);
+    if (bad != PLAAC_OK) {
+        plaac_node_batch_free(nb);
+        return bad;
+    }
+    *out = nb;
+    return PLAAC_OK;
+}
+
+void plaac_node_batch_free(plaac_node_batch *nb) {
+    if (!nb) return;
+    for (auto &P : nb->part)
+        if (P.b) plaac_batch_free(P.b);
+    delete nb;
+}
+
+plaac_status plaac_node_batch_histogram(plaac_node_batch *nb, int64_t counts[PLAAC_NAA]) {
+    if (!nb || !nb->node) return PLAAC_ERR_ARG;
+    plaac_node *node = nb->node;
+    if (!counts) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_batch_histogram: null counts");
+    for (int i = 0; i < PLAAC_NAA; ++i) counts[i] = 0;
+    const size_t parts = nb->part.size();
+    std::vector<int64_t> part;
+    std::vector<plaac_status> st;
+    std::vector<std::string> why;
+    try {
+        part.assign(parts * PLAAC_NAA, 0);
+        st.assign(parts, PLAAC_OK);
+        why.assign(parts, std::string());
+    } catch (...) {
+        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+    }
+    run_parts(parts, st, why, [&](size_t k) {
+        if (nb->part[k].b) st[k] = plaac_batch_histogram(nb->part[k].b, part.data() + k * PLAAC_NAA);
+    });
+    const plaac_status bad = parts_status(node, st, why);
+    if (bad != PLAAC_OK) return bad;
+    for (size_t k = 0; k < parts; ++k) // the one reduction of the path: 22 x int64 per device
+        for (int i = 0; i < PLAAC_NAA; ++i) counts[i] += part[k * PLAAC_NAA + i];
+    return PLAAC_OK;
+}
+
+// rows[point][record]: every shard scores its resident records (npoints == 0: the contexts' current parameters, with
+// tracks when asked for) and puts its rows / track slices back to their places in the caller's arrays
+static plaac_status node_batch_run(plaac_node_batch *nb, const plaac_params *points, uint32_t npoints, plaac_row *const *rows,
+                                   const plaac_tracks *tracks) {
+    plaac_node *node = nb->node;
+    const size_t parts = nb->part.size();
+    const uint32_t nout = npoints ? npoints : 1u;
+    std::vector<plaac_status> st;
+    std::vector<std::string> why;
+    try {
+        st.assign(parts, PLAAC_OK);
+        why.assign(parts, std::string());
+    } catch (...) {
+        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+    }
+    run_parts(parts, st, why, [&](size_t k) {
+        const plaac_node_batch::Part &P = nb->part[k];
+        const size_t n = P.idx.size();
+        if (!P.b || n == 0) return;
+        std::vector<plaac_row> tmp(n * nout);
+        std::vector<plaac_row *> tp(nout);
+        for (uint32_t i = 0; i < nout; ++i) tp[i] = tmp.data() + (size_t)i * n;
+        std::vector<uint8_t> t8;
+        std::vector<double> t64;
+        plaac_tracks tt{};
+        const uint64_t total = P.offs[n];
+        if (tracks) { // the shard's tracks in its own residue numbering, scattered record by record afterwards
+            t8.resize(2 * (size_t)total + 2);
+            t64.resize(10 * (size_t)total + 10);
+            double *b = t64.data();
+            tt = plaac_tracks{t8.data(), t8.data() + total, b,           b + total,     b + 2 * total, b + 3 * total,
+                              b + 4 * total, b + 5 * total, b + 6 * total, b + 7 * total, b + 8 * total, b + 9 * total};
+        }
+        st[k] = npoints ? plaac_batch_sweep(P.b, points, npoints, tp.data()) : plaac_batch_score(P.b, tp[0], tracks ? &tt : nullptr);
+        if (st[k] != PLAAC_OK) return;
+        for (uint32_t i = 0; i < nout; ++i)
+            for (size_t r = 0; r < n; ++r) rows[i][P.idx[r]] = tp[i][r];
+        if (tracks) {
+            uint8_t *const d8[2] = {tracks->vit, tracks->map};
+            const uint8_t *const s8[2] = {tt.vit, tt.map};
+            double *const dd[10] = {tracks->charge, tracks->hydro,      tracks->fi,     tracks->plaacllr, tracks->papa,
+                                    tracks->fix2,   tracks->plaacllrx2, tracks->papax2, tracks->post0,    tracks->post1};
+            const double *const sd[10] = {tt.charge, tt.hydro, tt.fi, tt.plaacllr, tt.papa, tt.fix2, tt.plaacllrx2, tt.papax2,
+                                          tt.post0,  tt.post1};
+            for (size_t r = 0; r < n; ++r) {
+                const uint64_t so = P.offs[r], len = P.offs[r + 1] - so, dof = P.src_off[r];
+                for (int a = 0; a < 2; ++a) std::memcpy(d8[a] + dof, s8[a] + so, (size_t)len);
+                for (int a = 0; a < 10; ++a) std::memcpy(dd[a] + dof, sd[a] + so, (size_t)len * sizeof(double));
+            }
+        }
+    });
+    return parts_status(node, st, why);
+}
+
+plaac_status plaac_node_batch_score(plaac_node_batch *nb, plaac_row *rows, const plaac_tracks *tracks) {
+    if (!nb || !nb->node) return PLAAC_ERR_ARG;
+    if (nb->nprot == 0) return PLAAC_OK;
+    if (!rows) return node_fail(nb->node, PLAAC_ERR_ARG, "plaac_node_batch_score: null rows");
+    if (tracks) {
+        const void *all[] = {tracks->vit,  tracks->map,  tracks->charge,     tracks->hydro,  tracks->fi,    tracks->plaacllr,
+                             tracks->papa, tracks->fix2, tracks->plaacllrx2, tracks->papax2, tracks->post0, tracks->post1};
+        for (const void *q : all)
+            if (!q) return node_fail(nb->node, PLAAC_ERR_ARG, "tracks struct has a null array");
+    }
+    plaac_row *one[1] = {rows};
+    return node_batch_run(nb, nullptr, 0, one, tracks);
+}
+
+plaac_status plaac_node_batch_sweep(plaac_node_batch *nb, const plaac_params *points, uint32_t npoints,
+                                    plaac_row *const *rows) {
+    if (!nb || !nb->node) return PLAAC_ERR_ARG;
+    if (nb->nprot == 0 || npoints == 0) return PLAAC_OK;
+    if (!points || !rows) return node_fail(nb->node, PLAAC_ERR_ARG, "plaac_node_batch_sweep: null argument");
+    for (uint32_t i = 0; i < npoints; ++i)
+        if (!rows[i]) return node_fail(nb->node, PLAAC_ERR_ARG, "plaac_node_batch_sweep: null row array");
+    return node_batch_run(nb, points, npoints, rows, nullptr);
+}
+
+// ---- one-shot forms: upload, use, free -----------------------------------------------------------------------------
 plaac_status plaac_node_histogram(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
                                   int64_t counts[PLAAC_NAA]) {
     if (!node || !counts || (nprot && !offsets)) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_histogram: null argument");
     for (int i = 0; i < PLAAC_NAA; ++i) counts[i] = 0;
     if (nprot == 0) return PLAAC_OK;
-    std::vector<int64_t> part;
-    try {
-        part.assign(node->ctx.size() * PLAAC_NAA, 0);
-    } catch (...) {
-        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
-    }
-    const plaac_status st = for_each_part(node, offsets, nprot, [&](size_t k, uint32_t a, uint32_t b, const uint64_t *offs) {
-        return plaac_histogram(node->ctx[k], codes + offsets[a], offs, b - a, part.data() + k * PLAAC_NAA);
-    });
+    plaac_node_batch *nb = nullptr;
+    plaac_status st = plaac_node_batch_upload(node, codes, offsets, nprot, &nb);
     if (st != PLAAC_OK) return st;
-    for (size_t k = 0; k < node->ctx.size(); ++k) // the one reduction of the path: 22 x int64 per device
-        for (int i = 0; i < PLAAC_NAA; ++i) counts[i] += part[k * PLAAC_NAA + i];
-    return PLAAC_OK;
+    st = plaac_node_batch_histogram(nb, counts);
+    plaac_node_batch_free(nb);
+    return st;
 }
 
 plaac_status plaac_node_score(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
                               plaac_row *rows, const plaac_tracks *tracks) {
     if (!node || (nprot && (!offsets || !rows))) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_score: null argument");
     if (nprot == 0) return PLAAC_OK;
-    return for_each_part(node, offsets, nprot, [&](size_t k, uint32_t a, uint32_t b, const uint64_t *offs) {
-        plaac_tracks t, *tp = nullptr;
-        if (tracks) { // per-residue arrays are indexed like `codes`: the shard's slice starts at its first residue
-            const uint64_t o = offsets[a];
-            t = plaac_tracks{tracks->vit + o,   tracks->map + o,  tracks->charge + o,     tracks->hydro + o,
-                             tracks->fi + o,    tracks->plaacllr + o, tracks->papa + o,   tracks->fix2 + o,
-                             tracks->plaacllrx2 + o, tracks->papax2 + o, tracks->post0 + o, tracks->post1 + o};
-            tp = &t;
-        }
-        return plaac_score(node->ctx[k], codes + offsets[a], offs, b - a, rows + a, tp);
-    });
+    plaac_node_batch *nb = nullptr;
+    plaac_status st = plaac_node_batch_upload(node, codes, offsets, nprot, &nb);
+    if (st != PLAAC_OK) return st;
+    st = plaac_node_batch_score(nb, rows, tracks);
+    plaac_node_batch_free(nb);
+    return st;
 }
 
 } // extern "C"

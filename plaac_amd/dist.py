@@ -38,17 +38,13 @@ def init_process_group(backend=None):
 
 
 def shard_plan(offsets, world):
-    """Deal proteins to ranks so that every rank gets about the same number of RESIDUES:
-    sort by length (descending) and deal in a boustrophedon (0..w-1, w-1..0, ...). Returns a list of
-    index arrays (ascending input order inside each shard, so per-shard output stays in file order)."""
-    lens = np.diff(np.asarray(offsets).astype(np.int64))
-    order = np.argsort(-lens, kind="stable")
-    pos = np.arange(len(order))
-    lap, col = pos // world, pos % world
-    owner_sorted = np.where(lap % 2 == 0, col, world - 1 - col)
-    owner = np.empty(len(order), dtype=np.int64)
-    owner[order] = owner_sorted
-    return [np.nonzero(owner == r)[0] for r in range(world)]
+    """Deal proteins to ranks so that every rank gets about the same number of RESIDUES and the same share of the long
+    proteins: sort by length (descending, stable) and deal in a boustrophedon (0..w-1, w-1..0, ...). This IS the C
+    partitioner of the node layer (plaac_shard_plan, plaac_amd/csrc/plaac_node.cpp) - one scheme for C and Python.
+    Returns a list of int64 index arrays (ascending input order inside each shard, so per-shard output stays in file
+    order)."""
+    from . import native
+    return [p.astype(np.int64) for p in native.shard_plan(np.asarray(offsets).astype(np.uint64), world)]
 
 
 def extract_shard(codes, offsets, idx):
@@ -65,18 +61,15 @@ def extract_shard(codes, offsets, idx):
     return out, new_off
 
 
-def shard_plan_torch(offsets, world, rank):
-    """shard_plan(offsets, world)[rank] on a torch device (bench.py cuts a 10 M-sequence proteome that lives in HBM):
-    the same deal - stable descending-length sort, boustrophedon over the ranks - as an ascending int64 index tensor."""
+def shard_plan_torch(offsets, world, rank=None):
+    """shard_plan for offsets that live on a torch device (bench.py cuts a 10 M-sequence proteome resident in HBM): the
+    offsets come to the host once (8 bytes per record), the C partitioner deals them, the index arrays go back as
+    ascending int64 tensors on the same device. rank=None: the plans of all ranks (a list), else that rank's."""
     import torch
-    offsets = offsets.to(torch.int64)
-    lens = offsets[1:] - offsets[:-1]
-    order = torch.sort(-lens, stable=True).indices
-    pos = torch.arange(order.numel(), device=offsets.device, dtype=torch.int64)
-    lap, col = pos // world, pos % world
-    owner_sorted = torch.where(lap % 2 == 0, col, world - 1 - col)
-    mine = order[owner_sorted == rank]
-    return torch.sort(mine).values
+    plans = shard_plan(offsets.detach().cpu().numpy(), world)
+    if rank is not None:
+        return torch.from_numpy(plans[rank]).to(offsets.device)
+    return [torch.from_numpy(p).to(offsets.device) for p in plans]
 
 
 def extract_shard_torch(codes, offsets, idx):

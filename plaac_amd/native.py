@@ -73,6 +73,8 @@ EXPORTS = (
     "plaac_fi_integer_form", "plaac_calibration_reads", "plaac_clock_probe", "plaac_ctx_set_overlap",
     "plaac_device_count", "plaac_node_create", "plaac_node_destroy", "plaac_node_size", "plaac_node_ctx",
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
+    "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
+    "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free",
 )
 
 _lib = None
@@ -140,6 +142,14 @@ def load():
     L.plaac_node_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.plaac_node_last_error.argtypes = [C.c_void_p]
     L.plaac_node_last_error.restype = C.c_char_p
+    L.plaac_node_set_overlap.argtypes = [C.c_void_p, C.c_int]
+    L.plaac_shard_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.plaac_node_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.plaac_node_batch_histogram.argtypes = [C.c_void_p, C.c_void_p]
+    L.plaac_node_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.plaac_node_batch_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.plaac_node_batch_free.argtypes = [C.c_void_p]
+    L.plaac_node_batch_free.restype = None
     L.plaac_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.plaac_batch_histogram.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -387,8 +397,80 @@ class Node:
         return (rows, tr) if tracks else rows
 
 
+    def set_overlap(self, on=True):
+        self._check(self._L.plaac_node_set_overlap(self._h, 1 if on else 0))
+
+    def upload(self, codes, offsets):
+        """plaac_node_batch_upload: the batch cut with plaac_shard_plan, every shard resident on its device"""
+        return NodeBatch(self, codes, offsets)
+
+
+class NodeBatch:
+    """plaac_node_batch: one upload for the background pass, the scoring pass(es) and parameter sweeps on all devices of a
+    node; rows / tracks come back in input order."""
+
+    def __init__(self, node, codes, offsets):
+        self.node = node
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.nprot = len(offsets) - 1
+        self.total = int(offsets[-1]) if self.nprot > 0 else 0
+        self._h = C.c_void_p()
+        node._check(node._L.plaac_node_batch_upload(node._h, codes.ctypes.data, offsets.ctypes.data, self.nprot,
+                                                    C.byref(self._h)))
+
+    def histogram(self):
+        counts = np.zeros(NAA, dtype=np.int64)
+        self.node._check(self.node._L.plaac_node_batch_histogram(self._h, counts.ctypes.data))
+        return counts
+
+    def score(self, tracks=False):
+        rows = np.zeros(self.nprot, dtype=ROW_DTYPE)
+        tr, tptr, T = None, None, None
+        if tracks:
+            tr = alloc_tracks(self.total)
+            T = Tracks(**{k: tr[k].ctypes.data for k in TRACK_U8 + TRACK_F64})
+            tptr = C.addressof(T)
+        self.node._check(self.node._L.plaac_node_batch_score(self._h, rows.ctypes.data, tptr))
+        return (rows, tr) if tracks else rows
+
+    def sweep(self, param_sets):
+        param_sets = list(param_sets)
+        pts = (Params * len(param_sets))(*param_sets)
+        rows = [np.zeros(self.nprot, dtype=ROW_DTYPE) for _ in param_sets]
+        ptrs = (C.c_void_p * len(rows))(*[r.ctypes.data for r in rows])
+        self.node._check(self.node._L.plaac_node_batch_sweep(self._h, C.addressof(pts), len(param_sets), C.addressof(ptrs)))
+        return rows
+
+    def close(self):
+        if self._h:
+            self.node._L.plaac_node_batch_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def device_count():
     return int(load().plaac_device_count())
+
+
+def shard_plan(offsets, parts):
+    """plaac_shard_plan (the one partitioner of every multi-GPU layer: sort by length, deal): a list of `parts` uint32
+    index arrays, the records of each shard in ascending input order. Host-only."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    nprot = len(offsets) - 1
+    index = np.empty(max(nprot, 0), dtype=np.uint32)
+    start = np.zeros(parts + 1, dtype=np.uint32)
+    st = load().plaac_shard_plan(offsets.ctypes.data, max(nprot, 0), int(parts), index.ctypes.data, start.ctypes.data)
+    if st != PLAAC_OK:
+        raise PlaacError(st, "plaac_shard_plan rejected its arguments")
+    return [index[int(start[k]):int(start[k + 1])] for k in range(parts)]
 
 
 class Batch:

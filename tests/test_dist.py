@@ -74,6 +74,35 @@ def test_shard_plan_balances_residues_and_keeps_every_protein():
             assert np.all(np.diff(p) > 0)
 
 
+def _numpy_shard_plan(offsets, world):
+    """the scheme restated in numpy (sort by length, deal): stable descending-length sort, boustrophedon"""
+    lens = np.diff(np.asarray(offsets).astype(np.int64))
+    order = np.argsort(-lens, kind="stable")
+    pos = np.arange(len(order))
+    lap, col = pos // world, pos % world
+    owner_sorted = np.where(lap % 2 == 0, col, world - 1 - col)
+    owner = np.empty(len(order), dtype=np.int64)
+    owner[order] = owner_sorted
+    return [np.nonzero(owner == r)[0] for r in range(world)]
+
+
+def test_the_c_partitioner_is_the_length_dealt_scheme():
+    """plaac_shard_plan (C: the node layer, dist.py and bench.py all call it) against the numpy restatement, incl. ties in
+    length (stability), empty records, more shards than records, one record, no record"""
+    from plaac_amd import dist as pdist
+    rng = np.random.default_rng(11)
+    cases = [np.concatenate([rng.integers(0, 300, 4000), [70000, 36000, 36000, 0, 0, 11]]), rng.integers(5, 8, 1000),
+             np.array([5, 5, 5]), np.array([7]), np.array([], dtype=np.int64), rng.integers(0, 1 << 20, 513)]
+    for lens in cases:
+        offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens)
+        for world in (1, 2, 3, 5, 8, 16):
+            got, want = pdist.shard_plan(offs, world), _numpy_shard_plan(offs, world)
+            assert len(got) == world
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w)
+
+
 def test_extract_shard_roundtrip():
     from plaac_amd import dist as pdist
     rng = np.random.default_rng(1)

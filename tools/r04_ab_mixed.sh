@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/r04_ab_mixed.sh - GPU suite in both forms, then same-box A/B of PLAAC_MIXED=0|1 on the share, cfg2, cfg3 and the full batch
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+timeout 900 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -5
+PLAAC_MIXED_GROUPS=3 timeout 900 python3 -m pytest tests/test_gpu_parity.py tests/test_real_proteomes.py -x -q -m gpu 2>&1 | tail -3
+line() { python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'ms/step', d['ms_per_step'], 'alone', (d['config'].get('step_by_itself') or {}).get('ms_per_step'), {k: round(x,3) for k,x in d['roofline']['kernel_ms'].items()}, (d.get('cpu_baseline') or {}).get('gpu_rows_match_oracle'))"; }
+for rep in 1 2; do for m in 0 1; do
+  PLAAC_MIXED=$m timeout 300 python3 bench.py --nprot 1250000 --no-e2e --no-cpu-baseline --no-clock-probe --no-host-leg --steps 40 2>/dev/null | line "share mixed=$m"
+done; done
+for m in 0 1; do
+  PLAAC_MIXED=$m timeout 300 python3 bench.py --config 2 --steps 200 --no-e2e --no-cpu-baseline --no-clock-probe --no-host-leg 2>/dev/null | line "cfg2 mixed=$m"
+  PLAAC_MIXED=$m timeout 300 python3 bench.py --config 3 --steps 100 --no-e2e --no-cpu-baseline --no-clock-probe --no-host-leg 2>/dev/null | line "cfg3 mixed=$m"
+done
+timeout 300 python3 bench.py --nprot 1250000 --no-e2e --no-clock-probe --no-host-leg --steps 40 2>/dev/null | line "share mixed=1 checked"
+timeout 300 python3 bench.py --no-e2e --no-cpu-baseline --no-clock-probe --no-host-leg --steps 20 2>/dev/null | line "cfg4 full"
