@@ -254,6 +254,9 @@ plaac_status plaac_node_batch_score(plaac_node_batch *b, plaac_row *rows, const 
 plaac_status plaac_node_batch_sweep(plaac_node_batch *b, const plaac_params *points, uint32_t npoints,
                                     plaac_row *const *rows);
 void plaac_node_batch_free(plaac_node_batch *b);
+/* records / residues of the uploaded batch: the sizes of the row and track arrays the calls above fill */
+uint32_t plaac_node_batch_records(const plaac_node_batch *b);
+uint64_t plaac_node_batch_residues(const plaac_node_batch *b);
 
 /* Summary mode scores the FoldIndex / PAPA window tracks in two tiers: a filter that decides from error-bounded
  * prefix sums, and the exact fixed-order kernel for every protein the bounds cannot decide (results are identical

@@ -37,4 +37,20 @@ final class PlaacNative {
     /** rowsOut: nprot * ROW_BYTES; tracks: null (summary mode) or TRACKS direct buffers of total-residue elements */
     static native void score(long node, ByteBuffer codes, ByteBuffer offsets, int nprot, ByteBuffer rowsOut,
                              ByteBuffer[] tracks);
+
+    // ---- resident batches: ONE upload for the background pass (plaac.java:377-384), the scoring pass (:755) and every
+    // point of a parameter sweep - the reference runs a sweep as one main() per point (plaac.java:337-353,
+    // web/lib/server.rb:152-155), i.e. it reads and encodes the same proteome once per point. The batch is cut over the
+    // node's devices by length-sorted dealing (plaac_shard_plan); rows come back in input order.
+    // A direct ByteBuffer holds at most 2^31 - 1 bytes: upload a proteome above 2.1 G residues as several batches.
+    /** uploads the batch to the node's devices; returns the plaac_node_batch handle */
+    static native long batchUpload(long node, ByteBuffer codes, ByteBuffer offsets, int nprot);
+    static native void batchFree(long batch);
+    static native void batchHistogram(long batch, long[] counts22);
+    /** scores with the node's CURRENT parameters (nodeSetParams between calls: the two-pass run on one upload) */
+    static native void batchScore(long batch, ByteBuffer rowsOut, ByteBuffer[] tracks);
+    /** npoints parameter sets (params: npoints * paramsBytes() bytes) over the resident batch; rowsOut[i]: nprot * ROW_BYTES */
+    static native void batchSweep(long batch, ByteBuffer params, int npoints, ByteBuffer[] rowsOut);
+    /** pipelines of batches: consecutive scoring calls of a context may overlap on the device (plaac_ctx_set_overlap) */
+    static native void nodeSetOverlap(long node, boolean on);
 }

@@ -6,6 +6,7 @@
 #include <jni.h>
 
 #include <cstdint>
+#include <new>
 #include <string>
 
 #include "plaac_native.h"
@@ -133,6 +134,103 @@ JNIEXPORT void JNICALL Java_PlaacNative_score(JNIEnv *env, jclass, jlong node, j
     }
     if (plaac_node_score(node_of(node), c, off, (uint32_t)nprot, rows, tp) != PLAAC_OK)
         raise(env, node_error(node));
+}
+
+// ---- resident batches (plaac_node_batch_*). A batch handle does not know its node's error text once it is gone, so the
+// natives below take their message from plaac_node_last_error of the node the batch was uploaded to, which the shim keeps
+// beside the handle: the Java side passes the batch handle only, the C side looks the node up in the batch.
+struct BatchRef {
+    plaac_node_batch *b;
+    plaac_node *node;
+};
+static BatchRef *ref_of(jlong h) { return reinterpret_cast<BatchRef *>(static_cast<intptr_t>(h)); }
+
+JNIEXPORT jlong JNICALL Java_PlaacNative_batchUpload(JNIEnv *env, jclass, jlong node, jobject codes, jobject offsets,
+                                                     jint nprot) {
+    if (nprot < 0) {
+        raise(env, "batchUpload: negative nprot");
+        return 0;
+    }
+    if (!node_of(node)) {
+        raise(env, "null node handle");
+        return 0;
+    }
+    const uint64_t *off = (const uint64_t *)direct(env, offsets, 8ull * ((uint64_t)nprot + 1), "offsets");
+    if (!off) return 0;
+    const uint8_t *c = (const uint8_t *)direct(env, codes, off[nprot], "codes");
+    if (!c) return 0;
+    plaac_node_batch *b = nullptr;
+    if (plaac_node_batch_upload(node_of(node), c, off, (uint32_t)nprot, &b) != PLAAC_OK) {
+        raise(env, node_error(node));
+        return 0;
+    }
+    BatchRef *r = new (std::nothrow) BatchRef{b, node_of(node)};
+    if (!r) {
+        plaac_node_batch_free(b);
+        raise(env, "out of host memory");
+        return 0;
+    }
+    return (jlong) reinterpret_cast<intptr_t>(r);
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_batchFree(JNIEnv *, jclass, jlong batch) {
+    BatchRef *r = ref_of(batch);
+    if (!r) return;
+    plaac_node_batch_free(r->b);
+    delete r;
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_batchHistogram(JNIEnv *env, jclass, jlong batch, jlongArray counts22) {
+    BatchRef *r = ref_of(batch);
+    if (!r) return raise(env, "null batch handle");
+    if (!counts22 || env->GetArrayLength(counts22) != PLAAC_NAA) return raise(env, "batchHistogram: a long[22] is required");
+    int64_t counts[PLAAC_NAA];
+    if (plaac_node_batch_histogram(r->b, counts) != PLAAC_OK) return raise(env, plaac_node_last_error(r->node));
+    jlong out[PLAAC_NAA];
+    for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (jlong)counts[i];
+    env->SetLongArrayRegion(counts22, 0, PLAAC_NAA, out);
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_batchScore(JNIEnv *env, jclass, jlong batch, jobject rowsOut, jobjectArray tracks) {
+    BatchRef *r = ref_of(batch);
+    if (!r) return raise(env, "null batch handle");
+    const uint64_t nprot = plaac_node_batch_records(r->b), totalResidues = plaac_node_batch_residues(r->b);
+    plaac_row *rows = (plaac_row *)direct(env, rowsOut, (uint64_t)nprot * sizeof(plaac_row), "rowsOut");
+    if (!rows) return;
+    plaac_tracks t, *tp = nullptr;
+    if (tracks) {
+        if (env->GetArrayLength(tracks) != 12) return raise(env, "tracks must be 12 direct buffers");
+        void *a[12];
+        for (int i = 0; i < 12; ++i) {
+            a[i] = direct(env, env->GetObjectArrayElement(tracks, i), (uint64_t)totalResidues * (i < 2 ? 1u : 8u), "tracks[i]");
+            if (!a[i]) return;
+        }
+        t = plaac_tracks{(uint8_t *)a[0], (uint8_t *)a[1], (double *)a[2], (double *)a[3], (double *)a[4], (double *)a[5],
+                         (double *)a[6],  (double *)a[7],  (double *)a[8], (double *)a[9], (double *)a[10], (double *)a[11]};
+        tp = &t;
+    }
+    if (plaac_node_batch_score(r->b, rows, tp) != PLAAC_OK) raise(env, plaac_node_last_error(r->node));
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_batchSweep(JNIEnv *env, jclass, jlong batch, jobject params, jint npoints,
+                                                   jobjectArray rowsOut) {
+    BatchRef *r = ref_of(batch);
+    if (!r) return raise(env, "null batch handle");
+    if (npoints < 0 || npoints > 4096) return raise(env, "batchSweep: between 0 and 4096 points");
+    const uint64_t nprot = plaac_node_batch_records(r->b);
+    if (!rowsOut || env->GetArrayLength(rowsOut) != npoints) return raise(env, "batchSweep: one row buffer per point");
+    const plaac_params *P = (const plaac_params *)direct(env, params, (uint64_t)npoints * plaac_sizeof_params(), "params");
+    if (!P) return;
+    plaac_row *rows[4096];
+    for (jint i = 0; i < npoints; ++i) {
+        rows[i] = (plaac_row *)direct(env, env->GetObjectArrayElement(rowsOut, i), (uint64_t)nprot * sizeof(plaac_row), "rowsOut[i]");
+        if (!rows[i]) return;
+    }
+    if (plaac_node_batch_sweep(r->b, P, (uint32_t)npoints, rows) != PLAAC_OK) raise(env, plaac_node_last_error(r->node));
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_nodeSetOverlap(JNIEnv *env, jclass, jlong node, jboolean on) {
+    if (plaac_node_set_overlap(node_of(node), on ? 1 : 0) != PLAAC_OK) raise(env, node_error(node));
 }
 
 } // extern "C"

@@ -158,6 +158,7 @@ struct plaac_ctx {
     // of the high class -, every other wave-group in the throughput forms on the normal class's role streams.
     bool mixed = true;
     uint32_t mixed_groups = 0; // PLAAC_MIXED_GROUPS (tests): the long run takes at least this many wave-groups
+    uint32_t mixed_min_rest = 2048; // PLAAC_MIXED_MIN_REST: wave-groups outside the long run from which the forms are mixed
     bool last_mixed = false;
     hipEvent_t lev[2] = {nullptr, nullptr}; // long run of a call done (per parity)
     bool core_par = true;  // PLAAC_CORE_PAR=0: always the serial masked prefix chain (k_core_chain) in the latency form
@@ -648,6 +649,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if (const char *mx = std::getenv("PLAAC_MIXED")) ctx->mixed = mx[0] != '0';
         if (const char *mg = std::getenv("PLAAC_MIXED_GROUPS")) ctx->mixed_groups = (uint32_t)std::max(0, std::atoi(mg));
+        if (const char *mr = std::getenv("PLAAC_MIXED_MIN_REST")) ctx->mixed_min_rest = (uint32_t)std::max(1, std::atoi(mr));
         if ((e = hipMalloc((void **)&ctx->d_huge, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(huge)", e);
         if (const char *ov = std::getenv("PLAAC_OVERLAP")) ctx->overlap = ov[0] == '1';
         if (const char *cl = std::getenv("PLAAC_CORE_LONG_LIST")) ctx->core_long_list = cl[0] == '1';
@@ -963,7 +965,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         uint32_t base, len; // a segment of the centre list: first slot, slots (its count is d_ccount[segment index])
     };
     std::vector<KbSeg> kb_segs; // of the filter group
-    bool kb_refine_pending = false;
+    hipStream_t kb_side = nullptr; // mixed forms: the stream of the long wave-groups' filter kernel (set with the forms)
+    bool maybe_huge = true;        // false once the host knows from the plan words that no protein has >= 65,535 residues
     auto launch_tracks = [&](size_t g) -> plaac_status { // K-B: needs only the order, not the packed copy
         if (!d_tracks) {
             const long base = kb_base(g);
@@ -1034,14 +1037,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                     // the exact values at the chosen centres (k_refine_centres) of one list segment; in lane form on a
                     // stream of its own, so that a chunk is refined while the filter kernel walks the next one
                     // (a stream of the priority class the chain kernels do NOT use in this batch: its queues are free)
-                    const hipStream_t srf = skb;
                     auto refine_segment = [&](uint32_t base, uint32_t len, hipStream_t after) -> plaac_status {
                         const size_t sg = kb_segs.size();
                         kb_segs.push_back(KbSeg{base, len});
-                        if (srf != after) {
-                            PL_HIP(ctx, hipEventRecord(ctx->kbev[sg], after));
-                            PL_HIP(ctx, hipStreamWaitEvent(srf, ctx->kbev[sg], 0));
-                        }
+                        const hipStream_t srf = after; // (on the stream of the kernel that filled the segment)
                         // a resident grid that strides over the list: 8 one-wave blocks of 20 KB per CU hold the LDS of every
                         // CU until the list is through - 7 per CU when the next call may plan beside this kernel (its
                         // planning kernels take 8 / 16 KB per block; with 32 KB they waited for this kernel's end: 3.3 ms)
@@ -1057,14 +1056,25 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                         // descending-length plan) stay with the stream form. Called after the packed copy has been enqueued.
                         const uint32_t lgroups = std::min<uint32_t>(ctx->h_pin[3], ngroups);
                         const uint32_t nlong = std::min<uint64_t>((uint64_t)lgroups * 64u, nprot);
+                        // Mixed forms (kb_side set): the long wave-groups' filter kernel and its refine launch - chains of
+                        // 36,000-residue proteins, 0.3 - 0.7 ms in which the caller's stream did nothing wide - go on a side
+                        // stream (the throughput-form window stream, idle most of a step), behind the list counters'
+                        // reset; the exact tier below waits for them. The caller's stream is what a pipeline of batches is
+                        // bound by (its kernels of consecutive calls run strictly one after the other).
+                        const hipStream_t slong = (kb_side && !ctx->serial) ? kb_side : skb;
                         if (nlong) {
+                            if (slong != skb) {
+                                PL_HIP(ctx, hipEventRecord(ctx->kbev[plaac_ctx::KB_MAXSEG - 1], skb));
+                                PL_HIP(ctx, hipStreamWaitEvent(slong, ctx->kbev[plaac_ctx::KB_MAXSEG - 1], 0));
+                            }
                             // (four proteins per block instead of 32: lane k of a block takes protein blockIdx + k * gridDim, so
                             //  a larger grid leaves the lanes from 4 on without one - the long proteins spread over 8 x the waves)
                             hipLaunchKernelGGL(k_tracks20f<true>, dim3((nlong + 3u) / 4u),
-                                               dim3(64), 0, skb, d_codes, PL.order, nlong, total_residues, tab,
+                                               dim3(64), 0, slong, d_codes, PL.order, nlong, total_residues, tab,
                                                ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount,
                                                ctx->d_fblist, ctx->d_fbcount);
-                            if ((rc = refine_segment(0u, nlong, skb)) != PLAAC_OK) return rc;
+                            if ((rc = refine_segment(0u, nlong, slong)) != PLAAC_OK) return rc;
+                            if (slong != skb) PL_HIP(ctx, hipEventRecord(ctx->jev[5], slong));
                         }
                         // one launch per run of the packed copy, behind the run's copy
                         const std::vector<uint32_t> &runs = *kb_runs;
@@ -1083,24 +1093,18 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                                                PL.packed, PL.grow, rows, huge, ctx->d_clist + base, ctx->d_crow + base,
                                                ctx->d_ccount + sg, ctx->d_fblist, ctx->d_fbcount);
                             if (k == last_run && tail_allowed) { // nothing after this point reads the plan or the packed copy
-                                whole_plan();
+                                if (maybe_huge) whole_plan();
+                                else whole_plan_launched = true; // (the host has the plan words here: no protein of 65,535 residues)
                                 PL_HIP(ctx, hipEventRecord(ctx->tail_ev2[par], skb));
                                 ctx->tail_open2[par] = true;
                             }
                             if ((rc = refine_segment(base, len, sk)) != PLAAC_OK) return rc;
                         }
                         filter_group = (long)g;
-                        if (srf != skb) { // the caller's stream goes on (exact tier, later groups) and is joined here
-                            PL_HIP(ctx, hipEventRecord(ctx->jev[5], srf));
-                            kb_refine_pending = true;
-                        }
+                        if (nlong && slong != skb) PL_HIP(ctx, hipStreamWaitEvent(skb, ctx->jev[5], 0)); // the fallback list is complete
                         hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
                                            d_offsets, PL.neff, PL.order, nprot, total_residues, tab, rows, tp, huge,
                                            0u, ctx->d_fblist, ctx->d_fbcount);
-                        if (kb_refine_pending) {
-                            PL_HIP(ctx, hipStreamWaitEvent(skb, ctx->jev[5], 0));
-                            kb_refine_pending = false;
-                        }
                     } else if (gfi[g] && ctx->fi_int_allowed)
                         hipLaunchKernelGGL(k_tracks20f<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, PL.order, nprot,
                                            total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
@@ -1129,7 +1133,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             if (d_tracks)
                 hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, PL.neff,
                                    PL.order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint4 *)nullptr, (const uint32_t *)nullptr);
-            else if (!whole_plan_launched)
+            else if (!whole_plan_launched && maybe_huge)
                 whole_plan();
         } else if (wmax <= 32) LAUNCH_KB(128);
         else if (wmax <= 96) LAUNCH_KB(256);
@@ -1151,10 +1155,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     // previous one, which read the buffers it writes: that call's side streams, and its window kernels up to its tail.
     // (single-point summary calls: measured neutral for track mode and sweeps, whose steps are not bound by their two ends)
     const bool head_aside = ctx->overlap && !ctx->serial && ctx->ncalls > 0 && npoints == 1 && !d_tracks;
-    // (after a call in mixed forms - long run on the high class's Viterbi / forward stream, the other runs on the normal
-    //  class's role streams -: the high class's window stream)
+    // (after a call in mixed forms: the stream this call's long run will take - hlA of this parity, idle since the call before
+    //  the previous one, whose last event the head waits for anyway)
     const hipStream_t sh = !head_aside ? st
-                           : ctx->last_mixed ? ctx->aux[plaac_ctx::R_WIN]
+                           : ctx->last_mixed ? ctx->aux[par ? plaac_ctx::R_FWD : plaac_ctx::R_VIT]
                                              : (ctx->last_chain_bound ? ctx->auxn[plaac_ctx::R_VIT] : ctx->aux[plaac_ctx::R_VIT]);
     // (Measured and dropped: the chain kernels - they write the rows - additionally waiting for the caller's stream as it
     //  stands at the entry of the call, which would let the caller order consumers of the row buffers on that stream: the
@@ -1246,7 +1250,10 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     uint32_t gl = 0u;
     if (mixed) {
         const uint32_t lgw = ctx->h_pin[3];
-        gl = (ctx->latency_mode != 1 && lgw > 0u && lgw < CORE_MAX_GROUPS) ? std::min(lgw, ngroups) : ngroups;
+        // (a split pays when the other wave-groups are many - their throughput forms save instructions, but cost a dozen more
+        //  launches: config 2, 92 wave-groups, 0.53 -> 0.70 ms per step when split, bound by the host's launch calls)
+        gl = (ctx->latency_mode != 1 && lgw > 0u && lgw < CORE_MAX_GROUPS && lgw < ngroups && ngroups - lgw >= ctx->mixed_min_rest)
+                 ? lgw : ngroups;
         if (ctx->mixed_groups > 0u && ctx->latency_mode != 1) gl = std::min(std::max(ctx->h_pin[3] < CORE_MAX_GROUPS ? ctx->h_pin[3] : ngroups, ctx->mixed_groups), ngroups);
     }
     const bool lat_all = latency_mode && !mixed; // the latency forms as kernels of their own for every wave-group (track mode; PLAAC_MIXED=0)
@@ -1309,16 +1316,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if (sweep_lat && ctx->h_pin[3] < ngroups) vsegb = {0u, ctx->h_pin[3], ngroups};
     auto seg_first = [&](size_t k) { return segb[k] * 64u; };
     auto seg_count = [&](size_t k) { return (uint32_t)(std::min<uint64_t>((uint64_t)segb[k + 1] * 64u, nprot) - seg_first(k)); };
-    for (size_t k = 0; k < ntseg; ++k) {
-        const uint32_t first = seg_first(k), cnt = seg_count(k);
-        hipLaunchKernelGGL(k_pack, dim3((cnt + 15u) / 16u), dim3(256), 0, spk, d_codes, d_offsets, PL.neff,
-                           PL.order + first, cnt, total_residues, PL.grow + segb[k], PL.packed);
-        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->pkev[k], spk));
-    }
-    PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], spk));
-    pack_events = &ctx->pkev[0];
-    kb_runs = &segb;
-    if (!ctx->serial && kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
     // Streams of the sweep groups after the first. Chain-bound sweeps: the Viterbi and forward chains of the longest
     // protein bound the call once per GROUP, and streams map onto four hardware queues per priority class - with every
     // group's streams in the high class (ten streams on four queues) the chains of different groups queued up behind each
@@ -1343,17 +1340,12 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     const std::vector<hipStream_t> &gs = !gs_spread.empty() ? gs_spread : (chain_bound ? ctx->gstreams : ctx->gstreams_n);
     if (!ctx->serial) {
         if (!chain_bound || mixed) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn);
-                                     // mixed forms: the throughput-form runs likewise, the long run on `hl` below
+                                     // mixed forms: the throughput-form runs likewise, the long run on hlA / hlB below
             sv = ctx->auxn[plaac_ctx::R_VIT];
             sf = ctx->auxn[plaac_ctx::R_FWD];
             sw = ctx->auxn[plaac_ctx::R_WIN];
             sb = ctx->auxn[plaac_ctx::R_BWD];
             sw2 = ctx->auxn[plaac_ctx::R_WIN2];
-        }
-        // (the role streams wait for the packed copy run by run, see wait_run; the streams of further sweep groups for all)
-        for (size_t k = 0; k < 3 * (ng - 1); ++k) {
-            PL_HIP(ctx, hipStreamWaitEvent(gs[k], evs[E_PACK + 1], 0));
-            if (head_aside) PL_HIP(ctx, hipStreamWaitEvent(gs[k], ctx->ka_done[par ^ 1u], 0));
         }
     }
     const bool ka_wait = d_tracks || !single || !ctx->last_single_summary || chain_bound != ctx->last_chain_bound;
@@ -1367,25 +1359,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if (head_aside && k == 0 && ka_wait) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->ka_done[par ^ 1u], 0));
         return PLAAC_OK;
     };
-    // the stream of the long run (mixed forms): two streams of the high class in turn, so that the long runs of consecutive
-    // overlapping calls run side by side (their scratch exists per call parity)
-    const hipStream_t hl = ctx->aux[par ? plaac_ctx::R_FWD : plaac_ctx::R_VIT];
-    // track mode: the backward recurrence is a chain of its own, beside the forward one
-    // (E_BWD .. E_BWD + 1 time the backward kernels in track mode and the long run in mixed forms)
-    PL_HIP(ctx, hipEventRecord(evs[E_BWD], mixed ? hl : sb));
-    for (size_t k = 0; d_tracks && k < ntseg; ++k) {
-        const uint32_t first = seg_first(k), cnt = seg_count(k);
-        if ((rc = wait_run(sb, k)) != PLAAC_OK) return rc;
-        if (latency_mode)
-            hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, sb,
-                               PL.order + first, cnt, gtab0, PL.packed, PL.grow + segb[k], ctx->d_bwd);
-        else
-            hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sb, d_offsets, PL.neff,
-                               PL.order + first, cnt, gtab0, PL.packed, PL.grow + segb[k], ctx->d_bwd);
-        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tbev[k], sb));
-    }
-    if (!mixed) PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
-
     // masked core window of the long wave-groups (single-point calls): prefix sums position-parallel on the chain's
     // rounding grid where the tables and the protein allow it (k_core_par), the serial chain for whatever it flags, then
     // every window per packed row and the ordered reduction
@@ -1415,6 +1388,85 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
                            gbits, (const CorePart *)corepart, rows, c);
         return PLAAC_OK;
     };
+    // mixed forms: the long run's streams, per call parity (two pairs of the high class's four): A carries the call's head
+    // (plan, packed copy of the long run), k_long and, at the end, the event "the chain kernels of this call are through";
+    // B the Viterbi pass of the long wave-groups and their core search (2.5 + 0.5 ms beside the 3.2 ms forward chain)
+    const hipStream_t hlA = ctx->aux[par ? plaac_ctx::R_FWD : plaac_ctx::R_VIT];
+    const hipStream_t hlB = ctx->aux[par ? plaac_ctx::R_WIN2 : plaac_ctx::R_WIN];
+    // the packed copy, run by run. Mixed forms: the long run's few rows on the head's stream, and the long run is enqueued
+    // before anything else (measured: the host needs 0.5 ms for the window-track launches, during which the 3.2 ms chain
+    // did not start); the other wave-groups' copy goes on the forward stream (not in front of the long chain).
+    for (size_t k = 0; k < ntseg; ++k) {
+        const uint32_t first = seg_first(k), cnt = seg_count(k);
+        const hipStream_t sp = (mixed && !run_is_long(k)) ? sf : spk;
+        if (sp != spk) PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->pkev[0], 0)); // (the row offsets: behind k_scan_u32)
+        hipLaunchKernelGGL(k_pack, dim3((cnt + 15u) / 16u), dim3(256), 0, sp, d_codes, d_offsets, PL.neff,
+                           PL.order + first, cnt, total_residues, PL.grow + segb[k], PL.packed);
+        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->pkev[k], sp));
+        if (k == 0 && mixed) {
+            PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], spk));
+            const DevTables *tab = gtab0;
+            plaac_row *rows0 = d_rows[0];
+            uint32_t *gbits = PL.bits;
+            const uint32_t lcnt = (uint32_t)std::min<uint64_t>((uint64_t)gl * 64u, nprot);
+            SweepTargets tl{};
+            for (int j = 0; j < MAXC; ++j) {
+                tl.c[j] = (uint32_t)points[0].corelength;
+                tl.rows[j] = rows0;
+            }
+            tl.stop_after = ctx->vit_stop;
+            tl.long_groups_elsewhere = core_long ? 1u : 0u;
+            tl.first = 0u;
+            double *const lmarg = PL.lat, *const h0 = PL.lat + nprot, *const vend = PL.lat + 2 * (size_t)nprot;
+            if ((rc = wait_run(hlA, 0)) != PLAAC_OK) return rc;
+            if ((rc = wait_run(hlB, 0)) != PLAAC_OK) return rc;
+            PL_HIP(ctx, hipEventRecord(evs[E_BWD], hlA));
+            hipLaunchKernelGGL(k_long, dim3(4u * ((lcnt + KA_THREADS - 1) / KA_THREADS)), dim3(KA_THREADS), 0, hlA, d_offsets,
+                               PL.neff, PL.order, lcnt, tab, PL.packed, PL.grow, tl, lmarg, h0);
+            hipLaunchKernelGGL((k_vit<1, true, true>), dim3((lcnt + KA_THREADS - 1) / KA_THREADS), dim3(KA_THREADS), 0, hlB,
+                               d_codes, d_offsets, PL.neff, PL.order, lcnt, tab, PL.packed, PL.grow, gbits, tl,
+                               (uint32_t *)nullptr, (uint32_t *)nullptr, vend);
+            if (core_long && tl.stop_after == 0u &&
+                (rc = launch_core_long(tab, gbits, tl.c[0], rows0, hlB, 0u, 0, true)) != PLAAC_OK)
+                return rc;
+            PL_HIP(ctx, hipEventRecord(ctx->lev[par], hlB));
+            PL_HIP(ctx, hipStreamWaitEvent(hlA, ctx->lev[par], 0));
+            hipLaunchKernelGGL(k_finish, dim3((lcnt + 255u) / 256u), dim3(256), 0, hlA, PL.order, lcnt, rows0, lmarg, h0, vend);
+            PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], hlA));
+        }
+    }
+    if (!mixed) PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], spk));
+    // (the role streams wait for the packed copy run by run, see wait_run; the streams of further sweep groups for all)
+    for (size_t k = 0; !ctx->serial && k < 3 * (ng - 1); ++k) {
+        PL_HIP(ctx, hipStreamWaitEvent(gs[k], evs[E_PACK + 1], 0));
+        if (head_aside) PL_HIP(ctx, hipStreamWaitEvent(gs[k], ctx->ka_done[par ^ 1u], 0));
+    }
+    pack_events = &ctx->pkev[0];
+    kb_runs = &segb;
+    // (mixed forms: the window-track launches - a dozen calls, 0.5 ms of host time - come after the throughput-form runs have
+    //  been enqueued: the caller's stream is still busy with the previous call's tail, the chip is not)
+    const bool kb_deferred = mixed && kb_after_pack;
+    if (mixed) {
+        kb_side = sw;
+        maybe_huge = (uint64_t)ctx->h_pin[2] * 16u >= 65535u;
+    }
+    if (!ctx->serial && kb_after_pack && !kb_deferred && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
+    // track mode: the backward recurrence is a chain of its own, beside the forward one
+    // (E_BWD .. E_BWD + 1 time the backward kernels in track mode and the long run in mixed forms)
+    if (!mixed) PL_HIP(ctx, hipEventRecord(evs[E_BWD], sb));
+    for (size_t k = 0; d_tracks && k < ntseg; ++k) {
+        const uint32_t first = seg_first(k), cnt = seg_count(k);
+        if ((rc = wait_run(sb, k)) != PLAAC_OK) return rc;
+        if (latency_mode)
+            hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, sb,
+                               PL.order + first, cnt, gtab0, PL.packed, PL.grow + segb[k], ctx->d_bwd);
+        else
+            hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sb, d_offsets, PL.neff,
+                               PL.order + first, cnt, gtab0, PL.packed, PL.grow + segb[k], ctx->d_bwd);
+        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tbev[k], sb));
+    }
+    if (!mixed) PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
+
     const hipStream_t sv0 = sv, sf0 = sf, sw0 = sw;
     for (size_t g = 0; g < ng; ++g) {
         const Group &G = groups[g];
@@ -1437,30 +1489,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         // every lane-per-protein kernel below is launched per run of wave-groups (one run unless the call is pipelined,
         // see segb): the run's slice of the plan (`order + first`, its count, `grow + first group`), behind the run's
         // packed copy; sweep groups beyond the first have waited for the whole copy on their own streams
-        // mixed forms: the long run first - forward pairs, Viterbi, the two window roles of the long wave-groups as one grid,
-        // then their core search and their HMMall / HMMvit, all on the long stream (nothing crosses streams)
-        if (mixed) {
-            const uint32_t lcnt = (uint32_t)std::min<uint64_t>((uint64_t)gl * 64u, nprot);
-            SweepTargets tl{};
-            for (int k = 0; k < MAXC; ++k) {
-                tl.c[k] = (uint32_t)points[G.first].corelength;
-                tl.rows[k] = rows0;
-            }
-            tl.stop_after = ctx->vit_stop;
-            tl.long_groups_elsewhere = core_long ? 1u : 0u;
-            tl.first = 0u;
-            if ((rc = wait_run(hl, 0)) != PLAAC_OK) return rc;
-            hipLaunchKernelGGL(k_long, dim3(5u * ((lcnt + KA_THREADS - 1) / KA_THREADS)), dim3(KA_THREADS), 0, hl, d_codes,
-                               d_offsets, PL.neff, PL.order, lcnt, tab, PL.packed, PL.grow, gbits, tl, PL.lat, PL.lat + nprot,
-                               PL.lat + 2 * (size_t)nprot);
-            if (core_long && tl.stop_after == 0u &&
-                (rc = launch_core_long(tab, gbits, tl.c[0], rows0, hl, G.first, 0, true)) != PLAAC_OK)
-                return rc;
-            hipLaunchKernelGGL(k_finish, dim3((lcnt + 255u) / 256u), dim3(256), 0, hl, PL.order, lcnt, rows0, PL.lat,
-                               PL.lat + nprot, PL.lat + 2 * (size_t)nprot);
-            PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], hl));
-            PL_HIP(ctx, hipEventRecord(ctx->lev[par], hl));
-        }
         // forward pass: once per group
         if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
 #define LAUNCH_FWD(TRK, EXTF, FIRST, CNT, G0)                                                                      \
@@ -1626,6 +1654,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             }
         }
     }
+    if (kb_deferred && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
     if (single) { // HMMall / HMMvit from lmarginalprob, lviterbiprob (in the row) and hmm0's total: on the Viterbi stream,
                   // behind the kernels that produced the other two terms, so that it runs beside the window kernel
         if (!ctx->serial) {
@@ -1667,7 +1696,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventRecord(ctx->jev[3], sb));
         PL_HIP(ctx, hipEventRecord(ctx->jev[4], sw2));
         for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[k], 0));
-        if (mixed) PL_HIP(ctx, hipStreamWaitEvent(st, ctx->lev[par], 0));
 
         for (size_t k = 0; k < 3 * (ng - 1); ++k) {
             PL_HIP(ctx, hipEventRecord(ctx->gjev[k], gs[k]));
@@ -1675,9 +1703,16 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         }
         // "the side streams of this call are through" as ONE event (overlapping calls wait for it): on the Viterbi stream
         // behind the other four - or, for sweeps (streams per group), on the caller's stream behind everything
-        if (single) {
+        if (mixed) {
+            // on the long run's own stream, behind its last kernel: nothing of the NEXT call is ever enqueued there (the next
+            // use of this stream is the head of the call after it, which waits for this event anyway), so no role stream is
+            // held up by it (on the Viterbi stream, round 3's place, the next call's Viterbi kernel waited for this call's
+            // 3 ms long run)
+            for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(hlA, ctx->jev[k], 0));
+            PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], hlA));
+            PL_HIP(ctx, hipStreamWaitEvent(st, ctx->ka_done[par], 0));
+        } else if (single) {
             for (int k = 1; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->jev[k], 0));
-            if (mixed) PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->lev[par], 0));
             PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], sv));
         } else {
             PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], st));

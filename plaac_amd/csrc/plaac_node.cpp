@@ -32,6 +32,7 @@ struct plaac_node {
 struct plaac_node_batch {
     plaac_node *node = nullptr;
     uint32_t nprot = 0;
+    uint64_t total = 0;
     struct Part {
         plaac_batch *b = nullptr;
         std::vector<uint32_t> idx;      // records of this shard, ascending input order
@@ -254,6 +255,7 @@ plaac_status plaac_node_batch_upload(plaac_node *node, const uint8_t *codes, con
         nb = new plaac_node_batch();
         nb->node = node;
         nb->nprot = nprot;
+        nb->total = nprot ? offsets[nprot] - offsets[0] : 0;
         nb->part.resize(parts);
         index.resize(nprot);
         start.resize(parts + 1);
@@ -300,6 +302,9 @@ plaac_status plaac_node_batch_upload(plaac_node *node, const uint8_t *codes, con
     *out = nb;
     return PLAAC_OK;
 }
+
+uint32_t plaac_node_batch_records(const plaac_node_batch *nb) { return nb ? nb->nprot : 0u; }
+uint64_t plaac_node_batch_residues(const plaac_node_batch *nb) { return nb ? nb->total : 0ull; }
 
 void plaac_node_batch_free(plaac_node_batch *nb) {
     if (!nb) return;

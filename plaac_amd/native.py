@@ -74,7 +74,8 @@ EXPORTS = (
     "plaac_device_count", "plaac_node_create", "plaac_node_destroy", "plaac_node_size", "plaac_node_ctx",
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
-    "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free",
+    "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
+    "plaac_node_batch_residues",
 )
 
 _lib = None
@@ -150,6 +151,10 @@ def load():
     L.plaac_node_batch_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.plaac_node_batch_free.argtypes = [C.c_void_p]
     L.plaac_node_batch_free.restype = None
+    L.plaac_node_batch_records.argtypes = [C.c_void_p]
+    L.plaac_node_batch_records.restype = C.c_uint32
+    L.plaac_node_batch_residues.argtypes = [C.c_void_p]
+    L.plaac_node_batch_residues.restype = C.c_uint64
     L.plaac_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.plaac_batch_histogram.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

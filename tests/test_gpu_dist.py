@@ -101,6 +101,44 @@ def test_node_over_two_contexts_equals_one_context():
         native.Node(P, [99])
 
 
+def test_node_resident_batch_two_pass_and_sweep_equal_independent_oracle_runs():
+    """plaac_node_batch_* over {0, 0}: ONE upload of the (length-dealt) shards serves the background pass, the scoring pass
+    with the parameters built from it (the reference's two passes over one input, plaac.java:377-384 then :755) and the
+    nine-point sweep of BASELINE config 5 (the reference: one main() per point, plaac.java:337-353); every table against
+    an independent oracle run, tracks against a single context; overlap switched on for the node's contexts."""
+    from oracle import oracle_ctypes as oc
+    from plaac_amd import native, synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(3, nprot=1500, seed=9, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+    nprot = len(offs) - 1
+    for devices in ([0, 0], [0, 0, 0]):
+        with native.Node(P, devices) as node:
+            node.set_overlap(True)
+            with node.upload(codes, offs) as nb:
+                counts = nb.histogram()
+                assert np.array_equal(counts, oc.histogram(codes, offs))
+                bgc = counts.astype(np.float64)
+                node.set_params(native.make_params(alpha=0.5, bgcounts=bgc))
+                rows = nb.score()
+                want = oc.score_batch(oc.build_params(alpha=0.5, bgcounts=bgc), codes, offs, nthreads=4)
+                assert rows.tobytes() == want.tobytes(), "two-pass rows on one upload differ from the oracle"
+                rows_t, tr = nb.score(tracks=True)
+                assert rows_t.tobytes() == want.tobytes()
+                with native.Context(native.make_params(alpha=0.5, bgcounts=bgc)) as c1:
+                    _, wtr = c1.score(codes, offs, tracks=True)
+                for k in native.TRACK_U8 + native.TRACK_F64:
+                    assert tr[k].tobytes() == wtr[k].tobytes(), k
+                grid = [(a, c) for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)]
+                got = nb.sweep([native.make_params(alpha=a, corelength=c, bgcounts=bgc) for a, c in grid])
+                for (a, c), g in zip(grid, got):
+                    w = oc.score_batch(oc.build_params(alpha=a, corelength=c, bgcounts=bgc), codes, offs, nthreads=4)
+                    assert g.tobytes() == w.tobytes(), ("sweep point", a, c)
+                assert len(got) == 9 and len(got[0]) == nprot
+    # the shards are the length-dealt ones of plaac_shard_plan (same as plaac_amd.dist.shard_plan), not contiguous ranges
+    plan = native.shard_plan(offs, 2)
+    assert np.any(np.diff(plan[0]) > 1) and sorted(np.concatenate(plan).tolist()) == list(range(nprot))
+
+
 def test_bench_two_ranks_strong_scaling_line(tmp_path):
     """bench.py at N = 2 (its default at N > 1: ONE proteome cut by plaac_amd.dist.shard_plan over the ranks, rows
     gathered to rank 0 and put back into input order, the gathered table checked against the oracle): RCCL with two

@@ -15,3 +15,4 @@ for m in 0 1; do
 done
 timeout 300 python3 bench.py --nprot 1250000 --no-e2e --no-clock-probe --no-host-leg --steps 40 2>/dev/null | line "share mixed=1 checked"
 timeout 300 python3 bench.py --no-e2e --no-cpu-baseline --no-clock-probe --no-host-leg --steps 20 2>/dev/null | line "cfg4 full"
+bash tools/r04_trace.sh share 3 --nprot 1250000
