@@ -181,6 +181,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="every step is ordered behind the whole previous step (default: "
                     "plaac_ctx_set_overlap - the planning and packing of a step run beside the last window kernels of the "
                     "step before it)")
+    ap.add_argument("--no-predict", action="store_true", help="N = 1: skip the predicted strong-scaling leg (the 1/8 share "
+                    "of the proteome timed by itself)")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the shader-clock measurement (extra untimed steps)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive plaac_score calls on a 1.25 M-sequence "
                     "sample (counter passes: their launches would be averaged into the per-launch means)")
@@ -296,6 +298,9 @@ def main():
         sweep_rows = [torch.zeros(W.nmax * RB, dtype=torch.uint8, device=dev) for _ in range(npoints)] if sweep_params else None
         scored = [torch.cuda.Event() for _ in range(nslots)]
         gathered = [torch.cuda.Event() for _ in range(nslots)]
+        # the exchange timed by itself: events around every gather on the stream it runs on (the driver's 8-GPU curve then
+        # decomposes into the scoring step and the RCCL gather)
+        gather_t = [] if world > 1 else None
         step_no = [0]
 
         def gather(buf):
@@ -334,7 +339,11 @@ def main():
                         scored[b].record(stream)
                         with torch.cuda.stream(comm):
                             comm.wait_event(scored[b])
+                            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            g0.record(comm)
                             gather(rows_pp[b])
+                            g1.record(comm)
+                            gather_t.append((g0, g1))
                             gathered[b].record(comm)
 
         def fence():
@@ -356,7 +365,12 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        return dt, {"rows": rows_pp[0], "final": final, "gather_list": gather_list, "sweep_rows": sweep_rows, "trk": trk}
+        gms = None
+        if gather_t:
+            ts = [a.elapsed_time(b_) for a, b_ in gather_t[nwarm:]]
+            gms = sum(ts) / max(1, len(ts))
+        return dt, {"rows": rows_pp[0], "final": final, "gather_list": gather_list, "sweep_rows": sweep_rows, "trk": trk,
+                    "gather_ms": gms}
 
     dt, bufs = run_region(main_work, args.steps, args.warmup, args.tracks)
     nprot, total = main_work.nprot, main_work.total
@@ -425,6 +439,26 @@ def main():
                      "what": "plaac_ctx_set_overlap off: every step behind the whole previous step (extra untimed steps)"}
         for c in ctxs:
             c.set_overlap(True)
+    # What one GPU of an 8-GPU strong-scaling run would take: the share plaac_shard_plan deals rank 0 of 8 (1.25 M sequences
+    # of the 10 M), timed like the main region (overlapping steps, no gather). efficiency = full step / (8 x share step):
+    # the ceiling of the 8-GPU curve before any exchange - a single GPU can measure it, the curve itself needs the node.
+    predicted = None
+    if (rank == 0 and world == 1 and args.config == 4 and not args.nprot and not args.tracks and not args.sweep
+            and not args.no_predict):
+        idx8 = pdist.shard_plan_torch(offsets_full, 8, 0)
+        c8, o8 = pdist.extract_shard_torch(codes_full, offsets_full, idx8)
+        w8 = Work(c8, o8, None, idx8.numel())
+        sdt, sb = run_region(w8, max(args.steps, 20), 3, False)
+        del sb
+        share_ms = sdt / max(args.steps, 20) * 1e3
+        predicted = {"n_gpus": 8, "share_sequences": int(idx8.numel()), "share_residues": w8.total,
+                     "share_ms_per_step": round(share_ms, 4), "full_ms_per_step": round(dt / args.steps * 1e3, 4),
+                     "efficiency": round(dt / args.steps * 1e3 / (8 * share_ms), 4),
+                     "what": "rank 0's share of 8 (plaac_shard_plan) scored on this GPU, overlapping steps, no gather; "
+                             "efficiency = full-proteome step / (8 x share step): the ceiling of strong scaling before "
+                             "the row gather (extra untimed steps)"}
+        del w8, c8, o8, idx8
+        torch.cuda.empty_cache()
     # PCIe-inclusive rate (never `value`): the host-buffer entry point plaac_score on a bounded sample - residues and
     # offsets from host memory in, rows to host memory out, through the library's pinned staging
     host_io = None
@@ -482,6 +516,8 @@ def main():
     kern = {"k_vit": ktimes["vit"], "k_fwd": ktimes["fwd"], "k_win": ktimes["win"], "k_tracks": ktimes["tracks"]}
     if args.tracks:
         kern["k_bwd"] = ktimes["bwd"]
+    elif ktimes["bwd"] > 0.05:  # summary mode, mixed forms: slot 7 times the long run (k_long + Viterbi of the long groups + core search)
+        kern["k_long"] = ktimes["bwd"]
     dom = max(kern, key=kern.get)
     dom_ms = kern[dom]
     tb = native.TRACK_BYTES_PER_RESIDUE if args.tracks else 0
@@ -529,6 +565,8 @@ def main():
         "algorithmic_bytes": path_bytes, "measured_copy_GBps": copy_gbps,
         "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
         "kernels_overlap": "k_vit, k_fwd, k_win, k_tracks run concurrently on 4 HIP streams; total = first launch -> join"
+                           + ("; chain-bound batch in mixed forms: bwd = the long run (latency forms of the long wave-groups on "
+                              "two more streams), vit / fwd / win = the throughput-form runs" if (not args.tracks and ktimes["bwd"] > 0.05) else "")
                            + ("; consecutive steps overlap (plaac_ctx_set_overlap): the planning and packing of a step run "
                               "beside the last window kernels of the step before, so total (a call's latency) exceeds "
                               "ms_per_step" if (overlap and not args.tracks and not args.sweep) else "")
@@ -681,10 +719,13 @@ def main():
             "consecutive_steps_overlap": bool(overlap) and not args.tracks and not args.sweep,
             "hip_hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4 per priority class)"),
             "step_by_itself": by_itself,
+            "predicted_strong_scaling": predicted,
+            "gather_ms_per_step": None if bufs.get("gather_ms") is None else round(bufs["gather_ms"], 4),
             "exchange": ("%s gather of 160 B rows to rank 0" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
             if world > 1 else "none (1 GPU)",
             "timed_region_s": round(dt, 3), "exact_tier_fallbacks_rank0": fallbacks,
         },
+        "predicted_strong_efficiency": None if not predicted else predicted["efficiency"],
         "roofline": roofline,
         "cpu_baseline": cpu,
         "e2e": e2e,

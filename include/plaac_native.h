@@ -153,6 +153,15 @@ plaac_status plaac_histogram(plaac_ctx *ctx, const uint8_t *codes, const uint64_
 plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
                          plaac_row *rows, const plaac_tracks *tracks);
 
+/* Pipelined form of plaac_score (summary mode) for hosts that stream batches through one context - the reference's
+ * loop over records (plaac.java:755) as a loop over batches: plaac_score_begin copies the batch to the device on a copy
+ * stream of the context's own (beside the kernels of the batch before it), enqueues its scoring kernels and returns;
+ * plaac_score_end waits for the OLDEST batch begun and copies its rows out (input order). At most two batches may be
+ * pending. With plaac_ctx_set_overlap on, the device work of consecutive batches overlaps as well (bin/plaac does both:
+ * one context per GPU, two batches in flight). The buffers handed to _begin may be reused as soon as it returns. */
+plaac_status plaac_score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot);
+plaac_status plaac_score_end(plaac_ctx *ctx, plaac_row *rows);
+
 /* ---- resident batches: upload once, use many times -------------------------------------------------------
  * The reference makes one full pass over the input for the background counts and a second one for scoring
  * (plaac.java:377-384 then :755), and a parameter sweep (BASELINE config 5) re-scores the same proteome under

@@ -218,6 +218,7 @@ struct Batch {
     std::vector<double> t64;
     plaac_tracks tr{};
     plaac_status st = PLAAC_OK;
+    bool begun = false; // pipelined scoring: plaac_score_begin has taken the batch (plaac_score_end is owed)
     std::string err;
     ~Batch() {
         if (f && owned) plaac_fasta_free(f);
@@ -282,6 +283,10 @@ class Reorder {
     void wait_room(uint64_t seq) { // called by a worker BEFORE it scores batch `seq`
         std::unique_lock<std::mutex> l(m);
         cv_room.wait(l, [&] { return seq < next + window; });
+    }
+    bool has_room(uint64_t seq) {
+        std::lock_guard<std::mutex> l(m);
+        return seq < next + window;
     }
     void put(BatchPtr b) {
         std::lock_guard<std::mutex> l(m);
@@ -380,7 +385,9 @@ struct Engine {
             }
             if (devs.empty()) {
                 const int n = plaac_device_count();
-                const int per = (int)env_u64("PLAAC_CTX_PER_DEVICE", 2);
+                // pipelined scoring (default): ONE context per GPU with two batches in flight; PLAAC_PIPELINE=0: the
+                // synchronous entry point on two contexts per GPU (round 3)
+                const int per = (int)env_u64("PLAAC_CTX_PER_DEVICE", env_u64("PLAAC_PIPELINE", 1) ? 1 : 2);
                 for (int k = 0; k < per; ++k)
                     for (int d = 0; d < n; ++d) devs.push_back(d);
             }
@@ -391,6 +398,9 @@ struct Engine {
             }
             st = plaac_node_create(&P, devs.data(), (int)devs.size(), &node);
             if (st != PLAAC_OK) err = plaac_node_last_error(nullptr);
+            // consecutive batches of a context overlap on the device too (the head of a batch beside the tail of the one
+            // before it; the long chains of consecutive batches side by side)
+            else if (env_u64("PLAAC_PIPELINE", 1) && env_u64("PLAAC_OVERLAP_CALLS", 1)) (void)plaac_node_set_overlap(node, 1);
         });
     }
     bool ready(const plaac_params &P) {
@@ -435,10 +445,28 @@ bool open_stream(const std::string &path, plaac_fasta_stream **fs) {
     return true;
 }
 
-template <class Prep, class Work, class Sink>
+// `finish` (nullable functor): pipelined scoring - `work` only BEGINS a batch (plaac_score_begin: upload + kernels
+// enqueued), `finish` collects it (plaac_score_end); a worker keeps two batches in flight on its context, so that the
+// upload of a batch, the download of the one before it and the host's own copies run beside the kernels.
+struct NoFinish {
+    plaac_status operator()(plaac_ctx *, struct Batch &) const { return PLAAC_OK; }
+    static constexpr bool enabled = false;
+};
+template <class F>
+struct Finish {
+    F f;
+    plaac_status operator()(plaac_ctx *c, struct Batch &b) const { return f(c, b); }
+    static constexpr bool enabled = true;
+};
+template <class F>
+Finish<F> make_finish(F f) {
+    return Finish<F>{f};
+}
+
+template <class Prep, class Work, class Sink, class Fin = NoFinish>
 bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, plaac_fasta_stream *fs, const Stream &sp,
                   std::vector<plaac_fasta *> *replay, std::vector<plaac_fasta *> *keep, uint64_t keep_bytes, Prep &&prep,
-                  Work &&work, Sink &&sink) {
+                  Work &&work, Sink &&sink, Fin finish = Fin()) {
     if (!fs && !replay) return true; // nothing to read
     // A pass that keeps its parsed batches anyway (the background pass, up to keep_bytes) lets the reader run as far
     // ahead as it likes: it parses through the few hundred ms in which the GPU contexts come up instead of stopping
@@ -503,18 +531,40 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
     for (int k = 0; k < nctx; ++k)
         workers.emplace_back([&, k] {
             plaac_ctx *ctx = plaac_node_ctx(eng.node, k);
-            for (;;) {
-                BatchPtr b = q.get();
-                if (!b) break;
-                ro.wait_room(b->seq);
-                if (!failed) {
-                    b->st = work(ctx, *b);
-                    if (b->st != PLAAC_OK) {
-                        b->err = plaac_last_error(ctx);
+            BatchPtr pend; // pipelined scoring: the batch begun in the previous round
+            auto collect_pending = [&] { // (an end is owed for every begin, whatever has failed since)
+                if (pend->begun) {
+                    const plaac_status st = finish(ctx, *pend);
+                    if (st != PLAAC_OK && pend->st == PLAAC_OK) {
+                        pend->st = st;
+                        pend->err = plaac_last_error(ctx);
                         failed = true;
                     }
                 }
-                ro.put(std::move(b));
+                ro.put(std::move(pend));
+            };
+            for (;;) {
+                BatchPtr b = q.get();
+                if (b) {
+                    // A worker never waits for room while it holds a begun batch: that batch may be the very one the printer
+                    // is waiting for (a slow worker - the first call of a context measures its streams - sits on the oldest
+                    // batch while the others run the window full of finished ones).
+                    if (pend && !ro.has_room(b->seq)) collect_pending();
+                    ro.wait_room(b->seq);
+                    if (!failed) {
+                        b->st = work(ctx, *b);
+                        if (b->st != PLAAC_OK) {
+                            b->err = plaac_last_error(ctx);
+                            failed = true;
+                        } else {
+                            b->begun = Fin::enabled;
+                        }
+                    }
+                }
+                if (pend) collect_pending();
+                if (!b) break;
+                if (Fin::enabled) pend = std::move(b);
+                else ro.put(std::move(b));
             }
         });
     bool ok = true;
@@ -637,10 +687,16 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
     uint64_t nres = 0, nrec = 0;
     std::fflush(stdout);
     Writer writer; // from here on the table goes through the writer thread
-    const bool ok = run_pipeline(
-        eng, P, o.input, fs, sp, replay, nullptr, 0, [](Batch &) {},
+    const bool pipelined = env_u64("PLAAC_PIPELINE", 1) != 0;
+    auto collect = make_finish([](plaac_ctx *ctx, Batch &b) { return plaac_score_end(ctx, b.rows.data()); });
+    auto run = [&](auto &&...a) {
+        return pipelined ? run_pipeline(std::forward<decltype(a)>(a)..., collect) : run_pipeline(std::forward<decltype(a)>(a)...);
+    };
+    const bool ok = run(
+        eng, P, o.input, fs, sp, replay, (std::vector<plaac_fasta *> *)nullptr, (uint64_t)0, [](Batch &) {},
         [&](plaac_ctx *ctx, Batch &b) {
             b.rows.resize(b.f->nrec);
+            if (pipelined) return plaac_score_begin(ctx, b.f->codes, b.f->offsets, b.f->nrec);
             return plaac_score(ctx, b.f->codes, b.f->offsets, b.f->nrec, b.rows.data(), nullptr);
         },
         [&](Batch &b) {

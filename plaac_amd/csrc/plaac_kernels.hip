@@ -166,6 +166,20 @@ struct plaac_ctx {
     bool fi_int = false;   // the tables in d_tab qualify for FoldIndex in integers (derive_fi_int)
     bool fi_int_allowed = true; // PLAAC_FI_INT=0: always the fp64 form of the filter kernel
     size_t cap_fwd = 0, cap_bwd = 0;
+    // Pipelined host-buffer scoring (plaac_score_begin / _end): two batches in flight. Each slot owns its device copies of
+    // the batch and its rows; uploads and downloads go through `xfer`, a copy stream of their own, so that the upload of
+    // batch k+1 and the download of batch k run beside the kernels (which are on `stream` and the side streams).
+    struct Slot {
+        uint8_t *d_codes = nullptr;
+        uint64_t *d_offsets = nullptr;
+        plaac_row *d_rows = nullptr;
+        size_t cap_codes = 0, cap_offs = 0, cap_rows = 0;
+        uint32_t nprot = 0;
+        uint64_t call_no = 0; // ncalls of the scoring call (its join event is ev[call_no % EV_SETS][E_JOIN]); ~0: nothing enqueued
+        bool busy = false;
+    } slot[2];
+    unsigned slot_next = 0, slot_oldest = 0, slots_busy = 0;
+    hipStream_t xfer = nullptr;
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
     uint64_t *d_offsets = nullptr;
@@ -752,6 +766,13 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+    for (auto &sl : ctx->slot)
+        for (void *b : {(void *)sl.d_codes, (void *)sl.d_offsets, (void *)sl.d_rows})
+            if (b) (void)hipFree(b);
+    if (ctx->xfer) {
+        (void)hipStreamSynchronize(ctx->xfer);
+        (void)hipStreamDestroy(ctx->xfer);
+    }
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
     for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_crow, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount,
                     (void *)ctx->pl[0].lat, (void *)ctx->pl[1].lat})
@@ -1931,8 +1952,11 @@ static plaac_status copy_out(plaac_ctx *ctx, void *dst, const void *src, size_t 
     return PLAAC_OK;
 }
 
-static plaac_status stage_in(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
-                             uint64_t *total_out) {
+// host batch -> device copies (d_codes / d_offsets, grown on demand) on stream `sx`, codes validated; returns with the
+// copies complete
+static plaac_status stage_in_to(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                                uint64_t *total_out, uint8_t *&d_codes, size_t &cap_codes, uint64_t *&d_offsets,
+                                size_t &cap_offs, hipStream_t sx) {
     if (!offsets) return fail(ctx, PLAAC_ERR_ARG, "null offsets");
     if (offsets[0] != 0) return fail(ctx, PLAAC_ERR_ARG, "offsets[0] must be 0");
     for (uint32_t p = 0; p < nprot; ++p) {
@@ -1942,23 +1966,30 @@ static plaac_status stage_in(plaac_ctx *ctx, const uint8_t *codes, const uint64_
     const uint64_t total = offsets[nprot];
     if (total && !codes) return fail(ctx, PLAAC_ERR_ARG, "null codes");
     plaac_status rc;
-    if ((rc = grow(ctx, ctx->d_codes, ctx->cap_codes, (size_t)total + 64)) != PLAAC_OK) return rc;
-    if ((rc = grow(ctx, ctx->d_offsets, ctx->cap_offs, (size_t)nprot + 1)) != PLAAC_OK) return rc;
-    if (total && (rc = copy_in(ctx, ctx->d_codes, codes, total, ctx->stream)) != PLAAC_OK) return rc;
-    if ((rc = copy_in(ctx, ctx->d_offsets, offsets, sizeof(uint64_t) * ((size_t)nprot + 1), ctx->stream)) != PLAAC_OK)
-        return rc;
+    if ((rc = grow(ctx, d_codes, cap_codes, (size_t)total + 64)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, d_offsets, cap_offs, (size_t)nprot + 1)) != PLAAC_OK) return rc;
+    if (total && (rc = copy_in(ctx, d_codes, codes, total, sx)) != PLAAC_OK) return rc;
+    if ((rc = copy_in(ctx, d_offsets, offsets, sizeof(uint64_t) * ((size_t)nprot + 1), sx)) != PLAAC_OK) return rc;
     // codes must be 0..21 (they index the kernels' tables): checked on the device, the upload is there anyway
     if (total) {
         if (!ctx->d_flag) PL_HIP(ctx, hipMalloc((void **)&ctx->d_flag, sizeof(uint32_t)));
-        PL_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(uint32_t), ctx->stream));
+        PL_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(uint32_t), sx));
         const unsigned vb = (unsigned)std::min<uint64_t>(((total >> 4) + 255u) / 256u + 1u, 2048u);
-        hipLaunchKernelGGL(k_validate, dim3(vb), dim3(256), 0, ctx->stream, ctx->d_codes, total, ctx->d_flag);
-        PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 1, ctx->d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipLaunchKernelGGL(k_validate, dim3(vb), dim3(256), 0, sx, d_codes, total, ctx->d_flag);
+        PL_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 1, ctx->d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, sx));
+        PL_HIP(ctx, hipStreamSynchronize(sx));
         if (ctx->h_pin[1]) return fail(ctx, PLAAC_ERR_ARG, "residue code > 21");
+    } else {
+        PL_HIP(ctx, hipStreamSynchronize(sx));
     }
     *total_out = total;
     return PLAAC_OK;
+}
+
+static plaac_status stage_in(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                             uint64_t *total_out) {
+    return stage_in_to(ctx, codes, offsets, nprot, total_out, ctx->d_codes, ctx->cap_codes, ctx->d_offsets, ctx->cap_offs,
+                       ctx->stream);
 }
 
 plaac_status plaac_histogram(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
@@ -2048,6 +2079,44 @@ plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *o
     plaac_status rc = stage_in(ctx, codes, offsets, nprot, &total);
     if (rc != PLAAC_OK) return rc;
     return score_resident_to_host(ctx, ctx->d_codes, ctx->d_offsets, nprot, total, rows, tracks);
+}
+
+plaac_status plaac_score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (ctx->slots_busy >= 2) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_begin: two batches are pending (call plaac_score_end)");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->xfer) PL_HIP(ctx, hipStreamCreateWithFlags(&ctx->xfer, hipStreamNonBlocking));
+    plaac_ctx::Slot &S = ctx->slot[ctx->slot_next];
+    S.nprot = nprot;
+    S.call_no = ~0ull;
+    if (nprot) {
+        uint64_t total = 0;
+        plaac_status rc = stage_in_to(ctx, codes, offsets, nprot, &total, S.d_codes, S.cap_codes, S.d_offsets, S.cap_offs, ctx->xfer);
+        if (rc != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, S.d_rows, S.cap_rows, (size_t)nprot)) != PLAAC_OK) return rc;
+        const uint64_t call_no = ctx->ncalls;
+        rc = plaac_score_device(ctx, S.d_codes, S.d_offsets, nprot, total, S.d_rows, nullptr, ctx->stream);
+        if (rc != PLAAC_OK) return rc;
+        S.call_no = call_no;
+    }
+    S.busy = true;
+    ctx->slot_next ^= 1u;
+    ++ctx->slots_busy;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_score_end(plaac_ctx *ctx, plaac_row *rows) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (ctx->slots_busy == 0) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end: no batch is pending");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    plaac_ctx::Slot &S = ctx->slot[ctx->slot_oldest];
+    S.busy = false; // (whatever happens below, the slot is given up)
+    ctx->slot_oldest ^= 1u;
+    --ctx->slots_busy;
+    if (S.nprot == 0 || S.call_no == ~0ull) return PLAAC_OK;
+    if (!rows) return fail(ctx, PLAAC_ERR_ARG, "null rows");
+    PL_HIP(ctx, hipEventSynchronize(ctx->ev[S.call_no % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
+    return copy_out(ctx, rows, S.d_rows, sizeof(plaac_row) * (size_t)S.nprot, ctx->xfer);
 }
 
 struct plaac_batch {

@@ -75,7 +75,7 @@ EXPORTS = (
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
-    "plaac_node_batch_residues",
+    "plaac_node_batch_residues", "plaac_score_begin", "plaac_score_end",
 )
 
 _lib = None
@@ -119,6 +119,8 @@ def load():
     L.plaac_last_error.restype = C.c_char_p
     L.plaac_histogram.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.plaac_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.plaac_score_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.plaac_score_end.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_score_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
     L.plaac_histogram_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -278,6 +280,29 @@ class Context:
         self._check(self._L.plaac_score(self._h, codes.ctypes.data, offsets.ctypes.data, nprot, rows.ctypes.data,
                                         tptr))
         return (rows, tr) if tracks else rows
+
+    # ---- pipelined host-buffer scoring: two batches in flight (plaac_score_begin / plaac_score_end) ----
+    def score_begin(self, codes, offsets):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self._L.plaac_score_begin(self._h, codes.ctypes.data, offsets.ctypes.data, len(offsets) - 1))
+        return len(offsets) - 1
+
+    def score_end(self, nprot):
+        """rows of the OLDEST pending batch (`nprot` = what score_begin returned for it)"""
+        rows = np.zeros(nprot, dtype=ROW_DTYPE)
+        self._check(self._L.plaac_score_end(self._h, rows.ctypes.data))
+        return rows
+
+    def score_stream(self, batches):
+        """scores an iterable of (codes, offsets) batches with two in flight; yields the row arrays in order"""
+        pending = []
+        for codes, offsets in batches:
+            pending.append(self.score_begin(codes, offsets))
+            if len(pending) == 2:
+                yield self.score_end(pending.pop(0))
+        while pending:
+            yield self.score_end(pending.pop(0))
 
     # ---- resident batch: upload once, histogram / score (under several parameter sets) many times ----
     def upload(self, codes, offsets):

@@ -904,6 +904,40 @@ def test_overlapped_consecutive_calls_give_the_same_rows(native, oracle, monkeyp
             assert_rows_equal(got, want[k], "batch %d (filter tier from %s wave-groups in lane form)" % (k, lane))
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_pipelined_host_scoring_two_batches_in_flight(native, oracle, overlap):
+    """plaac_score_begin / plaac_score_end (what bin/plaac's workers call): batches of different kinds streamed through ONE
+    context with two in flight - the upload of a batch and the download of the one before it on the copy stream, beside the
+    kernels -, with and without overlapping device work; an empty batch and a chain-bound one in the middle; a third
+    begin without an end is refused; every batch's rows equal the oracle's."""
+    from plaac_amd import synth
+    P0 = native.make_params()
+    rng = np.random.default_rng(77)
+    batches = [synth.make_batch(4, nprot=6000, seed=21, fg=np.array(P0.fg), bg=np.array(P0.bg), stop_fraction=0.05),
+               synth.residues(np.array([30000, 5000, 300, 20]), np.array(P0.fg), np.array(P0.bg), rng),
+               (np.zeros(0, np.uint8), np.zeros(1, np.uint64)),
+               synth.make_batch(2, nprot=900, seed=22, fg=np.array(P0.fg), bg=np.array(P0.bg)),
+               _adversarial_batch(native),
+               synth.make_batch(4, nprot=11000, seed=23, fg=np.array(P0.fg), bg=np.array(P0.bg), stop_fraction=0.05)]
+    want = [oracle.score_batch(oracle.build_params(), c, o, nthreads=8) for c, o in batches]
+    with native.Context(P0) as ctx:
+        ctx.set_overlap(overlap)
+        for rep in range(2):
+            got = list(ctx.score_stream(batches))
+            assert len(got) == len(batches)
+            for k, (g, w) in enumerate(zip(got, want)):
+                assert_rows_equal(g, w, "pipelined batch %d (overlap %s, round %d)" % (k, overlap, rep))
+        n0 = ctx.score_begin(*batches[0])
+        n1 = ctx.score_begin(*batches[3])
+        with pytest.raises(native.PlaacError):
+            ctx.score_begin(*batches[3])
+        assert_rows_equal(ctx.score_end(n0), want[0], "after a refused third begin")
+        assert_rows_equal(ctx.score_end(n1), want[3], "second pending batch")
+        with pytest.raises(native.PlaacError):
+            ctx.score_end(1)
+        assert_rows_equal(ctx.score(*batches[3]), want[3], "the synchronous entry point afterwards")
+
+
 def test_overlapping_calls_of_every_kind_in_any_order(native, oracle):
     """plaac_ctx_set_overlap with the kinds of call mixed on one context, back to back without a wait: summary calls that are
     throughput-bound and chain-bound (the kernel forms and the streams change between calls), a track-mode call, a sweep -
