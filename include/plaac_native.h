@@ -312,6 +312,30 @@ plaac_status plaac_clock_probe(plaac_ctx *ctx, uint32_t micros, double *mhz);
  * Host-only: needs no device. */
 int plaac_fi_integer_form(const plaac_params *params, int32_t info[6]);
 
+/* DIAGNOSTIC / tests (host only, needs no device): the schedule of a scoring call as text. A call is some forty kernel
+ * launches on up to ten streams; which kernels, in which forms, on which streams is decided by a pure function of the
+ * call's kind, the words the planning kernels send back, the context's history and the environment switches
+ * (plaac_amd/csrc/schedule.hip.inc). This entry point runs that function for a DESCRIBED call - no batch, no device - and
+ * writes one line per decision ("F name=value") and per operation ("L stream kernel ... accesses", "R stream event",
+ * "W stream event"; "ALIAS a b": two stream slots that are one stream). tests/test_schedule.py walks the decision table with
+ * it and checks that no wait can deadlock and that conflicting accesses to a buffer are ordered, within a call and across
+ * overlapping calls. The environment switches are read at the call. Returns the length written, or -1 (buffer too small). */
+typedef struct plaac_sched_query {
+    uint32_t nprot;
+    uint32_t npoints;            /* 1, or the points of a sweep */
+    uint64_t residues;
+    uint32_t total_rows, rows_first, long_groups, long_rows; /* what the planning kernels would report */
+    uint32_t run_mark[7];
+    uint32_t ngroups_sweep;      /* sweep groups (<= 11) */
+    uint32_t group_members[11];  /* points per group (sum = npoints) */
+    int32_t kb_base[11];         /* per group: -1, or the earlier group whose window tracks it shares */
+    int32_t lane_possible, fast20, wmax, core_par_tables; /* properties of the tables (all groups alike) */
+    int32_t tracks, overlap;
+    uint64_t ncalls;             /* calls the context has scored before this one */
+    int32_t last_chain_bound, last_mixed, last_single_summary, old_tail;
+} plaac_sched_query;
+long plaac_debug_schedule(const plaac_sched_query *q, char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

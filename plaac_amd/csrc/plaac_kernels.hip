@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <thread>
@@ -56,6 +57,9 @@ static inline void cpu_relax() {
 #include "kernels_windows_filter.hip.inc"
 #include "kernels_windows_lane.hip.inc"
 #include "kernels_misc.hip.inc"
+#include "schedule.hip.inc"
+
+constexpr int E_JOIN_IDX = sched::E_JOIN; // index of a call's join event in its set of timing events
 
 } // namespace
 
@@ -99,10 +103,10 @@ struct plaac_ctx {
         size_t cap_bits = 0, cap_corelist = 0, cap_corecount = 0, cap_corep = 0, cap_corepart = 0;
     } pl[2];
     double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
-    bool core_long_list = false; // PLAAC_CORE_LONG_LIST=1 (experiment, read at creation like every other knob)
+    sched::Knobs knobs; // the environment switches, read once at creation
     uint32_t *h_pin = nullptr; // pinned words: [0] total packed rows of a call, [1] upload validation flag, [2..5] see score_points
     uint32_t *d_hpin = nullptr; // the same words as the device sees them
-    bool poll_ok = true;        // the host polls h_pin[5] for the plan words (false: stream synchronisation)
+    bool poll_ok = true;        // the host polls h_pin[5] for the plan words (false: stream synchronisation; PLAAC_POLL_PLAN=0)
     unsigned long polled = 0, synced = 0; // DIAGNOSTIC (PLAAC_STREAM_DEBUG): calls served either way
     // pinned staging for the host-buffer entry points (pageable memcpy runs at a tenth of the link rate)
     static constexpr size_t STAGE_BYTES = 16u << 20;
@@ -114,16 +118,10 @@ struct plaac_ctx {
     uint4 *d_clist = nullptr; // refine list: (offset lo, offset hi, length, centre) + row index in d_crow
     uint32_t *d_crow = nullptr;
     size_t cap_crow = 0;
-    unsigned rf_grid = 256u * 8u; // blocks of k_refine_centres (it strides over the list)
     uint32_t *d_ccount = nullptr, *d_fbcount = nullptr;
     uint4 *d_fblist = nullptr; // plan items of the proteins the filter tier hands to the exact tier
     size_t cap_clist = 0, cap_ccount = 0, cap_fblist = 0;
-    bool kb_filter = true; // PLAAC_KB_FILTER=0: exact stream kernel (k_tracks20s) in summary mode too
-    bool sweep_spread = true; // PLAAC_SWEEP_SPREAD=0: every further group of a chain-bound sweep on extra high-class streams
-    bool sweep_latency = true; // PLAAC_SWEEP_LATENCY=0: chain-bound sweeps keep the throughput form of k_vit for every wave-group
-    bool kb_lane = true;   // PLAAC_KB_LANE=0: the filter tier in stream form (k_tracks20f) for every protein
-    uint32_t kb_lane_min_groups = 4096; // PLAAC_KB_LANE_MIN_GROUPS (tests: 1 = lane form for any batch)
-    static constexpr int KB_MAXSEG = 10;
+    static constexpr int KB_MAXSEG = sched::KB_MAXSEG;
     // PLAAC_KB_CHUNKS (1..8): chunks of the lane-form filter, each refined on a second stream while the next is filtered.
     // Measured at 10 M sequences: 1 chunk (filter, refine, exact tier in a row on the caller's stream) 21.0 ms, 4 chunks
     // 21.1 ms, 8 chunks with a second hardware queue feeding the filter 20.5 ms; holding the chain kernels back until
@@ -131,7 +129,7 @@ struct plaac_ctx {
     // step is bound by the sum of the kernels' issue time, not by their order, and the extra event hops cost the small
     // batches 0.3 ms. Default 1.
     hipEvent_t kbev[KB_MAXSEG] = {};
-    static constexpr int TRK_MAXSEG = 8;  // track mode: runs of wave-groups (k_post of one run beside the chains of the next)
+    static constexpr int TRK_MAXSEG = sched::TRK_MAXSEG; // track mode: runs of wave-groups (k_post of one run beside the chains of the next)
     hipEvent_t tfev[TRK_MAXSEG] = {}, tbev[TRK_MAXSEG] = {}, tpev = nullptr; // forward / backward of a run done; posteriors done
     hipEvent_t pkev[TRK_MAXSEG] = {}; // packed copy of a run done
     // Consecutive calls may overlap (plaac_ctx_set_overlap): the planning and packing of a call - HBM-bound, they touch the
@@ -144,27 +142,13 @@ struct plaac_ctx {
     bool overlap = false, tail_open2[2] = {false, false}, last_chain_bound = false, last_single_summary = false;
     hipEvent_t tail_ev2[2] = {nullptr, nullptr}, ka_done[2] = {nullptr, nullptr};
     uint32_t *d_huge = nullptr; // four words, used in turn: the tail of call k reads its word while call k+2 already plans
-    int pipe_segments = 1; // PLAAC_PIPE_SEGMENTS: runs of a pipelined single-point call in summary mode. Measured at 10 M
-                           // sequences, same box: 20.04 / 20.29 / 19.84 / 20.13 ms with 1 / 2 / 4 / 8 runs - the 2.4 ms of
-                           // planning and packing at the head of the step are filled, and the scoring kernels then share
-                           // the chip with the copy and take that much longer (the step is bound by its total work). In a
-                           // chain-bound batch the runs behind the first wait for its longest chain (3.8 -> 4.9 ms at the
-                           // 1.25 M share): never pipelined.
-    uint32_t segment_min_rows = 32768u; // PLAAC_SEGMENT_MIN_ROWS: packed rows from which a call is cut into runs (tests lower it)
-    int track_segments = 2; // PLAAC_TRACK_SEGMENTS (1.25 M-sequence share, same-box A/Bs on two boxes: 1 run 21.3 / 21.4 ms, 2 runs 21.2, 4 runs 20.9 / 21.8)
-    bool core_list = true; // PLAAC_CORE_LIST=0: sweep 3 inside k_vit for every batch
     // Chain-bound single-point summary calls in MIXED FORMS (round 4, PLAAC_MIXED=0: latency forms for every wave-group as
-    // in round 3): the long wave-groups as one grid (k_long) on a stream of its own - long_stream[call parity], two streams
-    // of the high class -, every other wave-group in the throughput forms on the normal class's role streams.
-    bool mixed = true;
-    uint32_t mixed_groups = 0; // PLAAC_MIXED_GROUPS (tests): the long run takes at least this many wave-groups
-    uint32_t mixed_min_rest = 2048; // PLAAC_MIXED_MIN_REST: wave-groups outside the long run from which the forms are mixed
+    // in round 3): the long wave-groups on two streams of the high class per call parity, every other wave-group in the
+    // throughput forms on the normal class's role streams (schedule.hip.inc, decide_forms).
     bool last_mixed = false;
     hipEvent_t lev[2] = {nullptr, nullptr}; // long run of a call done (per parity)
-    bool core_par = true;  // PLAAC_CORE_PAR=0: always the serial masked prefix chain (k_core_chain) in the latency form
     bool core_par_ok = false; // the tables in d_tab pass core_par_tables_ok
     bool fi_int = false;   // the tables in d_tab qualify for FoldIndex in integers (derive_fi_int)
-    bool fi_int_allowed = true; // PLAAC_FI_INT=0: always the fp64 form of the filter kernel
     size_t cap_fwd = 0, cap_bwd = 0;
     // Pipelined host-buffer scoring (plaac_score_begin / _end): two batches in flight. Each slot owns its device copies of
     // the batch and its rows; uploads and downloads go through `xfer`, a copy stream of their own, so that the upload of
@@ -200,7 +184,8 @@ struct plaac_ctx {
     // 0-7 1-6 2-5-9 3-4-8 for ten fresh streams, 0-3 1-4 after others had been destroyed). So the context MEASURES which of
     // its candidate streams collide with each other and with the caller's stream (assign_role_streams) and gives the
     // roles that run together streams that do not. The window-track kernels (KB) run on the caller's stream.
-    enum Role { R_WIN = 0, R_VIT = 1, R_FWD = 2, R_KB = 3, R_BWD = 4, R_WIN2 = 5, NROLES = 6 };
+    enum Role { R_WIN = sched::R_WIN, R_VIT = sched::R_VIT, R_FWD = sched::R_FWD, R_KB = sched::R_KB, R_BWD = sched::R_BWD,
+                R_WIN2 = sched::R_WIN2, NROLES = sched::NROLES };
     static constexpr int NCAND = 8;
     hipStream_t cand[2][NCAND] = {}; // [0] normal, [1] high priority: every side stream the context created
     int ncand[2] = {0, 0};
@@ -214,11 +199,6 @@ struct plaac_ctx {
     // time, and high-priority chain kernels only keep the window kernel's waves out of the SIMDs until they are done
     // (chains, then windows, one after the other); at equal priority the two mix and hide each other's latencies
     hipStream_t auxn[NROLES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t vit_stop = 0; // DIAGNOSTIC, PLAAC_VIT_STOP=1|2: k_vit stops after that sweep (timing the sweeps; results are wrong)
-    int latency_mode = -1; // PLAAC_LATENCY_MODE=0/1 forces the throughput / latency forms of the K-A kernels (-1: per batch)
-    bool serial = false;                              // PLAAC_SERIAL_STREAMS=1: everything on one stream
-    bool generic_tracks = false;                      // PLAAC_GENERIC_TRACKS=1: never use the ww=41 fast path
-    bool per_protein_tracks = false;                  // PLAAC_KB_PER_PROTEIN=1: ww=41 fast path, one protein at a time
     std::string err;
 };
 
@@ -467,8 +447,7 @@ const char *check_divtab(plaac_ctx *ctx) {
 // PLAAC_STREAM_PROBE=0: candidates in creation order, unmeasured.
 const char *assign_role_streams(plaac_ctx *ctx, int cls, hipStream_t st) {
     constexpr int NMAX = plaac_ctx::NCAND;
-    const char *off = std::getenv("PLAAC_STREAM_PROBE");
-    const bool probe = !(off && off[0] == '0');
+    const bool probe = ctx->knobs.stream_probe;
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     auto collide = [&](hipStream_t a, hipStream_t b, bool &out) -> bool { // false: HIP failure
@@ -541,7 +520,7 @@ const char *assign_role_streams(plaac_ctx *ctx, int cls, hipStream_t st) {
     if (cls) ctx->aux[plaac_ctx::R_BWD] = ctx->aux[plaac_ctx::R_WIN2];
     else ctx->auxn[plaac_ctx::R_WIN2] = ctx->auxn[plaac_ctx::R_WIN];
     ctx->role_cost[cls] = probe ? best_cost : -1;
-    if (std::getenv("PLAAC_STREAM_DEBUG")) { // DIAGNOSTIC: the measured collisions and the assignment, on stderr
+    if (ctx->knobs.stream_debug) { // DIAGNOSTIC: the measured collisions and the assignment, on stderr
         std::fprintf(stderr, "plaac: %s-priority streams, %d candidates, collisions:", cls ? "high" : "normal", n);
         for (int a = 0; a < n; ++a)
             for (int b = a + 1; b < n; ++b)
@@ -605,6 +584,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     }
     ctx->device = device_id;
     ctx->params = *params;
+    ctx->knobs = sched::read_knobs(); // every environment switch, once
     auto bail = [&](const char *what, hipError_t err) {
         g_create_err = std::string(what) + ": " + hipGetErrorString(err);
         plaac_ctx_destroy(ctx);
@@ -636,24 +616,6 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         for (auto &fe : ctx->fev)
             if ((e = hipEventCreateWithFlags(&fe, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
-        const char *ser = std::getenv("PLAAC_SERIAL_STREAMS");
-        ctx->serial = ser && ser[0] == '1';
-        const char *gen = std::getenv("PLAAC_GENERIC_TRACKS");
-        ctx->generic_tracks = gen && gen[0] == '1';
-        const char *ppt = std::getenv("PLAAC_KB_PER_PROTEIN");
-        ctx->per_protein_tracks = ppt && ppt[0] == '1';
-        if (const char *rg = std::getenv("PLAAC_RF_GRID")) ctx->rf_grid = (unsigned)std::max(1, std::atoi(rg));
-        // (a host that raised the runtime's hardware queues - GPU_MAX_HW_QUEUES >= 12, before HIP initialised - has a queue
-        //  for every chain of a three-group sweep: every group then keeps streams of its own. Measured, 9 points over the
-        //  1.25 M share: 4 queues 14.4 / 18.0 ms spread / own streams, 8 queues 14.4 / 16.7, 12 queues 14.4 / 12.6)
-        if (const char *hq = std::getenv("GPU_MAX_HW_QUEUES")) ctx->sweep_spread = std::atoi(hq) < 12;
-        if (const char *ss = std::getenv("PLAAC_SWEEP_SPREAD")) ctx->sweep_spread = ss[0] != '0';
-        if (const char *sl = std::getenv("PLAAC_SWEEP_LATENCY")) ctx->sweep_latency = sl[0] != '0';
-        const char *kbf = std::getenv("PLAAC_KB_FILTER");
-        ctx->kb_filter = !(kbf && kbf[0] == '0');
-        const char *kbl = std::getenv("PLAAC_KB_LANE");
-        ctx->kb_lane = !(kbl && kbl[0] == '0');
-        if (const char *mg = std::getenv("PLAAC_KB_LANE_MIN_GROUPS")) ctx->kb_lane_min_groups = (uint32_t)std::max(1, std::atoi(mg));
         for (auto *arr : {ctx->tfev, ctx->tbev, ctx->pkev})
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -661,28 +623,10 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         for (auto *arr : {ctx->tail_ev2, ctx->ka_done, ctx->lev})
             for (int k = 0; k < 2; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        if (const char *mx = std::getenv("PLAAC_MIXED")) ctx->mixed = mx[0] != '0';
-        if (const char *mg = std::getenv("PLAAC_MIXED_GROUPS")) ctx->mixed_groups = (uint32_t)std::max(0, std::atoi(mg));
-        if (const char *mr = std::getenv("PLAAC_MIXED_MIN_REST")) ctx->mixed_min_rest = (uint32_t)std::max(1, std::atoi(mr));
         if ((e = hipMalloc((void **)&ctx->d_huge, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(huge)", e);
-        if (const char *ov = std::getenv("PLAAC_OVERLAP")) ctx->overlap = ov[0] == '1';
-        if (const char *cl = std::getenv("PLAAC_CORE_LONG_LIST")) ctx->core_long_list = cl[0] == '1';
-        if (const char *ps = std::getenv("PLAAC_PIPE_SEGMENTS"))
-            ctx->pipe_segments = std::max(1, std::min((int)plaac_ctx::TRK_MAXSEG, std::atoi(ps)));
-        if (const char *mr = std::getenv("PLAAC_SEGMENT_MIN_ROWS")) ctx->segment_min_rows = (uint32_t)std::max(1, std::atoi(mr));
-        if (const char *ts = std::getenv("PLAAC_TRACK_SEGMENTS"))
-            ctx->track_segments = std::max(1, std::min((int)plaac_ctx::TRK_MAXSEG, std::atoi(ts)));
+        ctx->overlap = ctx->knobs.overlap_default;
         for (auto &ke : ctx->kbev)
             if ((e = hipEventCreateWithFlags(&ke, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        const char *cp = std::getenv("PLAAC_CORE_PAR");
-        ctx->core_par = !(cp && cp[0] == '0');
-        const char *cl = std::getenv("PLAAC_CORE_LIST");
-        ctx->core_list = !(cl && cl[0] == '0');
-        const char *fii = std::getenv("PLAAC_FI_INT");
-        ctx->fi_int_allowed = !(fii && fii[0] == '0');
-        if (const char *vs = std::getenv("PLAAC_VIT_STOP")) ctx->vit_stop = (uint32_t)std::atoi(vs);
-        const char *lat = std::getenv("PLAAC_LATENCY_MODE");
-        if (lat && (lat[0] == '0' || lat[0] == '1')) ctx->latency_mode = lat[0] - '0';
     }
     for (auto &set : ctx->ev)
         for (auto &ev : set)
@@ -698,7 +642,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     std::memset(ctx->h_pin, 0, 64);
     if ((e = hipHostGetDevicePointer((void **)&ctx->d_hpin, ctx->h_pin, 0)) != hipSuccess)
         return bail("hipHostGetDevicePointer", e);
-    if (const char *pl = std::getenv("PLAAC_POLL_PLAN")) ctx->poll_ok = pl[0] != '0';
+    ctx->poll_ok = ctx->knobs.poll_plan;
     if ((e = hipMalloc((void **)&ctx->d_divtab, sizeof(KbDivTab))) != hipSuccess) return bail("hipMalloc(divtab)", e);
     if ((e = hipMalloc((void **)&ctx->d_fbcount, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(fbcount)", e);
     if ((e = hipMemset(ctx->d_fbcount, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(fbcount)", e);
@@ -753,7 +697,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (std::getenv("PLAAC_STREAM_DEBUG"))
+    if (ctx->knobs.stream_debug)
         std::fprintf(stderr, "plaac: plan words polled in %lu calls, stream-synchronised in %lu\n", ctx->polled, ctx->synced);
     if (ctx->d_bwd) (void)hipFree(ctx->d_bwd);
     void *bufs[] = {ctx->d_tab,        ctx->d_fwd,         ctx->d_codes,      ctx->d_offsets,
@@ -834,13 +778,449 @@ plaac_status plaac_ctx_sync(plaac_ctx *ctx) {
     return PLAAC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// A scoring call = the schedule of schedule.hip.inc + this launcher.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// the device side of one call: pointers and sizes the launcher hands to the kernels
+struct CallData {
+    const uint8_t *d_codes;
+    const uint64_t *d_offsets;
+    uint32_t nprot, ngroups;
+    uint64_t total;
+    const plaac_params *points;
+    plaac_row *const *d_rows;
+    TrackPtrs tp;
+    bool tracks;
+    const DevTables *gtab0;
+    plaac_ctx::PlanBufs *PL;
+    size_t bits_stride = 0, total_rows = 0;
+    hipStream_t st;
+    hipEvent_t *evs;
+    uint32_t seq;
+    const uint32_t *huge;
+    size_t core_lrows = 0;
+};
+
+hipStream_t slot_stream(plaac_ctx *ctx, const CallData &D, uint8_t slot) {
+    using namespace sched;
+    if (slot == S_CALLER) return D.st;
+    if (slot < S_NO) return ctx->aux[slot - S_HI];
+    if (slot < S_G) return ctx->auxn[slot - S_NO];
+    if (slot < S_GN) return ctx->gstreams[slot - S_G];
+    return ctx->gstreams_n[slot - S_GN];
+}
+
+hipEvent_t slot_event(plaac_ctx *ctx, const CallData &D, uint16_t e) {
+    using namespace sched;
+    const unsigned idx = e & 255u, par = (unsigned)(ctx->ncalls & 1u);
+    switch (e >> 8) {
+    case EK_T: return D.evs[idx];
+    case EK_PK: return ctx->pkev[idx];
+    case EK_J: return ctx->jev[idx];
+    case EK_F: return ctx->fev[idx];
+    case EK_L: return ctx->lev[par];
+    case EK_KA: return ctx->ka_done[idx];
+    case EK_TAIL: return ctx->tail_ev2[idx];
+    case EK_KB: return ctx->kbev[idx];
+    case EK_TF: return ctx->tfev[idx];
+    case EK_TB: return ctx->tbev[idx];
+    case EK_TP: return ctx->tpev;
+    case EK_G: return ctx->gev[idx];
+    case EK_GJ: return ctx->gjev[idx];
+    default: return ctx->ev[(ctx->ncalls - idx) % plaac_ctx::EV_SETS][E_JOIN_IDX]; // EK_PREVJOIN
+    }
+}
+
+// Op -> HIP. One switch: the kernels' arguments are formed here and nowhere else.
+plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C, const sched::Forms &F, const sched::PlanWords &W,
+                     const std::deque<sched::Op> &ops, size_t from) {
+    using namespace sched;
+    const Knobs &K = ctx->knobs;
+    plaac_ctx::PlanBufs &PL = *D.PL;
+    const uint32_t nprot = D.nprot, ngroups = D.ngroups;
+    auto seg_first = [&](const std::vector<uint32_t> &sb, size_t k) { return sb[k] * 64u; };
+    auto seg_count = [&](const std::vector<uint32_t> &sb, size_t k) {
+        return (uint32_t)(std::min<uint64_t>((uint64_t)sb[k + 1] * 64u, nprot) - sb[k] * 64u);
+    };
+    double *const lmarg = PL.lat, *const h0 = PL.lat ? PL.lat + nprot : nullptr, *const vend = PL.lat ? PL.lat + 2 * (size_t)nprot : nullptr;
+    for (size_t i = from; i < ops.size(); ++i) {
+        const Op &o = ops[i];
+        const hipStream_t s = slot_stream(ctx, D, o.stream);
+        if (o.kind == Op::RECORD) {
+            PL_HIP(ctx, hipEventRecord(slot_event(ctx, D, o.event), s));
+            if ((o.event >> 8) == EK_TAIL) ctx->tail_open2[o.event & 255u] = true;
+            continue;
+        }
+        if (o.kind == Op::WAIT) {
+            PL_HIP(ctx, hipStreamWaitEvent(s, slot_event(ctx, D, o.event), 0));
+            continue;
+        }
+        const GroupKind *G = o.group < C.groups.size() ? &C.groups[o.group] : nullptr;
+        const DevTables *tab = D.gtab0 + o.group;
+        plaac_row *rows0 = G ? D.d_rows[G->first_point] : D.d_rows[0];
+        uint32_t *gbits = PL.bits ? PL.bits + D.bits_stride * o.group : nullptr;
+        // the core lengths / row arrays of this launch (members m0 .. m0 + nc - 1 of the group; unused slots repeat the last)
+        SweepTargets tg{};
+        if (G) {
+            for (int k = 0; k < MAXC; ++k) {
+                const uint32_t idx = G->first_point + o.m0 + (uint32_t)std::min<int>(k, (int)o.nc - 1);
+                tg.c[k] = (uint32_t)D.points[idx].corelength;
+                tg.rows[k] = D.d_rows[idx];
+            }
+        }
+        tg.stop_after = K.vit_stop;
+        switch ((Kern)o.kern) {
+        case K_MEMSET_HIST: PL_HIP(ctx, hipMemsetAsync(PL.hist, 0, sizeof(uint32_t) * (LEN_BINS + 1), s)); break;
+        case K_MEMSET_FBCOUNT: PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), s)); break;
+        case K_MEMSET_CCOUNT: PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t) * KB_MAXSEG, s)); break;
+        case K_MEMSET_CORECOUNT:
+            PL_HIP(ctx, hipMemsetAsync(C.single() ? PL.corecount : PL.corecount + o.group, 0, sizeof(uint32_t), s));
+            break;
+        case K_MEMSET_COREFLAGS:
+            if (!PL.coreflags) PL_HIP(ctx, hipMalloc((void **)&PL.coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
+            PL_HIP(ctx, hipMemsetAsync(PL.coreflags, 0, sizeof(uint32_t) * (size_t)W.long_groups * 64u, s));
+            break;
+        case K_PLAN_LENGTHS: {
+            const unsigned plb = (nprot + PLAN_THREADS * PLAN_ITEMS - 1) / (PLAN_THREADS * PLAN_ITEMS);
+            hipLaunchKernelGGL(k_plan_lengths, dim3(plb), dim3(PLAN_THREADS), 0, s, D.d_codes, D.d_offsets, nprot, PL.neff, PL.hist);
+            break;
+        }
+        case K_PLAN_SCAN:
+            hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, s, PL.hist, ctx->d_huge + (ctx->ncalls & 3u));
+            break;
+        case K_PLAN_SCATTER: {
+            const unsigned plb = (nprot + PLAN_THREADS * PLAN_ITEMS - 1) / (PLAN_THREADS * PLAN_ITEMS);
+            hipLaunchKernelGGL(k_plan_scatter, dim3(plb), dim3(PLAN_THREADS), 0, s, PL.neff, nprot, PL.hist, D.d_offsets, PL.order);
+            break;
+        }
+        case K_GROUP_ROWS:
+            hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, s, PL.neff, PL.order, nprot, ngroups, PL.grow);
+            break;
+        case K_SCAN_U32:
+            // the scan writes the words the host needs (h_pin[0] total rows, [2] rows of the first wave-group, [3] the long
+            // wave-groups, [4] their rows, [6..12] run boundaries) into pinned host memory and then this call's sequence
+            // number into h_pin[5]: the host polls that word
+            for (int k = 6; k < 6 + SCAN_SEGS - 1; ++k) ctx->h_pin[k] = 0xffffffffu; // (no rows: the scan leaves them alone)
+            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(SCAN_THREADS), 0, s, PL.grow, ngroups, CORE_LONG_ROWS, CORE_MAX_GROUPS,
+                               ctx->d_hpin, D.seq);
+            break;
+        case K_PACK: {
+            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
+            hipLaunchKernelGGL(k_pack, dim3((cnt + 15u) / 16u), dim3(256), 0, s, D.d_codes, D.d_offsets, PL.neff, PL.order + first,
+                               cnt, D.total, PL.grow + F.segb[o.run], PL.packed);
+            break;
+        }
+        case K_LONG: {
+            const uint32_t lcnt = (uint32_t)std::min<uint64_t>((uint64_t)F.gl * 64u, nprot);
+            hipLaunchKernelGGL(k_long, dim3(4u * ((lcnt + KA_THREADS - 1) / KA_THREADS)), dim3(KA_THREADS), 0, s, D.d_offsets,
+                               PL.neff, PL.order, lcnt, tab, PL.packed, PL.grow, tg, lmarg, h0);
+            break;
+        }
+        case K_VIT: {
+            uint32_t first, cnt, g0;
+            if (o.sel == 1) { // the long run of a call in mixed forms
+                first = 0u, cnt = (uint32_t)std::min<uint64_t>((uint64_t)F.gl * 64u, nprot), g0 = 0u;
+                tg.long_groups_elsewhere = F.core_long ? 1u : 0u;
+            } else {
+                first = seg_first(F.vsegb, o.run), cnt = seg_count(F.vsegb, o.run), g0 = F.vsegb[o.run];
+                tg.long_groups_elsewhere = (F.core_long && !F.mixed) ? 1u : 0u; // (mixed forms: the long wave-groups are the long run's)
+            }
+            tg.first = first;
+            const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
+            uint32_t *cl_list = C.single() ? PL.corelist : (PL.corelist ? PL.corelist + (size_t)nprot * o.group : nullptr);
+            uint32_t *cl_count = C.single() ? PL.corecount : (PL.corecount ? PL.corecount + o.group : nullptr);
+            if (!o.list) cl_list = cl_count = nullptr;
+#define VIT_ARGS D.d_codes, D.d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + g0, gbits, tg, cl_list, cl_count, vend
+#define LAUNCH_VIT(NC, LAT, EXT, LIST) hipLaunchKernelGGL((k_vit<NC, LAT, EXT, LIST>), dim3(abk), dim3(KA_THREADS), 0, s, VIT_ARGS)
+#define LAUNCH_VIT_NC(LAT, EXT, LIST)                                                                              \
+    switch (o.nc) {                                                                                                \
+    case 1: LAUNCH_VIT(1, LAT, EXT, LIST); break;                                                                  \
+    case 2: LAUNCH_VIT(2, LAT, EXT, LIST); break;                                                                  \
+    case 3: LAUNCH_VIT(3, LAT, EXT, LIST); break;                                                                  \
+    default: LAUNCH_VIT(4, LAT, EXT, LIST); break;                                                                 \
+    }
+            if (o.lat && o.ext) LAUNCH_VIT(1, true, true, false);
+            else if (o.lat) LAUNCH_VIT_NC(true, false, false)
+            else if (o.ext && o.list) LAUNCH_VIT(1, false, true, true);
+            else if (o.list) LAUNCH_VIT_NC(false, false, true)
+            else if (o.ext) LAUNCH_VIT(1, false, true, false);
+            else LAUNCH_VIT_NC(false, false, false)
+#undef LAUNCH_VIT_NC
+#undef LAUNCH_VIT
+#undef VIT_ARGS
+            break;
+        }
+        case K_CORE_PAR:
+        case K_CORE_CHAIN:
+        case K_CORE_EVAL:
+        case K_CORE_REDUCE: {
+            const unsigned lg = W.long_groups; // (the kernels re-check every group: lengths >= 65535 are not ordered)
+            double *corep = PL.corep + D.core_lrows * 1024u * o.a;
+            CorePart *corepart = (CorePart *)PL.corepart + D.core_lrows * 64u * o.a;
+            if (o.kern == K_CORE_PAR)
+                hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, s, D.d_codes, PL.order, nprot, tab, PL.grow,
+                                   gbits, corep, PL.coreflags);
+            else if (o.kern == K_CORE_CHAIN)
+                hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, s, PL.order, nprot, tab, PL.packed, PL.grow, gbits, corep,
+                                   o.sel ? PL.coreflags : (const uint32_t *)nullptr);
+            else if (o.kern == K_CORE_EVAL)
+                hipLaunchKernelGGL(k_core_eval, dim3(W.long_rows), dim3(64), 0, s, PL.order, nprot, ngroups, PL.grow, corep, corepart,
+                                   tg.c[0]);
+            else
+                hipLaunchKernelGGL(k_core_reduce, dim3(lg * 64u), dim3(64), 0, s, D.d_codes, PL.order, nprot, tab, PL.grow, gbits,
+                                   (const CorePart *)corepart, tg.rows[0], tg.c[0]);
+            break;
+        }
+        case K_CORE_LIST: {
+            const unsigned lgrid = std::min((nprot + KA_THREADS - 1) / KA_THREADS, 2048u);
+            uint32_t *cl_list = C.single() ? PL.corelist : PL.corelist + (size_t)nprot * o.group;
+            uint32_t *cl_count = C.single() ? PL.corecount : PL.corecount + o.group;
+            tg.long_groups_elsewhere = (F.core_long && !F.mixed) ? 1u : 0u;
+            tg.first = 0u;
+#define LAUNCH_CORE_LIST(NC)                                                                                       \
+    hipLaunchKernelGGL(k_core_list<NC>, dim3(lgrid), dim3(KA_THREADS), 0, s, D.d_codes, D.total, PL.order, tab, PL.packed,  \
+                       PL.grow, gbits, tg, cl_list, cl_count)
+            switch (o.nc) {
+            case 1: LAUNCH_CORE_LIST(1); break;
+            case 2: LAUNCH_CORE_LIST(2); break;
+            case 3: LAUNCH_CORE_LIST(3); break;
+            default: LAUNCH_CORE_LIST(4); break;
+            }
+#undef LAUNCH_CORE_LIST
+            break;
+        }
+        case K_FWD: {
+            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
+#define LAUNCH_FWD(TRK, EXTF)                                                                                      \
+    hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_codes, \
+                       D.d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + F.segb[o.run], rows0, \
+                       TRK ? ctx->d_fwd : (double2 *)nullptr, PL.lat, nprot)
+            if (o.trk && o.ext) LAUNCH_FWD(true, true);
+            else if (o.trk) LAUNCH_FWD(true, false);
+            else if (o.ext) LAUNCH_FWD(false, true);
+            else LAUNCH_FWD(false, false);
+#undef LAUNCH_FWD
+            break;
+        }
+        case K_FWD_PAIR: {
+            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
+            const dim3 grid((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2));
+            if (o.trk)
+                hipLaunchKernelGGL(k_fwd_pair<true>, grid, dim3(KA_THREADS), 0, s, PL.order + first, cnt, tab, PL.packed,
+                                   PL.grow + F.segb[o.run], PL.lat, ctx->d_fwd);
+            else
+                hipLaunchKernelGGL(k_fwd_pair<false>, grid, dim3(KA_THREADS), 0, s, PL.order + first, cnt, tab, PL.packed,
+                                   PL.grow + F.segb[o.run], PL.lat, (double2 *)nullptr);
+            break;
+        }
+        case K_BWD: {
+            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
+            hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+                               PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + F.segb[o.run], ctx->d_bwd);
+            break;
+        }
+        case K_BWD_PAIR: {
+            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
+            hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, s,
+                               PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + F.segb[o.run], ctx->d_bwd);
+            break;
+        }
+        case K_WIN: {
+            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
+            const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
+#define LAUNCH_WIN(NC, ROLE)                                                                                       \
+    hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, s, D.d_codes, D.d_offsets, PL.neff,      \
+                       PL.order + first, cnt, tab, PL.packed, PL.grow + F.segb[o.run], tg, h0)
+            if (o.role == 2) LAUNCH_WIN(1, 2);
+            else if (o.role == 3) LAUNCH_WIN(1, 3);
+            else
+                switch (o.nc) {
+                case 1: LAUNCH_WIN(1, 0); break;
+                case 2: LAUNCH_WIN(2, 0); break;
+                case 3: LAUNCH_WIN(3, 0); break;
+                default: LAUNCH_WIN(4, 0); break;
+                }
+#undef LAUNCH_WIN
+            break;
+        }
+        case K_FINISH: {
+            const uint32_t lcnt = (uint32_t)std::min<uint64_t>((uint64_t)F.gl * 64u, nprot);
+            const uint32_t f0 = o.sel ? 0u : o.a, cnt = o.sel ? lcnt : nprot - o.a;
+            hipLaunchKernelGGL(k_finish, dim3((cnt + 255u) / 256u), dim3(256), 0, s, PL.order + f0, cnt, D.d_rows[0], lmarg, h0, vend);
+            break;
+        }
+        case K_POST: {
+            const unsigned post_grid = (unsigned)((D.total_rows + POST_ROWS - 1) / POST_ROWS);
+#define POST_ARGS D.d_offsets, PL.neff, PL.order, nprot, ngroups, PL.grow, D.gtab0, ctx->d_fwd, ctx->d_bwd, PL.bits, D.tp, o.a, o.b
+            if (o.sel == 1) hipLaunchKernelGGL((k_post<true, false>), dim3(post_grid), dim3(64), 0, s, POST_ARGS);
+            else if (o.sel == 2) hipLaunchKernelGGL((k_post<false, true>), dim3(post_grid), dim3(64), 0, s, POST_ARGS);
+            else hipLaunchKernelGGL((k_post<true, true>), dim3(post_grid), dim3(64), 0, s, POST_ARGS);
+#undef POST_ARGS
+            break;
+        }
+        case K_REPLICATE: {
+            SweepTargets tr{};
+            for (int k = 1; k <= o.nc; ++k) tr.rows[k] = D.d_rows[G->first_point + o.m0 + (uint32_t)k - 1];
+            hipLaunchKernelGGL(k_replicate, dim3((nprot + 255u) / 256u), dim3(256), 0, s, rows0, tr, (int)o.nc, nprot);
+            break;
+        }
+        // ---- K-B: window tracks ----
+        case K_TRACKS_RING: {
+#define LAUNCH_KB(RING)                                                                                            \
+    do {                                                                                                           \
+        if (o.trk)                                                                                                 \
+            hipLaunchKernelGGL((k_tracks<RING, true>), dim3(nprot), dim3(64), 0, s, D.d_codes, D.d_offsets, PL.neff, PL.order, \
+                               nprot, tab, rows0, D.tp);                                                           \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, s, D.d_codes, D.d_offsets, PL.neff, PL.order, \
+                               nprot, tab, rows0, D.tp);                                                           \
+    } while (0)
+            if (o.sel == 0) LAUNCH_KB(128);
+            else if (o.sel == 1) LAUNCH_KB(256);
+            else LAUNCH_KB(1024);
+#undef LAUNCH_KB
+            break;
+        }
+        case K_TRACKS20_WHOLE: {
+            // the stream form keeps 32 proteins on one int32 position axis; a batch with a protein of >= 65535 residues is left
+            // to the one-protein-at-a-time form. The planner raises a device flag for such a batch and both kernels are
+            // enqueued: the one the flag rules out returns at once (no host round trip before the window kernel starts).
+            const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
+            if (o.trk)
+                hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, s, D.d_codes, D.d_offsets, PL.neff, PL.order, nprot,
+                                   D.total, tab, rows0, D.tp, D.huge, (uint32_t)o.sel, (const uint4 *)nullptr, (const uint32_t *)nullptr);
+            else
+                hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, s, D.d_codes, D.d_offsets, PL.neff, PL.order, nprot,
+                                   D.total, tab, rows0, D.tp, D.huge, (uint32_t)o.sel, (const uint4 *)nullptr, (const uint32_t *)nullptr);
+            break;
+        }
+        case K_TRACKS20_LIST: {
+            const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
+            hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, s, D.d_codes, D.d_offsets, PL.neff,
+                               PL.order, nprot, D.total, tab, rows0, D.tp, D.huge, 0u, ctx->d_fblist, ctx->d_fbcount);
+            break;
+        }
+        case K_TRACKS20S: {
+            const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
+            if (o.trk)
+                hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, s, D.d_codes, PL.order, nprot, D.total, tab,
+                                   ctx->d_divtab, rows0, D.tp, D.huge);
+            else
+                hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, s, D.d_codes, PL.order, nprot, D.total, tab,
+                                   ctx->d_divtab, rows0, D.tp, D.huge);
+            break;
+        }
+        case K_TRACKS20F: {
+            const dim3 grid((o.a + o.b - 1) / o.b);
+            if (o.sel)
+                hipLaunchKernelGGL(k_tracks20f<true>, grid, dim3(64), 0, s, D.d_codes, PL.order, o.a, D.total, tab, ctx->d_divtab,
+                                   rows0, D.huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
+            else
+                hipLaunchKernelGGL(k_tracks20f<false>, grid, dim3(64), 0, s, D.d_codes, PL.order, o.a, D.total, tab, ctx->d_divtab,
+                                   rows0, D.huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
+            break;
+        }
+        case K_TRACKSL: {
+            const uint32_t g0 = o.a, g1 = o.b, base = g0 * 64u;
+            hipLaunchKernelGGL(k_tracksL, dim3((g1 - g0 + KL_THREADS / 64 - 1) / (KL_THREADS / 64)), dim3(KL_THREADS), 0, s, PL.order,
+                               nprot, g0, g1, tab, ctx->d_divtab, PL.packed, PL.grow, rows0, D.huge, ctx->d_clist + base,
+                               ctx->d_crow + base, ctx->d_ccount + o.seg, ctx->d_fblist, ctx->d_fbcount);
+            break;
+        }
+        case K_REFINE: {
+            // a resident grid that strides over the list: 8 one-wave blocks of 20 KB per CU hold the LDS of every CU until the
+            // list is through - 7 per CU when the next call may plan beside this kernel (its planning kernels take 8 / 16 KB
+            // per block; with 32 KB they waited for this kernel's end: 3.3 ms)
+            const unsigned rounds = (o.b + RF_SLOTS - 1) / RF_SLOTS;
+            if (o.sel)
+                hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min(rounds, K.rf_grid)), dim3(64), 0, s, D.d_codes, D.total, tab,
+                                   ctx->d_divtab, rows0, D.huge, ctx->d_clist + o.a, ctx->d_crow + o.a, ctx->d_ccount + o.seg);
+            else
+                hipLaunchKernelGGL(k_refine_centres<false>, dim3(std::min(rounds, F.tail_allowed ? K.rf_grid / 8u * 7u : K.rf_grid)),
+                                   dim3(64), 0, s, D.d_codes, D.total, tab, ctx->d_divtab, rows0, D.huge, ctx->d_clist + o.a,
+                                   ctx->d_crow + o.a, ctx->d_ccount + o.seg);
+            break;
+        }
+        case K_COPY_WINDOW_FIELDS:
+            hipLaunchKernelGGL(k_copy_window_fields, dim3((nprot + 255u) / 256u), dim3(256), 0, s,
+                               (const plaac_row *)D.d_rows[C.groups[(size_t)G->kb_base].first_point], rows0, nprot);
+            break;
+        case K_LLR_AT_CENTRE_LISTED:
+            hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, s, D.d_codes, D.d_offsets,
+                               PL.neff, nprot, tab, (const plaac_row *)D.d_rows[C.groups[o.a].first_point], rows0, ctx->d_fblist,
+                               ctx->d_fbcount, D.huge);
+            break;
+        case K_LLR_AT_CENTRE_ALL:
+            hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 1u << 20)), dim3(256), 0, s, D.d_codes, D.d_offsets,
+                               PL.neff, nprot, tab, (const plaac_row *)D.d_rows[C.groups[o.a].first_point], rows0);
+            break;
+        default: return fail(ctx, PLAAC_ERR_DEVICE, "unknown operation in the schedule");
+        }
+    }
+    return PLAAC_OK;
+}
+
+// CallKind of a call: the sweep groups of the points and what K-B needs to know about them (host only)
+void describe_groups(const plaac_ctx *ctx, const plaac_params *points, uint32_t npoints, bool tracks,
+                     const std::vector<DevTables> *host_tabs, sched::CallKind &C) {
+    using namespace sched;
+    const Knobs &K = ctx->knobs;
+    C.groups.clear();
+    for (uint32_t i = 0; i < npoints; ++i) { // same tables up to the core length
+        bool placed = false;
+        for (GroupKind &g : C.groups) {
+            plaac_params a = points[g.first_point], b = points[i];
+            a.corelength = b.corelength = 0;
+            // (members of a group are consecutive points in the callers this library has; a group is first_point .. + members)
+            if (std::memcmp(&a, &b, sizeof a) == 0 && g.first_point + g.members == i) {
+                ++g.members;
+                placed = true;
+                break;
+            }
+        }
+        if (!placed) {
+            GroupKind g;
+            g.first_point = i;
+            C.groups.push_back(g);
+        }
+    }
+    for (size_t g = 0; g < C.groups.size(); ++g) {
+        GroupKind &G = C.groups[g];
+        const plaac_params &P = points[G.first_point];
+        G.fi_int = host_tabs ? (*host_tabs)[g].fi_int != 0 : ctx->fi_int;
+        G.wmax = std::max(P.ww1 / 2, std::max(P.ww2 / 2, P.ww3 / 2));
+        G.fast20 = P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && !K.generic_tracks;
+        // K-B base: an earlier group whose window tracks differ only through the llr table (another alpha of a sweep); such a
+        // group needs PAPAllr / PAPAllr2 at the known PAPA centre only (k_llr_at_centre)
+        G.kb_base = -1;
+        if (P.ww3 / 2 <= LLRAT_MAXW)
+            for (size_t h = 0; h < g && G.kb_base < 0; ++h) {
+                const plaac_params &Q = points[C.groups[h].first_point];
+                if (P.ww1 == Q.ww1 && P.ww2 == Q.ww2 && P.ww3 == Q.ww3 && P.adjustprolines == Q.adjustprolines &&
+                    std::memcmp(P.cc, Q.cc, sizeof P.cc) == 0 && std::memcmp(P.hydro2, Q.hydro2, sizeof P.hydro2) == 0 &&
+                    std::memcmp(P.charge, Q.charge, sizeof P.charge) == 0 && std::memcmp(P.lodpapa, Q.lodpapa, sizeof P.lodpapa) == 0)
+                    G.kb_base = (long)h;
+            }
+        // the lane-per-protein form of the filter tier (k_tracksL): summary mode, half windows of 20, FoldIndex in integers
+        G.lane_possible = !tracks && K.kb_filter && K.kb_lane && !K.generic_tracks && !K.per_protein_tracks && P.ww1 / 2 == TW &&
+                          P.ww2 / 2 == TW && P.ww3 / 2 == TW && G.fi_int && K.fi_int_allowed && G.kb_base < 0;
+        G.core_par_tables = npoints == 1 && ctx->core_par_ok && std::memcmp(&points[G.first_point], &ctx->params, sizeof(plaac_params)) == 0;
+    }
+}
+
+} // namespace
+
 // One planned pass over a resident batch for `npoints` parameter sets (npoints == 1: the ordinary call).
 // Points whose tables differ only in the core length form a group: the plan, the packed copy, the forward pass,
 // the window tracks and Viterbi + traceback run once per group; only the two prefix-sum window searches run per
-// core length (inside the same kernels, up to MAXC at a time).
+// core length (inside the same kernels, up to MAXC at a time). The WHAT and WHERE of the call is decided and listed by
+// schedule.hip.inc; this function allocates, hands the two halves of the schedule to the launcher and keeps the books.
 static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,
                                  uint64_t total_residues, const plaac_params *points, uint32_t npoints,
                                  plaac_row *const *d_rows, const plaac_tracks *d_tracks, void *stream_) {
+    using namespace sched;
     if (nprot == 0 || npoints == 0) return PLAAC_OK;
     if (!d_offsets || !d_rows || !points || (!d_codes && total_residues))
         return fail(ctx, PLAAC_ERR_ARG, "null device buffer");
@@ -850,78 +1230,65 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if (!d_rows[i]) return fail(ctx, PLAAC_ERR_ARG, "null row array");
         if (const char *why = check_params(points[i])) return fail(ctx, PLAAC_ERR_ARG, why);
     }
-    TrackPtrs tp{};
+    CallData D{};
     if (d_tracks) {
-        tp = TrackPtrs{d_tracks->vit,   d_tracks->map,  d_tracks->charge,     d_tracks->hydro,
-                       d_tracks->fi,    d_tracks->plaacllr, d_tracks->papa,   d_tracks->fix2,
-                       d_tracks->plaacllrx2, d_tracks->papax2, d_tracks->post0, d_tracks->post1};
-        const void *all[] = {tp.vit, tp.map, tp.charge, tp.hydro, tp.fi, tp.plaacllr,
-                             tp.papa, tp.fix2, tp.plaacllrx2, tp.papax2, tp.post0, tp.post1};
+        D.tp = TrackPtrs{d_tracks->vit,   d_tracks->map,  d_tracks->charge,     d_tracks->hydro,
+                         d_tracks->fi,    d_tracks->plaacllr, d_tracks->papa,   d_tracks->fix2,
+                         d_tracks->plaacllrx2, d_tracks->papax2, d_tracks->post0, d_tracks->post1};
+        const void *all[] = {D.tp.vit, D.tp.map, D.tp.charge, D.tp.hydro, D.tp.fi, D.tp.plaacllr,
+                             D.tp.papa, D.tp.fix2, D.tp.plaacllrx2, D.tp.papax2, D.tp.post0, D.tp.post1};
         for (const void *q : all)
             if (!q) return fail(ctx, PLAAC_ERR_ARG, "tracks struct has a null array");
     }
     PL_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
-
-    // ---- group the points: same tables up to the core length
-    struct Group {
-        uint32_t first;
-        std::vector<uint32_t> members;
-    };
-    std::vector<Group> groups;
-    for (uint32_t i = 0; i < npoints; ++i) {
-        bool placed = false;
-        for (Group &g : groups) {
-            plaac_params a = points[g.first], b = points[i];
-            a.corelength = b.corelength = 0;
-            if (std::memcmp(&a, &b, sizeof a) == 0) {
-                g.members.push_back(i);
-                placed = true;
-                break;
-            }
-        }
-        if (!placed) groups.push_back(Group{i, {i}});
-    }
-    const size_t ng = groups.size();
-
+    const Knobs &K = ctx->knobs;
+    const hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     plaac_status rc;
-    const unsigned par = (unsigned)(ctx->ncalls & 1u); // this call's plan buffers, `huge` word and body events
+
+    // ---- what is asked for: the sweep groups, their tables
+    CallKind C;
+    C.nprot = nprot, C.ngroups = (nprot + 63u) / 64u, C.residues = total_residues, C.npoints = npoints, C.tracks = d_tracks != nullptr;
+    C.ncalls = ctx->ncalls, C.overlap = ctx->overlap, C.last_chain_bound = ctx->last_chain_bound, C.last_mixed = ctx->last_mixed;
+    C.last_single_summary = ctx->last_single_summary;
+    const unsigned par = C.par(); // this call's plan buffers, `huge` word and body events
+    C.old_tail = ctx->tail_open2[par];
+    ctx->tail_open2[par] = false;
+    const bool own_tables = !(npoints == 1 && std::memcmp(&points[0], &ctx->params, sizeof(plaac_params)) == 0);
+    std::vector<DevTables> host_tabs;
+    describe_groups(ctx, points, npoints, C.tracks, nullptr, C);
+    if (C.groups.size() > (size_t)MAXG) return fail(ctx, PLAAC_ERR_ARG, "too many distinct parameter groups in one sweep");
+    const size_t ng = C.groups.size();
+    D.gtab0 = ctx->d_tab; // device tables: slot 0 keeps the ctx parameters (single-point calls), sweep groups use slots of d_tabs
+    if (own_tables) {
+        if ((rc = grow(ctx, ctx->d_tabs, ctx->cap_tabs, ng)) != PLAAC_OK) return rc;
+        host_tabs.resize(ng);
+        for (size_t g = 0; g < ng; ++g) fill_tables(points[C.groups[g].first_point], host_tabs[g]);
+        describe_groups(ctx, points, npoints, C.tracks, &host_tabs, C); // (FoldIndex in integers: per group's tables)
+        PL_HIP(ctx, hipMemcpyAsync(ctx->d_tabs, host_tabs.data(), sizeof(DevTables) * ng, hipMemcpyHostToDevice, st));
+        PL_HIP(ctx, hipStreamSynchronize(st)); // `host_tabs` is a temporary
+        D.gtab0 = ctx->d_tabs;
+    }
+
+    // ---- buffers whose size does not depend on the plan
     plaac_ctx::PlanBufs &PL = ctx->pl[par];
     if ((rc = grow(ctx, PL.neff, PL.cap_prot, (size_t)nprot)) != PLAAC_OK) return rc;
     if ((rc = grow(ctx, PL.order, PL.cap_order, (size_t)nprot)) != PLAAC_OK) return rc;
-    const uint32_t ngroups = (nprot + 63u) / 64u;
-    if ((rc = grow(ctx, PL.grow, PL.cap_grow, (size_t)ngroups + 3)) != PLAAC_OK) return rc;
-    const bool single = npoints == 1; // one parameter point: hmm0's running sum is computed once (k_fwd / k_win), k_finish
-    if (single && (rc = grow(ctx, PL.lat, PL.cap_lat, 3 * (size_t)nprot)) != PLAAC_OK) return rc;
-    if (!d_tracks && ctx->kb_filter) { // lists of the filter form of the window kernel
+    if ((rc = grow(ctx, PL.grow, PL.cap_grow, (size_t)C.ngroups + 3)) != PLAAC_OK) return rc;
+    if (C.single() && (rc = grow(ctx, PL.lat, PL.cap_lat, 3 * (size_t)nprot)) != PLAAC_OK) return rc;
+    if (!d_tracks && K.kb_filter) { // lists of the filter form of the window kernel
         if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, (size_t)nprot)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_crow, ctx->cap_crow, (size_t)nprot)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, ctx->d_ccount, ctx->cap_ccount, (size_t)plaac_ctx::KB_MAXSEG)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_ccount, ctx->cap_ccount, (size_t)KB_MAXSEG)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_fblist, ctx->cap_fblist, (size_t)nprot)) != PLAAC_OK) return rc;
-    }
-    // device tables: slot 0 keeps the ctx parameters (single-point calls), sweep groups use slots 1..ng
-    const DevTables *gtab0 = ctx->d_tab;
-    std::vector<char> gfi(ng, ctx->fi_int ? 1 : 0); // per group: FoldIndex in integers
-    if (!(npoints == 1 && std::memcmp(&points[0], &ctx->params, sizeof(plaac_params)) == 0)) {
-        if ((rc = grow(ctx, ctx->d_tabs, ctx->cap_tabs, ng)) != PLAAC_OK) return rc;
-        std::vector<DevTables> host(ng);
-        for (size_t g = 0; g < ng; ++g) {
-            fill_tables(points[groups[g].first], host[g]);
-            gfi[g] = host[g].fi_int != 0;
-        }
-        PL_HIP(ctx, hipMemcpyAsync(ctx->d_tabs, host.data(), sizeof(DevTables) * ng, hipMemcpyHostToDevice, st));
-        PL_HIP(ctx, hipStreamSynchronize(st)); // `host` is a temporary
-        gtab0 = ctx->d_tabs;
     }
     while (ctx->gev.size() < ng) {
         hipEvent_t e = nullptr;
         PL_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->gev.push_back(e);
     }
-    // The groups of a sweep are independent of each other: every group gets its own three side streams (and its
-    // own traceback-bit buffer), so that the long serial chains of all groups advance together instead of one
-    // group's tail after the other's.
-    while (!ctx->serial && ctx->gstreams.size() < 3 * (ng - 1)) {
+    // The groups of a sweep are independent of each other: every group gets its own three side streams (and its own
+    // traceback-bit buffer), so that the long serial chains of all groups advance together
+    while (!K.serial && ctx->gstreams.size() < 3 * (ng - 1)) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         hipStream_t a = nullptr;
@@ -934,307 +1301,40 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         PL_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->gjev.push_back(e);
     }
-
-    hipEvent_t *evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
-    enum { E_START = 0, E_PLAN = 1, E_VIT = 2, E_FWD = 4, E_WIN = 6, E_TRK = 8, E_JOIN = 10, E_PACK = 11, E_BWD = 13 };
-    if (!ctx->serial && (!ctx->roles_assigned || ctx->roles_for != st)) { // normal-class roles: apart from `st`, too
+    if (!K.serial && (!ctx->roles_assigned || ctx->roles_for != st)) { // normal-class roles: apart from `st`, too
         if (ctx->ncalls > 0) // (the probe kernels must not run beside a batch that is still being scored)
-            PL_HIP(ctx, hipEventSynchronize(ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
+            PL_HIP(ctx, hipEventSynchronize(ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][E_JOIN_IDX]));
         if (const char *why = assign_role_streams(ctx, 0, st)) return fail(ctx, PLAAC_ERR_DEVICE, why);
         ctx->roles_for = st;
         ctx->roles_assigned = true;
     }
-    hipStream_t sv = ctx->serial ? st : ctx->aux[plaac_ctx::R_VIT], sf = ctx->serial ? st : ctx->aux[plaac_ctx::R_FWD],
-                sw = ctx->serial ? st : ctx->aux[plaac_ctx::R_WIN], sb = ctx->serial ? st : ctx->aux[plaac_ctx::R_BWD],
-                sw2 = ctx->serial ? st : ctx->aux[plaac_ctx::R_WIN2];
-    // the window-track kernels (K-B) run on the caller's stream, behind the planning kernels (no fork, no join)
-    const hipStream_t skb = st;
 
-    // K-B base of a group: an earlier group whose window tracks differ only through the llr table (another alpha of
-    // a sweep); such a group needs PAPAllr / PAPAllr2 at the known PAPA centre only (k_llr_at_centre)
-    auto kb_base = [&](size_t g) -> long {
-        const plaac_params &P = points[groups[g].first];
-        if (P.ww3 / 2 > LLRAT_MAXW) return -1;
-        for (size_t h = 0; h < g; ++h) {
-            const plaac_params &Q = points[groups[h].first];
-            if (P.ww1 == Q.ww1 && P.ww2 == Q.ww2 && P.ww3 == Q.ww3 && P.adjustprolines == Q.adjustprolines &&
-                std::memcmp(P.cc, Q.cc, sizeof P.cc) == 0 && std::memcmp(P.hydro2, Q.hydro2, sizeof P.hydro2) == 0 &&
-                std::memcmp(P.charge, Q.charge, sizeof P.charge) == 0 &&
-                std::memcmp(P.lodpapa, Q.lodpapa, sizeof P.lodpapa) == 0)
-                return (long)h;
-        }
-        return -1;
-    };
-    // the lane-per-protein form of the filter tier (k_tracksL): summary mode, half windows of 20, FoldIndex in integers;
-    // it reads the packed rows, so its group's window kernels are enqueued after k_pack (PLAAC_KB_LANE=0: stream form)
-    // A lane walks its protein alone, so the form needs enough proteins to fill the chip: 4096 wave-groups = 16 waves on
-    // each of the 256 CUs (config 2, 92 groups: 0.69 ms in stream form, 1.27 ms in lane form; the 1.25 M-sequence share,
-    // 19.5 k groups: 4.14 against 3.74 ms); smaller batches keep the position-parallel stream form. Where the lane form is
-    // possible the window kernels of the first group are enqueued after the planning round trip, in either form.
-    auto lane_possible = [&](size_t g) -> bool {
-        const plaac_params &P = points[groups[g].first];
-        return !d_tracks && ctx->kb_filter && ctx->kb_lane && !ctx->generic_tracks && !ctx->per_protein_tracks &&
-               P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && gfi[g] && ctx->fi_int_allowed && kb_base(g) < 0;
-    };
-    // the kernels after the filter kernel of a single-point summary call read no plan buffer: the next call may plan beside them
-    const bool tail_allowed = ctx->overlap && !ctx->serial && npoints == 1 && !d_tracks;
-    const hipEvent_t *pack_events = nullptr;     // lane form: the packed copy is made in runs of wave-groups (set with the
-    const std::vector<uint32_t> *kb_runs = nullptr; // plan words); run k = groups [(*kb_runs)[k], (*kb_runs)[k+1])
-    auto lane_form = [&](size_t g) -> bool { return lane_possible(g) && ngroups >= ctx->kb_lane_min_groups; };
-    long filter_group = -1; // the group whose filter-tier lists (centres, fallbacks) the ctx buffers hold
-    struct KbSeg {
-        uint32_t base, len; // a segment of the centre list: first slot, slots (its count is d_ccount[segment index])
-    };
-    std::vector<KbSeg> kb_segs; // of the filter group
-    hipStream_t kb_side = nullptr; // mixed forms: the stream of the long wave-groups' filter kernel (set with the forms)
-    bool maybe_huge = true;        // false once the host knows from the plan words that no protein has >= 65,535 residues
-    auto launch_tracks = [&](size_t g) -> plaac_status { // K-B: needs only the order, not the packed copy
-        if (!d_tracks) {
-            const long base = kb_base(g);
-            if (base >= 0) {
-                const plaac_row *src = d_rows[groups[(size_t)base].first];
-                plaac_row *dst = d_rows[groups[g].first];
-                if (base == filter_group) {
-                    // the base group went through the filter tier: its list of centres is still in place. Copy the
-                    // fields that do not depend on llr, then the llr track alone at the listed centres (nine proteins
-                    // per wave), and the one-wave-per-protein kernel only for what the exact tier scored
-                    const uint32_t *huge = ctx->d_huge + (ctx->ncalls & 3u);
-                    hipLaunchKernelGGL(k_copy_window_fields, dim3((nprot + 255u) / 256u), dim3(256), 0, skb, src, dst, nprot);
-                    for (size_t sg = 0; sg < kb_segs.size(); ++sg) // (the base group's centre lists, segment by segment)
-                        hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min((kb_segs[sg].len + RF_SLOTS - 1) / RF_SLOTS, ctx->rf_grid)),
-                                           dim3(64), 0, skb, d_codes, total_residues, gtab0 + g, ctx->d_divtab, dst, huge,
-                                           ctx->d_clist + kb_segs[sg].base, ctx->d_crow + kb_segs[sg].base, ctx->d_ccount + sg);
-                    hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, skb, d_codes,
-                                       d_offsets, PL.neff, nprot, gtab0 + g, src, dst, ctx->d_fblist,
-                                       ctx->d_fbcount, huge);
-                } else {
-                    hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 1u << 20)), dim3(256), 0, skb, d_codes,
-                                       d_offsets, PL.neff, nprot, gtab0 + g, src, dst);
-                }
-                return PLAAC_OK;
-            }
-        }
-        const plaac_params &P = points[groups[g].first];
-        const DevTables *tab = gtab0 + g;
-        plaac_row *rows = d_rows[groups[g].first];
-        const int wmax = std::max(P.ww1 / 2, std::max(P.ww2 / 2, P.ww3 / 2));
-        const bool fast20 = P.ww1 / 2 == TW && P.ww2 / 2 == TW && P.ww3 / 2 == TW && !ctx->generic_tracks;
-        if (g == 0) PL_HIP(ctx, hipEventRecord(evs[E_TRK], skb));
-#define LAUNCH_KB(RING)                                                                                            \
-    do {                                                                                                           \
-        if (d_tracks)                                                                                              \
-            hipLaunchKernelGGL((k_tracks<RING, true>), dim3(nprot), dim3(64), 0, skb, d_codes, d_offsets,           \
-                               PL.neff, PL.order, nprot, tab, rows, tp);                                   \
-        else                                                                                                       \
-            hipLaunchKernelGGL((k_tracks<RING, false>), dim3(nprot), dim3(64), 0, skb, d_codes, d_offsets,          \
-                               PL.neff, PL.order, nprot, tab, rows, tp);                                   \
-    } while (0)
-        // the stream form keeps 32 proteins on one int32 position axis; a batch with a protein of >= 65535 residues is
-        // left to the one-protein-at-a-time form. The planner raises a device flag for such a batch and both kernels are
-        // enqueued: the one the flag rules out returns at once (no host round trip before the window kernel starts).
-        if (fast20) {
-            const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
-            const uint32_t *huge = ctx->d_huge + (ctx->ncalls & 3u);
-            const uint32_t only_if_huge = ctx->per_protein_tracks ? 0u : 1u; // PLAAC_KB_PER_PROTEIN=1: always this form
-            // the one-protein-at-a-time kernel over the WHOLE plan (it returns at once unless the batch has a protein too
-            // long for the stream kernels). It reads the plan, so with overlapping calls it goes before the tail.
-            bool whole_plan_launched = false;
-            auto whole_plan = [&]() {
-                hipLaunchKernelGGL(k_tracks20<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, PL.neff,
-                                   PL.order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint4 *)nullptr,
-                                   (const uint32_t *)nullptr);
-                whole_plan_launched = true;
-            };
-            if (!ctx->per_protein_tracks) {
-                if (d_tracks) {
-                    hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, PL.order, nprot,
-                                       total_residues, tab, ctx->d_divtab, rows, tp, huge);
-                } else if (ctx->kb_filter) {
-                    // summary mode: decisions from error-bounded prefix sums, exact values at the chosen centre only,
-                    // whatever the bounds cannot decide goes to the exact per-protein kernel through the fallback list
-                    PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), skb));
-                    PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t) * plaac_ctx::KB_MAXSEG, skb));
-                    kb_segs.clear();
-                    // the exact values at the chosen centres (k_refine_centres) of one list segment; in lane form on a
-                    // stream of its own, so that a chunk is refined while the filter kernel walks the next one
-                    // (a stream of the priority class the chain kernels do NOT use in this batch: its queues are free)
-                    auto refine_segment = [&](uint32_t base, uint32_t len, hipStream_t after) -> plaac_status {
-                        const size_t sg = kb_segs.size();
-                        kb_segs.push_back(KbSeg{base, len});
-                        const hipStream_t srf = after; // (on the stream of the kernel that filled the segment)
-                        // a resident grid that strides over the list: 8 one-wave blocks of 20 KB per CU hold the LDS of every
-                        // CU until the list is through - 7 per CU when the next call may plan beside this kernel (its
-                        // planning kernels take 8 / 16 KB per block; with 32 KB they waited for this kernel's end: 3.3 ms)
-                        const unsigned rounds = (len + RF_SLOTS - 1) / RF_SLOTS;
-                        const unsigned rgrid = std::min(rounds, tail_allowed ? ctx->rf_grid / 8u * 7u : ctx->rf_grid);
-                        hipLaunchKernelGGL(k_refine_centres<false>, dim3(rgrid),
-                                           dim3(64), 0, srf, d_codes, total_residues, tab, ctx->d_divtab, rows, huge,
-                                           ctx->d_clist + base, ctx->d_crow + base, ctx->d_ccount + sg);
-                        return PLAAC_OK;
-                    };
-                    if (lane_form(g)) {
-                        // one lane per protein over the packed rows (k_tracksL); the long wave-groups (a prefix of the
-                        // descending-length plan) stay with the stream form. Called after the packed copy has been enqueued.
-                        const uint32_t lgroups = std::min<uint32_t>(ctx->h_pin[3], ngroups);
-                        const uint32_t nlong = std::min<uint64_t>((uint64_t)lgroups * 64u, nprot);
-                        // Mixed forms (kb_side set): the long wave-groups' filter kernel and its refine launch - chains of
-                        // 36,000-residue proteins, 0.3 - 0.7 ms in which the caller's stream did nothing wide - go on a side
-                        // stream (the throughput-form window stream, idle most of a step), behind the list counters'
-                        // reset; the exact tier below waits for them. The caller's stream is what a pipeline of batches is
-                        // bound by (its kernels of consecutive calls run strictly one after the other).
-                        const hipStream_t slong = (kb_side && !ctx->serial) ? kb_side : skb;
-                        if (nlong) {
-                            if (slong != skb) {
-                                PL_HIP(ctx, hipEventRecord(ctx->kbev[plaac_ctx::KB_MAXSEG - 1], skb));
-                                PL_HIP(ctx, hipStreamWaitEvent(slong, ctx->kbev[plaac_ctx::KB_MAXSEG - 1], 0));
-                            }
-                            // (four proteins per block instead of 32: lane k of a block takes protein blockIdx + k * gridDim, so
-                            //  a larger grid leaves the lanes from 4 on without one - the long proteins spread over 8 x the waves)
-                            hipLaunchKernelGGL(k_tracks20f<true>, dim3((nlong + 3u) / 4u),
-                                               dim3(64), 0, slong, d_codes, PL.order, nlong, total_residues, tab,
-                                               ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount,
-                                               ctx->d_fblist, ctx->d_fbcount);
-                            if ((rc = refine_segment(0u, nlong, slong)) != PLAAC_OK) return rc;
-                            if (slong != skb) PL_HIP(ctx, hipEventRecord(ctx->jev[5], slong));
-                        }
-                        // one launch per run of the packed copy, behind the run's copy
-                        const std::vector<uint32_t> &runs = *kb_runs;
-                        size_t last_run = 0; // the last run this kernel has groups in
-                        for (size_t k = 0; k + 1 < runs.size(); ++k)
-                            if (runs[k + 1] > std::max(runs[k], lgroups)) last_run = k;
-                        for (size_t k = 0; k + 1 < runs.size(); ++k) {
-                            const hipStream_t sk = skb;
-                            const uint32_t g0 = std::max(runs[k], lgroups), g1 = runs[k + 1];
-                            if (!ctx->serial) PL_HIP(ctx, hipStreamWaitEvent(skb, pack_events[k], 0));
-                            if (g1 <= g0) continue;
-                            const size_t sg = kb_segs.size();
-                            const uint32_t base = g0 * 64u, len = std::min<uint64_t>((uint64_t)g1 * 64u, nprot) - base;
-                            hipLaunchKernelGGL(k_tracksL, dim3((g1 - g0 + KL_THREADS / 64 - 1) / (KL_THREADS / 64)),
-                                               dim3(KL_THREADS), 0, sk, PL.order, nprot, g0, g1, tab, ctx->d_divtab,
-                                               PL.packed, PL.grow, rows, huge, ctx->d_clist + base, ctx->d_crow + base,
-                                               ctx->d_ccount + sg, ctx->d_fblist, ctx->d_fbcount);
-                            if (k == last_run && tail_allowed) { // nothing after this point reads the plan or the packed copy
-                                if (maybe_huge) whole_plan();
-                                else whole_plan_launched = true; // (the host has the plan words here: no protein of 65,535 residues)
-                                PL_HIP(ctx, hipEventRecord(ctx->tail_ev2[par], skb));
-                                ctx->tail_open2[par] = true;
-                            }
-                            if ((rc = refine_segment(base, len, sk)) != PLAAC_OK) return rc;
-                        }
-                        filter_group = (long)g;
-                        if (nlong && slong != skb) PL_HIP(ctx, hipStreamWaitEvent(skb, ctx->jev[5], 0)); // the fallback list is complete
-                        hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
-                                           d_offsets, PL.neff, PL.order, nprot, total_residues, tab, rows, tp, huge,
-                                           0u, ctx->d_fblist, ctx->d_fbcount);
-                    } else if (gfi[g] && ctx->fi_int_allowed)
-                        hipLaunchKernelGGL(k_tracks20f<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, PL.order, nprot,
-                                           total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
-                                           ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
-                    else
-                        hipLaunchKernelGGL(k_tracks20f<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, PL.order, nprot,
-                                           total_residues, tab, ctx->d_divtab, rows, huge, ctx->d_clist, ctx->d_crow,
-                                           ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
-                    if (!lane_form(g)) {
-                        filter_group = (long)g;
-                        if (tail_allowed) {
-                            whole_plan();
-                            PL_HIP(ctx, hipEventRecord(ctx->tail_ev2[par], skb));
-                            ctx->tail_open2[par] = true;
-                        }
-                        if ((rc = refine_segment(0u, nprot, skb)) != PLAAC_OK) return rc;
-                        hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, skb, d_codes,
-                                           d_offsets, PL.neff, PL.order, nprot, total_residues, tab, rows, tp, huge,
-                                           0u, ctx->d_fblist, ctx->d_fbcount);
-                    }
-                } else {
-                    hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, skb, d_codes, PL.order, nprot,
-                                       total_residues, tab, ctx->d_divtab, rows, tp, huge);
-                }
-            }
-            if (d_tracks)
-                hipLaunchKernelGGL(k_tracks20<true>, dim3(kb_grid), dim3(64), 0, skb, d_codes, d_offsets, PL.neff,
-                                   PL.order, nprot, total_residues, tab, rows, tp, huge, only_if_huge, (const uint4 *)nullptr, (const uint32_t *)nullptr);
-            else if (!whole_plan_launched && maybe_huge)
-                whole_plan();
-        } else if (wmax <= 32) LAUNCH_KB(128);
-        else if (wmax <= 96) LAUNCH_KB(256);
-        else LAUNCH_KB(1024);
-#undef LAUNCH_KB
-        if (g == 0) PL_HIP(ctx, hipEventRecord(evs[E_TRK + 1], skb));
-        return PLAAC_OK;
-    };
+    D.d_codes = d_codes, D.d_offsets = d_offsets, D.nprot = nprot, D.ngroups = C.ngroups, D.total = total_residues;
+    D.points = points, D.d_rows = d_rows, D.tracks = C.tracks, D.PL = &PL, D.st = st;
+    D.evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
+    D.seq = (uint32_t)(ctx->ncalls + 1) | 0x80000000u;
+    D.huge = ctx->d_huge + (ctx->ncalls & 3u);
 
-    // the ctx's plan / scratch buffers are shared by consecutive calls: order this call after the previous one even
-    // when the caller hands in a different stream
-    // the call before the previous one used THESE plan buffers; did it leave a tail event (summary mode, single point)?
-    const bool old_tail = ctx->tail_open2[par];
-    ctx->tail_open2[par] = false;
-    if (ctx->ncalls > 0)
-        PL_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][E_JOIN], 0));
-    // Overlapping calls: the head (planning, packed copy) goes on a stream of its own - the Viterbi stream of the priority
-    // class the previous call's chain kernels did NOT use: an idle hardware queue - and waits only for the call before the
-    // previous one, which read the buffers it writes: that call's side streams, and its window kernels up to its tail.
-    // (single-point summary calls: measured neutral for track mode and sweeps, whose steps are not bound by their two ends)
-    const bool head_aside = ctx->overlap && !ctx->serial && ctx->ncalls > 0 && npoints == 1 && !d_tracks;
-    // (after a call in mixed forms: the stream this call's long run will take - hlA of this parity, idle since the call before
-    //  the previous one, whose last event the head waits for anyway)
-    const hipStream_t sh = !head_aside ? st
-                           : ctx->last_mixed ? ctx->aux[par ? plaac_ctx::R_FWD : plaac_ctx::R_VIT]
-                                             : (ctx->last_chain_bound ? ctx->auxn[plaac_ctx::R_VIT] : ctx->aux[plaac_ctx::R_VIT]);
-    // (Measured and dropped: the chain kernels - they write the rows - additionally waiting for the caller's stream as it
-    //  stands at the entry of the call, which would let the caller order consumers of the row buffers on that stream: the
-    //  chains of call k+1 then start behind the whole of call k, 17.8 -> 19.1 ms per 10 M-sequence step, config 2 0.57 ->
-    //  0.77 ms. The header asks for row buffers that are free when the call is made instead.)
-    if (head_aside && ctx->ncalls > 1) {
-        if (old_tail) {
-            PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->tail_ev2[par], 0));
-            PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->ka_done[par], 0));
-        } else {
-            PL_HIP(ctx, hipStreamWaitEvent(sh, ctx->ev[(ctx->ncalls - 2) % plaac_ctx::EV_SETS][E_JOIN], 0));
-        }
-    }
-    PL_HIP(ctx, hipEventRecord(evs[E_START], sh));
-    PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), st)); // plaac_last_exact_fallbacks: this call's count
-    PL_HIP(ctx, hipMemsetAsync(PL.hist, 0, sizeof(uint32_t) * (LEN_BINS + 1), sh));
-    const unsigned pb = (nprot + 255u) / 256u;
-    const unsigned plb = (nprot + PLAN_THREADS * PLAN_ITEMS - 1) / (PLAN_THREADS * PLAN_ITEMS);
-    hipLaunchKernelGGL(k_plan_lengths, dim3(plb), dim3(PLAN_THREADS), 0, sh, d_codes, d_offsets, nprot, PL.neff,
-                       PL.hist);
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, sh, PL.hist, ctx->d_huge + (ctx->ncalls & 3u));
-    hipLaunchKernelGGL(k_plan_scatter, dim3(plb), dim3(PLAN_THREADS), 0, sh, PL.neff, nprot, PL.hist,
-                       d_offsets, PL.order);
-    PL_HIP(ctx, hipEventRecord(evs[E_PLAN], sh));
-    if (head_aside) PL_HIP(ctx, hipStreamWaitEvent(st, evs[E_PLAN], 0)); // the window kernels read the plan
-    // The three K-A roles and K-B are independent given the plan: fork the K-A side onto high-priority streams
-    // so the long serial chains (which set the wall time) overlap each other and the throughput-bound window
-    // kernel. K-B starts right away on the caller's stream; the packing of the K-A input runs beside it.
-    const bool kb_after_pack = lane_form(0);
-    if (!ctx->serial) {
-        if (!kb_after_pack && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
-        if (!head_aside) PL_HIP(ctx, hipStreamWaitEvent(sv, evs[E_PLAN], 0));
-    }
-    const hipStream_t spk = head_aside ? sh : sv; // the packed copy follows the plan on the head's stream
-    // group rows of the interleaved copy; their total is the one value the host needs back (buffer sizes)
-    PL_HIP(ctx, hipEventRecord(evs[E_PACK], spk));
-    hipLaunchKernelGGL(k_group_rows, dim3((ngroups + 255u) / 256u), dim3(256), 0, spk, PL.neff, PL.order, nprot,
-                       ngroups, PL.grow);
-    // the scan writes the four words the host needs (h_pin[0] total rows, [2] rows of the first wave-group, [3] the long
-    // wave-groups the k_core_* kernels serve - a prefix of the plan -, [4] their rows) into pinned host memory and then
-    // this call's sequence number into h_pin[5]: the host polls that word (no copy kernels, no interrupt-driven
-    // synchronisation: ~40 us per call, 6 % of a config-2 step). If the word does not arrive (memory not coherent on
-    // this system, a failed launch) the stream is synchronised as before and polling is switched off for the context.
-    const uint32_t seq = (uint32_t)(ctx->ncalls + 1) | 0x80000000u;
-    for (int k = 6; k < 6 + SCAN_SEGS - 1; ++k) ctx->h_pin[k] = 0xffffffffu; // (no rows: the scan leaves them alone)
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(SCAN_THREADS), 0, spk, PL.grow, ngroups, CORE_LONG_ROWS, CORE_MAX_GROUPS,
-                       ctx->d_hpin, seq);
+    // ---- the head: planning kernels, group 0's window tracks where they need no packed copy, the row offsets
+    Forms F;
+    PlanWords W;
+    KbState kb;
+    Sched S;
+    decide_entry(K, C, F);
+    emit_head(K, C, F, S);
+    if (!K.serial && !F.kb_after_pack) emit_tracks(K, C, F, W, 0, kb, S, false);
+    emit_head_rows(K, C, F, S);
+    if ((rc = run_ops(ctx, D, C, F, W, S.ops, 0)) != PLAAC_OK) return rc;
     PL_HIP(ctx, hipGetLastError());
+    // ---- the one host round trip: the plan words (polled from pinned memory; if the word does not arrive - memory not
+    // coherent on this system, a failed launch - the stream is synchronised as before and polling is switched off)
     {
         volatile uint32_t *hp = ctx->h_pin;
         bool arrived = false;
         if (ctx->poll_ok) {
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned spins = 0;; ++spins) {
-                if (__atomic_load_n(&ctx->h_pin[5], __ATOMIC_ACQUIRE) == seq) {
+                if (__atomic_load_n(&ctx->h_pin[5], __ATOMIC_ACQUIRE) == D.seq) {
                     arrived = true;
                     ++ctx->polled;
                     break;
@@ -1246,509 +1346,97 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
             }
         }
         if (!arrived) {
-            PL_HIP(ctx, hipStreamSynchronize(spk));
+            PL_HIP(ctx, hipStreamSynchronize(slot_stream(ctx, D, F.s_pack)));
             ++ctx->synced;
-            if (ctx->poll_ok && hp[5] != seq) return fail(ctx, PLAAC_ERR_DEVICE, "plan words did not reach the host");
+            if (ctx->poll_ok && hp[5] != D.seq) return fail(ctx, PLAAC_ERR_DEVICE, "plan words did not reach the host");
             ctx->poll_ok = false;
         }
     }
-    const size_t total_rows = ctx->h_pin[0];
-    // Is this batch bound by the serial chain of its longest protein (16-residue rows of the first wave-group x ~150 ns
-    // per residue) rather than by throughput (~12 ps per residue)? Then the lane-per-protein kernels take the forms
-    // that shorten one wave's chain (k_win as two kernels) at the price of a few more instructions in total.
-    const bool chain_bound =
-        ctx->latency_mode >= 0 ? ctx->latency_mode == 1 : (uint64_t)ctx->h_pin[2] * 384000ull > total_residues;
-    // (track mode too, since round 3: k_fwd_pair<true> / k_bwd_pair store the forward / backward pairs k_post combines)
-    const bool latency_mode = !ctx->serial && npoints == 1 && chain_bound;
-    // MIXED FORMS (round 4; summary mode): only the long wave-groups - the prefix of the plan whose proteins have >= 2048
-    // residues, h_pin[3] groups - take the latency forms, as ONE grid (k_long) on a stream of its own; every other
-    // wave-group takes the throughput forms (fewer instructions in total: one lane per protein in the forward pass, one
-    // window kernel, the pinned Viterbi step, the core list). gl = wave-groups of the long run: all of them when the batch
-    // has no long group or more than the core kernels serve (then the call is the latency form of round 3 in one grid), and
-    // under PLAAC_LATENCY_MODE=1 (the tests force the latency forms on small batches that way); PLAAC_MIXED_GROUPS=n (tests):
-    // at least n groups in the long run.
-    const bool mixed = latency_mode && !d_tracks && ctx->mixed;
-    uint32_t gl = 0u;
-    if (mixed) {
-        const uint32_t lgw = ctx->h_pin[3];
-        // (a split pays when the other wave-groups are many - their throughput forms save instructions, but cost a dozen more
-        //  launches: config 2, 92 wave-groups, 0.53 -> 0.70 ms per step when split, bound by the host's launch calls)
-        gl = (ctx->latency_mode != 1 && lgw > 0u && lgw < CORE_MAX_GROUPS && lgw < ngroups && ngroups - lgw >= ctx->mixed_min_rest)
-                 ? lgw : ngroups;
-        if (ctx->mixed_groups > 0u && ctx->latency_mode != 1) gl = std::min(std::max(ctx->h_pin[3] < CORE_MAX_GROUPS ? ctx->h_pin[3] : ngroups, ctx->mixed_groups), ngroups);
-    }
-    const bool lat_all = latency_mode && !mixed; // the latency forms as kernels of their own for every wave-group (track mode; PLAAC_MIXED=0)
-    const bool use_core_list = ctx->core_list && ((!latency_mode && !chain_bound) || (mixed && gl < ngroups)); // (sweeps: one list per group)
-    // the long wave-groups (proteins of >= 2048 residues) of a single-point call take the position-parallel core search
-    // (PLAAC_CORE_LONG_LIST=1, EXPERIMENT: also in the list form of throughput-bound batches, where the listed long
-    // proteins are k_core_list's tail. Measured at 10 M sequences: 23.0 against 22.2 ms - the tail was hidden, the extra
-    // kernels are not.)
-    const bool long_in_list = ctx->core_long_list;
-    // Chain-bound SWEEPS (round 3): the long wave-groups (proteins of >= 2048 residues) are a run of their own and take the
-    // latency form of the Viterbi kernel - unpinned steps, and their core windows (one trailing chain per core length in
-    // the throughput form: 10.3 ms for three core lengths with a 36,000-residue protein) from k_core_chain / _eval /
-    // _reduce: one prefix chain per group, the windows per core length. Every other wave-group keeps the throughput form
-    // (the unpinned form takes 180 registers: as the form of the whole batch its 4,800 blocks waited for register space).
-    const bool sweep_lat = !single && chain_bound && !ctx->serial && !d_tracks && ctx->sweep_latency &&
-                           ctx->h_pin[2] >= CORE_LONG_ROWS && ctx->h_pin[3] > 0u && ctx->h_pin[3] < CORE_MAX_GROUPS;
-    const bool core_long = sweep_lat || (single && (latency_mode || (use_core_list && long_in_list)) &&
-                                         ctx->h_pin[2] >= CORE_LONG_ROWS);
-    const size_t core_lrows = core_long ? (size_t)ctx->h_pin[4] : 0;
-    const size_t core_copies = sweep_lat ? ng : 1; // (the groups of a sweep run side by side: scratch per group)
-    if (core_long) { // scratch of k_core_*: the rows of the first CORE_MAX_GROUPS wave-groups
-        if ((rc = grow(ctx, PL.corep, PL.cap_corep, core_lrows * 1024u * core_copies)) != PLAAC_OK) return rc;
+    W.total_rows = ctx->h_pin[0], W.rows_first = ctx->h_pin[2], W.long_groups = ctx->h_pin[3], W.long_rows = ctx->h_pin[4];
+    for (int k = 0; k < SCAN_SEGS - 1; ++k) W.run_mark[k] = ctx->h_pin[6 + k];
+
+    // ---- the forms of this call, the buffers they need
+    decide_forms(K, C, W, F);
+    D.total_rows = W.total_rows;
+    D.core_lrows = F.core_lrows;
+    if (F.core_long) { // scratch of k_core_*: the rows of the first CORE_MAX_GROUPS wave-groups
+        if ((rc = grow(ctx, PL.corep, PL.cap_corep, F.core_lrows * 1024u * F.core_copies)) != PLAAC_OK) return rc;
         char *&cp = reinterpret_cast<char *&>(PL.corepart);
-        if ((rc = grow(ctx, cp, PL.cap_corepart, core_lrows * 64u * sizeof(CorePart) * core_copies)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, cp, PL.cap_corepart, F.core_lrows * 64u * sizeof(CorePart) * F.core_copies)) != PLAAC_OK) return rc;
     }
-    if (use_core_list) {
+    if (F.use_core_list) {
         if ((rc = grow(ctx, PL.corelist, PL.cap_corelist, (size_t)nprot * ng)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, PL.corecount, PL.cap_corecount, ng)) != PLAAC_OK) return rc;
     }
-    if ((rc = grow(ctx, PL.packed, PL.cap_packed, total_rows * 64u + 64u)) != PLAAC_OK) return rc;
-    const size_t bits_stride = total_rows * 64u + 64u; // one traceback-bit buffer per group
-    if ((rc = grow(ctx, PL.bits, PL.cap_bits, bits_stride * ng)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, PL.packed, PL.cap_packed, W.total_rows * 64u + 64u)) != PLAAC_OK) return rc;
+    D.bits_stride = W.total_rows * 64u + 64u; // one traceback-bit buffer per group
+    if ((rc = grow(ctx, PL.bits, PL.cap_bits, D.bits_stride * ng)) != PLAAC_OK) return rc;
     if (d_tracks) {
-        if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, ctx->d_bwd, ctx->cap_bwd, total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_fwd, ctx->cap_fwd, W.total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, ctx->d_bwd, ctx->cap_bwd, W.total_rows * 16u * 64u + 64u)) != PLAAC_OK) return rc;
     }
-    // Single-point calls on large batches are PIPELINED over runs of wave-groups of about equal row counts (the scan left
-    // the groups that hold the rows k/8 of the total in h_pin[6..12]): the packed copy is made run by run and every
-    // lane-per-protein kernel is launched per run (`order`, `grow`, `nprot` of the run), behind the run's copy. The copy is
-    // HBM-bound, the kernels are bound by instruction issue: the second run is packed while the first is scored (the
-    // 10 M-sequence step began with 2.4 ms of planning and packing during which no scoring kernel could start). In track
-    // mode k_post of a run (HBM-bound too: 50 bytes per residue) likewise runs beside the chains of the later runs. The
-    // longest proteins - the chains that bound small batches - are all in the first run.
-    std::vector<uint32_t> segb{0u};
-    if (single && !ctx->serial && total_rows >= ctx->segment_min_rows) { // (small batches: nothing to hide, launches to pay)
-        const int nseg = d_tracks ? ctx->track_segments : (chain_bound ? 1 : ctx->pipe_segments);
-        for (int k = 1; k < nseg; ++k) {
-            const uint32_t g = ctx->h_pin[6 + SCAN_SEGS * k / nseg - 1];
-            if (g != 0xffffffffu && g > segb.back() && g < ngroups) segb.push_back(g);
-        }
-    }
-    if (mixed && gl > 0u && gl < ngroups) segb.push_back(gl); // mixed forms: the long run and the rest (packed separately: the
-                                                              // long run starts behind its own few rows)
-    segb.push_back(ngroups);
-    const size_t ntseg = segb.size() - 1;
-    auto run_is_long = [&](size_t k) { return mixed && segb[k + 1] <= gl; };
-    // the Viterbi kernel's own runs (chain-bound sweeps: the long wave-groups apart, see sweep_lat; the forward and window
-    // kernels of a sweep stay one launch each: as two they only queue up behind each other)
-    std::vector<uint32_t> vsegb = segb;
-    if (sweep_lat && ctx->h_pin[3] < ngroups) vsegb = {0u, ctx->h_pin[3], ngroups};
-    auto seg_first = [&](size_t k) { return segb[k] * 64u; };
-    auto seg_count = [&](size_t k) { return (uint32_t)(std::min<uint64_t>((uint64_t)segb[k + 1] * 64u, nprot) - seg_first(k)); };
-    // Streams of the sweep groups after the first. Chain-bound sweeps: the Viterbi and forward chains of the longest
-    // protein bound the call once per GROUP, and streams map onto four hardware queues per priority class - with every
-    // group's streams in the high class (ten streams on four queues) the chains of different groups queued up behind each
-    // other (three Viterbi chains in a row: 12.6 of 20.2 ms for nine points over the 1.25 M share). The second and third
-    // group therefore take the role streams a summary sweep leaves idle: their Viterbi chains (10 ms alone for three core
-    // lengths) the normal class's Viterbi stream and the high class's second-window stream - every Viterbi chain a queue
-    // of its own -, their window chains (7 ms) the normal class's forward and window streams (measured apart from each
-    // other and from the caller's stream), their forward chains (5 ms) behind the first group's forward and window chains.
-    // Further groups take the extra streams as before.
-    // Throughput-bound sweeps: the first group has the normal class (see auxn), the other groups' nine streams shared its
-    // four queues (and the caller's, behind the window kernels) while the high class stood idle: the second group takes
-    // the high class's role streams, the third its second-window stream and places behind the second group's chains.
-    std::vector<hipStream_t> gs_spread;
-    if (ng > 1 && !d_tracks && ctx->sweep_spread && !ctx->serial) {
-        gs_spread = chain_bound ? ctx->gstreams : ctx->gstreams_n;
-        const hipStream_t pick_c[6] = {ctx->auxn[plaac_ctx::R_VIT], ctx->aux[plaac_ctx::R_FWD], ctx->auxn[plaac_ctx::R_FWD],
-                                       ctx->aux[plaac_ctx::R_WIN2], ctx->aux[plaac_ctx::R_WIN], ctx->auxn[plaac_ctx::R_WIN]};
-        const hipStream_t pick_t[6] = {ctx->aux[plaac_ctx::R_VIT], ctx->aux[plaac_ctx::R_FWD], ctx->aux[plaac_ctx::R_WIN],
-                                       ctx->aux[plaac_ctx::R_WIN2], ctx->aux[plaac_ctx::R_FWD], ctx->aux[plaac_ctx::R_WIN]};
-        for (size_t k = 0; k < 6 && k < gs_spread.size(); ++k) gs_spread[k] = chain_bound ? pick_c[k] : pick_t[k];
-    }
-    const std::vector<hipStream_t> &gs = !gs_spread.empty() ? gs_spread : (chain_bound ? ctx->gstreams : ctx->gstreams_n);
-    if (!ctx->serial) {
-        if (!chain_bound || mixed) { // throughput-bound: the chain kernels run at the window kernel's priority (see auxn);
-                                     // mixed forms: the throughput-form runs likewise, the long run on hlA / hlB below
-            sv = ctx->auxn[plaac_ctx::R_VIT];
-            sf = ctx->auxn[plaac_ctx::R_FWD];
-            sw = ctx->auxn[plaac_ctx::R_WIN];
-            sb = ctx->auxn[plaac_ctx::R_BWD];
-            sw2 = ctx->auxn[plaac_ctx::R_WIN2];
-        }
-    }
-    const bool ka_wait = d_tracks || !single || !ctx->last_single_summary || chain_bound != ctx->last_chain_bound;
-    auto wait_run = [&](hipStream_t s, size_t k) -> plaac_status { // stream s may touch run k of the packed copy
-        if (!ctx->serial) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->pkev[k], 0));
-        // ... and, with overlapping calls, the chain kernels' scratch (path bits, core lists, latency-form words, forward /
-        // backward pairs) only when the previous call's side streams are through with it
-        // (not a single-point summary call that takes the same forms as the previous call: every role then runs on the
-        //  stream it had in that call, in order behind its own kernels; what crosses streams - lmarginalprob and hmm0's
-        //  total for k_finish - exists per call, and the path bits / core scratch stay on the Viterbi stream)
-        if (head_aside && k == 0 && ka_wait) PL_HIP(ctx, hipStreamWaitEvent(s, ctx->ka_done[par ^ 1u], 0));
-        return PLAAC_OK;
-    };
-    // masked core window of the long wave-groups (single-point calls): prefix sums position-parallel on the chain's
-    // rounding grid where the tables and the protein allow it (k_core_par), the serial chain for whatever it flags, then
-    // every window per packed row and the ordered reduction
-    // `copy`: which scratch copy (the sweep group; 0 for single-point calls); `prefix`: compute the masked prefix sums (they
-    // do not depend on the core length: once per group); then the windows of ONE core length into `rows`
-    auto launch_core_long = [&](const DevTables *tab, uint32_t *gbits, uint32_t c, plaac_row *rows, hipStream_t s,
-                                uint32_t point, size_t copy, bool prefix) -> plaac_status {
-        const unsigned lg = ctx->h_pin[3]; // (the kernels re-check every group: lengths >= 65535 are not ordered)
-        double *corep = PL.corep + core_lrows * 1024u * copy;
-        CorePart *corepart = (CorePart *)PL.corepart + core_lrows * 64u * copy;
-        if (prefix) {
-            const bool par = copy == 0 && single && ctx->core_par && ctx->core_par_ok &&
-                             std::memcmp(&points[point], &ctx->params, sizeof(plaac_params)) == 0;
-            if (par) {
-                if (!PL.coreflags)
-                    PL_HIP(ctx, hipMalloc((void **)&PL.coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
-                PL_HIP(ctx, hipMemsetAsync(PL.coreflags, 0, sizeof(uint32_t) * (size_t)lg * 64u, s));
-                hipLaunchKernelGGL(k_core_par, dim3(lg * 64u), dim3(64 * CP_WAVES), 0, s, d_codes, PL.order, nprot, tab,
-                                   PL.grow, gbits, corep, PL.coreflags);
-            }
-            hipLaunchKernelGGL(k_core_chain, dim3(lg), dim3(64), 0, s, PL.order, nprot, tab, PL.packed, PL.grow,
-                               gbits, corep, par ? PL.coreflags : (const uint32_t *)nullptr);
-        }
-        hipLaunchKernelGGL(k_core_eval, dim3(ctx->h_pin[4]), dim3(64), 0, s, PL.order, nprot, ngroups, PL.grow,
-                           corep, corepart, c);
-        hipLaunchKernelGGL(k_core_reduce, dim3(lg * 64u), dim3(64), 0, s, d_codes, PL.order, nprot, tab, PL.grow,
-                           gbits, (const CorePart *)corepart, rows, c);
-        return PLAAC_OK;
-    };
-    // mixed forms: the long run's streams, per call parity (two pairs of the high class's four): A carries the call's head
-    // (plan, packed copy of the long run), k_long and, at the end, the event "the chain kernels of this call are through";
-    // B the Viterbi pass of the long wave-groups and their core search (2.5 + 0.5 ms beside the 3.2 ms forward chain)
-    const hipStream_t hlA = ctx->aux[par ? plaac_ctx::R_FWD : plaac_ctx::R_VIT];
-    const hipStream_t hlB = ctx->aux[par ? plaac_ctx::R_WIN2 : plaac_ctx::R_WIN];
-    // the packed copy, run by run. Mixed forms: the long run's few rows on the head's stream, and the long run is enqueued
-    // before anything else (measured: the host needs 0.5 ms for the window-track launches, during which the 3.2 ms chain
-    // did not start); the other wave-groups' copy goes on the forward stream (not in front of the long chain).
-    for (size_t k = 0; k < ntseg; ++k) {
-        const uint32_t first = seg_first(k), cnt = seg_count(k);
-        const hipStream_t sp = (mixed && !run_is_long(k)) ? sf : spk;
-        if (sp != spk) PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->pkev[0], 0)); // (the row offsets: behind k_scan_u32)
-        hipLaunchKernelGGL(k_pack, dim3((cnt + 15u) / 16u), dim3(256), 0, sp, d_codes, d_offsets, PL.neff,
-                           PL.order + first, cnt, total_residues, PL.grow + segb[k], PL.packed);
-        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->pkev[k], sp));
-        if (k == 0 && mixed) {
-            PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], spk));
-            const DevTables *tab = gtab0;
-            plaac_row *rows0 = d_rows[0];
-            uint32_t *gbits = PL.bits;
-            const uint32_t lcnt = (uint32_t)std::min<uint64_t>((uint64_t)gl * 64u, nprot);
-            SweepTargets tl{};
-            for (int j = 0; j < MAXC; ++j) {
-                tl.c[j] = (uint32_t)points[0].corelength;
-                tl.rows[j] = rows0;
-            }
-            tl.stop_after = ctx->vit_stop;
-            tl.long_groups_elsewhere = core_long ? 1u : 0u;
-            tl.first = 0u;
-            double *const lmarg = PL.lat, *const h0 = PL.lat + nprot, *const vend = PL.lat + 2 * (size_t)nprot;
-            if ((rc = wait_run(hlA, 0)) != PLAAC_OK) return rc;
-            if ((rc = wait_run(hlB, 0)) != PLAAC_OK) return rc;
-            PL_HIP(ctx, hipEventRecord(evs[E_BWD], hlA));
-            hipLaunchKernelGGL(k_long, dim3(4u * ((lcnt + KA_THREADS - 1) / KA_THREADS)), dim3(KA_THREADS), 0, hlA, d_offsets,
-                               PL.neff, PL.order, lcnt, tab, PL.packed, PL.grow, tl, lmarg, h0);
-            hipLaunchKernelGGL((k_vit<1, true, true>), dim3((lcnt + KA_THREADS - 1) / KA_THREADS), dim3(KA_THREADS), 0, hlB,
-                               d_codes, d_offsets, PL.neff, PL.order, lcnt, tab, PL.packed, PL.grow, gbits, tl,
-                               (uint32_t *)nullptr, (uint32_t *)nullptr, vend);
-            if (core_long && tl.stop_after == 0u &&
-                (rc = launch_core_long(tab, gbits, tl.c[0], rows0, hlB, 0u, 0, true)) != PLAAC_OK)
-                return rc;
-            PL_HIP(ctx, hipEventRecord(ctx->lev[par], hlB));
-            PL_HIP(ctx, hipStreamWaitEvent(hlA, ctx->lev[par], 0));
-            hipLaunchKernelGGL(k_finish, dim3((lcnt + 255u) / 256u), dim3(256), 0, hlA, PL.order, lcnt, rows0, lmarg, h0, vend);
-            PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], hlA));
-        }
-    }
-    if (!mixed) PL_HIP(ctx, hipEventRecord(evs[E_PACK + 1], spk));
-    // (the role streams wait for the packed copy run by run, see wait_run; the streams of further sweep groups for all)
-    for (size_t k = 0; !ctx->serial && k < 3 * (ng - 1); ++k) {
-        PL_HIP(ctx, hipStreamWaitEvent(gs[k], evs[E_PACK + 1], 0));
-        if (head_aside) PL_HIP(ctx, hipStreamWaitEvent(gs[k], ctx->ka_done[par ^ 1u], 0));
-    }
-    pack_events = &ctx->pkev[0];
-    kb_runs = &segb;
-    // (mixed forms: the window-track launches - a dozen calls, 0.5 ms of host time - come after the throughput-form runs have
-    //  been enqueued: the caller's stream is still busy with the previous call's tail, the chip is not)
-    const bool kb_deferred = mixed && kb_after_pack;
-    if (mixed) {
-        kb_side = sw;
-        maybe_huge = (uint64_t)ctx->h_pin[2] * 16u >= 65535u;
-    }
-    if (!ctx->serial && kb_after_pack && !kb_deferred && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
-    // track mode: the backward recurrence is a chain of its own, beside the forward one
-    // (E_BWD .. E_BWD + 1 time the backward kernels in track mode and the long run in mixed forms)
-    if (!mixed) PL_HIP(ctx, hipEventRecord(evs[E_BWD], sb));
-    for (size_t k = 0; d_tracks && k < ntseg; ++k) {
-        const uint32_t first = seg_first(k), cnt = seg_count(k);
-        if ((rc = wait_run(sb, k)) != PLAAC_OK) return rc;
-        if (latency_mode)
-            hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, sb,
-                               PL.order + first, cnt, gtab0, PL.packed, PL.grow + segb[k], ctx->d_bwd);
-        else
-            hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sb, d_offsets, PL.neff,
-                               PL.order + first, cnt, gtab0, PL.packed, PL.grow + segb[k], ctx->d_bwd);
-        if (!ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tbev[k], sb));
-    }
-    if (!mixed) PL_HIP(ctx, hipEventRecord(evs[E_BWD + 1], sb));
 
-    const hipStream_t sv0 = sv, sf0 = sf, sw0 = sw;
-    for (size_t g = 0; g < ng; ++g) {
-        const Group &G = groups[g];
-        const DevTables *tab = gtab0 + g;
-        plaac_row *rows0 = d_rows[G.first];
-        const bool timed = g == 0;
-        // streams of this group
-        hipStream_t sv = sv0, sf = sf0, sw = sw0;
-        if (g > 0 && !ctx->serial) {
-            sv = gs[3 * (g - 1)];
-            sf = gs[3 * (g - 1) + 1];
-            sw = gs[3 * (g - 1) + 2];
-        }
-        uint32_t *gbits = PL.bits + bits_stride * g;
-        const hipStream_t win3_stream = d_tracks ? sw : sw2;
-        // K-B of this group (group 0 was launched before the host round trip; serialised mode launches it last)
-        if (g > 0 && !ctx->serial) {
-            if ((rc = launch_tracks(g)) != PLAAC_OK) return rc;
-        }
-        // every lane-per-protein kernel below is launched per run of wave-groups (one run unless the call is pipelined,
-        // see segb): the run's slice of the plan (`order + first`, its count, `grow + first group`), behind the run's
-        // packed copy; sweep groups beyond the first have waited for the whole copy on their own streams
-        // forward pass: once per group
-        if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD], sf));
-#define LAUNCH_FWD(TRK, EXTF, FIRST, CNT, G0)                                                                      \
-    hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3(((CNT) + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, sf, d_codes, \
-                       d_offsets, PL.neff, PL.order + (FIRST), (CNT), tab, PL.packed, PL.grow + (G0),  \
-                       rows0, TRK ? ctx->d_fwd : (double2 *)nullptr, PL.lat, nprot)
-        for (size_t k = 0; k < ntseg; ++k) {
-            const uint32_t first = seg_first(k), cnt = seg_count(k);
-            if (run_is_long(k)) continue; // (k_long)
-            if (g == 0 && (rc = wait_run(sf, k)) != PLAAC_OK) return rc;
-            if (lat_all && d_tracks)
-                hipLaunchKernelGGL(k_fwd_pair<true>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
-                                   sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], PL.lat,
-                                   ctx->d_fwd);
-            else if (lat_all)
-                hipLaunchKernelGGL(k_fwd_pair<false>, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0,
-                                   sf, PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], PL.lat,
-                                   (double2 *)nullptr);
-            else if (d_tracks && single) LAUNCH_FWD(true, true, first, cnt, segb[k]);
-            else if (d_tracks) LAUNCH_FWD(true, false, first, cnt, segb[k]);
-            else if (single) LAUNCH_FWD(false, true, first, cnt, segb[k]);
-            else LAUNCH_FWD(false, false, first, cnt, segb[k]);
-            if (d_tracks && !ctx->serial) PL_HIP(ctx, hipEventRecord(ctx->tfev[k], sf));
-        }
-#undef LAUNCH_FWD
-        if (timed) PL_HIP(ctx, hipEventRecord(evs[E_FWD + 1], sf));
-        // Viterbi / windows: up to MAXC core lengths per launch
-        for (size_t m0 = 0; m0 < G.members.size(); m0 += MAXC) {
-            const int nc = (int)std::min<size_t>(MAXC, G.members.size() - m0);
-            SweepTargets tg{};
-            for (int k = 0; k < MAXC; ++k) {
-                const uint32_t idx = G.members[m0 + (size_t)std::min(k, nc - 1)];
-                tg.c[k] = (uint32_t)points[idx].corelength;
-                tg.rows[k] = d_rows[idx];
-            }
-            const bool t0 = timed && m0 == 0;
-            tg.stop_after = ctx->vit_stop;
-            tg.long_groups_elsewhere = (core_long && !mixed) ? 1u : 0u; // (mixed forms: the long wave-groups are k_long's)
-            if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT], sv));
-            // the core list of this launch: the call's (single point), or the sweep group's own, reused by its launches
-            uint32_t *cl_list = single ? PL.corelist : PL.corelist + (size_t)nprot * g;
-            uint32_t *cl_count = single ? PL.corecount : PL.corecount + g;
-            if (g == 0 && (rc = wait_run(sv, 0)) != PLAAC_OK) return rc; // (the list is scratch of the chain kernels)
-            if (use_core_list) PL_HIP(ctx, hipMemsetAsync(cl_count, 0, sizeof(uint32_t), sv));
-            for (size_t k = 0; k + 1 < vsegb.size(); ++k) {
-                const uint32_t first = vsegb[k] * 64u;
-                const uint32_t cnt = (uint32_t)(std::min<uint64_t>((uint64_t)vsegb[k + 1] * 64u, nprot) - first);
-                const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
-                if (mixed && run_is_long(k)) continue; // (k_long; vsegb == segb in single-point calls)
-                if (g == 0 && (rc = wait_run(sv, std::min(k, ntseg - 1))) != PLAAC_OK) return rc;
-                tg.first = first;
-#define VIT_ARGS d_codes, d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + vsegb[k], gbits, tg
-#define LAUNCH_VIT(NC) hipLaunchKernelGGL((k_vit<NC>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS)
-#define LAUNCH_VIT_LIST(NC) hipLaunchKernelGGL((k_vit<NC, false, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, cl_list, cl_count)
-                double *const vend = PL.lat ? PL.lat + 2 * (size_t)nprot : nullptr; // (EXT forms: single-point calls)
-                if (lat_all)
-                    hipLaunchKernelGGL((k_vit<1, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, (uint32_t *)nullptr,
-                                       (uint32_t *)nullptr, vend);
-                else if (sweep_lat && vsegb[k + 1] <= ctx->h_pin[3]) // the run of the long wave-groups
-                    switch (nc) {
-                    case 1: hipLaunchKernelGGL((k_vit<1, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
-                    case 2: hipLaunchKernelGGL((k_vit<2, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
-                    case 3: hipLaunchKernelGGL((k_vit<3, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
-                    default: hipLaunchKernelGGL((k_vit<4, true, false>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS); break;
-                    }
-                else if (single && use_core_list) // throughput-bound: sweep 3 only for proteins that can have a core
-                    hipLaunchKernelGGL((k_vit<1, false, true, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, cl_list, cl_count,
-                                       vend);
-                else if (use_core_list) { // sweep groups
-                    switch (nc) {
-                    case 1: LAUNCH_VIT_LIST(1); break;
-                    case 2: LAUNCH_VIT_LIST(2); break;
-                    case 3: LAUNCH_VIT_LIST(3); break;
-                    default: LAUNCH_VIT_LIST(4); break;
-                    }
-                } else if (single) // hmm0's running sum is k_fwd's (k_finish)
-                    hipLaunchKernelGGL((k_vit<1, false, true>), dim3(abk), dim3(KA_THREADS), 0, sv, VIT_ARGS, (uint32_t *)nullptr,
-                                       (uint32_t *)nullptr, vend);
-                else
-                    switch (nc) {
-                    case 1: LAUNCH_VIT(1); break;
-                    case 2: LAUNCH_VIT(2); break;
-                    case 3: LAUNCH_VIT(3); break;
-                    default: LAUNCH_VIT(4); break;
-                    }
-#undef LAUNCH_VIT_LIST
-#undef LAUNCH_VIT
-#undef VIT_ARGS
-            }
-            tg.first = 0u;
-            // after the runs: the core window of the long wave-groups, then sweep 3 for the listed proteins
-            if (tg.stop_after == 0u) {
-                // (the long wave-groups first: the chain of a 36,000-residue protein on the list would be the tail of the step)
-                if (core_long && !mixed && (latency_mode || (single && use_core_list)) &&
-                    (rc = launch_core_long(tab, gbits, tg.c[0], tg.rows[0], sv, G.first, 0, true)) != PLAAC_OK)
-                    return rc;
-                for (int k = 0; sweep_lat && k < nc; ++k) // (the path bits of the group: the same for every launch)
-                    if ((rc = launch_core_long(tab, gbits, tg.c[k], tg.rows[k], sv, G.first, g, m0 == 0 && k == 0)) != PLAAC_OK)
-                        return rc;
-                if (use_core_list) {
-                    const unsigned lgrid = std::min((nprot + KA_THREADS - 1) / KA_THREADS, 2048u);
-#define LAUNCH_CORE_LIST(NC)                                                                                       \
-    hipLaunchKernelGGL(k_core_list<NC>, dim3(lgrid), dim3(KA_THREADS), 0, sv, d_codes, total_residues, PL.order, tab, \
-                       PL.packed, PL.grow, gbits, tg, cl_list, cl_count)
-                    switch (single ? 1 : nc) {
-                    case 1: LAUNCH_CORE_LIST(1); break;
-                    case 2: LAUNCH_CORE_LIST(2); break;
-                    case 3: LAUNCH_CORE_LIST(3); break;
-                    default: LAUNCH_CORE_LIST(4); break;
-                    }
-#undef LAUNCH_CORE_LIST
-                }
-            }
-            if (t0) PL_HIP(ctx, hipEventRecord(evs[E_VIT + 1], sv));
-            if (t0) PL_HIP(ctx, hipEventRecord(evs[E_WIN], sw));
-            for (size_t k = 0; k < ntseg; ++k) {
-                const uint32_t first = seg_first(k), cnt = seg_count(k);
-                const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
-                if (run_is_long(k)) continue; // (k_long)
-                if (g == 0 && (rc = wait_run(sw, k)) != PLAAC_OK) return rc;
-                if (g == 0 && lat_all && win3_stream != sw && (rc = wait_run(win3_stream, k)) != PLAAC_OK) return rc;
-#define LAUNCH_WIN(NC, ROLE, STREAM)                                                                               \
-    hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, STREAM, d_codes, d_offsets, PL.neff, \
-                       PL.order + first, cnt, tab, PL.packed, PL.grow + segb[k], tg,                   \
-                       PL.lat ? PL.lat + nprot : (double *)nullptr)
-                if (lat_all) { // two halves side by side (LLR window | MW window + means + hmm0's running sum)
-                    LAUNCH_WIN(1, 2, sw);
-                    // MW window + means + hmm0's running sum as ONE kernel beside the LLR kernel. (As two kernels on two more
-                    // streams they were measured back to back, not side by side: the runtime maps streams onto four hardware
-                    // queues, the fifth and sixth stream share theirs, and 1.6 + 1.3 ms in a row outlast the forward chain.)
-                    // (Round 3, with the streams' hardware queues measured: the MW window and the means + hmm0's sum as two
-                    //  kernels, the fifth chain on a free queue of the normal class: 3.77 against 3.71 ms at the 1.25 M share -
-                    //  the step is the forward / Viterbi chain by then.)
-                    // (track mode: the backward chain has the stream of the second window kernel - the priority class has four
-                    //  hardware queues - so both window kernels go on the first one's, 5.8 + 2.7 ms in a row beside 13 ms chains)
-                    LAUNCH_WIN(1, 3, win3_stream);
-                } else {
-                    switch (nc) {
-                    case 1: LAUNCH_WIN(1, 0, sw); break;
-                    case 2: LAUNCH_WIN(2, 0, sw); break;
-                    case 3: LAUNCH_WIN(3, 0, sw); break;
-                    default: LAUNCH_WIN(4, 0, sw); break;
-                    }
-                }
-#undef LAUNCH_WIN
-            }
-            if (t0) PL_HIP(ctx, hipEventRecord(evs[E_WIN + 1], sw));
-        }
-        if (ctx->serial) {
-            if ((rc = launch_tracks(g)) != PLAAC_OK) return rc;
-        }
-        // fields that do not depend on the core length: copy from the group's first row array to the others
-        if (G.members.size() > 1) {
-            if (!ctx->serial) {
-                PL_HIP(ctx, hipEventRecord(ctx->gev[g], sf));
-                PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gev[g], 0));
-            }
-            for (size_t m0 = 1; m0 < G.members.size(); m0 += MAXC - 1) {
-                const int nd = (int)std::min<size_t>(MAXC - 1, G.members.size() - m0);
-                SweepTargets tg{};
-                for (int k = 1; k <= nd; ++k) tg.rows[k] = d_rows[G.members[m0 + (size_t)k - 1]];
-                hipLaunchKernelGGL(k_replicate, dim3(pb), dim3(256), 0, st, rows0, tg, nd, nprot);
-            }
-        }
-    }
-    if (kb_deferred && (rc = launch_tracks(0)) != PLAAC_OK) return rc;
-    if (single) { // HMMall / HMMvit from lmarginalprob, lviterbiprob (in the row) and hmm0's total: on the Viterbi stream,
-                  // behind the kernels that produced the other two terms, so that it runs beside the window kernel
-        if (!ctx->serial) {
-            PL_HIP(ctx, hipEventRecord(ctx->fev[0], sf));
-            PL_HIP(ctx, hipEventRecord(ctx->fev[1], lat_all ? (d_tracks ? sw : sw2) : sb)); // latency forms: hmm0's total comes from k_win<1,3>
-            PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[0], 0));
-            PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->fev[1], 0));
-        }
-        // (mixed forms: the long run has formed its own on the long stream; here the throughput-form runs)
-        const uint32_t f0 = mixed ? (uint32_t)std::min<uint64_t>((uint64_t)gl * 64u, nprot) : 0u;
-        if (nprot > f0)
-            hipLaunchKernelGGL(k_finish, dim3((nprot - f0 + 255u) / 256u), dim3(256), 0, sv, PL.order + f0, nprot - f0, d_rows[0],
-                               PL.lat, PL.lat + nprot, PL.lat + 2 * (size_t)nprot);
-    }
-    // posteriors + MAP bytes (track mode): k_post<true, false> of a run needs the run's k_fwd and k_bwd; it goes on the
-    // window kernels' stream (they are the first chains to finish) and runs beside the chains of the later runs and the
-    // window-track kernel. (On a stream of the other priority class - a sixth hardware queue - its first launch was
-    // not served before one of the five busy queues ran empty: measured, 14.6 ms into the step.) Viterbi bytes:
-    // k_post<false, true> behind k_vit on its stream.
-    const unsigned post_grid = (unsigned)((total_rows + POST_ROWS - 1) / POST_ROWS);
-    if (d_tracks && total_rows && !ctx->serial) {
-        const hipStream_t sp = sw;
-        for (size_t k = 0; k < ntseg; ++k) {
-            PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->tfev[k], 0));
-            PL_HIP(ctx, hipStreamWaitEvent(sp, ctx->tbev[k], 0));
-            hipLaunchKernelGGL((k_post<true, false>), dim3(post_grid), dim3(64), 0, sp, d_offsets, PL.neff, PL.order,
-                               nprot, ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, PL.bits, tp, segb[k], segb[k + 1]);
-        }
-        PL_HIP(ctx, hipEventRecord(ctx->tpev, sp));
-        PL_HIP(ctx, hipStreamWaitEvent(st, ctx->tpev, 0));
-        hipLaunchKernelGGL((k_post<false, true>), dim3(post_grid), dim3(64), 0, sv, d_offsets, PL.neff, PL.order, nprot,
-                           ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, PL.bits, tp, 0u, ngroups);
-    }
-    if (!ctx->serial) {
-        // join: everything enqueued on the side streams so far
-        PL_HIP(ctx, hipEventRecord(ctx->jev[0], sv));
-        PL_HIP(ctx, hipEventRecord(ctx->jev[1], sf));
-        PL_HIP(ctx, hipEventRecord(ctx->jev[2], sw));
-        PL_HIP(ctx, hipEventRecord(ctx->jev[3], sb));
-        PL_HIP(ctx, hipEventRecord(ctx->jev[4], sw2));
-        for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(st, ctx->jev[k], 0));
-
-        for (size_t k = 0; k < 3 * (ng - 1); ++k) {
-            PL_HIP(ctx, hipEventRecord(ctx->gjev[k], gs[k]));
-            PL_HIP(ctx, hipStreamWaitEvent(st, ctx->gjev[k], 0));
-        }
-        // "the side streams of this call are through" as ONE event (overlapping calls wait for it): on the Viterbi stream
-        // behind the other four - or, for sweeps (streams per group), on the caller's stream behind everything
-        if (mixed) {
-            // on the long run's own stream, behind its last kernel: nothing of the NEXT call is ever enqueued there (the next
-            // use of this stream is the head of the call after it, which waits for this event anyway), so no role stream is
-            // held up by it (on the Viterbi stream, round 3's place, the next call's Viterbi kernel waited for this call's
-            // 3 ms long run)
-            for (int k = 0; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(hlA, ctx->jev[k], 0));
-            PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], hlA));
-            PL_HIP(ctx, hipStreamWaitEvent(st, ctx->ka_done[par], 0));
-        } else if (single) {
-            for (int k = 1; k < 5; ++k) PL_HIP(ctx, hipStreamWaitEvent(sv, ctx->jev[k], 0));
-            PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], sv));
-        } else {
-            PL_HIP(ctx, hipEventRecord(ctx->ka_done[par], st));
-        }
-    }
-    if (d_tracks && total_rows && ctx->serial)
-        hipLaunchKernelGGL((k_post<true, true>), dim3(post_grid), dim3(64), 0, st, d_offsets, PL.neff, PL.order, nprot,
-                           ngroups, PL.grow, gtab0, ctx->d_fwd, ctx->d_bwd, PL.bits, tp, 0u, ngroups);
-    PL_HIP(ctx, hipEventRecord(evs[E_JOIN], st));
+    // ---- the body
+    const size_t body = S.ops.size();
+    emit_body(K, C, F, W, kb, S);
+    if (K.stream_debug && ctx->ncalls < 4) std::fprintf(stderr, "plaac: schedule of call %lu\n%s", (unsigned long)ctx->ncalls, dump(S).c_str());
+    if ((rc = run_ops(ctx, D, C, F, W, S.ops, body)) != PLAAC_OK) return rc;
     PL_HIP(ctx, hipGetLastError());
-    ctx->last_chain_bound = chain_bound;
-    ctx->last_mixed = mixed;
-    ctx->last_single_summary = single && !d_tracks;
+    ctx->last_chain_bound = F.chain_bound;
+    ctx->last_mixed = F.mixed;
+    ctx->last_single_summary = C.single() && !d_tracks;
     ctx->ncalls++;
     return PLAAC_OK;
+}
+
+long plaac_debug_schedule(const plaac_sched_query *q, char *buf, size_t cap) {
+    using namespace sched;
+    if (!q || !buf || q->nprot == 0 || q->npoints == 0 || q->ngroups_sweep == 0 || q->ngroups_sweep > (uint32_t)MAXG) return -1;
+    const Knobs K = read_knobs();
+    CallKind C;
+    C.nprot = q->nprot, C.ngroups = (q->nprot + 63u) / 64u, C.residues = q->residues, C.npoints = q->npoints, C.tracks = q->tracks != 0;
+    C.ncalls = q->ncalls, C.overlap = q->overlap != 0, C.last_chain_bound = q->last_chain_bound != 0;
+    C.last_mixed = q->last_mixed != 0, C.last_single_summary = q->last_single_summary != 0, C.old_tail = q->old_tail != 0;
+    uint32_t pt = 0;
+    for (uint32_t g = 0; g < q->ngroups_sweep; ++g) {
+        GroupKind G;
+        G.first_point = pt, G.members = std::max(1u, q->group_members[g]);
+        pt += G.members;
+        G.kb_base = q->kb_base[g] >= 0 && q->kb_base[g] < (int32_t)g ? q->kb_base[g] : -1;
+        G.fast20 = q->fast20 != 0 && !K.generic_tracks, G.wmax = q->wmax, G.fi_int = q->lane_possible != 0;
+        G.lane_possible = q->lane_possible != 0 && !C.tracks && K.kb_filter && K.kb_lane && !K.generic_tracks && !K.per_protein_tracks &&
+                          K.fi_int_allowed && G.kb_base < 0;
+        G.core_par_tables = q->core_par_tables != 0 && q->npoints == 1;
+        C.groups.push_back(G);
+    }
+    if (pt != q->npoints) return -1;
+    PlanWords W;
+    W.total_rows = q->total_rows, W.rows_first = q->rows_first, W.long_groups = q->long_groups, W.long_rows = q->long_rows;
+    for (int k = 0; k < SCAN_SEGS - 1; ++k) W.run_mark[k] = q->run_mark[k];
+    Forms F;
+    KbState kb;
+    Sched S;
+    decide_entry(K, C, F);
+    emit_head(K, C, F, S);
+    if (!K.serial && !F.kb_after_pack) emit_tracks(K, C, F, W, 0, kb, S, false);
+    emit_head_rows(K, C, F, S);
+    const size_t body = S.ops.size();
+    decide_forms(K, C, W, F);
+    emit_body(K, C, F, W, kb, S);
+    std::string out;
+    char line[320];
+    std::snprintf(line, sizeof line,
+                  "F par=%u head_aside=%d tail_allowed=%d kb_after_pack=%d chain_bound=%d latency_mode=%d mixed=%d lat_all=%d gl=%u "
+                  "use_core_list=%d sweep_lat=%d core_long=%d kb_deferred=%d maybe_huge=%d ka_wait=%d runs=%zu body=%zu serial=%d\n",
+                  C.par(), F.head_aside, F.tail_allowed, F.kb_after_pack, F.chain_bound, F.latency_mode, F.mixed, F.lat_all, F.gl,
+                  F.use_core_list, F.sweep_lat, F.core_long, F.kb_deferred, F.maybe_huge, F.ka_wait, F.ntseg(), body, K.serial ? 1 : 0);
+    out += line;
+    std::snprintf(line, sizeof line, "ALIAS %u %u\nALIAS %u %u\n", hi(R_BWD), hi(R_WIN2), no(R_WIN2), no(R_WIN));
+    out += line;
+    out += dump(S);
+    if (out.size() + 1 > cap) return -1;
+    std::memcpy(buf, out.c_str(), out.size() + 1);
+    return (long)out.size();
 }
 
 plaac_status plaac_score_device(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets, uint32_t nprot,

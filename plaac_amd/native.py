@@ -75,7 +75,7 @@ EXPORTS = (
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
-    "plaac_node_batch_residues", "plaac_score_begin", "plaac_score_end",
+    "plaac_node_batch_residues", "plaac_score_begin", "plaac_score_end", "plaac_debug_schedule",
 )
 
 _lib = None
@@ -119,6 +119,8 @@ def load():
     L.plaac_last_error.restype = C.c_char_p
     L.plaac_histogram.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.plaac_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.plaac_debug_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.plaac_debug_schedule.restype = C.c_long
     L.plaac_score_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.plaac_score_end.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_score_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
@@ -488,6 +490,26 @@ class NodeBatch:
 
 def device_count():
     return int(load().plaac_device_count())
+
+
+class SchedQuery(C.Structure):
+    """plaac_sched_query"""
+    _fields_ = [("nprot", C.c_uint32), ("npoints", C.c_uint32), ("residues", C.c_uint64), ("total_rows", C.c_uint32),
+                ("rows_first", C.c_uint32), ("long_groups", C.c_uint32), ("long_rows", C.c_uint32),
+                ("run_mark", C.c_uint32 * 7), ("ngroups_sweep", C.c_uint32), ("group_members", C.c_uint32 * 11),
+                ("kb_base", C.c_int32 * 11), ("lane_possible", C.c_int32), ("fast20", C.c_int32), ("wmax", C.c_int32),
+                ("core_par_tables", C.c_int32), ("tracks", C.c_int32), ("overlap", C.c_int32), ("ncalls", C.c_uint64),
+                ("last_chain_bound", C.c_int32), ("last_mixed", C.c_int32), ("last_single_summary", C.c_int32),
+                ("old_tail", C.c_int32)]
+
+
+def debug_schedule(q):
+    """plaac_debug_schedule: the schedule of a described scoring call as text (host only; no device needed)"""
+    buf = C.create_string_buffer(1 << 18)
+    n = load().plaac_debug_schedule(C.addressof(q), buf, len(buf))
+    if n < 0:
+        raise PlaacError(PLAAC_ERR_ARG, "plaac_debug_schedule rejected the query")
+    return buf.value.decode()
 
 
 def shard_plan(offsets, parts):
