@@ -118,7 +118,8 @@ struct plaac_ctx {
     uint4 *d_clist = nullptr; // refine list: (offset lo, offset hi, length, centre) + row index in d_crow
     uint32_t *d_crow = nullptr;
     size_t cap_crow = 0;
-    uint32_t *d_ccount = nullptr, *d_fbcount = nullptr;
+    uint32_t *d_kbcnt = nullptr;   // four sets of list counters, used in turn (see CallData::counters)
+    uint32_t *d_fbcount = nullptr; // = d_kbcnt (context creation uses the word as the reciprocal check's error count)
     uint4 *d_fblist = nullptr; // plan items of the proteins the filter tier hands to the exact tier
     size_t cap_clist = 0, cap_ccount = 0, cap_fblist = 0;
     static constexpr int KB_MAXSEG = sched::KB_MAXSEG;
@@ -644,8 +645,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         return bail("hipHostGetDevicePointer", e);
     ctx->poll_ok = ctx->knobs.poll_plan;
     if ((e = hipMalloc((void **)&ctx->d_divtab, sizeof(KbDivTab))) != hipSuccess) return bail("hipMalloc(divtab)", e);
-    if ((e = hipMalloc((void **)&ctx->d_fbcount, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(fbcount)", e);
-    if ((e = hipMemset(ctx->d_fbcount, 0, sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(fbcount)", e);
+    if ((e = hipMalloc((void **)&ctx->d_kbcnt, sizeof(uint32_t) * 4 * KB_COUNTER_WORDS)) != hipSuccess) return bail("hipMalloc(counters)", e);
+    if ((e = hipMemset(ctx->d_kbcnt, 0, sizeof(uint32_t) * 4 * KB_COUNTER_WORDS)) != hipSuccess) return bail("hipMemset(counters)", e);
+    ctx->d_fbcount = ctx->d_kbcnt;
     hipLaunchKernelGGL(k_build_divtab, dim3(((2 * TW + 1) * (2 * TW + 1) + 256) / 256), dim3(256), 0, ctx->stream,
                        ctx->d_divtab);
     hipLaunchKernelGGL(k_check_recip, dim3((RECIP_CHECK_MAX + 255u) / 256u), dim3(256), 0, ctx->stream, RECIP_CHECK_MAX,
@@ -718,7 +720,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         (void)hipStreamDestroy(ctx->xfer);
     }
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
-    for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_crow, (void *)ctx->d_ccount, (void *)ctx->d_fblist, (void *)ctx->d_fbcount,
+    for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_crow, (void *)ctx->d_kbcnt, (void *)ctx->d_fblist,
                     (void *)ctx->pl[0].lat, (void *)ctx->pl[1].lat})
         if (b) (void)hipFree(b);
     for (auto &pb : ctx->pl)
@@ -800,6 +802,9 @@ struct CallData {
     hipEvent_t *evs;
     uint32_t seq;
     const uint32_t *huge;
+    // this call's set of list counters (k_plan_scan resets it): [0] fallback list, [1 .. KB_MAXSEG] centre-list segments,
+    // [16 ..] core lists of the sweep groups
+    uint32_t *counters, *fbcount, *ccount, *corecount;
     size_t core_lrows = 0;
 };
 
@@ -873,11 +878,6 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         tg.stop_after = K.vit_stop;
         switch ((Kern)o.kern) {
         case K_MEMSET_HIST: PL_HIP(ctx, hipMemsetAsync(PL.hist, 0, sizeof(uint32_t) * (LEN_BINS + 1), s)); break;
-        case K_MEMSET_FBCOUNT: PL_HIP(ctx, hipMemsetAsync(ctx->d_fbcount, 0, sizeof(uint32_t), s)); break;
-        case K_MEMSET_CCOUNT: PL_HIP(ctx, hipMemsetAsync(ctx->d_ccount, 0, sizeof(uint32_t) * KB_MAXSEG, s)); break;
-        case K_MEMSET_CORECOUNT:
-            PL_HIP(ctx, hipMemsetAsync(C.single() ? PL.corecount : PL.corecount + o.group, 0, sizeof(uint32_t), s));
-            break;
         case K_MEMSET_COREFLAGS:
             if (!PL.coreflags) PL_HIP(ctx, hipMalloc((void **)&PL.coreflags, sizeof(uint32_t) * CORE_MAX_GROUPS * 64u));
             PL_HIP(ctx, hipMemsetAsync(PL.coreflags, 0, sizeof(uint32_t) * (size_t)W.long_groups * 64u, s));
@@ -888,7 +888,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             break;
         }
         case K_PLAN_SCAN:
-            hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, s, PL.hist, ctx->d_huge + (ctx->ncalls & 3u));
+            hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(256), 0, s, PL.hist, ctx->d_huge + (ctx->ncalls & 3u), D.counters);
             break;
         case K_PLAN_SCATTER: {
             const unsigned plb = (nprot + PLAN_THREADS * PLAN_ITEMS - 1) / (PLAN_THREADS * PLAN_ITEMS);
@@ -930,7 +930,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             tg.first = first;
             const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
             uint32_t *cl_list = C.single() ? PL.corelist : (PL.corelist ? PL.corelist + (size_t)nprot * o.group : nullptr);
-            uint32_t *cl_count = C.single() ? PL.corecount : (PL.corecount ? PL.corecount + o.group : nullptr);
+            uint32_t *cl_count = D.corecount + o.group;
             if (!o.list) cl_list = cl_count = nullptr;
 #define VIT_ARGS D.d_codes, D.d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + g0, gbits, tg, cl_list, cl_count, vend
 #define LAUNCH_VIT(NC, LAT, EXT, LIST) hipLaunchKernelGGL((k_vit<NC, LAT, EXT, LIST>), dim3(abk), dim3(KA_THREADS), 0, s, VIT_ARGS)
@@ -976,7 +976,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         case K_CORE_LIST: {
             const unsigned lgrid = std::min((nprot + KA_THREADS - 1) / KA_THREADS, 2048u);
             uint32_t *cl_list = C.single() ? PL.corelist : PL.corelist + (size_t)nprot * o.group;
-            uint32_t *cl_count = C.single() ? PL.corecount : PL.corecount + o.group;
+            uint32_t *cl_count = D.corecount + o.group;
             tg.long_groups_elsewhere = (F.core_long && !F.mixed) ? 1u : 0u;
             tg.first = 0u;
 #define LAUNCH_CORE_LIST(NC)                                                                                       \
@@ -1099,7 +1099,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         case K_TRACKS20_LIST: {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
             hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, s, D.d_codes, D.d_offsets, PL.neff,
-                               PL.order, nprot, D.total, tab, rows0, D.tp, D.huge, 0u, ctx->d_fblist, ctx->d_fbcount);
+                               PL.order, nprot, D.total, tab, rows0, D.tp, D.huge, 0u, ctx->d_fblist, D.fbcount);
             break;
         }
         case K_TRACKS20S: {
@@ -1116,17 +1116,17 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             const dim3 grid((o.a + o.b - 1) / o.b);
             if (o.sel)
                 hipLaunchKernelGGL(k_tracks20f<true>, grid, dim3(64), 0, s, D.d_codes, PL.order, o.a, D.total, tab, ctx->d_divtab,
-                                   rows0, D.huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
+                                   rows0, D.huge, ctx->d_clist, ctx->d_crow, D.ccount, ctx->d_fblist, D.fbcount);
             else
                 hipLaunchKernelGGL(k_tracks20f<false>, grid, dim3(64), 0, s, D.d_codes, PL.order, o.a, D.total, tab, ctx->d_divtab,
-                                   rows0, D.huge, ctx->d_clist, ctx->d_crow, ctx->d_ccount, ctx->d_fblist, ctx->d_fbcount);
+                                   rows0, D.huge, ctx->d_clist, ctx->d_crow, D.ccount, ctx->d_fblist, D.fbcount);
             break;
         }
         case K_TRACKSL: {
             const uint32_t g0 = o.a, g1 = o.b, base = g0 * 64u;
             hipLaunchKernelGGL(k_tracksL, dim3((g1 - g0 + KL_THREADS / 64 - 1) / (KL_THREADS / 64)), dim3(KL_THREADS), 0, s, PL.order,
                                nprot, g0, g1, tab, ctx->d_divtab, PL.packed, PL.grow, rows0, D.huge, ctx->d_clist + base,
-                               ctx->d_crow + base, ctx->d_ccount + o.seg, ctx->d_fblist, ctx->d_fbcount);
+                               ctx->d_crow + base, D.ccount + o.seg, ctx->d_fblist, D.fbcount);
             break;
         }
         case K_REFINE: {
@@ -1136,11 +1136,11 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             const unsigned rounds = (o.b + RF_SLOTS - 1) / RF_SLOTS;
             if (o.sel)
                 hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min(rounds, K.rf_grid)), dim3(64), 0, s, D.d_codes, D.total, tab,
-                                   ctx->d_divtab, rows0, D.huge, ctx->d_clist + o.a, ctx->d_crow + o.a, ctx->d_ccount + o.seg);
+                                   ctx->d_divtab, rows0, D.huge, ctx->d_clist + o.a, ctx->d_crow + o.a, D.ccount + o.seg);
             else
                 hipLaunchKernelGGL(k_refine_centres<false>, dim3(std::min(rounds, F.tail_allowed ? K.rf_grid / 8u * 7u : K.rf_grid)),
                                    dim3(64), 0, s, D.d_codes, D.total, tab, ctx->d_divtab, rows0, D.huge, ctx->d_clist + o.a,
-                                   ctx->d_crow + o.a, ctx->d_ccount + o.seg);
+                                   ctx->d_crow + o.a, D.ccount + o.seg);
             break;
         }
         case K_COPY_WINDOW_FIELDS:
@@ -1150,7 +1150,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         case K_LLR_AT_CENTRE_LISTED:
             hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, s, D.d_codes, D.d_offsets,
                                PL.neff, nprot, tab, (const plaac_row *)D.d_rows[C.groups[o.a].first_point], rows0, ctx->d_fblist,
-                               ctx->d_fbcount, D.huge);
+                               D.fbcount, D.huge);
             break;
         case K_LLR_AT_CENTRE_ALL:
             hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 1u << 20)), dim3(256), 0, s, D.d_codes, D.d_offsets,
@@ -1278,7 +1278,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if (!d_tracks && K.kb_filter) { // lists of the filter form of the window kernel
         if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, (size_t)nprot)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_crow, ctx->cap_crow, (size_t)nprot)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, ctx->d_ccount, ctx->cap_ccount, (size_t)KB_MAXSEG)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, ctx->d_fblist, ctx->cap_fblist, (size_t)nprot)) != PLAAC_OK) return rc;
     }
     while (ctx->gev.size() < ng) {
@@ -1314,6 +1313,8 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     D.evs = ctx->ev[ctx->ncalls % plaac_ctx::EV_SETS];
     D.seq = (uint32_t)(ctx->ncalls + 1) | 0x80000000u;
     D.huge = ctx->d_huge + (ctx->ncalls & 3u);
+    D.counters = ctx->d_kbcnt + (size_t)KB_COUNTER_WORDS * (ctx->ncalls & 3u);
+    D.fbcount = D.counters, D.ccount = D.counters + 1, D.corecount = D.counters + 16;
 
     // ---- the head: planning kernels, group 0's window tracks where they need no packed copy, the row offsets
     Forms F;
@@ -1366,7 +1367,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     }
     if (F.use_core_list) {
         if ((rc = grow(ctx, PL.corelist, PL.cap_corelist, (size_t)nprot * ng)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, PL.corecount, PL.cap_corecount, ng)) != PLAAC_OK) return rc;
     }
     if ((rc = grow(ctx, PL.packed, PL.cap_packed, W.total_rows * 64u + 64u)) != PLAAC_OK) return rc;
     D.bits_stride = W.total_rows * 64u + 64u; // one traceback-bit buffer per group
@@ -1542,7 +1542,7 @@ plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count) {
     if (ctx->ncalls == 0) return PLAAC_OK;
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PL_HIP(ctx, hipEventSynchronize(ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
-    PL_HIP(ctx, hipMemcpy(count, ctx->d_fbcount, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    PL_HIP(ctx, hipMemcpy(count, ctx->d_kbcnt + (size_t)KB_COUNTER_WORDS * ((ctx->ncalls - 1) & 3u), sizeof(uint32_t), hipMemcpyDeviceToHost));
     return PLAAC_OK;
 }
 

@@ -27,8 +27,8 @@ E_JOIN = 10
 BUF = ["NEFF", "HIST", "ORDER", "GROW", "HUGE", "HPIN", "PACKED", "BITS", "LMARG", "H0", "VEND", "CORELIST", "CORECOUNT",
        "COREFLAGS", "COREP", "COREPART", "FWDP", "BWDP", "CLIST", "CCOUNT", "FBLIST", "FBCOUNT", "ROW_VIT", "ROW_CORE",
        "ROW_HMMVIT", "ROW_HMMALL", "ROW_MW", "ROW_LLR", "ROW_KB", "ROW_KBLLR", "TRK_WIN", "TRK_POST", "TRK_VIT"]
-PER_PARITY = {"NEFF", "HIST", "ORDER", "GROW", "PACKED", "BITS", "LMARG", "H0", "VEND", "CORELIST", "CORECOUNT", "COREFLAGS",
-              "COREP", "COREPART"}
+PER_PARITY = {"NEFF", "HIST", "ORDER", "GROW", "PACKED", "BITS", "LMARG", "H0", "VEND", "CORELIST", "COREFLAGS", "COREP", "COREPART"}
+FOUR_SETS = {"HUGE", "FBCOUNT", "CCOUNT", "CORECOUNT"}  # four copies used in turn: the tail of call k reads its own while call k+2 plans
 PER_CALL = {b for b in BUF if b.startswith("ROW_") or b.startswith("TRK_")} | {"HPIN"}  # the caller's buffers: distinct per call
 
 
@@ -106,7 +106,7 @@ class Model:
             else:
                 for mode, b, q in o[3]:
                     name = BUF[b]
-                    key = (name,) + ((par,) if name in PER_PARITY else (callno & 3,) if name == "HUGE" else (callno,) if name in PER_CALL else ())
+                    key = (name,) + ((par,) if name in PER_PARITY else (callno & 3,) if name in FOUR_SETS else (callno,) if name in PER_CALL else ())
                     for (m2, q2, s2, n2, d2) in self.acc.get(key, []):
                         if (mode == "r" and m2 == "r") or (mode == "a" and m2 == "a") or (q != q2 and 255 not in (q, q2)):
                             continue  # (q = 255: every part of the buffer)
@@ -164,12 +164,12 @@ def test_no_wait_can_deadlock_and_conflicting_accesses_are_ordered(native, shape
     elif mode == "sweep2":
         kw.update(points=(1, 5), kb_base=(-1, -1))
     m = Model()
-    for c, forms, alias, ops in consecutive(native, shape, 4, **kw):
+    for c, forms, alias, ops in consecutive(native, shape, 6, **kw):
         m.run(c, forms, alias, ops, "%s/%s/overlap=%s call %d" % (shape, mode, overlap, c))
     assert not m.errors, "\n".join(m.errors[:12])
 
 
-KNOBS = [{"PLAAC_SERIAL_STREAMS": "1"}, {"PLAAC_MIXED": "0"}, {"PLAAC_LATENCY_MODE": "1"}, {"PLAAC_LATENCY_MODE": "0"},
+KNOBS = [{"PLAAC_SERIAL_STREAMS": "1"}, {"PLAAC_KB_SIDE": "0"}, {"PLAAC_MIXED": "0"}, {"PLAAC_LATENCY_MODE": "1"}, {"PLAAC_LATENCY_MODE": "0"},
          {"PLAAC_KB_LANE": "0"}, {"PLAAC_KB_FILTER": "0"}, {"PLAAC_CORE_LIST": "0"}, {"PLAAC_MIXED_GROUPS": "3", "PLAAC_MIXED_MIN_REST": "1"},
          {"PLAAC_KB_LANE_MIN_GROUPS": "1"}, {"PLAAC_PIPE_SEGMENTS": "4", "PLAAC_SEGMENT_MIN_ROWS": "1"},
          {"PLAAC_TRACK_SEGMENTS": "4", "PLAAC_SEGMENT_MIN_ROWS": "1"}, {"PLAAC_SWEEP_SPREAD": "0"}, {"PLAAC_SWEEP_LATENCY": "0"},
