@@ -529,12 +529,19 @@ def main():
     # HBM traffic and executed instruction counts: PMC counters cannot be read from inside this process;
     # tools/pmc.sh collects them for this same workload and leaves the per-launch figures under profiles/
     traffic, traffic_all, exec_ops, issue_instr, traffic_cal, traffic_all_cal, fetch_cal, issue_classes = (None,) * 8
+    stale_counters = None
     import glob
     for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
         try:
             with open(pth) as fh:
                 tj = json.load(fh)
             if tj.get("workload") == [args.config, nprot, bool(args.tracks)] and not args.sweep:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pmc_summary
+                counters_sha, tree_sha = tj.get("kernels_source_sha16"), pmc_summary.kernels_sha()
+                if counters_sha != tree_sha:  # counters of other kernel sources are not this code's: say so, quote nothing
+                    stale_counters = {"file": os.path.basename(pth), "counters_for_sources": counters_sha, "tree_sources": tree_sha}
+                    continue
                 per = tj["bytes_per_launch"]
                 # the kernels timed under `dom`: k_tracks = the window stream (filter + refine + exact tier, or the exact
                 # stream kernel), k_vit = Viterbi + the core list
@@ -599,7 +606,9 @@ def main():
             "shader_clock": clock,
             "frac_at_measured_clock": None if not (issue_classes and clock and clock.get("under_load_MHz_mean")) else round(
                 issue_classes["cycles_per_step"] / 1024 / (clock["under_load_MHz_mean"] * 1e6) * 1e3 / step_ms, 4),
-            "source": "SQ_INSTS_VALU (fp64 / other) + SQ_INSTS_LDS over all kernels of a step, profiles/pmc_traffic.json"},
+            "source": "SQ_INSTS_VALU (fp64 / other) + SQ_INSTS_LDS over all kernels of a step, profiles/*pmc_traffic*.json "
+                      "collected for the kernel sources of this tree (sha checked); costs: profiles/r04_issue_classes.json"},
+        "pmc_counters_stale": stale_counters,
         "shader_clock": clock,
         "host_buffers_pcie_inclusive": host_io,
     }

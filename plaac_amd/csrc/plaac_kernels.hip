@@ -243,6 +243,43 @@ bool lse_clamp_ok(const plaac_params &P) {
     return last >= 0.0 && last < 0x1p-57;
 }
 
+// May they take lse_lut<2>, the form without any clamp? Then every log-sum-exp of the forward and backward recurrences
+// (plaac.java:3360-3368, :3383-3391) must have operands less than 40 apart - the reference's own in-range test (:1027) - for
+// ANY residue sequence. The two states of the chain cannot drift apart further than the tables allow:
+//   forward:  a_j(t) = LSE_i(lt[i][j] + a_i(t-1)) + le_j(x_t), and max_i(.) <= LSE_i(.) <= max_i(.) + ln 2, so
+//             |a_0 - a_1| <= Df := max(max_i lt[i][0] - min_i lt[i][1], max_i lt[i][1] - min_i lt[i][0]) + ln 2 + E,
+//             E := max_x |le_0(x) - le_1(x)| (also at t = 0: |li_0 - li_1| + E); the operands lt[0][j] + a_0, lt[1][j] + a_1
+//             of the next step differ by at most Df + max_j |lt[0][j] - lt[1][j]|;
+//   backward: b_i(t) = LSE_j((lt[i][j] + b_j(t+1)) + le_j(x_{t+1})): |b_0 - b_1| <= Db := max_j |lt[0][j] - lt[1][j]| + ln 2
+//             (also at the end: |lf_0 - lf_1|); the operands differ by at most max_i |lt[i][0] - lt[i][1]| + Db + E.
+// One unit of slack covers the table's interpolation error (3e-6 per step, not accumulating: the bound is per step) and
+// the roundings. The reference's tables: 18.1 / 18.0. PLAAC_LSE_CLAMP=0 or 1: never.
+bool lse_range_ok(const plaac_params &P) {
+    if (const char *e = std::getenv("PLAAC_LSE_CLAMP"))
+        if (e[0] == '0' || e[0] == '1') return false;
+    const plaac_hmm &H = P.hmm1;
+    double E = 0.0;
+    for (int k = 0; k < NAA; ++k) {
+        if (!std::isfinite(H.le[0][k]) || !std::isfinite(H.le[1][k])) return false;
+        E = std::max(E, std::fabs(H.le[0][k] - H.le[1][k]));
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (!std::isfinite(H.li[i]) || !std::isfinite(H.lf[i])) return false;
+        for (int j = 0; j < 2; ++j)
+            if (!std::isfinite(H.lt[i][j])) return false;
+    }
+    const double ln2 = 0.6931471805599453;
+    const double col = std::max(std::max(H.lt[0][0], H.lt[1][0]) - std::min(H.lt[0][1], H.lt[1][1]),
+                                std::max(H.lt[0][1], H.lt[1][1]) - std::min(H.lt[0][0], H.lt[1][0]));
+    const double Df = std::max(col + ln2 + E, std::fabs(H.li[0] - H.li[1]) + E);
+    const double rows = std::max(std::fabs(H.lt[0][0] - H.lt[1][0]), std::fabs(H.lt[0][1] - H.lt[1][1])); // same target state
+    const double cols = std::max(std::fabs(H.lt[0][0] - H.lt[0][1]), std::fabs(H.lt[1][0] - H.lt[1][1])); // same source state
+    const double Of = Df + rows;
+    const double Db = std::max(rows + ln2, std::fabs(H.lf[0] - H.lf[1]));
+    const double Ob = cols + Db + E;
+    return std::max(Of, Ob) + 1.0 < 39.9;
+}
+
 void fill_tables(const plaac_params &P, DevTables &D) {
     std::memset(&D, 0, sizeof D);
     for (int k = 0; k < NAA; ++k) {
@@ -272,7 +309,7 @@ void fill_tables(const plaac_params &P, DevTables &D) {
     D.ww3 = P.ww3;
     D.adjustprolines = P.adjustprolines;
     std::memcpy(D.loglut, P.loglut, sizeof P.loglut); // D.loglut[LUTLEN], [LUTLEN + 1] stay 0.0
-    D.lse_clamp = lse_clamp_ok(P) ? 1 : 0;
+    D.lse_clamp = lse_range_ok(P) ? 2 : (lse_clamp_ok(P) ? 1 : 0);
     derive_fi_int(P, D);
 }
 

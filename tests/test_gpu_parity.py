@@ -460,14 +460,16 @@ def test_stream_and_per_protein_window_kernels_agree(native, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.gpu
-@pytest.mark.parametrize("clamp", ["1", "0"])
+@pytest.mark.parametrize("clamp", ["2", "1", "0"])
 @pytest.mark.parametrize("mode", ["0", "1"])
 def test_log_sum_exp_with_and_without_its_in_range_select(native, oracle, monkeypatch, clamp, mode):
     """the forward / backward kernels leave out the in-range select of the LUT log-sum-exp when the tables allow it
-    (lse_clamp_ok: every emission log-probability <= -0.125, the table's last entry below 2^-57); PLAAC_LSE_CLAMP=0 keeps
-    the select. Both must give the oracle's rows and posteriors, in the throughput and the latency forms - also for
-    tables that do NOT qualify (a background of nearly one residue: an emission log-probability close to zero)."""
+    (lse_clamp_ok: every emission log-probability <= -0.125, the table's last entry below 2^-57; PLAAC_LSE_CLAMP=1 stops
+    there) and the clamp of the table index as well when the two states provably never drift 39 apart (lse_range_ok, the
+    default for the reference's tables); PLAAC_LSE_CLAMP=0 keeps the select. All must give the oracle's rows and posteriors,
+    in the throughput and the latency forms - also for tables that do NOT qualify: a background of nearly one residue (an
+    emission log-probability close to zero: no clamped form) and one with a residue of frequency 1e-12 (emission log-odds
+    of 25: the drift bound fails, the unclamped form is refused)."""
     from plaac_amd import synth
     monkeypatch.setenv("PLAAC_LSE_CLAMP", clamp)
     monkeypatch.setenv("PLAAC_LATENCY_MODE", mode)
@@ -475,7 +477,9 @@ def test_log_sum_exp_with_and_without_its_in_range_select(native, oracle, monkey
     codes, offs = synth.make_batch(2, nprot=700, seed=5, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.05)
     lopsided = np.full(22, 1e-4)
     lopsided[13] = 1.0  # background almost all proline: log(freq) ~ -0.002 > -0.125
-    for kw in ({}, {"alpha": 0.0, "bgcounts": lopsided}):
+    rare = np.ones(22)
+    rare[5] = 1e-12
+    for kw in ({}, {"alpha": 0.0, "bgcounts": lopsided}, {"alpha": 0.0, "bgcounts": rare}):
         with native.Context(native.make_params(**kw)) as c:
             check_batch(native, oracle, c, codes, offs, tracks=True, what="lse clamp %s mode %s %s" % (clamp, mode, kw), **kw)
 

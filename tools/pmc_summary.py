@@ -6,7 +6,7 @@ bytes of a wide coalesced streaming read and other access widths are uncalibrate
  (a) the raw figure, (b) the guide's x2-corrected figure (used as `traffic`), and (c) a calibration on this
 repo's own access shapes (plaac_calibration_reads: three streaming reads of known size).
 The instruction-issue roof (`issue_model`) combines the dynamic instruction counts of the PMC passes with the measured
-per-class issue costs and the static class shares of profiles/r03_issue_classes.json (tools/issue_model.py)."""
+per-class issue costs and the static class shares of profiles/r04_issue_classes.json (tools/issue_model.py)."""
 import collections
 import csv
 import glob
@@ -14,8 +14,20 @@ import json
 import os
 import sys
 
-KEYS = ("k_calib_read<16, 0>", "k_calib_read<4, 0>", "k_calib_read<4, 1>", "k_tracksL", "k_tracks20f", "k_refine_centres", "k_core_list", "k_core_chain", "k_core_eval", "k_core_reduce", "k_fwd_pair", "k_finish", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
+KEYS = ("k_long", "k_core_par", "k_calib_read<16, 0>", "k_calib_read<4, 0>", "k_calib_read<4, 1>", "k_tracksL", "k_tracks20f", "k_refine_centres", "k_core_list", "k_core_chain", "k_core_eval", "k_core_reduce", "k_fwd_pair", "k_finish", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
         "k_plan_scatter", "k_pack", "k_group_rows", "k_scan_u32")
+
+
+def kernels_sha():
+    """sha256 (first 16 hex digits) over the kernel sources of the tree: bench.py quotes the counters only for THIS code"""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plaac_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def kernel_key(name):
@@ -85,7 +97,7 @@ def main(root):
     issue = None
     try:
         cls = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                                          "r03_issue_classes.json")))
+                                          "r04_issue_classes.json")))
         cost = cls["cost_cycles"]
         per, tot = {}, 0.0
         for k, c in step.items():
@@ -115,7 +127,7 @@ def main(root):
     if R:
         mode = cfg.get("mode") == "tracks"
         wl = {"cfg2": 2, "cfg3": 3, "cfg4": 4}.get(cfg.get("workload", "")[:4], 4)
-        json.dump({"workload": [wl, P, mode], "source": "tools/pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+        json.dump({"workload": [wl, P, mode], "kernels_source_sha16": kernels_sha(), "source": "tools/pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                    "passes); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md gfx950 correction",
                    "bytes_per_launch": {k: round(v["hbm_bytes_gfx950_corrected"]) for k, v in traffic.items()
                                         if not k.startswith("k_calib")},
