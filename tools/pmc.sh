@@ -5,7 +5,7 @@
 #   3. PMC passes (one counter set per pass, never combined with sys/hip/hsa traces), kernels serialised
 #   4. tools/pmc_summary.py -> gpurun_out/pmc/summary.json and pmc_traffic.json (copy both to profiles/)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-clock-probe --no-host-leg --calibrate $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-clock-probe --no-host-leg --no-predict --calibrate $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/trace_concurrent -- python3 bench.py $ARGS > gpurun_out/pmc/trace_concurrent.json 2> gpurun_out/pmc/trace_concurrent.err || echo "FAILED trace_concurrent"
 export PLAAC_SERIAL_STREAMS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/trace_serial -- python3 bench.py $ARGS > gpurun_out/pmc/trace_serial.json 2> gpurun_out/pmc/trace_serial.err || echo "FAILED trace_serial"

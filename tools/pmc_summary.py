@@ -19,12 +19,13 @@ KEYS = ("k_long", "k_core_par", "k_calib_read<16, 0>", "k_calib_read<4, 0>", "k_
 
 
 def kernels_sha():
-    """sha256 (first 16 hex digits) over the kernel sources of the tree: bench.py quotes the counters only for THIS code"""
+    """sha256 (first 16 hex digits) over the KERNEL sources of the tree (csrc/kernels_*.hip.inc: the device code; the host's
+    scheduling and launcher files are not part of it): bench.py quotes the counters only for THIS device code"""
     import hashlib
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plaac_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(root)):
-        if f.endswith((".hip", ".inc")):
+        if f.startswith("kernels_") and f.endswith(".hip.inc"):
             h.update(f.encode())
             h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()[:16]

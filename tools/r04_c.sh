@@ -1,6 +1,5 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4
-timeout -k 10 600 python3 -m pytest tests -x -q -m gpu --timeout=200 > $O/c_all.txt 2>&1; tail -6 $O/c_all.txt
-PLAAC_MIXED_GROUPS=3 PLAAC_MIXED_MIN_REST=1 timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_real_proteomes.py -x -q -m gpu --timeout=200 > $O/c_mixed.txt 2>&1; tail -4 $O/c_mixed.txt
-PLAAC_OVERLAP=1 timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout=200 > $O/c_ov.txt 2>&1; tail -4 $O/c_ov.txt
+PLAAC_MIXED=0 bash tools/r04_trace.sh cfg3_unmixed 2 --config 3
+bash tools/r04_trace.sh cfg3_mixed 2 --config 3
+grep -h "k_fwd_pair\|k_long\|k_vit<1, true\|k_win<1, [23]>" gpurun_out/r4/timeline_cfg3_unmixed.txt gpurun_out/r4/timeline_cfg3_mixed.txt
