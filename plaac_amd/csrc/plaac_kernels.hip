@@ -77,7 +77,7 @@ struct plaac_ctx {
     std::vector<hipStream_t> gstreams; // side streams of the 2nd, 3rd ... group of a sweep (three each), high priority
     std::vector<hipStream_t> gstreams_n; // the same at normal priority (throughput-bound batches, see auxn)
     std::vector<hipEvent_t> gjev;      // their join events
-    hipEvent_t jev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // join events of the side streams
+    hipEvent_t jev[8] = {}; // join events of the side streams
     hipEvent_t fev[2] = {nullptr, nullptr};                            // k_finish waits for the forward / window streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
@@ -101,6 +101,12 @@ struct plaac_ctx {
         double *corep = nullptr; // latency forms: masked prefix sums of the long wave-groups, packed row numbering
         void *corepart = nullptr; // their per-row best windows
         size_t cap_bits = 0, cap_corelist = 0, cap_corecount = 0, cap_corep = 0, cap_corepart = 0;
+        // summary-mode window kernels in filter form (per call parity since the filter tier of call k+1 runs beside the
+        // refine / exact tier of call k): refine list (offset lo, offset hi, length, centre) + row index, and the plan items
+        // of the proteins the filter tier hands to the exact tier
+        uint4 *clist = nullptr, *fblist = nullptr;
+        uint32_t *crow = nullptr;
+        size_t cap_clist = 0, cap_crow = 0, cap_fblist = 0;
     } pl[2];
     double2 *d_fwd = nullptr, *d_bwd = nullptr; // track mode: forward / backward pairs, group-interleaved
     sched::Knobs knobs; // the environment switches, read once at creation
@@ -114,14 +120,9 @@ struct plaac_ctx {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     uint32_t *d_flag = nullptr;
     KbDivTab *d_divtab = nullptr; // reciprocal tables of the window kernel
-    // summary-mode window kernel in filter form: centres per filter block, fallback list, [0] = its length
-    uint4 *d_clist = nullptr; // refine list: (offset lo, offset hi, length, centre) + row index in d_crow
-    uint32_t *d_crow = nullptr;
-    size_t cap_crow = 0;
     uint32_t *d_kbcnt = nullptr;   // four sets of list counters, used in turn (see CallData::counters)
     uint32_t *d_fbcount = nullptr; // = d_kbcnt (context creation uses the word as the reciprocal check's error count)
-    uint4 *d_fblist = nullptr; // plan items of the proteins the filter tier hands to the exact tier
-    size_t cap_clist = 0, cap_ccount = 0, cap_fblist = 0;
+    size_t cap_ccount = 0;
     static constexpr int KB_MAXSEG = sched::KB_MAXSEG;
     // PLAAC_KB_CHUNKS (1..8): chunks of the lane-form filter, each refined on a second stream while the next is filtered.
     // Measured at 10 M sequences: 1 chunk (filter, refine, exact tier in a row on the caller's stream) 21.0 ms, 4 chunks
@@ -141,7 +142,10 @@ struct plaac_ctx {
     // the caller's stream before the tail of the call that used buffers p; tail_open2[p]: that call recorded one) and
     // ka_done[p] (its side streams joined). The chain kernels of call k+1 wait for ka_done of call k (shared scratch).
     bool overlap = false, tail_open2[2] = {false, false}, last_chain_bound = false, last_single_summary = false;
+    bool last_kb_aside = false;
+    hipStream_t kbs[2] = {nullptr, nullptr}; // PLAAC_KB_CLASS=0: streams of the window-track kernels of overlapping calls (S_KBK, S_KBT)
     hipEvent_t tail_ev2[2] = {nullptr, nullptr}, ka_done[2] = {nullptr, nullptr};
+    hipEvent_t td_ev[2] = {nullptr, nullptr}; // EK_TD: the refine launch of the call with that parity is through (a scheduling hint)
     uint32_t *d_huge = nullptr; // four words, used in turn: the tail of call k reads its word while call k+2 already plans
     // Chain-bound single-point summary calls in MIXED FORMS (round 4, PLAAC_MIXED=0: latency forms for every wave-group as
     // in round 3): the long wave-groups on two streams of the high class per call parity, every other wave-group in the
@@ -648,6 +652,9 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
             plaac_ctx_destroy(ctx);
             return PLAAC_ERR_DEVICE;
         }
+        if (ctx->knobs.kb_aside && ctx->knobs.kb_class == 0)
+            for (auto &ks : ctx->kbs)
+                if ((e = hipStreamCreateWithPriority(&ks, hipStreamNonBlocking, 0)) != hipSuccess) return bail("hipStreamCreate", e);
         for (auto &je : ctx->jev)
             if ((e = hipEventCreateWithFlags(&je, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
@@ -658,7 +665,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&ctx->tpev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        for (auto *arr : {ctx->tail_ev2, ctx->ka_done, ctx->lev})
+        for (auto *arr : {ctx->tail_ev2, ctx->ka_done, ctx->lev, ctx->td_ev})
             for (int k = 0; k < 2; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipMalloc((void **)&ctx->d_huge, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(huge)", e);
@@ -757,8 +764,9 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         (void)hipStreamDestroy(ctx->xfer);
     }
     if (ctx->d_divtab) (void)hipFree(ctx->d_divtab);
-    for (void *b : {(void *)ctx->d_clist, (void *)ctx->d_crow, (void *)ctx->d_kbcnt, (void *)ctx->d_fblist,
-                    (void *)ctx->pl[0].lat, (void *)ctx->pl[1].lat})
+    for (void *b : {(void *)ctx->d_kbcnt, (void *)ctx->pl[0].lat, (void *)ctx->pl[1].lat, (void *)ctx->pl[0].clist,
+                    (void *)ctx->pl[1].clist, (void *)ctx->pl[0].crow, (void *)ctx->pl[1].crow, (void *)ctx->pl[0].fblist,
+                    (void *)ctx->pl[1].fblist})
         if (b) (void)hipFree(b);
     for (auto &pb : ctx->pl)
         for (void *b : {(void *)pb.bits, (void *)pb.corelist, (void *)pb.corecount, (void *)pb.coreflags, (void *)pb.corep,
@@ -786,6 +794,11 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
                 (void)hipStreamSynchronize(a);
                 (void)hipStreamDestroy(a);
             }
+    for (hipStream_t a : ctx->kbs)
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
     for (hipEvent_t e : ctx->gjev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->jev)
@@ -797,7 +810,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     for (hipEvent_t e : ctx->pkev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->tpev) (void)hipEventDestroy(ctx->tpev);
-    for (auto *arr : {ctx->tail_ev2, ctx->ka_done})
+    for (auto *arr : {ctx->tail_ev2, ctx->ka_done, ctx->td_ev})
         for (int k = 0; k < 2; ++k)
             if (arr[k]) (void)hipEventDestroy(arr[k]);
     if (ctx->d_huge) (void)hipFree(ctx->d_huge);
@@ -851,7 +864,8 @@ hipStream_t slot_stream(plaac_ctx *ctx, const CallData &D, uint8_t slot) {
     if (slot < S_NO) return ctx->aux[slot - S_HI];
     if (slot < S_G) return ctx->auxn[slot - S_NO];
     if (slot < S_GN) return ctx->gstreams[slot - S_G];
-    return ctx->gstreams_n[slot - S_GN];
+    if (slot < S_KBK) return ctx->gstreams_n[slot - S_GN];
+    return ctx->kbs[slot - S_KBK];
 }
 
 hipEvent_t slot_event(plaac_ctx *ctx, const CallData &D, uint16_t e) {
@@ -865,6 +879,7 @@ hipEvent_t slot_event(plaac_ctx *ctx, const CallData &D, uint16_t e) {
     case EK_L: return ctx->lev[par];
     case EK_KA: return ctx->ka_done[idx];
     case EK_TAIL: return ctx->tail_ev2[idx];
+    case EK_TD: return ctx->td_ev[idx];
     case EK_KB: return ctx->kbev[idx];
     case EK_TF: return ctx->tfev[idx];
     case EK_TB: return ctx->tbev[idx];
@@ -899,6 +914,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             PL_HIP(ctx, hipStreamWaitEvent(s, slot_event(ctx, D, o.event), 0));
             continue;
         }
+        if (K.skip_mask && ((K.skip_mask >> o.kern) & 1ull) && ctx->ncalls >= K.skip_from) continue; // (diagnostic)
         const GroupKind *G = o.group < C.groups.size() ? &C.groups[o.group] : nullptr;
         const DevTables *tab = D.gtab0 + o.group;
         plaac_row *rows0 = G ? D.d_rows[G->first_point] : D.d_rows[0];
@@ -1136,7 +1152,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         case K_TRACKS20_LIST: {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
             hipLaunchKernelGGL(k_tracks20<false>, dim3(std::min(kb_grid, 4096u)), dim3(64), 0, s, D.d_codes, D.d_offsets, PL.neff,
-                               PL.order, nprot, D.total, tab, rows0, D.tp, D.huge, 0u, ctx->d_fblist, D.fbcount);
+                               PL.order, nprot, D.total, tab, rows0, D.tp, D.huge, 0u, PL.fblist, D.fbcount);
             break;
         }
         case K_TRACKS20S: {
@@ -1153,17 +1169,17 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             const dim3 grid((o.a + o.b - 1) / o.b);
             if (o.sel)
                 hipLaunchKernelGGL(k_tracks20f<true>, grid, dim3(64), 0, s, D.d_codes, PL.order, o.a, D.total, tab, ctx->d_divtab,
-                                   rows0, D.huge, ctx->d_clist, ctx->d_crow, D.ccount, ctx->d_fblist, D.fbcount);
+                                   rows0, D.huge, PL.clist, PL.crow, D.ccount, PL.fblist, D.fbcount);
             else
                 hipLaunchKernelGGL(k_tracks20f<false>, grid, dim3(64), 0, s, D.d_codes, PL.order, o.a, D.total, tab, ctx->d_divtab,
-                                   rows0, D.huge, ctx->d_clist, ctx->d_crow, D.ccount, ctx->d_fblist, D.fbcount);
+                                   rows0, D.huge, PL.clist, PL.crow, D.ccount, PL.fblist, D.fbcount);
             break;
         }
         case K_TRACKSL: {
             const uint32_t g0 = o.a, g1 = o.b, base = g0 * 64u;
             hipLaunchKernelGGL(k_tracksL, dim3((g1 - g0 + KL_THREADS / 64 - 1) / (KL_THREADS / 64)), dim3(KL_THREADS), 0, s, PL.order,
-                               nprot, g0, g1, tab, ctx->d_divtab, PL.packed, PL.grow, rows0, D.huge, ctx->d_clist + base,
-                               ctx->d_crow + base, D.ccount + o.seg, ctx->d_fblist, D.fbcount);
+                               nprot, g0, g1, tab, ctx->d_divtab, PL.packed, PL.grow, rows0, D.huge, PL.clist + base,
+                               PL.crow + base, D.ccount + o.seg, PL.fblist, D.fbcount);
             break;
         }
         case K_REFINE: {
@@ -1173,11 +1189,11 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             const unsigned rounds = (o.b + RF_SLOTS - 1) / RF_SLOTS;
             if (o.sel)
                 hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min(rounds, K.rf_grid)), dim3(64), 0, s, D.d_codes, D.total, tab,
-                                   ctx->d_divtab, rows0, D.huge, ctx->d_clist + o.a, ctx->d_crow + o.a, D.ccount + o.seg);
+                                   ctx->d_divtab, rows0, D.huge, PL.clist + o.a, PL.crow + o.a, D.ccount + o.seg);
             else
                 hipLaunchKernelGGL(k_refine_centres<false>, dim3(std::min(rounds, F.tail_allowed ? K.rf_grid / 8u * 7u : K.rf_grid)),
-                                   dim3(64), 0, s, D.d_codes, D.total, tab, ctx->d_divtab, rows0, D.huge, ctx->d_clist + o.a,
-                                   ctx->d_crow + o.a, D.ccount + o.seg);
+                                   dim3(64), 0, s, D.d_codes, D.total, tab, ctx->d_divtab, rows0, D.huge, PL.clist + o.a,
+                                   PL.crow + o.a, D.ccount + o.seg);
             break;
         }
         case K_COPY_WINDOW_FIELDS:
@@ -1186,7 +1202,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             break;
         case K_LLR_AT_CENTRE_LISTED:
             hipLaunchKernelGGL(k_llr_at_centre, dim3(std::min((nprot + 3u) / 4u, 16384u)), dim3(256), 0, s, D.d_codes, D.d_offsets,
-                               PL.neff, nprot, tab, (const plaac_row *)D.d_rows[C.groups[o.a].first_point], rows0, ctx->d_fblist,
+                               PL.neff, nprot, tab, (const plaac_row *)D.d_rows[C.groups[o.a].first_point], rows0, PL.fblist,
                                D.fbcount, D.huge);
             break;
         case K_LLR_AT_CENTRE_ALL:
@@ -1287,6 +1303,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     C.nprot = nprot, C.ngroups = (nprot + 63u) / 64u, C.residues = total_residues, C.npoints = npoints, C.tracks = d_tracks != nullptr;
     C.ncalls = ctx->ncalls, C.overlap = ctx->overlap, C.last_chain_bound = ctx->last_chain_bound, C.last_mixed = ctx->last_mixed;
     C.last_single_summary = ctx->last_single_summary;
+    C.last_kb_aside = ctx->last_kb_aside;
     const unsigned par = C.par(); // this call's plan buffers, `huge` word and body events
     C.old_tail = ctx->tail_open2[par];
     ctx->tail_open2[par] = false;
@@ -1313,9 +1330,9 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     if ((rc = grow(ctx, PL.grow, PL.cap_grow, (size_t)C.ngroups + 3)) != PLAAC_OK) return rc;
     if (C.single() && (rc = grow(ctx, PL.lat, PL.cap_lat, 3 * (size_t)nprot)) != PLAAC_OK) return rc;
     if (!d_tracks && K.kb_filter) { // lists of the filter form of the window kernel
-        if ((rc = grow(ctx, ctx->d_clist, ctx->cap_clist, (size_t)nprot)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, ctx->d_crow, ctx->cap_crow, (size_t)nprot)) != PLAAC_OK) return rc;
-        if ((rc = grow(ctx, ctx->d_fblist, ctx->cap_fblist, (size_t)nprot)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, PL.clist, PL.cap_clist, (size_t)nprot)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, PL.crow, PL.cap_crow, (size_t)nprot)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, PL.fblist, PL.cap_fblist, (size_t)nprot)) != PLAAC_OK) return rc;
     }
     while (ctx->gev.size() < ng) {
         hipEvent_t e = nullptr;
@@ -1422,6 +1439,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     ctx->last_chain_bound = F.chain_bound;
     ctx->last_mixed = F.mixed;
     ctx->last_single_summary = C.single() && !d_tracks;
+    ctx->last_kb_aside = F.kb_aside;
     ctx->ncalls++;
     return PLAAC_OK;
 }
@@ -1434,6 +1452,7 @@ long plaac_debug_schedule(const plaac_sched_query *q, char *buf, size_t cap) {
     C.nprot = q->nprot, C.ngroups = (q->nprot + 63u) / 64u, C.residues = q->residues, C.npoints = q->npoints, C.tracks = q->tracks != 0;
     C.ncalls = q->ncalls, C.overlap = q->overlap != 0, C.last_chain_bound = q->last_chain_bound != 0;
     C.last_mixed = q->last_mixed != 0, C.last_single_summary = q->last_single_summary != 0, C.old_tail = q->old_tail != 0;
+    C.last_kb_aside = q->last_kb_aside != 0;
     uint32_t pt = 0;
     for (uint32_t g = 0; g < q->ngroups_sweep; ++g) {
         GroupKind G;
@@ -1464,9 +1483,10 @@ long plaac_debug_schedule(const plaac_sched_query *q, char *buf, size_t cap) {
     char line[320];
     std::snprintf(line, sizeof line,
                   "F par=%u head_aside=%d tail_allowed=%d kb_after_pack=%d chain_bound=%d latency_mode=%d mixed=%d lat_all=%d gl=%u "
-                  "use_core_list=%d sweep_lat=%d core_long=%d kb_deferred=%d maybe_huge=%d ka_wait=%d runs=%zu body=%zu serial=%d\n",
+                  "use_core_list=%d sweep_lat=%d core_long=%d kb_deferred=%d maybe_huge=%d ka_wait=%d runs=%zu body=%zu serial=%d kb_aside=%d\n",
                   C.par(), F.head_aside, F.tail_allowed, F.kb_after_pack, F.chain_bound, F.latency_mode, F.mixed, F.lat_all, F.gl,
-                  F.use_core_list, F.sweep_lat, F.core_long, F.kb_deferred, F.maybe_huge, F.ka_wait, F.ntseg(), body, K.serial ? 1 : 0);
+                  F.use_core_list, F.sweep_lat, F.core_long, F.kb_deferred, F.maybe_huge, F.ka_wait, F.ntseg(), body, K.serial ? 1 : 0,
+                  F.kb_aside);
     out += line;
     std::snprintf(line, sizeof line, "ALIAS %u %u\nALIAS %u %u\n", hi(R_BWD), hi(R_WIN2), no(R_WIN2), no(R_WIN));
     out += line;
@@ -1579,7 +1599,11 @@ plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count) {
     if (ctx->ncalls == 0) return PLAAC_OK;
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PL_HIP(ctx, hipEventSynchronize(ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
-    PL_HIP(ctx, hipMemcpy(count, ctx->d_kbcnt + (size_t)KB_COUNTER_WORDS * ((ctx->ncalls - 1) & 3u), sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // (DIAGNOSTIC, PLAAC_DEBUG_COUNTER=16: another word of the call's counter set - 16: the core list's length)
+    const char *dbg = std::getenv("PLAAC_DEBUG_COUNTER");
+    const size_t word = dbg ? (size_t)std::min(31L, std::max(0L, std::atol(dbg))) : 0u;
+    PL_HIP(ctx, hipMemcpy(count, ctx->d_kbcnt + (size_t)KB_COUNTER_WORDS * ((ctx->ncalls - 1) & 3u) + word, sizeof(uint32_t),
+                          hipMemcpyDeviceToHost));
     return PLAAC_OK;
 }
 
