@@ -1083,6 +1083,8 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         case K_WIN: {
             const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
             const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
+            if (const char *e = std::getenv("PLAAC_DEBUG_WIN")) // DIAGNOSTIC: 8 = no row stores (after the first calls; stale rows)
+                if (ctx->ncalls >= 2) tg.stop_after = (uint32_t)std::atoi(e);
 #define LAUNCH_WIN(NC, ROLE)                                                                                       \
     hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, s, D.d_codes, D.d_offsets, PL.neff,      \
                        PL.order + first, cnt, tab, PL.packed, PL.grow + F.segb[o.run], tg, h0)
@@ -1179,7 +1181,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             const uint32_t g0 = o.a, g1 = o.b, base = g0 * 64u;
             hipLaunchKernelGGL(k_tracksL, dim3((g1 - g0 + KL_THREADS / 64 - 1) / (KL_THREADS / 64)), dim3(KL_THREADS), 0, s, PL.order,
                                nprot, g0, g1, tab, ctx->d_divtab, PL.packed, PL.grow, rows0, D.huge, PL.clist + base,
-                               PL.crow + base, D.ccount + o.seg, PL.fblist, D.fbcount);
+                               PL.crow + base, D.ccount + o.seg, PL.fblist, D.fbcount, F.kb_prio_lane);
             break;
         }
         case K_REFINE: {
@@ -1189,11 +1191,11 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             const unsigned rounds = (o.b + RF_SLOTS - 1) / RF_SLOTS;
             if (o.sel)
                 hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min(rounds, K.rf_grid)), dim3(64), 0, s, D.d_codes, D.total, tab,
-                                   ctx->d_divtab, rows0, D.huge, PL.clist + o.a, PL.crow + o.a, D.ccount + o.seg);
+                                   ctx->d_divtab, rows0, D.huge, PL.clist + o.a, PL.crow + o.a, D.ccount + o.seg, F.kb_prio_refine);
             else
                 hipLaunchKernelGGL(k_refine_centres<false>, dim3(std::min(rounds, F.tail_allowed ? K.rf_grid / 8u * 7u : K.rf_grid)),
                                    dim3(64), 0, s, D.d_codes, D.total, tab, ctx->d_divtab, rows0, D.huge, PL.clist + o.a,
-                                   PL.crow + o.a, D.ccount + o.seg);
+                                   PL.crow + o.a, D.ccount + o.seg, F.kb_prio_refine);
             break;
         }
         case K_COPY_WINDOW_FIELDS:

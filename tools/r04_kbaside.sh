@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/r4
 out=gpurun_out/r4/kbaside.txt
 : > $out
-timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "overlap or identical or exact or lse or real" > gpurun_out/r4/kbaside_pytest.txt 2>&1 || { tail -30 gpurun_out/r4/kbaside_pytest.txt; exit 1; }
+timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu  > gpurun_out/r4/kbaside_pytest.txt 2>&1 || { tail -30 gpurun_out/r4/kbaside_pytest.txt; exit 1; }
 tail -2 gpurun_out/r4/kbaside_pytest.txt
 F="--steps 16 --warmup 4 --no-cpu-baseline --no-e2e --no-predict --no-clock-probe --no-host-leg"
 run() { # label, env...
@@ -16,10 +16,7 @@ for l in sys.stdin:
         d=json.loads(l); print('   ms_per_step', d['ms_per_step'], 'no_overlap', (d.get('config') or {}).get('no_overlap_ms_per_step'), 'match', (d.get('cpu_baseline') or {}).get('gpu_rows_match_oracle'))
 " >> $out || echo "   failed" >> $out
 }
-run "folded, bit columns" PLAAC_CORE_CBITS=0
-run "folded, bit columns, long groups core search in k_core_*" PLAAC_CORE_CBITS=0 PLAAC_CORE_LONG_LIST=1
-run "folded, compact bits, long groups core search in k_core_*" PLAAC_CORE_CBITS=1 PLAAC_CORE_LONG_LIST=1
-run "folded, bit columns" PLAAC_CORE_CBITS=0
-run "folded, bit columns, long groups core search in k_core_*" PLAAC_CORE_CBITS=0 PLAAC_CORE_LONG_LIST=1
-run "folded, compact bits, long groups core search in k_core_*" PLAAC_CORE_CBITS=1 PLAAC_CORE_LONG_LIST=1
+run "default" PLAAC_X=1
+run "default" PLAAC_X=1
+run "calibration: finish kernel, prio 0/0" PLAAC_FINISH_KERNEL=1 PLAAC_KB_PRIO=00
 cat $out
