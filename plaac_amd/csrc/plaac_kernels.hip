@@ -1083,8 +1083,6 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         case K_WIN: {
             const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
             const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
-            if (const char *e = std::getenv("PLAAC_DEBUG_WIN")) // DIAGNOSTIC: 8 = no row stores (after the first calls; stale rows)
-                if (ctx->ncalls >= 2) tg.stop_after = (uint32_t)std::atoi(e);
 #define LAUNCH_WIN(NC, ROLE)                                                                                       \
     hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, s, D.d_codes, D.d_offsets, PL.neff,      \
                        PL.order + first, cnt, tab, PL.packed, PL.grow + F.segb[o.run], tg, h0)
