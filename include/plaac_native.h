@@ -333,8 +333,6 @@ typedef struct plaac_sched_query {
     int32_t tracks, overlap;
     uint64_t ncalls;             /* calls the context has scored before this one */
     int32_t last_chain_bound, last_mixed, last_single_summary, old_tail;
-    int32_t last_kb_aside;       /* the previous call's window-track kernels ran off the caller's stream */
-    int32_t reserved;
 } plaac_sched_query;
 long plaac_debug_schedule(const plaac_sched_query *q, char *buf, size_t cap);
 

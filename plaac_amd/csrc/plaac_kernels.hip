@@ -77,7 +77,7 @@ struct plaac_ctx {
     std::vector<hipStream_t> gstreams; // side streams of the 2nd, 3rd ... group of a sweep (three each), high priority
     std::vector<hipStream_t> gstreams_n; // the same at normal priority (throughput-bound batches, see auxn)
     std::vector<hipEvent_t> gjev;      // their join events
-    hipEvent_t jev[8] = {}; // join events of the side streams
+    hipEvent_t jev[6] = {}; // join events of the side streams
     hipEvent_t fev[2] = {nullptr, nullptr};                            // k_finish waits for the forward / window streams
     plaac_params params;
     // plan / scratch buffers (grown on demand)
@@ -142,10 +142,7 @@ struct plaac_ctx {
     // the caller's stream before the tail of the call that used buffers p; tail_open2[p]: that call recorded one) and
     // ka_done[p] (its side streams joined). The chain kernels of call k+1 wait for ka_done of call k (shared scratch).
     bool overlap = false, tail_open2[2] = {false, false}, last_chain_bound = false, last_single_summary = false;
-    bool last_kb_aside = false;
-    hipStream_t kbs[2] = {nullptr, nullptr}; // PLAAC_KB_CLASS=0: streams of the window-track kernels of overlapping calls (S_KBK, S_KBT)
     hipEvent_t tail_ev2[2] = {nullptr, nullptr}, ka_done[2] = {nullptr, nullptr};
-    hipEvent_t td_ev[2] = {nullptr, nullptr}; // EK_TD: the refine launch of the call with that parity is through (a scheduling hint)
     uint32_t *d_huge = nullptr; // four words, used in turn: the tail of call k reads its word while call k+2 already plans
     // Chain-bound single-point summary calls in MIXED FORMS (round 4, PLAAC_MIXED=0: latency forms for every wave-group as
     // in round 3): the long wave-groups on two streams of the high class per call parity, every other wave-group in the
@@ -652,9 +649,6 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
             plaac_ctx_destroy(ctx);
             return PLAAC_ERR_DEVICE;
         }
-        if (ctx->knobs.kb_aside && ctx->knobs.kb_class == 0)
-            for (auto &ks : ctx->kbs)
-                if ((e = hipStreamCreateWithPriority(&ks, hipStreamNonBlocking, 0)) != hipSuccess) return bail("hipStreamCreate", e);
         for (auto &je : ctx->jev)
             if ((e = hipEventCreateWithFlags(&je, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
@@ -665,7 +659,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&ctx->tpev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        for (auto *arr : {ctx->tail_ev2, ctx->ka_done, ctx->lev, ctx->td_ev})
+        for (auto *arr : {ctx->tail_ev2, ctx->ka_done, ctx->lev})
             for (int k = 0; k < 2; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipMalloc((void **)&ctx->d_huge, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(huge)", e);
@@ -794,11 +788,6 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
                 (void)hipStreamSynchronize(a);
                 (void)hipStreamDestroy(a);
             }
-    for (hipStream_t a : ctx->kbs)
-        if (a) {
-            (void)hipStreamSynchronize(a);
-            (void)hipStreamDestroy(a);
-        }
     for (hipEvent_t e : ctx->gjev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->jev)
@@ -810,7 +799,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     for (hipEvent_t e : ctx->pkev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->tpev) (void)hipEventDestroy(ctx->tpev);
-    for (auto *arr : {ctx->tail_ev2, ctx->ka_done, ctx->td_ev})
+    for (auto *arr : {ctx->tail_ev2, ctx->ka_done})
         for (int k = 0; k < 2; ++k)
             if (arr[k]) (void)hipEventDestroy(arr[k]);
     if (ctx->d_huge) (void)hipFree(ctx->d_huge);
@@ -864,8 +853,7 @@ hipStream_t slot_stream(plaac_ctx *ctx, const CallData &D, uint8_t slot) {
     if (slot < S_NO) return ctx->aux[slot - S_HI];
     if (slot < S_G) return ctx->auxn[slot - S_NO];
     if (slot < S_GN) return ctx->gstreams[slot - S_G];
-    if (slot < S_KBK) return ctx->gstreams_n[slot - S_GN];
-    return ctx->kbs[slot - S_KBK];
+    return ctx->gstreams_n[slot - S_GN];
 }
 
 hipEvent_t slot_event(plaac_ctx *ctx, const CallData &D, uint16_t e) {
@@ -879,7 +867,6 @@ hipEvent_t slot_event(plaac_ctx *ctx, const CallData &D, uint16_t e) {
     case EK_L: return ctx->lev[par];
     case EK_KA: return ctx->ka_done[idx];
     case EK_TAIL: return ctx->tail_ev2[idx];
-    case EK_TD: return ctx->td_ev[idx];
     case EK_KB: return ctx->kbev[idx];
     case EK_TF: return ctx->tfev[idx];
     case EK_TB: return ctx->tbev[idx];
@@ -1303,7 +1290,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     C.nprot = nprot, C.ngroups = (nprot + 63u) / 64u, C.residues = total_residues, C.npoints = npoints, C.tracks = d_tracks != nullptr;
     C.ncalls = ctx->ncalls, C.overlap = ctx->overlap, C.last_chain_bound = ctx->last_chain_bound, C.last_mixed = ctx->last_mixed;
     C.last_single_summary = ctx->last_single_summary;
-    C.last_kb_aside = ctx->last_kb_aside;
     const unsigned par = C.par(); // this call's plan buffers, `huge` word and body events
     C.old_tail = ctx->tail_open2[par];
     ctx->tail_open2[par] = false;
@@ -1439,7 +1425,6 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     ctx->last_chain_bound = F.chain_bound;
     ctx->last_mixed = F.mixed;
     ctx->last_single_summary = C.single() && !d_tracks;
-    ctx->last_kb_aside = F.kb_aside;
     ctx->ncalls++;
     return PLAAC_OK;
 }
@@ -1452,7 +1437,6 @@ long plaac_debug_schedule(const plaac_sched_query *q, char *buf, size_t cap) {
     C.nprot = q->nprot, C.ngroups = (q->nprot + 63u) / 64u, C.residues = q->residues, C.npoints = q->npoints, C.tracks = q->tracks != 0;
     C.ncalls = q->ncalls, C.overlap = q->overlap != 0, C.last_chain_bound = q->last_chain_bound != 0;
     C.last_mixed = q->last_mixed != 0, C.last_single_summary = q->last_single_summary != 0, C.old_tail = q->old_tail != 0;
-    C.last_kb_aside = q->last_kb_aside != 0;
     uint32_t pt = 0;
     for (uint32_t g = 0; g < q->ngroups_sweep; ++g) {
         GroupKind G;
@@ -1483,10 +1467,9 @@ long plaac_debug_schedule(const plaac_sched_query *q, char *buf, size_t cap) {
     char line[320];
     std::snprintf(line, sizeof line,
                   "F par=%u head_aside=%d tail_allowed=%d kb_after_pack=%d chain_bound=%d latency_mode=%d mixed=%d lat_all=%d gl=%u "
-                  "use_core_list=%d sweep_lat=%d core_long=%d kb_deferred=%d maybe_huge=%d ka_wait=%d runs=%zu body=%zu serial=%d kb_aside=%d\n",
+                  "use_core_list=%d sweep_lat=%d core_long=%d kb_deferred=%d maybe_huge=%d ka_wait=%d runs=%zu body=%zu serial=%d\n",
                   C.par(), F.head_aside, F.tail_allowed, F.kb_after_pack, F.chain_bound, F.latency_mode, F.mixed, F.lat_all, F.gl,
-                  F.use_core_list, F.sweep_lat, F.core_long, F.kb_deferred, F.maybe_huge, F.ka_wait, F.ntseg(), body, K.serial ? 1 : 0,
-                  F.kb_aside);
+                  F.use_core_list, F.sweep_lat, F.core_long, F.kb_deferred, F.maybe_huge, F.ka_wait, F.ntseg(), body, K.serial ? 1 : 0);
     out += line;
     std::snprintf(line, sizeof line, "ALIAS %u %u\nALIAS %u %u\n", hi(R_BWD), hi(R_WIN2), no(R_WIN2), no(R_WIN));
     out += line;

@@ -500,7 +500,7 @@ class SchedQuery(C.Structure):
                 ("kb_base", C.c_int32 * 11), ("lane_possible", C.c_int32), ("fast20", C.c_int32), ("wmax", C.c_int32),
                 ("core_par_tables", C.c_int32), ("tracks", C.c_int32), ("overlap", C.c_int32), ("ncalls", C.c_uint64),
                 ("last_chain_bound", C.c_int32), ("last_mixed", C.c_int32), ("last_single_summary", C.c_int32),
-                ("old_tail", C.c_int32), ("last_kb_aside", C.c_int32), ("reserved", C.c_int32)]
+                ("old_tail", C.c_int32)]
 
 
 def debug_schedule(q):

@@ -21,7 +21,7 @@ import pytest
 
 from conftest import ROOT  # noqa: F401
 
-EK = dict(T=0, PK=1, J=2, F=3, L=4, KA=5, TAIL=6, KB=7, TF=8, TB=9, TP=10, G=11, GJ=12, PREVJOIN=13, TD=14)
+EK = dict(T=0, PK=1, J=2, F=3, L=4, KA=5, TAIL=6, KB=7, TF=8, TB=9, TP=10, G=11, GJ=12, PREVJOIN=13)
 E_JOIN = 10
 # buffers (schedule.hip.inc, enum Buf)
 BUF = ["NEFF", "HIST", "ORDER", "GROW", "HUGE", "HPIN", "PACKED", "BITS", "LMARG", "H0", "VEND", "CORELIST", "CORECOUNT",
@@ -34,7 +34,7 @@ PER_CALL = {b for b in BUF if b.startswith("ROW_") or b.startswith("TRK_")} | {"
 
 
 def query(native, nprot, residues, rows_first, long_groups=0, long_rows=0, total_rows=None, points=(1,), kb_base=None,
-          lane=True, fast20=True, wmax=20, tracks=False, overlap=False, ncalls=0, last=(0, 0, 0, 0), old_tail=0, marks=None):
+          lane=True, fast20=True, wmax=20, tracks=False, overlap=False, ncalls=0, last=(0, 0, 0), old_tail=0, marks=None):
     q = native.SchedQuery()
     q.nprot, q.residues, q.rows_first, q.long_groups, q.long_rows = nprot, residues, rows_first, long_groups, long_rows
     q.total_rows = total_rows if total_rows is not None else max(1, residues // 16 + nprot // 64)
@@ -48,8 +48,7 @@ def query(native, nprot, residues, rows_first, long_groups=0, long_rows=0, total
         q.kb_base[g] = -1 if kb_base is None else kb_base[g]
     q.lane_possible, q.fast20, q.wmax, q.core_par_tables = int(lane), int(fast20), wmax, 1
     q.tracks, q.overlap, q.ncalls = int(tracks), int(overlap), ncalls
-    q.last_chain_bound, q.last_mixed, q.last_single_summary = last[:3]
-    q.last_kb_aside = last[3] if len(last) > 3 else 0
+    q.last_chain_bound, q.last_mixed, q.last_single_summary = last
     q.old_tail = old_tail
     return q
 
@@ -102,7 +101,7 @@ class Model:
                     for k, v in self.events[key].items():
                         vc[k] = max(vc.get(k, 0), v)
                 first = recorded_later.get(key)
-                crosses = o[2][0] in (EK["PREVJOIN"], EK["KA"], EK["TAIL"], EK["TD"])
+                crosses = o[2][0] in (EK["PREVJOIN"], EK["KA"], EK["TAIL"])
                 if first is not None and first > i and not crosses:
                     self.errors.append("%s: op %d waits for event %s that this call only records later (op %d)" % (what, i, o[2], first))
             else:
@@ -143,13 +142,13 @@ SHAPES = {
 
 def consecutive(native, shape, n=4, monkey=None, **kw):
     """schedules of n consecutive calls of one kind, the history threaded from call to call"""
-    out, last, tails = [], (0, 0, 0, 0), {}
+    out, last, tails = [], (0, 0, 0), {}
     for c in range(n):
         q = query(native, *SHAPES[shape], ncalls=c, last=last, old_tail=tails.get(c - 2, 0), **kw)
         forms, alias, ops = parse(native.debug_schedule(q))
         out.append((c, forms, alias, ops))
         single_summary = int(q.npoints == 1 and not q.tracks)
-        last = (forms["chain_bound"], forms["mixed"], single_summary, forms["kb_aside"])
+        last = (forms["chain_bound"], forms["mixed"], single_summary)
         tails[c] = int(any(o[0] == "R" and o[2][0] == EK["TAIL"] for o in ops))
     return out
 
@@ -171,7 +170,7 @@ def test_no_wait_can_deadlock_and_conflicting_accesses_are_ordered(native, shape
     assert not m.errors, "\n".join(m.errors[:12])
 
 
-KNOBS = [{"PLAAC_SERIAL_STREAMS": "1"}, {"PLAAC_KB_SIDE": "0"}, {"PLAAC_KB_ASIDE": "1"}, {"PLAAC_KB_ASIDE": "1", "PLAAC_KB_CLASS": "0"}, {"PLAAC_HOLD_CHAINS": "1"}, {"PLAAC_FINISH_KERNEL": "1"}, {"PLAAC_MIXED": "0"}, {"PLAAC_LATENCY_MODE": "1"}, {"PLAAC_LATENCY_MODE": "0"},
+KNOBS = [{"PLAAC_SERIAL_STREAMS": "1"}, {"PLAAC_KB_SIDE": "0"}, {"PLAAC_FINISH_KERNEL": "1"}, {"PLAAC_KB_PRIO": "0"}, {"PLAAC_MIXED": "0"}, {"PLAAC_LATENCY_MODE": "1"}, {"PLAAC_LATENCY_MODE": "0"},
          {"PLAAC_KB_LANE": "0"}, {"PLAAC_KB_FILTER": "0"}, {"PLAAC_CORE_LIST": "0"}, {"PLAAC_MIXED_GROUPS": "3", "PLAAC_MIXED_MIN_REST": "1"},
          {"PLAAC_KB_LANE_MIN_GROUPS": "1"}, {"PLAAC_PIPE_SEGMENTS": "4", "PLAAC_SEGMENT_MIN_ROWS": "1"},
          {"PLAAC_TRACK_SEGMENTS": "4", "PLAAC_SEGMENT_MIN_ROWS": "1"}, {"PLAAC_SWEEP_SPREAD": "0"}, {"PLAAC_SWEEP_LATENCY": "0"},
@@ -198,17 +197,17 @@ def test_calls_of_different_kinds_in_a_row_stay_ordered(native):
     """the transitions: throughput-bound -> chain-bound (mixed) -> tracks -> sweep -> summary again, overlapping"""
     kinds = [("full", {}), ("share", {}), ("share", {}), ("cfg2", {}), ("cfg3", dict(tracks=True)),
              ("cfg3", dict(points=(3, 3, 3), kb_base=(-1, 0, 0))), ("share", {}), ("flat", {}), ("full", {}), ("share", {})]
-    m, last, tails = Model(), (0, 0, 0, 0), {}
+    m, last, tails = Model(), (0, 0, 0), {}
     for c, (shape, kw) in enumerate(kinds):
         q = query(native, *SHAPES[shape], ncalls=c, last=last, old_tail=tails.get(c - 2, 0), overlap=True, **kw)
         forms, alias, ops = parse(native.debug_schedule(q))
         m.run(c, forms, alias, ops, "mixed sequence call %d (%s)" % (c, shape))
-        last = (forms["chain_bound"], forms["mixed"], int(q.npoints == 1 and not q.tracks), forms["kb_aside"])
+        last = (forms["chain_bound"], forms["mixed"], int(q.npoints == 1 and not q.tracks))
         tails[c] = int(any(o[0] == "R" and o[2][0] == EK["TAIL"] for o in ops))
     assert not m.errors, "\n".join(m.errors[:12])
 
 
-def test_the_decision_table(native, monkeypatch):
+def test_the_decision_table(native):
     """the forms the library picks for BASELINE's configurations: config 2 / 3 chain-bound, all wave-groups in the
     long run; the 1.25 M-sequence share chain-bound in mixed forms; the 10 M batch throughput-bound with the core list"""
     f = {s: parse(native.debug_schedule(query(native, *SHAPES[s])))[0] for s in SHAPES}
@@ -223,23 +222,19 @@ def test_the_decision_table(native, monkeypatch):
     assert [x["head_aside"] for x in o] == [0, 1, 1] and all(x["tail_allowed"] for x in o)
     t = [c[1] for c in consecutive(native, "share", 3, overlap=True, tracks=True)]
     assert not any(x["head_aside"] or x["tail_allowed"] for x in t)
-    # PLAAC_KB_ASIDE=1 (experiment): the window-track kernels of overlapping throughput-bound calls leave the
-    # caller's stream (filter tier and refine / exact tier on two streams of their own); chain-bound calls, lone calls, track
-    # mode and sweeps keep it
-    assert not any(c[1]["kb_aside"] for c in consecutive(native, "full", 3, overlap=True))
-    monkeypatch.setenv("PLAAC_KB_ASIDE", "1")
-    assert [c[1]["kb_aside"] for c in consecutive(native, "full", 3, overlap=True)] == [1, 1, 1]
-    assert [c[1]["kb_aside"] for c in consecutive(native, "flat", 3, overlap=True)] == [1, 1, 1]
-    assert not any(c[1]["kb_aside"] for c in consecutive(native, "full", 3, overlap=False))
-    assert not any(c[1]["kb_aside"] for c in consecutive(native, "share", 3, overlap=True))
-    assert not any(c[1]["kb_aside"] for c in consecutive(native, "full", 3, overlap=True, tracks=True))
-    full = consecutive(native, "full", 3, overlap=True)[2][3]
-    assert not any(o[0] == "L" and o[1] == 0 for o in full), "kb_aside: the caller's stream only joins"
+    # throughput-bound single-point calls write HMMall / HMMvit from k_fwd / k_vit (no k_finish); chain-bound ones finish the long
+    # run with k_finish and let the throughput-form runs write their own
+    full = consecutive(native, "full", 2, overlap=True)[1][3]
+    assert not any(o[0] == "L" and o[2] == "k_finish" for o in full)
+    assert any(o[0] == "L" and o[2] == "k_fwd" and "ext=0" in o[4] for o in full)
+    share = consecutive(native, "share", 2, overlap=True)[1][3]
+    assert sum(1 for o in share if o[0] == "L" and o[2] == "k_finish") == 1
+    assert any(o[0] == "L" and o[2] == "k_fwd" and "ext=0" in o[4] for o in share)
     # a call has at most ~120 operations (the host's share of a 3 ms step)
     assert all(len(parse(native.debug_schedule(query(native, *SHAPES[s], overlap=True, ncalls=3, last=(1, 1, 1))))[2]) < 130 for s in SHAPES)
 
 
-def test_the_model_sees_a_missing_wait(native, monkeypatch):
+def test_the_model_sees_a_missing_wait(native):
     """the checker itself: take the share's schedule and drop, in turn, the wait of the long stream for the Viterbi side's
     event, the waits for the packed copy, and the record of a join event - every removal must be reported"""
     calls = consecutive(native, "share", 3, overlap=True)
@@ -258,14 +253,3 @@ def test_the_model_sees_a_missing_wait(native, monkeypatch):
     # the head of call k+2 no longer waits for the window kernels of call k, which read the plan it overwrites
     e = errors_without(lambda o: o[0] == "W" and o[2][0] == EK["TAIL"])
     assert any("call 2" in x and ("ORDER" in x or "PACKED" in x or "GROW" in x) for x in e), e[:3]
-    # kb_aside (throughput-bound overlapping calls): the filter tier of call k+2 writes the lists the refine / exact tier of call
-    # k reads on another stream - its wait for that call's join event is what orders them; and the tail's wait for the filter
-    monkeypatch.setenv("PLAAC_KB_ASIDE", "1")
-    calls = consecutive(native, "full", 4, overlap=True)
-    assert not errors_without(lambda o: False)
-    e = errors_without(lambda o: o[0] == "W" and o[2] == (EK["PREVJOIN"], 2))
-    assert any(("CLIST" in x or "FBLIST" in x) for x in e), e[:3]
-    e = errors_without(lambda o: o[0] == "W" and o[2][0] == EK["KB"])
-    assert any("k_refine_centres" in x and "CLIST" in x for x in e), e[:3]
-    e = errors_without(lambda o: o[0] == "W" and o[2] == (EK["J"], 7))
-    assert any("k_tracks20_list" in x for x in e), e[:3]  # (the join is what PREVJOIN(2) of the call after next rests on)
