@@ -831,6 +831,35 @@ def test_throughput_and_latency_forms_of_the_chain_kernels(native, oracle, monke
             assert_tracks_equal(tr, wtr, codes, offs, "mode %s %s" % (mode, kw))
 
 
+@pytest.mark.parametrize("knobs", [{"PLAAC_FINISH_KERNEL": "1"}, {"PLAAC_FINISH_KERNEL": "0", "PLAAC_KB_PRIO": "33"},
+                                   {"PLAAC_MIXED_GROUPS": "2", "PLAAC_MIXED_MIN_REST": "1", "PLAAC_FINISH_KERNEL": "1"},
+                                   {"PLAAC_MIXED_GROUPS": "2", "PLAAC_MIXED_MIN_REST": "1"}],
+                         ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_hmm_scores_from_the_chain_kernels_or_from_the_finishing_kernel(native, oracle, monkeypatch, knobs):
+    """HMMall / HMMvit (plaac.java:797-798) are hmm1's forward / Viterbi score minus hmm0's total. Throughput-bound calls and
+    the throughput-form runs of a call in mixed forms let k_fwd / k_vit carry hmm0's running sum and write the two fields
+    themselves (round 4: the finishing kernel's pass over the rows cost the step its whole stand-alone time);
+    PLAAC_FINISH_KERNEL=1 keeps the three terms apart and combines them in k_finish, as the latency forms always do. Same
+    bits either way, with the lane-form filter at either wave priority, for consecutive overlapping calls too."""
+    from plaac_amd import synth
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("PLAAC_KB_LANE_MIN_GROUPS", "1")
+    if "PLAAC_MIXED_GROUPS" not in knobs:
+        monkeypatch.setenv("PLAAC_LATENCY_MODE", "0")
+    P0 = native.make_params()
+    rng = np.random.default_rng(4404)
+    lens = np.concatenate([[2500, 2047, 1, 0, 16, 17, 79, 80, 81, 600], rng.integers(1, 500, 900)])
+    rng.shuffle(lens)
+    codes, offs = synth.residues(lens, np.array(P0.fg), np.array(P0.bg), rng, stop_fraction=0.1)
+    want = oracle.score_batch(oracle.build_params(), codes, offs, nthreads=8)
+    with native.Context(P0) as c:
+        assert_rows_equal(c.score(codes, offs), want, what="%s" % knobs)
+        c.set_overlap(True)
+        for rep, got in enumerate(c.score_stream([(codes, offs)] * 4)):
+            assert_rows_equal(got, want, what="%s, overlapping call %d" % (knobs, rep))
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 @pytest.mark.parametrize("nseg", ["2", "3", "8"])
 def test_calls_cut_into_runs_of_wave_groups(native, oracle, monkeypatch, mode, nseg):
