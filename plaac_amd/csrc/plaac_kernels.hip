@@ -1044,15 +1044,22 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
 #undef LAUNCH_FWD
             break;
         }
-        case K_FWD_PAIR: {
-            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
+        case K_FWD_PAIR:
+        case K_FWD_POST: { // (o.b > o.a: the wave-groups [o.a, o.b) of the run instead of all of it)
+            const bool part = o.b > o.a;
+            const uint32_t g0 = part ? o.a : F.segb[o.run];
+            const uint32_t first = part ? o.a * 64u : seg_first(F.segb, o.run);
+            const uint32_t cnt = part ? (uint32_t)(std::min<uint64_t>((uint64_t)o.b * 64u, nprot) - first) : seg_count(F.segb, o.run);
             const dim3 grid((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2));
-            if (o.trk)
+            if (o.kern == K_FWD_POST)
+                hipLaunchKernelGGL(k_fwd_post_pair, grid, dim3(KA_THREADS), 0, s, PL.order + first, cnt, tab, PL.packed, PL.grow + g0,
+                                   PL.lat, (const double2 *)ctx->d_bwd, D.tp);
+            else if (o.trk)
                 hipLaunchKernelGGL(k_fwd_pair<true>, grid, dim3(KA_THREADS), 0, s, PL.order + first, cnt, tab, PL.packed,
-                                   PL.grow + F.segb[o.run], PL.lat, ctx->d_fwd);
+                                   PL.grow + g0, PL.lat, ctx->d_fwd);
             else
                 hipLaunchKernelGGL(k_fwd_pair<false>, grid, dim3(KA_THREADS), 0, s, PL.order + first, cnt, tab, PL.packed,
-                                   PL.grow + F.segb[o.run], PL.lat, (double2 *)nullptr);
+                                   PL.grow + g0, PL.lat, (double2 *)nullptr);
             break;
         }
         case K_BWD: {

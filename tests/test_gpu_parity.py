@@ -860,6 +860,36 @@ def test_hmm_scores_from_the_chain_kernels_or_from_the_finishing_kernel(native, 
             assert_rows_equal(got, want, what="%s, overlapping call %d" % (knobs, rep))
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("vit_mixed", ["0", "1"])
+def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, oracle, monkeypatch, fused, vit_mixed):
+    """Chain-bound batches in track mode (round 4): the wave-groups without a long protein run the forward pass BEHIND the
+    backward pass and emit posteriors and MAP bytes on the way (k_fwd_post_pair; the reference's lpseq comes from position
+    0, plaac.java:3393-3396, so the order is exact); the long wave-groups keep forward array + k_post; the Viterbi kernel
+    takes its list form outside the long wave-groups. Every combination against the oracle: rows, the eight window tracks,
+    Viterbi / MAP bytes, posteriors - with the long wave-groups in the first run only, in several runs, and absent."""
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_TRACK_FUSED", fused)
+    monkeypatch.setenv("PLAAC_TRACK_VIT_MIXED", vit_mixed)
+    monkeypatch.setenv("PLAAC_MIXED_MIN_REST", "1")
+    monkeypatch.setenv("PLAAC_SEGMENT_MIN_ROWS", "1")
+    monkeypatch.setenv("PLAAC_LATENCY_MODE", "1")
+    P0 = native.make_params()
+    rng = np.random.default_rng(8800 + int(fused) * 2 + int(vit_mixed))
+    shapes = (np.concatenate([[9000, 2100, 2048, 1, 0, 16, 17], rng.integers(1, 600, 700)]),
+              np.concatenate([rng.integers(2048, 2600, 200), rng.integers(1, 300, 300)]),  # long wave-groups in more than one run
+              rng.integers(1, 400, 500))                                                    # none
+    for lens in shapes:
+        rng.shuffle(lens)
+        codes, offs = synth.residues(lens, np.array(P0.fg), np.array(P0.bg), rng, stop_fraction=0.1)
+        want, wtr = oracle.score_batch(oracle.build_params(), codes, offs, tracks=True, nthreads=8)
+        with native.Context(P0) as c:
+            trows, tr = c.score(codes, offs, tracks=True)
+        what = "fused %s, k_vit mixed %s, %d proteins" % (fused, vit_mixed, len(lens))
+        assert_rows_equal(trows, want, what)
+        assert_tracks_equal(tr, wtr, codes, offs, what)
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 @pytest.mark.parametrize("nseg", ["2", "3", "8"])
 def test_calls_cut_into_runs_of_wave_groups(native, oracle, monkeypatch, mode, nseg):
