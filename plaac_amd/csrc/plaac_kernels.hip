@@ -134,6 +134,7 @@ struct plaac_ctx {
     static constexpr int TRK_MAXSEG = sched::TRK_MAXSEG; // track mode: runs of wave-groups (k_post of one run beside the chains of the next)
     hipEvent_t tfev[TRK_MAXSEG] = {}, tbev[TRK_MAXSEG] = {}, tpev = nullptr; // forward / backward of a run done; posteriors done
     hipEvent_t pkev[TRK_MAXSEG] = {}; // packed copy of a run done
+    hipEvent_t rev[2 * TRK_MAXSEG] = {}; // EK_R
     // Consecutive calls may overlap (plaac_ctx_set_overlap): the planning and packing of a call - HBM-bound, they touch the
     // plan buffers only - run beside the "tail" of the previous call, the exact values at the PAPA centres and the exact
     // tier (k_refine_centres, k_tracks20 over the fallback list: instruction-bound, alone on the chip otherwise), which read
@@ -659,6 +660,8 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
             for (int k = 0; k < plaac_ctx::TRK_MAXSEG; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&ctx->tpev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        for (auto &re : ctx->rev)
+            if ((e = hipEventCreateWithFlags(&re, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         for (auto *arr : {ctx->tail_ev2, ctx->ka_done, ctx->lev})
             for (int k = 0; k < 2; ++k)
                 if ((e = hipEventCreateWithFlags(&arr[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -798,6 +801,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->pkev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->rev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->tpev) (void)hipEventDestroy(ctx->tpev);
     for (auto *arr : {ctx->tail_ev2, ctx->ka_done})
         for (int k = 0; k < 2; ++k)
@@ -867,6 +872,7 @@ hipEvent_t slot_event(plaac_ctx *ctx, const CallData &D, uint16_t e) {
     case EK_L: return ctx->lev[par];
     case EK_KA: return ctx->ka_done[idx];
     case EK_TAIL: return ctx->tail_ev2[idx];
+    case EK_R: return ctx->rev[idx];
     case EK_KB: return ctx->kbev[idx];
     case EK_TF: return ctx->tfev[idx];
     case EK_TB: return ctx->tbev[idx];
@@ -1044,17 +1050,13 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
 #undef LAUNCH_FWD
             break;
         }
-        case K_FWD_PAIR:
-        case K_FWD_POST: { // (o.b > o.a: the wave-groups [o.a, o.b) of the run instead of all of it)
+        case K_FWD_PAIR: { // (o.b > o.a: the wave-groups [o.a, o.b) of the run instead of all of it)
             const bool part = o.b > o.a;
             const uint32_t g0 = part ? o.a : F.segb[o.run];
             const uint32_t first = part ? o.a * 64u : seg_first(F.segb, o.run);
             const uint32_t cnt = part ? (uint32_t)(std::min<uint64_t>((uint64_t)o.b * 64u, nprot) - first) : seg_count(F.segb, o.run);
             const dim3 grid((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2));
-            if (o.kern == K_FWD_POST)
-                hipLaunchKernelGGL(k_fwd_post_pair, grid, dim3(KA_THREADS), 0, s, PL.order + first, cnt, tab, PL.packed, PL.grow + g0,
-                                   PL.lat, (const double2 *)ctx->d_bwd, D.tp);
-            else if (o.trk)
+            if (o.trk)
                 hipLaunchKernelGGL(k_fwd_pair<true>, grid, dim3(KA_THREADS), 0, s, PL.order + first, cnt, tab, PL.packed,
                                    PL.grow + g0, PL.lat, ctx->d_fwd);
             else
@@ -1062,16 +1064,22 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
                                    PL.grow + g0, PL.lat, (double2 *)nullptr);
             break;
         }
-        case K_BWD: {
-            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
-            hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
-                               PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + F.segb[o.run], ctx->d_bwd);
-            break;
-        }
-        case K_BWD_PAIR: {
-            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
-            hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, s,
-                               PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + F.segb[o.run], ctx->d_bwd);
+        case K_BWD:
+        case K_BWD_PAIR:
+        case K_FWD_POST_LANE: { // (o.b > o.a: the wave-groups [o.a, o.b) of the run instead of all of it)
+            const bool part = o.b > o.a;
+            const uint32_t g0 = part ? o.a : F.segb[o.run];
+            const uint32_t first = part ? o.a * 64u : seg_first(F.segb, o.run);
+            const uint32_t cnt = part ? (uint32_t)(std::min<uint64_t>((uint64_t)o.b * 64u, nprot) - first) : seg_count(F.segb, o.run);
+            if (o.kern == K_BWD)
+                hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+                                   PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + g0, ctx->d_bwd);
+            else if (o.kern == K_BWD_PAIR)
+                hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, s,
+                                   PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + g0, ctx->d_bwd);
+            else
+                hipLaunchKernelGGL(k_fwd_post, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+                                   PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, (const double2 *)ctx->d_bwd, D.tp);
             break;
         }
         case K_WIN: {

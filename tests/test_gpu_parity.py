@@ -864,7 +864,7 @@ def test_hmm_scores_from_the_chain_kernels_or_from_the_finishing_kernel(native, 
 @pytest.mark.parametrize("vit_mixed", ["0", "1"])
 def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, oracle, monkeypatch, fused, vit_mixed):
     """Chain-bound batches in track mode (round 4): the wave-groups without a long protein run the forward pass BEHIND the
-    backward pass and emit posteriors and MAP bytes on the way (k_fwd_post_pair; the reference's lpseq comes from position
+    backward pass and emit posteriors and MAP bytes on the way (k_fwd_post; the reference's lpseq comes from position
     0, plaac.java:3393-3396, so the order is exact); the long wave-groups keep forward array + k_post; the Viterbi kernel
     takes its list form outside the long wave-groups. Every combination against the oracle: rows, the eight window tracks,
     Viterbi / MAP bytes, posteriors - with the long wave-groups in the first run only, in several runs, and absent."""

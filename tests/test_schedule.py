@@ -21,7 +21,7 @@ import pytest
 
 from conftest import ROOT  # noqa: F401
 
-EK = dict(T=0, PK=1, J=2, F=3, L=4, KA=5, TAIL=6, KB=7, TF=8, TB=9, TP=10, G=11, GJ=12, PREVJOIN=13)
+EK = dict(T=0, PK=1, J=2, F=3, L=4, KA=5, TAIL=6, KB=7, TF=8, TB=9, TP=10, G=11, GJ=12, PREVJOIN=13, R=14)
 E_JOIN = 10
 # buffers (schedule.hip.inc, enum Buf)
 BUF = ["NEFF", "HIST", "ORDER", "GROW", "HUGE", "HPIN", "PACKED", "BITS", "LMARG", "H0", "VEND", "CORELIST", "CORECOUNT",
