@@ -1079,15 +1079,18 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
                                    PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + g0, ctx->d_bwd);
             else
                 hipLaunchKernelGGL(k_fwd_post, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
-                                   PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, (const double2 *)ctx->d_bwd, D.tp);
+                                   PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
             break;
         }
-        case K_WIN: {
-            const uint32_t first = seg_first(F.segb, o.run), cnt = seg_count(F.segb, o.run);
+        case K_WIN: { // (o.b > o.a: the wave-groups [o.a, o.b) of the run instead of all of it)
+            const bool part = o.b > o.a;
+            const uint32_t wg0 = part ? o.a : F.segb[o.run];
+            const uint32_t first = part ? o.a * 64u : seg_first(F.segb, o.run);
+            const uint32_t cnt = part ? (uint32_t)(std::min<uint64_t>((uint64_t)o.b * 64u, nprot) - first) : seg_count(F.segb, o.run);
             const unsigned abk = (cnt + KA_THREADS - 1) / KA_THREADS;
 #define LAUNCH_WIN(NC, ROLE)                                                                                       \
     hipLaunchKernelGGL((k_win<NC, ROLE>), dim3(abk), dim3(KA_THREADS), 0, s, D.d_codes, D.d_offsets, PL.neff,      \
-                       PL.order + first, cnt, tab, PL.packed, PL.grow + F.segb[o.run], tg, h0)
+                       PL.order + first, cnt, tab, PL.packed, PL.grow + wg0, tg, h0)
             if (o.role == 2) LAUNCH_WIN(1, 2);
             else if (o.role == 3) LAUNCH_WIN(1, 3);
             else
