@@ -88,7 +88,8 @@ struct plaac_ctx {
     struct PlanBufs {
         uint32_t *neff = nullptr, *hist = nullptr, *grow = nullptr;
         uint4 *order = nullptr, *packed = nullptr;
-        // [0, nprot) lmarginalprob of hmm1, [nprot, 2 nprot) total of hmm0 (single-point calls: k_finish combines them). Per
+        // [0, nprot) lmarginalprob of hmm1, [nprot, 2 nprot) total of hmm0 (single-point calls whose kernels leave the terms to
+        // k_finish: latency / mixed forms, track mode; throughput-bound calls write HMMall / HMMvit from k_fwd / k_vit). Per
         // call too: the forward / window kernels of the next call write theirs while k_finish of this one still reads.
         // [2 nprot, 3 nprot) end score of the Viterbi path (k_vit<.., EXT>; k_finish writes HMMvit).
         double *lat = nullptr;
