@@ -1,3 +1,4 @@
+"""CPU check of the bit-parallel run statistics of k_tracksL (no GPU)."""
 
 
 def test_run_statistics_of_sixteen_steps_at_once_equal_the_per_step_form():
