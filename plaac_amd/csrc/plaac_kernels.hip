@@ -1163,12 +1163,14 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         }
         case K_TRACKS20S: {
             const unsigned kb_grid = (nprot + KB_PROTEINS_PER_BLOCK - 1) / KB_PROTEINS_PER_BLOCK;
-            if (o.trk)
-                hipLaunchKernelGGL(k_tracks20s<true>, dim3(kb_grid), dim3(64), 0, s, D.d_codes, PL.order, nprot, D.total, tab,
-                                   ctx->d_divtab, rows0, D.tp, D.huge);
-            else
+            if (o.trk) {
+                // (input order behind the long proteins: see the kernel's segment table)
+                const unsigned na = std::min(kb_grid, K.track_consec);
+                hipLaunchKernelGGL(k_tracks20s<true>, dim3(na + kb_grid), dim3(64), 0, s, D.d_codes, PL.order, nprot, D.total, tab,
+                                   ctx->d_divtab, rows0, D.tp, D.huge, D.d_offsets, PL.neff, (uint32_t)na);
+            } else
                 hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, s, D.d_codes, PL.order, nprot, D.total, tab,
-                                   ctx->d_divtab, rows0, D.tp, D.huge);
+                                   ctx->d_divtab, rows0, D.tp, D.huge, D.d_offsets, PL.neff, 0u);
             break;
         }
         case K_TRACKS20F: {

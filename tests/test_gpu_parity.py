@@ -890,6 +890,33 @@ def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, orac
         assert_tracks_equal(tr, wtr, codes, offs, what)
 
 
+@pytest.mark.parametrize("consec", ["0", "1", "2", "2048"])
+def test_track_mode_window_kernel_in_input_order_behind_the_long_proteins(native, oracle, monkeypatch, consec):
+    """Track mode (round 4): the stream form of the window kernel takes 16 CONSECUTIVE records per block - a wave's track
+    stores then meet at the proteins' ends instead of leaving half-written 64-byte sectors to other waves - and only the
+    long proteins are dealt from the head of the plan, to the first blocks (PLAAC_TRACK_CONSEC = how many such blocks at
+    most; 0: every protein dealt from the plan, as in summary mode). Which proteins count as long is a length: 2048
+    residues, or more when the first blocks cannot hold all of those (forced here with one or two blocks). Rows and all
+    eight window tracks against the oracle: long proteins more than the first blocks hold, ties at the cut, skipped and
+    empty records among the consecutive ones, fewer records than one block, none at all."""
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_TRACK_CONSEC", consec)
+    P0 = native.make_params()
+    rng = np.random.default_rng(9100)
+    shapes = (np.concatenate([rng.integers(2048, 2060, 40), [2048] * 5, [2047] * 5, rng.integers(0, 500, 600)]),
+              np.concatenate([[2300] * 20, [2301] * 20, rng.integers(1, 80, 100)]),  # a tie at the cut of one / two blocks
+              rng.integers(1, 300, 9), np.array([0, 0, 5]), np.array([], dtype=np.int64))
+    for lens in shapes:
+        rng.shuffle(lens)
+        codes, offs = synth.residues(lens, np.array(P0.fg), np.array(P0.bg), rng, stop_fraction=0.1)
+        want, wtr = oracle.score_batch(oracle.build_params(), codes, offs, tracks=True, nthreads=8)
+        with native.Context(P0) as c:
+            trows, tr = c.score(codes, offs, tracks=True)
+        what = "PLAAC_TRACK_CONSEC=%s, %d proteins" % (consec, len(lens))
+        assert_rows_equal(trows, want, what)
+        assert_tracks_equal(tr, wtr, codes, offs, what)
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 @pytest.mark.parametrize("nseg", ["2", "3", "8"])
 def test_calls_cut_into_runs_of_wave_groups(native, oracle, monkeypatch, mode, nseg):
