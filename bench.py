@@ -560,6 +560,8 @@ def main():
                 issue_classes = tj.get("issue_model")
         except (OSError, ValueError, KeyError):
             pass
+    if traffic_all is not None:  # (older rounds' files of the same workload are still under profiles/: not this line's concern)
+        stale_counters = None
     path_ms = ktimes["total"]
     step_ms = dt / args.steps * 1e3
     # (rates are per timed step; with overlapping steps a call's own latency - first planning kernel to join - is longer)
