@@ -1072,14 +1072,20 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             const uint32_t g0 = part ? o.a : F.segb[o.run];
             const uint32_t first = part ? o.a * 64u : seg_first(F.segb, o.run);
             const uint32_t cnt = part ? (uint32_t)(std::min<uint64_t>((uint64_t)o.b * 64u, nprot) - first) : seg_count(F.segb, o.run);
-            if (o.kern == K_BWD)
-                hipLaunchKernelGGL(k_bwd, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+            if (o.kern == K_BWD && o.sel) // (checkpoints only: k_fwd_post<true> recomputes the pairs between them)
+                hipLaunchKernelGGL(k_bwd<true>, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+                                   PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + g0, ctx->d_bwd);
+            else if (o.kern == K_BWD)
+                hipLaunchKernelGGL(k_bwd<false>, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
                                    PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + g0, ctx->d_bwd);
             else if (o.kern == K_BWD_PAIR)
                 hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, s,
                                    PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + g0, ctx->d_bwd);
+            else if (o.sel)
+                hipLaunchKernelGGL(k_fwd_post<true>, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+                                   PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
             else
-                hipLaunchKernelGGL(k_fwd_post, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+                hipLaunchKernelGGL(k_fwd_post<false>, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
                                    PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
             break;
         }

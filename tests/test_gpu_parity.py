@@ -860,15 +860,21 @@ def test_hmm_scores_from_the_chain_kernels_or_from_the_finishing_kernel(native, 
             assert_rows_equal(got, want, what="%s, overlapping call %d" % (knobs, rep))
 
 
-@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("fused", ["0", "1", "every pair kept"])
 @pytest.mark.parametrize("vit_mixed", ["0", "1"])
 def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, oracle, monkeypatch, fused, vit_mixed):
     """Chain-bound batches in track mode (round 4): the wave-groups without a long protein run the forward pass BEHIND the
     backward pass and emit posteriors and MAP bytes on the way (k_fwd_post; the reference's lpseq comes from position
     0, plaac.java:3393-3396, so the order is exact); the long wave-groups keep forward array + k_post; the Viterbi kernel
-    takes its list form outside the long wave-groups. Every combination against the oracle: rows, the eight window tracks,
-    Viterbi / MAP bytes, posteriors - with the long wave-groups in the first run only, in several runs, and absent."""
+    takes its list form outside the long wave-groups. The backward pass keeps every eighth pair only (checkpoints) and the
+    forward pass recomputes the seven between two of them with the backward pass's own operations - or keeps them all
+    (PLAAC_TRACK_CKPT=0). Every combination against the oracle: rows, the eight window tracks, Viterbi / MAP bytes,
+    posteriors - with the long wave-groups in the first run only, in several runs, and absent; lengths around the multiples
+    of 8 and 16 (where a checkpoint is the protein's last pair, or the pair behind it does not exist)."""
     from plaac_amd import synth
+    if fused == "every pair kept":  # the fused pass reading a full backward array instead of recomputing between checkpoints
+        fused = "1"
+        monkeypatch.setenv("PLAAC_TRACK_CKPT", "0")
     monkeypatch.setenv("PLAAC_TRACK_FUSED", fused)
     monkeypatch.setenv("PLAAC_TRACK_VIT_MIXED", vit_mixed)
     monkeypatch.setenv("PLAAC_MIXED_MIN_REST", "1")
@@ -876,18 +882,20 @@ def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, orac
     monkeypatch.setenv("PLAAC_LATENCY_MODE", "1")
     P0 = native.make_params()
     rng = np.random.default_rng(8800 + int(fused) * 2 + int(vit_mixed))
-    shapes = (np.concatenate([[9000, 2100, 2048, 1, 0, 16, 17], rng.integers(1, 600, 700)]),
+    shapes = (np.concatenate([[9000, 2100, 2048, 1, 0, 16, 17, 2, 7, 8, 9, 15, 23, 24, 25, 31, 32, 33, 40, 41], rng.integers(1, 600, 700)]),
               np.concatenate([rng.integers(2048, 2600, 200), rng.integers(1, 300, 300)]),  # long wave-groups in more than one run
               rng.integers(1, 400, 500))                                                    # none
     for lens in shapes:
         rng.shuffle(lens)
         codes, offs = synth.residues(lens, np.array(P0.fg), np.array(P0.bg), rng, stop_fraction=0.1)
         want, wtr = oracle.score_batch(oracle.build_params(), codes, offs, tracks=True, nthreads=8)
-        with native.Context(P0) as c:
-            trows, tr = c.score(codes, offs, tracks=True)
-        what = "fused %s, k_vit mixed %s, %d proteins" % (fused, vit_mixed, len(lens))
-        assert_rows_equal(trows, want, what)
-        assert_tracks_equal(tr, wtr, codes, offs, what)
+        for runs in ("1", "2"):  # (the knobs are read when a context is created)
+            monkeypatch.setenv("PLAAC_TRACK_SEGMENTS", runs)
+            with native.Context(P0) as c:
+                trows, tr = c.score(codes, offs, tracks=True)
+            what = "fused %s, k_vit mixed %s, %s run(s), %d proteins" % (fused, vit_mixed, runs, len(lens))
+            assert_rows_equal(trows, want, what)
+            assert_tracks_equal(tr, wtr, codes, offs, what)
 
 
 @pytest.mark.parametrize("consec", ["0", "1", "2", "2048"])
