@@ -17,6 +17,7 @@ Inputs are resident in HBM before the timed region. Prints ONE JSON line on rank
 """
 import argparse
 import json
+import re
 import os
 import subprocess
 import sys
@@ -562,6 +563,21 @@ def main():
             pass
     if traffic_all is not None:  # (older rounds' files of the same workload are still under profiles/: not this line's concern)
         stale_counters = None
+    # track mode: tools/pmc.sh serialises the streams, which selects the throughput forms of the chain kernels - the traffic of
+    # the forms the library picks by itself comes from a separate pair of passes (tools/r04_pmc_tracks_default_forms.sh)
+    traffic_default_forms = None
+    if args.tracks and nprot == 1250000 and not args.sweep:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pmc_summary
+            with open(os.path.join(ROOT, "profiles", "r04_pmc_tracks_default_forms.txt")) as fh:
+                txt = fh.read()
+            sha = re.search(r"kernels_source_sha16: (\w+)", txt)
+            tot = re.search(r"all scoring kernels: ([0-9.]+) GB per step", txt)
+            if sha and tot and sha.group(1) == pmc_summary.kernels_sha():
+                traffic_default_forms = int(float(tot.group(1)) * 1e9)
+        except (OSError, ValueError):
+            pass
     path_ms = ktimes["total"]
     step_ms = dt / args.steps * 1e3
     # (rates are per timed step; with overlapping steps a call's own latency - first planning kernel to join - is longer)
@@ -569,6 +585,7 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_all_kernels": traffic_all,
+        "traffic_all_kernels_default_forms": traffic_default_forms,
         "traffic_calibrated": traffic_cal, "traffic_all_kernels_calibrated": traffic_all_cal,
         "fetch_calibration": fetch_cal,
         "algorithmic_bytes": path_bytes, "measured_copy_GBps": copy_gbps,

@@ -17,6 +17,10 @@ for f in glob.glob(root+'/*/*/*_counter_collection.csv'):
         tot[m.group(1)][r['Counter_Name']]+=float(r['Counter_Value'])
 n=4.0  # 1 warm-up + 3 timed steps per pass
 print("# tools/r04_pmc_tracks_default_forms.sh: track mode, 1.25 M sequences, default forms; GB per step = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / steps")
+import os
+sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import pmc_summary
+print("# kernels_source_sha16: %s" % pmc_summary.kernels_sha())
 s=0
 for k,c in sorted(tot.items(), key=lambda kv:-(2*kv[1].get('FETCH_SIZE',0)+kv[1].get('WRITE_SIZE',0))):
     gb=(2*c.get('FETCH_SIZE',0)+c.get('WRITE_SIZE',0))*1024/1e9/n
