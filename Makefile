@@ -39,8 +39,15 @@ asm: $(CSRC)/plaac_kernels.hip $(wildcard $(CSRC)/*.hip.inc)
 	$(HIPCC) $(HIPFLAGS) -Iinclude --cuda-device-only -S -o build/plaac_kernels.s $(CSRC)/plaac_kernels.hip \
 		-Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || true
 
+# the stand-alone measurement probes of tools/ (issue costs, hardware queues, counter calibration, store shapes): build/<name>
+PROBES = $(patsubst tools/%.hip,build/%,$(wildcard tools/*.hip))
+probes: $(PROBES)
+build/%: tools/%.hip
+	mkdir -p build
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+
 clean:
 	rm -f $(LIB) bin/plaac
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle cli asm clean jni jni-skipped
+.PHONY: all oracle cli asm clean jni jni-skipped probes
