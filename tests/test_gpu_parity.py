@@ -861,7 +861,7 @@ def test_hmm_scores_from_the_chain_kernels_or_from_the_finishing_kernel(native, 
 
 
 @pytest.mark.parametrize("fused", ["0", "1", "every pair kept"])
-@pytest.mark.parametrize("vit_mixed", ["0", "1"])
+@pytest.mark.parametrize("vit_mixed", ["0", "1", "throughput-bound"])
 def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, oracle, monkeypatch, fused, vit_mixed):
     """Chain-bound batches in track mode (round 4): the wave-groups without a long protein run the forward pass BEHIND the
     backward pass and emit posteriors and MAP bytes on the way (k_fwd_post; the reference's lpseq comes from position
@@ -875,13 +875,16 @@ def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, orac
     if fused == "every pair kept":  # the fused pass reading a full backward array instead of recomputing between checkpoints
         fused = "1"
         monkeypatch.setenv("PLAAC_TRACK_CKPT", "0")
+    latency = "1"
+    if vit_mixed == "throughput-bound":  # calls not bound by a chain take the same split, with the Viterbi pass in one form
+        vit_mixed, latency = "1", "0"
     monkeypatch.setenv("PLAAC_TRACK_FUSED", fused)
     monkeypatch.setenv("PLAAC_TRACK_VIT_MIXED", vit_mixed)
     monkeypatch.setenv("PLAAC_MIXED_MIN_REST", "1")
     monkeypatch.setenv("PLAAC_SEGMENT_MIN_ROWS", "1")
-    monkeypatch.setenv("PLAAC_LATENCY_MODE", "1")
+    monkeypatch.setenv("PLAAC_LATENCY_MODE", latency)
     P0 = native.make_params()
-    rng = np.random.default_rng(8800 + int(fused) * 2 + int(vit_mixed))
+    rng = np.random.default_rng(8800 + int(fused) * 2 + int(vit_mixed) + 10 * int(latency))
     shapes = (np.concatenate([[9000, 2100, 2048, 1, 0, 16, 17, 2, 7, 8, 9, 15, 23, 24, 25, 31, 32, 33, 40, 41], rng.integers(1, 600, 700)]),
               np.concatenate([rng.integers(2048, 2600, 200), rng.integers(1, 300, 300)]),  # long wave-groups in more than one run
               rng.integers(1, 400, 500))                                                    # none
@@ -893,7 +896,7 @@ def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, orac
             monkeypatch.setenv("PLAAC_TRACK_SEGMENTS", runs)
             with native.Context(P0) as c:
                 trows, tr = c.score(codes, offs, tracks=True)
-            what = "fused %s, k_vit mixed %s, %s run(s), %d proteins" % (fused, vit_mixed, runs, len(lens))
+            what = "fused %s, k_vit mixed %s, latency forms %s, %s run(s), %d proteins" % (fused, vit_mixed, latency, runs, len(lens))
             assert_rows_equal(trows, want, what)
             assert_tracks_equal(tr, wtr, codes, offs, what)
 
