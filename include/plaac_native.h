@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define PLAAC_ABI_VERSION 1
+/* 2 (round 5): plaac_node_batch_last_error; node batches are detached (not dangling) when their node is destroyed first;
+ * plaac_node_batch_upload rejects offsets[0] != 0; wire rows (plaac_wire_row) for the cross-process gather. A binding
+ * compares plaac_abi_version() with the PLAAC_ABI_VERSION it was compiled against before its first call. */
+#define PLAAC_ABI_VERSION 2
 #define PLAAC_NAA 22
 #define PLAAC_LUTLEN 4001
 
@@ -219,8 +222,9 @@ plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]);
 /* ---- all GPUs of one node ---------------------------------------------------------
  * The reference's serial per-protein loop (plaac.java:755, :610) sharded BY SEQUENCE: one plaac_ctx per listed
  * device (a device may be listed more than once: two contexts on one GPU overlap the copies of one batch with the
- * kernels of another), one host thread per context, contiguous record ranges of about equal residue counts, rows
- * written in input order. No data-path collective; the 22 x int64 histogram is summed on the host. Results are
+ * kernels of another), one host thread per context, the records dealt to the contexts by plaac_shard_plan (below:
+ * sorted by length, dealt in turn - equal residue counts and an equal share of the long proteins), rows written in
+ * input order. No data-path collective; the 22 x int64 histogram is summed on the host. Results are
  * identical to a single context's whatever the device list. device_ids == NULL or ndev <= 0: every visible device once.
  * Same calling rules as a ctx: single-caller, no process globals, status codes + plaac_node_last_error. */
 typedef struct plaac_node plaac_node;
@@ -251,7 +255,12 @@ plaac_status plaac_shard_plan(const uint64_t *offsets, uint32_t nprot, uint32_t 
  * device and stays there for the background pass (plaac.java:377-384), the scoring pass (:755) - the reference's two
  * passes over one input - and for parameter sweeps, which the reference runs as one `main` invocation per point
  * (plaac.java:337-353, web/lib/server.rb:152-155: nine uploads of the same proteome). Rows (and tracks) come back in
- * INPUT order. plaac_node_score / plaac_node_histogram are upload + use + free of such a batch. */
+ * INPUT order. plaac_node_score / plaac_node_histogram are upload + use + free of such a batch. offsets[0] must be 0 (rows
+ * and tracks are indexed from the first residue of the batch, as in the single-device entry points).
+ * LIFETIME: a batch belongs to its node. Free every batch before plaac_node_destroy; a batch that is still alive when its
+ * node is destroyed is DETACHED by the node (its device memory is released with the contexts): every later call on it
+ * returns PLAAC_ERR_ARG with the message of plaac_node_batch_last_error, and plaac_node_batch_free of it is still required
+ * (it releases the host side) and safe. */
 typedef struct plaac_node_batch plaac_node_batch;
 plaac_status plaac_node_batch_upload(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
                                      plaac_node_batch **out);
@@ -263,6 +272,8 @@ plaac_status plaac_node_batch_score(plaac_node_batch *b, plaac_row *rows, const 
 plaac_status plaac_node_batch_sweep(plaac_node_batch *b, const plaac_params *points, uint32_t npoints,
                                     plaac_row *const *rows);
 void plaac_node_batch_free(plaac_node_batch *b);
+/* message of the last failing call on the batch's node, or that the node is gone (bindings that keep only the batch handle) */
+const char *plaac_node_batch_last_error(const plaac_node_batch *b);
 /* records / residues of the uploaded batch: the sizes of the row and track arrays the calls above fill */
 uint32_t plaac_node_batch_records(const plaac_node_batch *b);
 uint64_t plaac_node_batch_residues(const plaac_node_batch *b);

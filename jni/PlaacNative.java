@@ -19,6 +19,8 @@ final class PlaacNative {
 
     private PlaacNative() {}
 
+    /** plaac_abi_version() of the loaded library (the shim's JNI_OnLoad has already refused another generation) */
+    static native int abiVersion();
     /** visible gfx950 devices */
     static native int deviceCount();
     /** sizeof(plaac_params): capacity of the params buffers below */
@@ -45,6 +47,7 @@ final class PlaacNative {
     // A direct ByteBuffer holds at most 2^31 - 1 bytes: upload a proteome above 2.1 G residues as several batches.
     /** uploads the batch to the node's devices; returns the plaac_node_batch handle */
     static native long batchUpload(long node, ByteBuffer codes, ByteBuffer offsets, int nprot);
+    /** required for every batch, also one whose node was destroyed first (such a batch is detached: its calls throw) */
     static native void batchFree(long batch);
     static native void batchHistogram(long batch, long[] counts22);
     /** scores with the node's CURRENT parameters (nodeSetParams between calls: the two-pass run on one upload) */

@@ -38,6 +38,13 @@ const char *node_error(jlong h) { return node_of(h) ? plaac_node_last_error(node
 
 extern "C" {
 
+// System.loadLibrary: refuse a libplaac_native.so of another ABI generation before any native is bound
+JNIEXPORT jint JNICALL JNI_OnLoad(JavaVM *, void *) {
+    return plaac_abi_version() == PLAAC_ABI_VERSION ? JNI_VERSION_1_6 : JNI_ERR;
+}
+
+JNIEXPORT jint JNICALL Java_PlaacNative_abiVersion(JNIEnv *, jclass) { return plaac_abi_version(); }
+
 JNIEXPORT jint JNICALL Java_PlaacNative_deviceCount(JNIEnv *, jclass) { return plaac_device_count(); }
 
 JNIEXPORT jint JNICALL Java_PlaacNative_paramsBytes(JNIEnv *, jclass) { return (jint)plaac_sizeof_params(); }
@@ -136,12 +143,11 @@ JNIEXPORT void JNICALL Java_PlaacNative_score(JNIEnv *env, jclass, jlong node, j
         raise(env, node_error(node));
 }
 
-// ---- resident batches (plaac_node_batch_*). A batch handle does not know its node's error text once it is gone, so the
-// natives below take their message from plaac_node_last_error of the node the batch was uploaded to, which the shim keeps
-// beside the handle: the Java side passes the batch handle only, the C side looks the node up in the batch.
+// ---- resident batches (plaac_node_batch_*). The Java side passes the batch handle only; error text comes from
+// plaac_node_batch_last_error, which also answers for a batch whose node was destroyed first (the library detaches such a
+// batch: its calls fail with a message, batchFree stays safe - no raw node pointer is kept here).
 struct BatchRef {
     plaac_node_batch *b;
-    plaac_node *node;
 };
 static BatchRef *ref_of(jlong h) { return reinterpret_cast<BatchRef *>(static_cast<intptr_t>(h)); }
 
@@ -164,7 +170,7 @@ JNIEXPORT jlong JNICALL Java_PlaacNative_batchUpload(JNIEnv *env, jclass, jlong 
         raise(env, node_error(node));
         return 0;
     }
-    BatchRef *r = new (std::nothrow) BatchRef{b, node_of(node)};
+    BatchRef *r = new (std::nothrow) BatchRef{b};
     if (!r) {
         plaac_node_batch_free(b);
         raise(env, "out of host memory");
@@ -185,7 +191,7 @@ JNIEXPORT void JNICALL Java_PlaacNative_batchHistogram(JNIEnv *env, jclass, jlon
     if (!r) return raise(env, "null batch handle");
     if (!counts22 || env->GetArrayLength(counts22) != PLAAC_NAA) return raise(env, "batchHistogram: a long[22] is required");
     int64_t counts[PLAAC_NAA];
-    if (plaac_node_batch_histogram(r->b, counts) != PLAAC_OK) return raise(env, plaac_node_last_error(r->node));
+    if (plaac_node_batch_histogram(r->b, counts) != PLAAC_OK) return raise(env, plaac_node_batch_last_error(r->b));
     jlong out[PLAAC_NAA];
     for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (jlong)counts[i];
     env->SetLongArrayRegion(counts22, 0, PLAAC_NAA, out);
@@ -209,7 +215,7 @@ JNIEXPORT void JNICALL Java_PlaacNative_batchScore(JNIEnv *env, jclass, jlong ba
                          (double *)a[6],  (double *)a[7],  (double *)a[8], (double *)a[9], (double *)a[10], (double *)a[11]};
         tp = &t;
     }
-    if (plaac_node_batch_score(r->b, rows, tp) != PLAAC_OK) raise(env, plaac_node_last_error(r->node));
+    if (plaac_node_batch_score(r->b, rows, tp) != PLAAC_OK) raise(env, plaac_node_batch_last_error(r->b));
 }
 
 JNIEXPORT void JNICALL Java_PlaacNative_batchSweep(JNIEnv *env, jclass, jlong batch, jobject params, jint npoints,
@@ -226,7 +232,7 @@ JNIEXPORT void JNICALL Java_PlaacNative_batchSweep(JNIEnv *env, jclass, jlong ba
         rows[i] = (plaac_row *)direct(env, env->GetObjectArrayElement(rowsOut, i), (uint64_t)nprot * sizeof(plaac_row), "rowsOut[i]");
         if (!rows[i]) return;
     }
-    if (plaac_node_batch_sweep(r->b, P, (uint32_t)npoints, rows) != PLAAC_OK) raise(env, plaac_node_last_error(r->node));
+    if (plaac_node_batch_sweep(r->b, P, (uint32_t)npoints, rows) != PLAAC_OK) raise(env, plaac_node_batch_last_error(r->b));
 }
 
 JNIEXPORT void JNICALL Java_PlaacNative_nodeSetOverlap(JNIEnv *env, jclass, jlong node, jboolean on) {

@@ -15,6 +15,8 @@
 #include <cstdint>
 #include <cstring>
 #include <exception>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -22,10 +24,16 @@
 
 #include "plaac_native.h"
 
+struct plaac_node_batch;
 struct plaac_node {
     std::vector<plaac_ctx *> ctx;
     std::vector<int> device;
     std::string err;
+    // the resident batches that are still alive: plaac_node_destroy releases their device memory and detaches them, so a
+    // batch freed AFTER its node (Python's NodeBatch.__del__ behind Node.close(), JNI batchFree behind nodeDestroy) is no
+    // use-after-free of the contexts
+    std::mutex live_mu;
+    std::vector<plaac_node_batch *> live;
 };
 
 // a batch whose shards are resident on the devices of a node
@@ -40,6 +48,7 @@ struct plaac_node_batch {
         std::vector<uint64_t> offs;     // ... and in the shard's own (starting at 0)
     };
     std::vector<Part> part;
+    bool identity = false; // one shard holding every record in input order: the caller's arrays are passed straight through
 };
 
 namespace {
@@ -153,8 +162,15 @@ plaac_status plaac_node_create(const plaac_params *params, const int *device_ids
     return PLAAC_OK;
 }
 
+static void release_parts(plaac_node_batch *nb);
+
 void plaac_node_destroy(plaac_node *node) {
     if (!node) return;
+    {
+        std::lock_guard<std::mutex> lock(node->live_mu);
+        for (plaac_node_batch *nb : node->live) release_parts(nb); // (the shells stay valid until plaac_node_batch_free)
+        node->live.clear();
+    }
     for (plaac_ctx *c : node->ctx)
         if (c) plaac_ctx_destroy(c);
     delete node;
@@ -245,6 +261,8 @@ plaac_status plaac_node_batch_upload(plaac_node *node, const uint8_t *codes, con
                                      plaac_node_batch **out) {
     if (!node || !out || (nprot && !offsets)) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_batch_upload: null argument");
     *out = nullptr;
+    // (as the single-device entry points: rows and tracks are indexed from the first residue of the batch)
+    if (nprot && offsets[0] != 0) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_batch_upload: offsets[0] must be 0");
     if (nprot && offsets[nprot] && !codes) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_batch_upload: null codes");
     const size_t parts = node->ctx.size();
     plaac_node_batch *nb = nullptr;
@@ -255,8 +273,9 @@ plaac_status plaac_node_batch_upload(plaac_node *node, const uint8_t *codes, con
         nb = new plaac_node_batch();
         nb->node = node;
         nb->nprot = nprot;
-        nb->total = nprot ? offsets[nprot] - offsets[0] : 0;
+        nb->total = nprot ? offsets[nprot] : 0;
         nb->part.resize(parts);
+        nb->identity = parts == 1;
         index.resize(nprot);
         start.resize(parts + 1);
         st.assign(parts, PLAAC_OK);
@@ -284,6 +303,10 @@ plaac_status plaac_node_batch_upload(plaac_node *node, const uint8_t *codes, con
         }
         P.src_off[n] = 0;
         if (n == 0) return;
+        if (nb->identity) { // one device: the shard IS the batch, no host copy of it
+            st[k] = plaac_batch_upload(node->ctx[k], codes, offsets, n, &P.b);
+            return;
+        }
         // the shard's records as one contiguous batch (runs of neighbouring records are copied in one piece)
         std::vector<uint8_t> shard((size_t)P.offs[n]);
         for (uint32_t i = 0; i < n;) {
@@ -299,17 +322,41 @@ plaac_status plaac_node_batch_upload(plaac_node *node, const uint8_t *codes, con
         plaac_node_batch_free(nb);
         return bad;
     }
+    try {
+        std::lock_guard<std::mutex> lock(node->live_mu);
+        node->live.push_back(nb);
+    } catch (...) {
+        plaac_node_batch_free(nb);
+        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+    }
     *out = nb;
     return PLAAC_OK;
+}
+
+const char *plaac_node_batch_last_error(const plaac_node_batch *nb) {
+    if (!nb) return "null batch handle";
+    return nb->node ? nb->node->err.c_str() : "the batch's node has been destroyed (the batch is detached: free it)";
 }
 
 uint32_t plaac_node_batch_records(const plaac_node_batch *nb) { return nb ? nb->nprot : 0u; }
 uint64_t plaac_node_batch_residues(const plaac_node_batch *nb) { return nb ? nb->total : 0ull; }
 
+// the device side of a batch (its contexts must still exist)
+static void release_parts(plaac_node_batch *nb) {
+    for (auto &P : nb->part) {
+        if (P.b) plaac_batch_free(P.b);
+        P.b = nullptr;
+    }
+    nb->node = nullptr;
+}
+
 void plaac_node_batch_free(plaac_node_batch *nb) {
     if (!nb) return;
-    for (auto &P : nb->part)
-        if (P.b) plaac_batch_free(P.b);
+    if (plaac_node *node = nb->node) { // (null: the node went first and has released the device side already)
+        std::lock_guard<std::mutex> lock(node->live_mu);
+        node->live.erase(std::remove(node->live.begin(), node->live.end(), nb), node->live.end());
+        release_parts(nb);
+    }
     delete nb;
 }
 
@@ -358,18 +405,23 @@ static plaac_status node_batch_run(plaac_node_batch *nb, const plaac_params *poi
         const plaac_node_batch::Part &P = nb->part[k];
         const size_t n = P.idx.size();
         if (!P.b || n == 0) return;
-        std::vector<plaac_row> tmp(n * nout);
+        if (nb->identity) { // one device, records in input order: straight into the caller's arrays, no second copy
+            st[k] = npoints ? plaac_batch_sweep(P.b, points, npoints, rows) : plaac_batch_score(P.b, rows[0], tracks);
+            return;
+        }
+        // (uninitialised: every row is written by the device copy; a 9-point sweep over a 1.25 M-record shard is 1.8 GB)
+        std::unique_ptr<plaac_row[]> tmp(new plaac_row[n * nout]);
         std::vector<plaac_row *> tp(nout);
-        for (uint32_t i = 0; i < nout; ++i) tp[i] = tmp.data() + (size_t)i * n;
-        std::vector<uint8_t> t8;
-        std::vector<double> t64;
+        for (uint32_t i = 0; i < nout; ++i) tp[i] = tmp.get() + (size_t)i * n;
+        std::unique_ptr<uint8_t[]> t8;
+        std::unique_ptr<double[]> t64;
         plaac_tracks tt{};
         const uint64_t total = P.offs[n];
         if (tracks) { // the shard's tracks in its own residue numbering, scattered record by record afterwards
-            t8.resize(2 * (size_t)total + 2);
-            t64.resize(10 * (size_t)total + 10);
-            double *b = t64.data();
-            tt = plaac_tracks{t8.data(), t8.data() + total, b,           b + total,     b + 2 * total, b + 3 * total,
+            t8.reset(new uint8_t[2 * (size_t)total + 2]);
+            t64.reset(new double[10 * (size_t)total + 10]);
+            double *b = t64.get();
+            tt = plaac_tracks{t8.get(), t8.get() + total, b,           b + total,     b + 2 * total, b + 3 * total,
                               b + 4 * total, b + 5 * total, b + 6 * total, b + 7 * total, b + 8 * total, b + 9 * total};
         }
         st[k] = npoints ? plaac_batch_sweep(P.b, points, npoints, tp.data()) : plaac_batch_score(P.b, tp[0], tracks ? &tt : nullptr);

@@ -6,6 +6,7 @@ CPU fallback; if the shared library is missing or no gfx950 device is usable the
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -15,7 +16,7 @@ LIB_PATH = os.environ.get("PLAAC_NATIVE_LIB") or os.path.join(_HERE, "libplaac_n
 
 NAA = 22
 LUTLEN = 4001
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 PLAAC_OK, PLAAC_ERR_ARG, PLAAC_ERR_DEVICE, PLAAC_ERR_NOMEM, PLAAC_ERR_IO = range(5)
 
@@ -75,7 +76,7 @@ EXPORTS = (
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
-    "plaac_node_batch_residues", "plaac_score_begin", "plaac_score_end", "plaac_debug_schedule",
+    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_score_begin", "plaac_score_end", "plaac_debug_schedule",
 )
 
 _lib = None
@@ -159,6 +160,8 @@ def load():
     L.plaac_node_batch_records.restype = C.c_uint32
     L.plaac_node_batch_residues.argtypes = [C.c_void_p]
     L.plaac_node_batch_residues.restype = C.c_uint64
+    L.plaac_node_batch_last_error.argtypes = [C.c_void_p]
+    L.plaac_node_batch_last_error.restype = C.c_char_p
     L.plaac_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.plaac_batch_histogram.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_batch_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -390,6 +393,12 @@ class Node:
         return int(self._L.plaac_node_size(self._h))
 
     def close(self):
+        # a batch belongs to its node: close the ones still alive first (the library would only detach them)
+        for ref in getattr(self, "_batches", []):
+            b = ref()
+            if b is not None:
+                b.close()
+        self._batches = []
         if self._h:
             self._L.plaac_node_destroy(self._h)
             self._h = C.c_void_p()
@@ -434,7 +443,11 @@ class Node:
 
     def upload(self, codes, offsets):
         """plaac_node_batch_upload: the batch cut with plaac_shard_plan, every shard resident on its device"""
-        return NodeBatch(self, codes, offsets)
+        b = NodeBatch(self, codes, offsets)
+        if not hasattr(self, "_batches"):
+            self._batches = []
+        self._batches = [r for r in self._batches if r() is not None] + [weakref.ref(b)]
+        return b
 
 
 class NodeBatch:
@@ -443,6 +456,7 @@ class NodeBatch:
 
     def __init__(self, node, codes, offsets):
         self.node = node
+        self._L = node._L
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.nprot = len(offsets) - 1
@@ -451,9 +465,14 @@ class NodeBatch:
         node._check(node._L.plaac_node_batch_upload(node._h, codes.ctypes.data, offsets.ctypes.data, self.nprot,
                                                     C.byref(self._h)))
 
+    def _check(self, st):
+        if st != PLAAC_OK:
+            msg = self._L.plaac_node_batch_last_error(self._h)
+            raise PlaacError(st, msg.decode() if msg else "?")
+
     def histogram(self):
         counts = np.zeros(NAA, dtype=np.int64)
-        self.node._check(self.node._L.plaac_node_batch_histogram(self._h, counts.ctypes.data))
+        self._check(self._L.plaac_node_batch_histogram(self._h, counts.ctypes.data))
         return counts
 
     def score(self, tracks=False):
@@ -463,7 +482,7 @@ class NodeBatch:
             tr = alloc_tracks(self.total)
             T = Tracks(**{k: tr[k].ctypes.data for k in TRACK_U8 + TRACK_F64})
             tptr = C.addressof(T)
-        self.node._check(self.node._L.plaac_node_batch_score(self._h, rows.ctypes.data, tptr))
+        self._check(self._L.plaac_node_batch_score(self._h, rows.ctypes.data, tptr))
         return (rows, tr) if tracks else rows
 
     def sweep(self, param_sets):
@@ -471,12 +490,12 @@ class NodeBatch:
         pts = (Params * len(param_sets))(*param_sets)
         rows = [np.zeros(self.nprot, dtype=ROW_DTYPE) for _ in param_sets]
         ptrs = (C.c_void_p * len(rows))(*[r.ctypes.data for r in rows])
-        self.node._check(self.node._L.plaac_node_batch_sweep(self._h, C.addressof(pts), len(param_sets), C.addressof(ptrs)))
+        self._check(self._L.plaac_node_batch_sweep(self._h, C.addressof(pts), len(param_sets), C.addressof(ptrs)))
         return rows
 
     def close(self):
-        if self._h:
-            self.node._L.plaac_node_batch_free(self._h)
+        if getattr(self, "_h", None):
+            self._L.plaac_node_batch_free(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -505,8 +524,11 @@ class SchedQuery(C.Structure):
 
 def debug_schedule(q):
     """plaac_debug_schedule: the schedule of a described scoring call as text (host only; no device needed)"""
-    buf = C.create_string_buffer(1 << 18)
-    n = load().plaac_debug_schedule(C.addressof(q), buf, len(buf))
+    for cap in (1 << 18, 1 << 25):  # (a sweep of thousands of points prints thousands of launches)
+        buf = C.create_string_buffer(cap)
+        n = load().plaac_debug_schedule(C.addressof(q), buf, len(buf))
+        if n >= 0:
+            break
     if n < 0:
         raise PlaacError(PLAAC_ERR_ARG, "plaac_debug_schedule rejected the query")
     return buf.value.decode()

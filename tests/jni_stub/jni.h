@@ -32,4 +32,8 @@ struct JNIEnv_ {
     jobject GetObjectArrayElement(jobjectArray a, jsize index);
 };
 typedef JNIEnv_ JNIEnv;
+struct JavaVM_;
+typedef JavaVM_ JavaVM;
+#define JNI_VERSION_1_6 0x00010006
+#define JNI_ERR (-1)
 #endif

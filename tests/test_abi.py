@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(native):
 
 def test_struct_layouts(native):
     L = native.load()
-    assert L.plaac_abi_version() == 1
+    assert L.plaac_abi_version() == 2
     assert L.plaac_sizeof_row() == 160 == native.ROW_DTYPE.itemsize
     assert L.plaac_sizeof_params() == C.sizeof(native.Params)
 

@@ -159,3 +159,45 @@ def test_bench_two_ranks_strong_scaling_line(tmp_path):
     assert line["cpu_baseline"]["gpu_rows_match_oracle"] is True
     assert line["cpu_baseline"]["checked_table"].startswith("gathered rows of all ranks")
     assert line["weak"]["scaling"] == "weak" and line["weak"]["value"] > 0
+
+
+def test_node_batch_outlives_its_node_safely_and_offsets_must_start_at_zero(native, oracle):
+    """(i) a resident batch freed AFTER its node used to dereference destroyed contexts; the node now detaches
+    the batches that are still alive (calls on them fail with a message, the free stays safe). (ii) plaac_node_batch_upload
+    accepted offsets[0] != 0 and then scattered tracks past the caller's arrays; it is rejected like in the single-device
+    entry points. (iii) a node of ONE context passes the caller's arrays straight through: same rows and tracks."""
+    import ctypes as C
+    from plaac_amd import synth
+    codes, offs = synth.make_batch(2, nprot=400, seed=12, stop_fraction=0.1)
+    L = native.load()
+    node = native.Node(devices=[0, 0])
+    nb = node.upload(codes, offs)
+    rows = nb.score()
+    want, wtr = oracle.score_batch(oracle.build_params(), codes, offs, tracks=True, nthreads=4)
+    assert rows.tobytes() == want.tobytes()
+    h = C.c_void_p(nb._h.value)  # keep the raw handle: close the node underneath it, as JNI nodeDestroy + batchFree would
+    nb._h = C.c_void_p()
+    L.plaac_node_destroy(node._h)
+    node._h = C.c_void_p()
+    out = np.zeros(len(offs) - 1, dtype=native.ROW_DTYPE)
+    assert L.plaac_node_batch_score(h, out.ctypes.data, None) == native.PLAAC_ERR_ARG
+    assert b"destroyed" in L.plaac_node_batch_last_error(h)
+    L.plaac_node_batch_free(h)  # must neither crash nor touch the contexts
+    # Python's own order: Node.close() closes its batches first
+    node = native.Node(devices=[0])
+    nb = node.upload(codes, offs)
+    node.close()
+    assert not nb._h
+    with native.Node(devices=[0]) as one:
+        shifted = offs + np.uint64(5)
+        with pytest.raises(native.PlaacError):
+            one.upload(np.concatenate([np.zeros(5, np.uint8), codes]), shifted)
+        with one.upload(codes, offs) as b1:  # identity plan: straight into the caller's arrays
+            r1, t1 = b1.score(tracks=True)
+        assert r1.tobytes() == want.tobytes()
+        for k in ("vit", "map", "fi", "papax2"):
+            a, b = t1[k], wtr[k]
+            keep = ~np.isnan(b) if b.dtype.kind == "f" else np.ones(len(b), bool)
+            last = (offs[1:][np.diff(offs) > 0] - 1).astype(np.int64)
+            keep[last[codes[last] == 21]] = False  # (a trimmed stop has no track values)
+            assert np.array_equal(a[keep], b[keep]), k

@@ -1106,3 +1106,27 @@ def test_overlapping_calls_of_every_kind_in_any_order(native, oracle):
         assert_rows_equal(rws.cpu().numpy().view(native.ROW_DTYPE).reshape(-1), want, what)
         if trk is not None:
             assert_tracks_equal({k: v.cpu().numpy() for k, v in trk.items()}, wtr, c, o, what)
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_sweep_group_of_more_than_256_core_lengths(native, oracle, monkeypatch, mode):
+    """ADVICE r04: the first member of a launch used to travel as a byte (Op::m0), so core lengths 256.. of one alpha were
+    never written and the caller got uninitialised rows with PLAAC_OK. 300 core lengths of one alpha + 3 of another, in the
+    throughput-bound (core list) and the chain-bound schedule; every point against its own oracle run."""
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_LATENCY_MODE", mode)
+    P = native.make_params()
+    codes, offs = synth.make_batch(2, nprot=150, seed=9, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+    extra = native.pack(["QNQNQNQNQNYYGGSSQQNN" * k for k in (2, 9, 17)] + ["A", ""])
+    codes = np.concatenate([codes, extra[0]])
+    offs = np.concatenate([offs, offs[-1] + extra[1][1:]]).astype(np.uint64)
+    cls = list(range(5, 305))
+    points = [(1.0, c) for c in cls] + [(0.5, c) for c in (30, 60, 90)]
+    with native.Context(P) as c:
+        with c.upload(codes, offs) as batch:
+            bg = batch.histogram().astype(np.float64)
+            got = batch.sweep([native.make_params(alpha=a, corelength=cl, bgcounts=bg) for a, cl in points])
+    assert len(got) == len(points)
+    for (a, cl), rows in zip(points, got):
+        want = oracle.score_batch(oracle.build_params(alpha=a, corelength=cl, bgcounts=bg), codes, offs, nthreads=8)
+        assert_rows_equal(rows, want, "alpha=%s c=%d mode=%s" % (a, cl, mode))

@@ -61,6 +61,8 @@ def parse(text):
             forms = {k: int(v) for k, v in (x.split("=") for x in t[1:])}
         elif t[0] == "ALIAS":
             alias[int(t[1])] = int(t[2])
+        elif t[0] == "X":
+            raise AssertionError("schedule dump reports: " + line)  # an access list overflowed: the hazard check would be unsound
         elif t[0] in "RW":
             k, i = t[2].split(".")
             ops.append((t[0], int(t[1]), (int(k), int(i))))
@@ -254,3 +256,37 @@ def test_the_model_sees_a_missing_wait(native):
     # the head of call k+2 no longer waits for the window kernels of call k, which read the plan it overwrites
     e = errors_without(lambda o: o[0] == "W" and o[2][0] == EK["TAIL"])
     assert any("call 2" in x and ("ORDER" in x or "PACKED" in x or "GROW" in x) for x in e), e[:3]
+
+
+def _field(line, name):
+    return int(next(x for x in line.split() if x.startswith(name + "=")).split("=")[1])
+
+
+@pytest.mark.parametrize("members", [(300,), (1, 700), (257, 3, 4096 - 260)])
+def test_every_member_of_a_large_sweep_group_is_served_exactly_once(native, members):
+    """ADVICE r04: Op::m0 was a byte, so members >= 256 of a sweep group were never written (and members 0.. were
+    rewritten). Every per-core-length kernel must cover first..first+members-1 of its group exactly once, for groups of
+    more than 256 core lengths and point numbers up to the JNI limit of 4096 (Access.q = point * 16 + part)."""
+    q = query(native, *SHAPES["cfg3"], points=members, kb_base=tuple([-1] * len(members)))
+    forms, alias, ops = parse(native.debug_schedule(q))
+    for g, m in enumerate(members):
+        for kern, first in (("k_vit", 0), ("k_win", 0), ("k_core_list", 0), ("k_replicate", 1)):
+            seen = []
+            for o in ops:
+                if o[0] == "L" and o[2] == kern and _field(o[4], "group") == g:
+                    if kern == "k_core_list" and not forms["use_core_list"]:
+                        continue
+                    m0, nc = _field(o[4], "m0"), _field(o[4], "nc")
+                    seen += list(range(m0, m0 + nc))
+            if kern == "k_core_list" and not seen:
+                continue
+            runs = max(1, forms["runs"]) if kern in ("k_vit", "k_win") else 1
+            want = sorted(list(range(first, m)) * (len(seen) // max(1, m - first)))
+            assert m - first == 0 or (sorted(seen) == want and len(seen) % (m - first) == 0), (kern, g, sorted(set(range(first, m)) - set(seen))[:5])
+    # the row parts a launch writes carry the point number: no wrap at point 4096
+    top = max(q_ for o in ops if o[0] == "L" for (_, b, q_) in o[3] if BUF[b].startswith("ROW_"))
+    assert top // 16 == sum(members) - 1
+    if sum(members) <= 400:  # (the happens-before model is quadratic in the accesses to a buffer)
+        m = Model()
+        m.run(0, forms, alias, ops, "large sweep")
+        assert not m.errors, "\n".join(m.errors[:12])
