@@ -7,11 +7,23 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-f
 CSRC      = plaac_amd/csrc
 LIB       = plaac_amd/libplaac_native.so
 
+# make DIAG=1: the same library with the result-breaking ablation switches compiled in (PLAAC_DEBUG_SKIP / _SKIP_FROM: named
+# kernels are not launched, rows stale; PLAAC_VIT_STOP; PLAAC_DEBUG_COUNTER) as plaac_amd/libplaac_native_diag.so, which
+# tools/r04_ablate*.sh load through PLAAC_NATIVE_LIB. The release library does not read them.
+DIAGLIB   = plaac_amd/libplaac_native_diag.so
+ifeq ($(DIAG),1)
+all: $(DIAGLIB)
+endif
+
 all: $(LIB) oracle $(if $(wildcard $(CSRC)/plaac_cli.cpp),cli) $(if $(JNI_H),jni)
 
 LIBSRC    = $(CSRC)/plaac_kernels.hip $(CSRC)/plaac_host.cpp $(CSRC)/plaac_node.cpp $(wildcard $(CSRC)/plaac_io.cpp)
 $(LIB): $(LIBSRC) $(wildcard $(CSRC)/*.hip.inc) $(wildcard include/*.h)
 	$(HIPCC) $(HIPFLAGS) -Iinclude -shared -o $@ $(LIBSRC) -Wl,-rpath,/opt/rocm/lib
+
+$(DIAGLIB): $(LIBSRC) $(wildcard $(CSRC)/*.hip.inc) $(wildcard include/*.h)
+	$(HIPCC) $(HIPFLAGS) -DPLAAC_DIAG=1 -Iinclude -shared -o $@ $(LIBSRC) -Wl,-rpath,/opt/rocm/lib
+diag: $(DIAGLIB)
 
 cli: bin/plaac
 bin/plaac: $(CSRC)/plaac_cli.cpp $(LIB)
@@ -47,7 +59,7 @@ build/%: tools/%.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
 
 clean:
-	rm -f $(LIB) bin/plaac
+	rm -f $(LIB) $(DIAGLIB) bin/plaac
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle cli asm clean jni jni-skipped probes
+.PHONY: all oracle cli asm clean jni jni-skipped probes diag

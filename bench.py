@@ -2,7 +2,10 @@
 """bench.py — PLAAC scoring hot path on MI355X: residues/s with roofline, CPU baseline and end-to-end leg.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--nprot P] [--weak] [--tracks] [--sweep]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or plainly `python bench.py --gpus N`: the parent then
+    starts the N rank processes itself, as fresh children, before it has touched torch or HIP, relays their output and
+    exits with the worst child status.
 
 Workload (BASELINE.json configs[3], the one `metric` is quoted on): UniRef50-shaped synthetic proteome,
 10 M sequences (~2.9 G residues), default parameters. It fits one GPU, so N = 1 scores ALL of it. At N > 1 the SAME
@@ -10,7 +13,8 @@ Workload (BASELINE.json configs[3], the one `metric` is quoted on): UniRef50-sha
 plaac_amd.dist.shard_plan (equal residue counts; 1.25 M sequences per GPU at N = 8 = BASELINE's "sharded 8 x MI355X"):
 strong scaling, and the same line carries a `weak` object (every rank scores the whole proteome; `--weak` makes that the
 headline instead). The 160-byte summary rows are gathered to rank 0 over RCCL and put back into input order there
-(the only exchange of the path, inside the timed region).
+(the only exchange of the path, inside the timed region) as 136-byte wire rows in blocks of their exact sizes
+(include/plaac_native.h: rank 0 rebuilds the other 24 bytes from its own offsets and the core length).
 A step = one pass of the whole hot path (plan + pack + recurrence kernels + window-track kernel [+ row
 gather]) over the resident proteome (reference loop replaced: cli/src/plaac.java:755-948).
 Inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0.
@@ -150,6 +154,45 @@ def check_slices(nfull):
     return out
 
 
+DIAGNOSTIC_ENV = ("PLAAC_DEBUG_SKIP", "PLAAC_DEBUG_SKIP_FROM", "PLAAC_DEBUG_COUNTER", "PLAAC_VIT_STOP")
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* set), from a parent that has imported neither torch nor anything that touches HIP.
+    Rank 0 prints the JSON line on the stdout it inherits. Returns the worst child status; when a rank fails the others
+    are given a moment and then stopped by their exact PIDs (a rank waiting in a collective for a dead peer never ends)."""
+    import signal
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+        sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    worst, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            rc = p.poll()
+            if rc is not None and rc != 0 and failed_at is None:
+                failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 20:
+            for p in procs:
+                if p.poll() is None:
+                    p.send_signal(signal.SIGTERM)
+            failed_at = time.monotonic() + 1e9  # (once)
+        time.sleep(0.2)
+    for p in procs:
+        rc = p.returncode
+        worst = max(worst, rc if rc > 0 else (128 - rc if rc < 0 else 0))
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +232,17 @@ def main():
                     "sample (counter passes: their launches would be averaged into the per-launch means)")
     ap.add_argument("--calibrate", action="store_true", help="after the timed region run the histogram kernel once "
                     "(it reads exactly R bytes): calibration of FETCH_SIZE for tools/pmc.sh")
+    ap.add_argument("--allow-diagnostics", action="store_true", help="run although PLAAC_DEBUG_* / PLAAC_VIT_STOP are set (only a "
+                    "DIAG build of the library reads them, and its rows are wrong by design: tools/r04_ablate*.sh)")
+    ap.add_argument("--no-tracks-leg", action="store_true", help="N = 1 default line: skip the `tracks` object (the 1.25 M-sequence "
+                    "share scored in per-residue track mode - the HBM-bound regime of the path - in the same run)")
     args = ap.parse_args()
+    set_diag = [k for k in DIAGNOSTIC_ENV if os.environ.get(k)]
+    if set_diag and not args.allow_diagnostics:
+        raise SystemExit("bench.py: %s set in the environment - result-breaking diagnostics; unset them or pass "
+                         "--allow-diagnostics (the line then says so)" % ", ".join(set_diag))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # (before torch / HIP are touched in this process)
     # Sweeps run nine chains (three per alpha group) beside the window kernels: with the HIP runtime's default of four
     # hardware queues per priority class they share queues; INTEGRATION.md recommends twelve for sweep-heavy hosts (the
     # library then gives every group streams of its own). Must be set before the runtime initialises; the host's choice.
@@ -235,19 +288,21 @@ def main():
 
     class Work:
         """one resident batch of this rank"""
-        def __init__(self, codes, offsets, plans, nmax):
+        def __init__(self, codes, offsets, plans, nmax, sizes=None):
             self.codes, self.offsets = codes, offsets
             self.nprot, self.total = offsets.numel() - 1, int(offsets[-1].item())
             self.plans = plans  # strong scaling, rank 0: the input indices of every rank's rows (else None)
-            self.nmax = nmax    # rows per gathered block (dist.gather wants equal blocks)
+            self.nmax = nmax    # rows of the largest shard (row buffers; equal blocks for dist.gather in weak mode)
+            self.sizes = sizes  # strong scaling: records of every rank's shard (exact block sizes of the wire-row gather)
 
     if strong:
         all_plans = pdist.shard_plan_torch(offsets_full, world)  # the C partitioner (plaac_shard_plan), every rank the same
         mine = all_plans[rank]
         c_s, o_s = pdist.extract_shard_torch(codes_full, offsets_full, mine)
         plans = all_plans if rank == 0 else None
+        sizes = [int(p_.numel()) for p_ in all_plans]
         del all_plans
-        main_work = Work(c_s, o_s, plans, (nfull + world - 1) // world)
+        main_work = Work(c_s, o_s, plans, max(sizes), sizes)
         del mine
     else:
         main_work = Work(codes_full, offsets_full, None, nfull)
@@ -282,8 +337,12 @@ def main():
                         for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)]
     npoints = len(sweep_params) if sweep_params else 1
 
-    def run_region(W, nsteps, nwarm, with_tracks):
-        """nwarm untimed + nsteps timed steps over W -> (seconds [max over ranks], buffers)"""
+    sweep_points = [(a, c) for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)]
+
+    def run_region(W, nsteps, nwarm, with_tracks, verify=False):
+        """nwarm untimed + nsteps timed steps over W -> (seconds [max over ranks], buffers). verify: after the clock has
+        stopped every output buffer is filled with 0xFF and ONE more (untimed) step runs - the buffers the caller then
+        checks against the oracle are that step's, so a step that skipped work cannot hide behind an earlier one's rows."""
         nslots = max(nctx, 2 if world > 1 else 1)
         rows_pp = [torch.zeros(W.nmax * RB, dtype=torch.uint8, device=dev) for _ in range(nslots)]
         d_tracks = trk = None
@@ -291,11 +350,20 @@ def main():
             trk = {k: torch.zeros(W.total, dtype=torch.uint8, device=dev) for k in native.TRACK_U8}
             trk.update({k: torch.zeros(W.total, dtype=torch.float64, device=dev) for k in native.TRACK_F64})
             d_tracks = {k: v.data_ptr() for k, v in trk.items()}
-        gather_list = final = None
+        # exchange (ii), strong scaling: 136-byte wire rows in blocks of their exact sizes, rank 0 rebuilds the rows from its
+        # own offsets and puts them in input order; weak scaling (every rank its own proteome, whose offsets rank 0 does not
+        # have): 160-byte rows in equal blocks
+        wire_mode = world > 1 and W.sizes is not None
+        gather_list = final = got = lens_of = None
         if world > 1 and rank == 0:
-            gather_list = [torch.empty(W.nmax * RB, dtype=torch.uint8, device=dev) for _ in range(world)]
-            if W.plans is not None:
-                final = torch.zeros(nfull, RB, dtype=torch.uint8, device=dev)
+            if wire_mode:
+                got = [None] + [torch.empty(W.sizes[r] * pdist.WIRE_ROW_BYTES, dtype=torch.uint8, device=dev) for r in range(1, world)]
+                lens_full = offsets_full[1:] - offsets_full[:-1]
+                lens_of = [lens_full[W.plans[r]] for r in range(world)]
+                final = [torch.zeros(nfull, RB, dtype=torch.uint8, device=dev) for _ in range(npoints)]
+            else:
+                gather_list = [torch.empty(W.nmax * RB, dtype=torch.uint8, device=dev) for _ in range(world)]
+        lens_local = (W.offsets[1:] - W.offsets[:-1]) if wire_mode else None
         sweep_rows = [torch.zeros(W.nmax * RB, dtype=torch.uint8, device=dev) for _ in range(npoints)] if sweep_params else None
         scored = [torch.cuda.Event() for _ in range(nslots)]
         gathered = [torch.cuda.Event() for _ in range(nslots)]
@@ -304,12 +372,23 @@ def main():
         gather_t = [] if world > 1 else None
         step_no = [0]
 
-        def gather(buf):
-            """exchange (ii): rows of every rank -> rank 0 (RCCL over xGMI), input order restored there"""
-            dist.gather(buf, gather_list, dst=0)
-            if final is not None:
-                for r in range(world):
-                    final[W.plans[r]] = gather_list[r].view(-1, RB)[:W.plans[r].numel()]
+        def gather(buf, point=0, corelength=60):
+            """exchange (ii): rows of every rank -> rank 0 (RCCL over xGMI: one point-to-point link per peer), input order
+            restored there"""
+            if not wire_mode:
+                dist.gather(buf, gather_list, dst=0)
+                return
+            if rank != 0:
+                wire = pdist.rows_to_wire_torch(buf[:W.nprot * RB], lens_local)
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, wire, 0)]):
+                    req.wait()
+                return
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, got[r], r) for r in range(1, world)]):
+                req.wait()
+            fin = final[point]
+            fin[W.plans[0]] = buf.view(-1, RB)[:W.nprot]
+            for r in range(1, world):
+                fin[W.plans[r]] = pdist.rows_from_wire_torch(got[r], lens_of[r], corelength)
 
         def step():
             b = step_no[0] % nslots
@@ -324,8 +403,8 @@ def main():
                     ctx.score_sweep_device(W.codes.data_ptr(), W.offsets.data_ptr(), W.nprot, W.total, sweep_params,
                                            [r.data_ptr() for r in sweep_rows], stream=stream.cuda_stream)
                     if world > 1:
-                        for r in sweep_rows:
-                            gather(r)
+                        for k, r in enumerate(sweep_rows):
+                            gather(r, k, sweep_points[k][1])
                     return
                 if two_pass:  # cfg3: background pass, table setup (plaac.java:444-500) and upload are part of the step
                     ctx.set_params(native.make_params(alpha=alpha, bgcounts=background_counts(W, ctx, stream).astype(np.float64)))
@@ -342,7 +421,7 @@ def main():
                             comm.wait_event(scored[b])
                             g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             g0.record(comm)
-                            gather(rows_pp[b])
+                            gather(rows_pp[b], k if sweep_params else 0, sweep_points[k][1] if sweep_params else P.corelength)
                             g1.record(comm)
                             gather_t.append((g0, g1))
                             gathered[b].record(comm)
@@ -370,10 +449,18 @@ def main():
         if gather_t:
             ts = [a.elapsed_time(b_) for a, b_ in gather_t[nwarm:]]
             gms = sum(ts) / max(1, len(ts))
-        return dt, {"rows": rows_pp[0], "final": final, "gather_list": gather_list, "sweep_rows": sweep_rows, "trk": trk,
-                    "gather_ms": gms}
+        last = (step_no[0] - 1) % nslots
+        if verify:  # the step that is checked: into poisoned buffers, after the clock has stopped
+            for t_ in rows_pp + (sweep_rows or []) + (final or []) + (list(trk.values()) if trk else []):
+                t_.fill_(0xFF) if t_.dtype == torch.uint8 else t_.view(torch.uint8).fill_(0xFF)
+            torch.cuda.synchronize(dev)
+            step()
+            fence()
+            last = (step_no[0] - 1) % nslots
+        return dt, {"rows": rows_pp[last], "final": final, "gather_list": gather_list, "sweep_rows": sweep_rows, "trk": trk,
+                    "gather_ms": gms, "verified_step": "one more untimed step into buffers filled with 0xFF" if verify else None}
 
-    dt, bufs = run_region(main_work, args.steps, args.warmup, args.tracks)
+    dt, bufs = run_region(main_work, args.steps, args.warmup, args.tracks, verify=True)
     nprot, total = main_work.nprot, main_work.total
     if world > 1:
         tot = torch.tensor([total, nprot], dtype=torch.int64, device=dev)
@@ -443,22 +530,40 @@ def main():
     # What one GPU of an 8-GPU strong-scaling run would take: the share plaac_shard_plan deals rank 0 of 8 (1.25 M sequences
     # of the 10 M), timed like the main region (overlapping steps, no gather). efficiency = full step / (8 x share step):
     # the ceiling of the 8-GPU curve before any exchange - a single GPU can measure it, the curve itself needs the node.
-    predicted = None
-    if (rank == 0 and world == 1 and args.config == 4 and not args.nprot and not args.tracks and not args.sweep
-            and not args.no_predict):
+    predicted = tracks_leg = None
+    if rank == 0 and world == 1 and args.config == 4 and not args.nprot and not args.tracks and not args.sweep and not (
+            args.no_predict and args.no_tracks_leg):
         idx8 = pdist.shard_plan_torch(offsets_full, 8, 0)
         c8, o8 = pdist.extract_shard_torch(codes_full, offsets_full, idx8)
         w8 = Work(c8, o8, None, idx8.numel())
-        sdt, sb = run_region(w8, max(args.steps, 20), 3, False)
-        del sb
-        share_ms = sdt / max(args.steps, 20) * 1e3
-        predicted = {"n_gpus": 8, "share_sequences": int(idx8.numel()), "share_residues": w8.total,
-                     "share_ms_per_step": round(share_ms, 4), "full_ms_per_step": round(dt / args.steps * 1e3, 4),
-                     "efficiency": round(dt / args.steps * 1e3 / (8 * share_ms), 4),
-                     "what": "rank 0's share of 8 (plaac_shard_plan) scored on this GPU, overlapping steps, no gather; "
-                             "efficiency = full-proteome step / (8 x share step): the ceiling of strong scaling before "
-                             "the row gather (extra untimed steps)"}
-        del w8, c8, o8, idx8
+        if not args.no_predict:
+            sdt, sb = run_region(w8, max(args.steps, 20), 3, False)
+            del sb
+            share_ms = sdt / max(args.steps, 20) * 1e3
+            predicted = {"n_gpus": 8, "share_sequences": int(idx8.numel()), "share_residues": w8.total,
+                         "share_ms_per_step": round(share_ms, 4), "full_ms_per_step": round(dt / args.steps * 1e3, 4),
+                         "efficiency": round(dt / args.steps * 1e3 / (8 * share_ms), 4),
+                         "what": "rank 0's share of 8 (plaac_shard_plan) scored on this GPU, overlapping steps, no gather; "
+                                 "efficiency = full-proteome step / (8 x share step): the ceiling of strong scaling before "
+                                 "the row gather (extra untimed steps)"}
+        # The HBM-bound regime of the path: per-residue track mode (plotsomefastas, plaac.java:587-649), 82 B
+        # written per residue, on the same share, timed like the main region; the tracks of its last step - made after the
+        # clock stopped, into buffers filled with 0xFF - are checked against the oracle below
+        if not args.no_tracks_leg:
+            tsteps = max(5, min(args.steps, 20))
+            tdt, tbufs = run_region(w8, tsteps, 2, True, verify=True)
+            t_ms = tdt / tsteps * 1e3
+            t_bytes = w8.total * (1 + native.TRACK_BYTES_PER_RESIDUE) + w8.nprot * 168
+            tracks_leg = {"workload": "rank 0's 1/8 share of the proteome (plaac_shard_plan: %d sequences, %d residues) in per-residue "
+                                      "track mode, one GPU" % (w8.nprot, w8.total),
+                          "steps": tsteps, "ms_per_step": round(t_ms, 4), "residues_per_sec": round(w8.total * tsteps / tdt, 1),
+                          "algorithmic_bytes": t_bytes, "path_achieved_GBps": round(t_bytes / (t_ms * 1e-3) / 1e9, 1),
+                          "peak_GBps": HBM_PEAK_GBPS, "frac": round(t_bytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                          "what": "83 B/residue + 168 B/protein (SURVEY 8d M4) / wall-clock step (fence - steps - fence), "
+                                  "inputs resident; frac = of the 8 TB/s HBM peak", "_bufs": tbufs, "_work": w8}
+        else:
+            del w8
+        del c8, o8, idx8
         torch.cuda.empty_cache()
     # PCIe-inclusive rate (never `value`): the host-buffer entry point plaac_score on a bounded sample - residues and
     # offsets from host memory in, rows to host memory out, through the library's pinned staging
@@ -527,6 +632,9 @@ def main():
     # average launch duration of the longest kernel (the four scoring kernels overlap, see kernels_overlap)
     path_bytes = total * (1 + tb + (1 if two_pass else 0)) + nprot * 168
     achieved = path_bytes / (dom_ms * 1e-3) / 1e9
+    if args.tracks:  # track mode: no one kernel stream carries the path's bytes - the figure is the step's
+        dom, dom_ms = "step", dt / args.steps * 1e3
+        achieved = path_bytes / (dom_ms * 1e-3) / 1e9
     # HBM traffic and executed instruction counts: PMC counters cannot be read from inside this process;
     # tools/pmc.sh collects them for this same workload and leaves the per-launch figures under profiles/
     traffic, traffic_all, exec_ops, issue_instr, traffic_cal, traffic_all_cal, fetch_cal, issue_classes = (None,) * 8
@@ -549,7 +657,7 @@ def main():
                 names = [k for k in per if k.startswith(dom)]
                 names += [k for k in per if (dom == "k_tracks" and k == "k_refine_centres") or
                           (dom == "k_vit" and k.startswith("k_core"))]
-                traffic = sum(per[k] for k in names) if names else None
+                traffic = sum(per[k] for k in names) if names else (tj.get("bytes_per_step") if dom == "step" else None)
                 traffic_all = tj.get("bytes_per_step")
                 perc = tj.get("bytes_per_launch_calibrated")
                 if perc:  # read factor measured on this repo's own access shapes instead of the guide's x2 for all
@@ -639,7 +747,7 @@ def main():
         from oracle import oracle_ctypes as oc
         nthreads = usable_cores()
         if strong:
-            chk_codes, chk_offs, chk_rows, chk_n = codes_full, offsets_full, bufs["final"].view(-1), nfull
+            chk_codes, chk_offs, chk_rows, chk_n = codes_full, offsets_full, bufs["final"][0].view(-1), nfull
         else:
             chk_codes, chk_offs, chk_rows, chk_n = main_work.codes, main_work.offsets, bufs["rows"], nprot
         if two_pass:  # same two-pass parameters as the GPU step (counts of the WHOLE input)
@@ -669,7 +777,7 @@ def main():
             for k, (a, c) in enumerate((a, c) for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)):
                 Pk = oc.build_params(alpha=a, corelength=c, bgcounts=counts.astype(np.float64))
                 wk = oc.score_batch(Pk, codes_h[:int(off_h[n_c])], off_h[:n_c + 1], nthreads=nthreads)
-                gk = bufs["sweep_rows"][k][:n_c * RB].cpu().numpy()
+                gk = (bufs["final"][k].view(-1) if strong else bufs["sweep_rows"][k])[:n_c * RB].cpu().numpy()
                 if gk.tobytes() != wk.tobytes():
                     bad.append(["sweep point", k])
             checked = 9 * n_c
@@ -687,6 +795,36 @@ def main():
                     bad.append([s, n])
                 checked += n
         match = not bad
+        if tracks_leg is not None:  # the track-mode leg: rows and all twelve tracks of its verified step against the oracle
+            tw, tb_ = tracks_leg.pop("_work"), tracks_leg.pop("_bufs")
+            n_t = min(tw.nprot, 4000)
+            o_t = tw.offsets[:n_t + 1].cpu().numpy().astype(np.uint64)
+            r_t = int(o_t[-1])
+            c_t = tw.codes[:r_t].cpu().numpy()
+            w_rows, w_trk = oc.score_batch(oc.build_params(), c_t, o_t, tracks=True, nthreads=nthreads)
+            keep = np.ones(r_t, bool)
+            lastpos = (o_t[1:][np.diff(o_t) > 0] - 1).astype(np.int64)
+            keep[lastpos[c_t[lastpos] == 21]] = False  # (the entry of a trimmed stop is unspecified)
+            tbad = []
+            if tb_["rows"][:n_t * RB].cpu().numpy().tobytes() != w_rows.tobytes():
+                tbad.append("rows")
+            for k in native.TRACK_U8 + native.TRACK_F64:
+                g = tb_["trk"][k][:r_t].cpu().numpy()[keep]
+                w = w_trk[k][keep]
+                if k in ("post0", "post1"):  # exp() on the device: rtol 1e-12 (every other track bit for bit)
+                    ok = np.allclose(g, w, rtol=1e-12, atol=0)
+                elif g.dtype.kind == "f":
+                    ok = np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(g.view(np.uint64)[~np.isnan(g)], w.view(np.uint64)[~np.isnan(w)])
+                else:
+                    ok = np.array_equal(g, w)
+                if not ok:
+                    tbad.append(k)
+            tracks_leg.update(gpu_tracks_match_oracle=not tbad, mismatching_tracks=tbad, sequences_checked=n_t,
+                              residues_checked_per_track=int(keep.sum()), verified_step=tb_["verified_step"],
+                              tolerance="rows, vit, map and the eight window tracks bit-identical; post0 / post1 rtol 1e-12")
+            if tbad:
+                rc = 3
+            del tw, tb_
         cpu = {
             "value": round(int(off_h[-1]) / dtn, 1), "unit": "residues/s", "cores": nthreads, "kind": "port",
             "sample": "first %d sequences (%d residues) of the proteome on %d OpenMP threads, second of two runs; "
@@ -718,6 +856,10 @@ def main():
     if cpu is not None and "reference_jar" not in cpu:
         cpu["reference_jar"] = time_reference_jar("", 0) if not os.environ.get("PLAAC_REF_JAR") else "skipped: no e2e leg"
 
+    if tracks_leg is not None:  # (--no-cpu-baseline: nothing was checked)
+        tracks_leg.pop("_work", None)
+        tracks_leg.pop("_bufs", None)
+        tracks_leg.setdefault("gpu_tracks_match_oracle", None)
     wl = {2: "cfg2 yeast-shaped proteome (5,880 sequences)", 3: "cfg3 human-shaped proteome (20,600 sequences), "
           "-a 0.5 with the background counted from the input inside every step (two-pass)",
           4: "cfg4 UniRef50-shaped, 10M sequences"}[args.config]
@@ -749,12 +891,18 @@ def main():
             "step_by_itself": by_itself,
             "predicted_strong_scaling": predicted,
             "gather_ms_per_step": None if bufs.get("gather_ms") is None else round(bufs["gather_ms"], 4),
-            "exchange": ("%s gather of 160 B rows to rank 0" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
+            "exchange": ("%s gather to rank 0: %s" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend,
+                         "136 B wire rows (include/plaac_native.h), point-to-point blocks of their exact sizes, rows rebuilt and "
+                         "put in input order on rank 0" if strong else "160 B rows in equal blocks (weak scaling)"))
             if world > 1 else "none (1 GPU)",
+            "wire_row_bytes": pdist.WIRE_ROW_BYTES if strong else None,
+            "verified_step": bufs.get("verified_step"),
+            "diagnostics_in_environment": set_diag or None,
             "timed_region_s": round(dt, 3), "exact_tier_fallbacks_rank0": fallbacks,
         },
         "predicted_strong_efficiency": None if not predicted else predicted["efficiency"],
         "roofline": roofline,
+        "tracks": tracks_leg,
         "cpu_baseline": cpu,
         "e2e": e2e,
     }

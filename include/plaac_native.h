@@ -104,6 +104,20 @@ typedef struct plaac_row {
     int32_t papa_cen;
 } plaac_row; /* 13 x f64 + 14 x i32 = 160 bytes */
 
+/* WIRE ROWS (round 5): what a summary row needs to cross a link (xGMI between ranks, a socket between hosts). Of the 160
+ * bytes the receiver can rebuild 24 from what it holds anyway - the batch's offsets and the core length:
+ *   prot_len  = offsets[i+1] - offsets[i] - (one trailing stop trimmed, plaac.java:758: a flag in bit 30 of mw_score)
+ *   mw_end    = mw_start + min(80, prot_len) - 1            (hss2 with min == max, :769-771, :1253-1256)
+ *   llr_end   = llr_start + corelength - 1, core_end likewise; -2 where the start is -1 (:1210-1215, :873-880)
+ *   papa_prop = papa_combo when there is a centre, NaN otherwise (:4944-4946, :4993)
+ * so a wire row is 12 doubles + 10 ints = 136 bytes (the field order of plaac_row without those five). A skipped record
+ * (prot_len 0) comes back as the all-zero row the scorer writes. plaac_rows_from_wire(plaac_rows_to_wire(rows)) == rows
+ * byte for byte (tests/test_dist.py; plaac_amd/dist.py does the same on the device for the RCCL gather). Host only. */
+#define PLAAC_WIRE_ROW_BYTES 136
+plaac_status plaac_rows_to_wire(const plaac_row *rows, const uint64_t *offsets, uint32_t n, uint8_t *wire);
+plaac_status plaac_rows_from_wire(const uint8_t *wire, const uint64_t *offsets, uint32_t n, int32_t corelength,
+                                  plaac_row *rows);
+
 /* Per-residue tracks (plotsomefastas, plaac.java:635-643): SoA arrays indexed by the
  * position of the residue in `codes` (the entry of a trimmed stop is unspecified).
  * All twelve pointers must be non-null when a tracks struct is passed. */

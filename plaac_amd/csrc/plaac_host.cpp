@@ -153,4 +153,60 @@ void plaac_encode(const char *text, size_t n, uint8_t *codes) {
     for (size_t i = 0; i < n; ++i) codes[i] = kCodeLut.t[(unsigned char)text[i]];
 }
 
+// ---- wire rows: what a summary row needs to cross a link (include/plaac_native.h) ----
+// Word layout of plaac_row as 40 x 32-bit words: 0..25 the thirteen doubles, 26..39 the fourteen ints. The wire row keeps
+// words 0..17 (llr_score .. papa_combo), 20..25 (papa_fi, papa_llr, papa_llr2), then mw_score (| stop flag << 30),
+// mw_start, llr_start, vit_maxrun, core_start, prd_start, prd_end, fi_numaa, fi_maxrun, papa_cen.
+static const int kWireWords[PLAAC_WIRE_ROW_BYTES / 4] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16,
+                                                         17, 20, 21, 22, 23, 24, 25, 26, 27, 29, 31, 32, 34, 35, 37, 38, 39};
+
+plaac_status plaac_rows_to_wire(const plaac_row *rows, const uint64_t *offsets, uint32_t n, uint8_t *wire) {
+    if (n && (!rows || !offsets || !wire)) return PLAAC_ERR_ARG;
+    static_assert(sizeof(plaac_row) == 160, "plaac_row layout");
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t w[40], o[PLAAC_WIRE_ROW_BYTES / 4];
+        std::memcpy(w, &rows[i], sizeof w);
+        const uint64_t raw = offsets[i + 1] - offsets[i];
+        const uint64_t flag = raw - (uint64_t)(uint32_t)rows[i].prot_len; // one trailing stop trimmed (:758)?
+        if (offsets[i + 1] < offsets[i] || flag > 1u || rows[i].mw_score < 0 || rows[i].mw_score > 80) return PLAAC_ERR_ARG;
+        for (int k = 0; k < PLAAC_WIRE_ROW_BYTES / 4; ++k) o[k] = w[kWireWords[k]];
+        o[24] |= (uint32_t)flag << 30;
+        std::memcpy(wire + (size_t)i * PLAAC_WIRE_ROW_BYTES, o, sizeof o);
+    }
+    return PLAAC_OK;
+}
+
+plaac_status plaac_rows_from_wire(const uint8_t *wire, const uint64_t *offsets, uint32_t n, int32_t corelength, plaac_row *rows) {
+    if ((n && (!rows || !offsets || !wire)) || corelength < 1) return PLAAC_ERR_ARG;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t w[40] = {0}, o[PLAAC_WIRE_ROW_BYTES / 4];
+        std::memcpy(o, wire + (size_t)i * PLAAC_WIRE_ROW_BYTES, sizeof o);
+        const uint32_t flag = (o[24] >> 30) & 1u;
+        o[24] &= ~(1u << 30);
+        for (int k = 0; k < PLAAC_WIRE_ROW_BYTES / 4; ++k) w[kWireWords[k]] = o[k];
+        plaac_row &r = rows[i];
+        std::memcpy(&r, w, sizeof w);
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] < flag) return PLAAC_ERR_ARG;
+        const uint64_t len = offsets[i + 1] - offsets[i] - flag;
+        if (len > 0x7fffffffull) return PLAAC_ERR_ARG;
+        r.prot_len = (int32_t)len;
+        if (len == 0) { // a skipped record (:762): its row is all zero
+            std::memset(&r, 0, sizeof r);
+            continue;
+        }
+        // hss2 with min == max == L returns end = start + L - 1, or (-1, -2) when L > n (:1210-1215, :1253-1256)
+        r.mw_end = r.mw_start + (int32_t)(len < 80 ? len : 80) - 1;          // :769-771
+        r.llr_end = r.llr_start >= 0 ? r.llr_start + corelength - 1 : -2;     // :782-783
+        r.core_end = r.core_start >= 0 ? r.core_start + corelength - 1 : -2;  // :818-833, :873-880
+        // papamaxprop = papax2[papamaxcenter] = the maximum itself when there is a centre, else NaN (:4944-4946, :4993)
+        if (r.papa_cen >= 0) {
+            r.papa_prop = r.papa_combo;
+        } else {
+            const uint64_t qnan = 0x7ff8000000000000ull;
+            std::memcpy(&r.papa_prop, &qnan, 8);
+        }
+    }
+    return PLAAC_OK;
+}
+
 } // extern "C"

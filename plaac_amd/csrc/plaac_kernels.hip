@@ -1609,9 +1609,10 @@ plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count) {
     if (ctx->ncalls == 0) return PLAAC_OK;
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PL_HIP(ctx, hipEventSynchronize(ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
-    // (DIAGNOSTIC, PLAAC_DEBUG_COUNTER=16: another word of the call's counter set - 16: the core list's length)
-    const char *dbg = std::getenv("PLAAC_DEBUG_COUNTER");
-    const size_t word = dbg ? (size_t)std::min(31L, std::max(0L, std::atol(dbg))) : 0u;
+    size_t word = 0;
+#ifdef PLAAC_DIAG // (diagnostic build only: PLAAC_DEBUG_COUNTER=16 reads another word of the call's counter set - 16: the core list's length)
+    if (const char *dbg = std::getenv("PLAAC_DEBUG_COUNTER")) word = (size_t)std::min(31L, std::max(0L, std::atol(dbg)));
+#endif
     PL_HIP(ctx, hipMemcpy(count, ctx->d_kbcnt + (size_t)KB_COUNTER_WORDS * ((ctx->ncalls - 1) & 3u) + word, sizeof(uint32_t),
                           hipMemcpyDeviceToHost));
     return PLAAC_OK;

@@ -12,6 +12,9 @@ import os
 import numpy as np
 
 ROW_BYTES = 160
+WIRE_ROW_BYTES = 136  # include/plaac_native.h, PLAAC_WIRE_ROW_BYTES
+# the 34 of a row's 40 32-bit words that cross the link (kWireWords of plaac_host.cpp); word 24 of the wire row = mw_score
+_WIRE_WORDS = list(range(18)) + list(range(20, 26)) + [26, 27, 29, 31, 32, 34, 35, 37, 38, 39]
 
 
 def env_world():
@@ -107,10 +110,56 @@ def allreduce_counts(counts, device=None):
     return t.cpu().numpy()
 
 
-def gather_rows(rows_local, idx_local, nprot_total, device=None):
+def rows_to_wire_torch(rows_u8, raw_len):
+    """plaac_rows_to_wire on a torch device: rows_u8 uint8 [n * 160], raw_len int64 [n] = the records' untrimmed lengths
+    -> uint8 [n * 136]. One gather of 34 of the 40 words of every row; 'one trailing stop was trimmed' (plaac.java:758)
+    rides in bit 30 of mw_score (0..80), so the receiver gets prot_len from its own offsets."""
+    import torch
+    w = rows_u8.view(torch.int32).view(-1, 40)
+    cols = torch.tensor(_WIRE_WORDS, dtype=torch.int64, device=w.device)
+    out = w.index_select(1, cols)
+    flag = raw_len.to(torch.int32) - w[:, 36]  # raw length - prot_len: 0 or 1
+    out[:, 24] |= flag << 30
+    return out.reshape(-1).view(torch.uint8)
+
+
+def rows_from_wire_torch(wire_u8, raw_len, corelength, out=None):
+    """plaac_rows_from_wire on a torch device: wire rows + the records' untrimmed lengths (the receiver's own offsets) +
+    the core length -> 160-byte rows (uint8 [n, 160]; written into `out` [n, 160] when given). Rebuilds prot_len, mw_end,
+    llr_end, core_end and papa_prop (reference: plaac.java:769-771, :782-783, :873-880, :4944-4946)."""
+    import torch
+    o = wire_u8.view(torch.int32).view(-1, 34)
+    n = o.shape[0]
+    w = torch.zeros(n, 40, dtype=torch.int32, device=o.device)
+    cols = torch.tensor(_WIRE_WORDS, dtype=torch.int64, device=o.device)
+    w[:, cols] = o
+    flag = (o[:, 24] >> 30) & 1
+    w[:, 26] = o[:, 24] & ~(1 << 30)
+    plen = raw_len.to(torch.int32) - flag
+    w[:, 36] = plen
+    c = int(corelength)
+    w[:, 28] = w[:, 27] + torch.clamp(plen, max=80) - 1
+    w[:, 30] = torch.where(w[:, 29] >= 0, w[:, 29] + (c - 1), torch.full_like(plen, -2))
+    w[:, 33] = torch.where(w[:, 32] >= 0, w[:, 32] + (c - 1), torch.full_like(plen, -2))
+    has = w[:, 39] >= 0
+    w[:, 18] = torch.where(has, w[:, 16], torch.zeros_like(plen))
+    w[:, 19] = torch.where(has, w[:, 17], torch.full_like(plen, 0x7ff80000))  # the quiet NaN the scorer writes
+    w[plen == 0] = 0  # skipped records (:762): all-zero rows
+    rows = w.view(torch.uint8).view(n, ROW_BYTES)
+    if out is not None:
+        out.copy_(rows)
+        return out
+    return rows
+
+
+def gather_rows(rows_local, idx_local, nprot_total, device=None, offsets=None, corelength=None, plans=None):
     """Exchange step (ii): gather per-rank row blocks to rank 0 and restore input order.
     rows_local: torch uint8 tensor [n_local*160] (any device) or a numpy structured/uint8 array.
-    Returns a uint8 numpy array [nprot_total*160] on rank 0, None elsewhere."""
+    Returns a uint8 numpy array [nprot_total*160] on rank 0, None elsewhere.
+    With `offsets` (the WHOLE batch's offsets, which every rank cut its shard from) and `corelength` the rows cross the
+    link as 136-byte wire rows in blocks of their exact sizes (point-to-point: every peer has its own xGMI link to rank 0,
+    nothing is padded); `plans` (on EVERY rank, or on none: the index arrays of all ranks, as shard_plan returns them - only
+    rank 0 reads them, the others just do not send theirs) saves the gather of the indices as well. Without offsets: 160-byte rows in equal padded blocks (dist.gather), as in rounds 1 - 4."""
     import torch
     import torch.distributed as dist
     if isinstance(rows_local, np.ndarray):
@@ -130,6 +179,33 @@ def gather_rows(rows_local, idx_local, nprot_total, device=None):
     dist.all_gather(sizes, n_local)
     sizes = [int(s.item()) for s in sizes]
     nmax = max(sizes)
+    if offsets is not None:
+        if corelength is None:
+            raise ValueError("gather_rows: wire rows need the core length the rows were scored with")
+        off_t = torch.as_tensor(np.asarray(offsets).astype(np.int64), device=rows_t.device)
+        lens = off_t[1:] - off_t[:-1]
+        wire = rows_to_wire_torch(rows_t, lens[idx_t])
+        if rank != 0:
+            ops = [dist.P2POp(dist.isend, wire, 0)] if wire.numel() else []
+            if plans is None:
+                ops.append(dist.P2POp(dist.isend, idx_t, 0))
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+            return None
+        got = [wire] + [torch.empty(sizes[r] * WIRE_ROW_BYTES, dtype=torch.uint8, device=rows_t.device) for r in range(1, world)]
+        gidx = [idx_t] + [torch.empty(sizes[r], dtype=torch.int64, device=rows_t.device) for r in range(1, world)]
+        ops = [dist.P2POp(dist.irecv, got[r], r) for r in range(1, world) if sizes[r]]
+        if plans is None:
+            ops += [dist.P2POp(dist.irecv, gidx[r], r) for r in range(1, world)]
+        else:
+            gidx = [torch.as_tensor(np.asarray(p, dtype=np.int64), device=rows_t.device) for p in plans]
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        out = torch.empty(nprot_total, ROW_BYTES, dtype=torch.uint8, device=rows_t.device)
+        for r in range(world):
+            if sizes[r]:
+                out[gidx[r]] = rows_from_wire_torch(got[r], lens[gidx[r]], corelength)
+        return out.reshape(-1).cpu().numpy()
     # equal-size blocks for dist.gather: pad the short shards
     pad_rows = torch.zeros(nmax * ROW_BYTES, dtype=torch.uint8, device=rows_t.device)
     pad_rows[:rows_t.numel()] = rows_t

@@ -76,7 +76,7 @@ EXPORTS = (
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
-    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_score_begin", "plaac_score_end", "plaac_debug_schedule",
+    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_debug_schedule",
 )
 
 _lib = None
@@ -160,6 +160,8 @@ def load():
     L.plaac_node_batch_records.restype = C.c_uint32
     L.plaac_node_batch_residues.argtypes = [C.c_void_p]
     L.plaac_node_batch_residues.restype = C.c_uint64
+    L.plaac_rows_to_wire.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.plaac_rows_from_wire.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
     L.plaac_node_batch_last_error.argtypes = [C.c_void_p]
     L.plaac_node_batch_last_error.restype = C.c_char_p
     L.plaac_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -532,6 +534,33 @@ def debug_schedule(q):
     if n < 0:
         raise PlaacError(PLAAC_ERR_ARG, "plaac_debug_schedule rejected the query")
     return buf.value.decode()
+
+
+WIRE_ROW_BYTES = 136
+
+
+def rows_to_wire(rows, offsets):
+    """plaac_rows_to_wire (host): 160-byte rows -> 136-byte wire rows (uint8 array [n * 136])"""
+    rows = np.ascontiguousarray(rows)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    wire = np.empty(n * WIRE_ROW_BYTES, dtype=np.uint8)
+    st = load().plaac_rows_to_wire(rows.ctypes.data, offsets.ctypes.data, n, wire.ctypes.data)
+    if st != PLAAC_OK:
+        raise PlaacError(st, "plaac_rows_to_wire rejected its arguments")
+    return wire
+
+
+def rows_from_wire(wire, offsets, corelength):
+    """plaac_rows_from_wire (host): the receiver's side - wire rows + the batch's offsets + the core length -> rows"""
+    wire = np.ascontiguousarray(wire, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    rows = np.zeros(n, dtype=ROW_DTYPE)
+    st = load().plaac_rows_from_wire(wire.ctypes.data, offsets.ctypes.data, n, int(corelength), rows.ctypes.data)
+    if st != PLAAC_OK:
+        raise PlaacError(st, "plaac_rows_from_wire rejected its arguments")
+    return rows
 
 
 def shard_plan(offsets, parts):

@@ -151,3 +151,13 @@ def test_cli_fails_loudly_without_a_gpu(tmp_path):
     r = subprocess.run([exe, "-B", os.path.join(ROOT, "tests", "golden", "prd_freq_scer_04.txt")], capture_output=True,
                        text=True, timeout=120)  # -B without -i: print the table, no device needed (:394-403)
     assert r.returncode == 0 and r.stdout.splitlines()[0] == "0.000000 # X" and len(r.stdout.splitlines()) == 22
+
+
+def test_release_library_does_not_contain_the_result_breaking_switches():
+    """PLAAC_DEBUG_SKIP / _SKIP_FROM (kernels not launched, rows stale), PLAAC_VIT_STOP and PLAAC_DEBUG_COUNTER are
+    compiled only into the diagnostic build (`make DIAG=1` -> libplaac_native_diag.so); a host's environment cannot switch
+    them on in the library that ships."""
+    blob = open(os.path.join(ROOT, "plaac_amd", "libplaac_native.so"), "rb").read()
+    for name in (b"PLAAC_DEBUG_SKIP", b"PLAAC_VIT_STOP", b"PLAAC_DEBUG_COUNTER"):
+        assert name not in blob, name
+    assert b"PLAAC_LATENCY_MODE" in blob  # (the form-selecting knobs, which change no result, are still read)

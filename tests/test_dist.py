@@ -41,14 +41,70 @@ def _worker(rank, world, port, tmp):
     rows_s = oc.score_batch(P2, c_s, o_s)
     # exchange (ii): gather rows to rank 0, input order
     out = pdist.gather_rows(rows_s, plan[rank], len(offs) - 1)
+    # ... and as 136-byte wire rows in blocks of their exact sizes, with and without the indices known to rank 0
+    out_w = pdist.gather_rows(rows_s, plan[rank], len(offs) - 1, offsets=offs, corelength=P2.corelength)
+    out_p = pdist.gather_rows(rows_s, plan[rank], len(offs) - 1, offsets=offs, corelength=P2.corelength, plans=plan)
+    # the adversarial set (NaN / -inf fields, no core, n < c, empty and stop-only records, trimmed stops) with a short
+    # core length, three ranks' worth of records dealt to two so that the blocks differ in size
+    from plaac_amd import native
+    ac, ao = _adversarial(native)
+    P3 = oc.build_params(corelength=25)
+    aplan = pdist.shard_plan(ao, world)
+    a_cs, a_os = pdist.extract_shard(ac, ao, aplan[rank])
+    a_rows = oc.score_batch(P3, a_cs, a_os)
+    out_a = pdist.gather_rows(a_rows, aplan[rank], len(ao) - 1, offsets=ao, corelength=25)
     if rank == 0:
         want = oc.score_batch(P2, codes, offs)
         assert out.tobytes() == want.tobytes()
+        assert out_w.tobytes() == want.tobytes(), "wire-row gather differs"
+        assert out_p.tobytes() == want.tobytes(), "wire-row gather with known plans differs"
+        want_a = oc.score_batch(P3, ac, ao)
+        assert np.isnan(want_a["core_score"]).any() and np.isinf(want_a["llr_score"]).any() and (want_a["prot_len"] == 0).any()
+        assert np.isnan(want_a["papa_prop"]).any() and (want_a["papa_cen"] >= 0).any()
+        assert out_a.tobytes() == want_a.tobytes(), "wire-row gather of the adversarial set differs"
         open(os.path.join(tmp, "ok"), "w").write("ok")
     else:
-        assert out is None
+        assert out is None and out_w is None and out_p is None and out_a is None
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _adversarial(native):
+    """records whose rows hold every sentinel: empty, stop-only, shorter than the core length / the PAPA window / the MW
+    window, homopolymers (exact ties), prion-like repeats (cores), with and without a trailing stop"""
+    rng = np.random.default_rng(8)
+    aas = "ACDEFGHIKLMNPQRSTVWY"
+    seqs = ["", "*", "A", "A*", "QN", "Q" * 24, "Q" * 25, "Q" * 25 + "*", "N" * 40, "N" * 41 + "*", "QNQNQNQNQNYYGGSSQQNN" * 6,
+            "K" * 79, "K" * 80, "K" * 81, "DE" * 60, "P" * 90 + "*", "X" * 50, "QNX*" * 20]
+    seqs += ["".join(rng.choice(list(aas), int(n))) + ("*" if k % 3 == 0 else "") for k, n in enumerate(rng.integers(1, 400, 40))]
+    return native.pack(seqs)
+
+
+def test_wire_rows_round_trip_on_host_and_in_torch():
+    """136-byte wire rows (include/plaac_native.h): from_wire(to_wire(rows)) == rows byte for byte, in C and in the torch
+    form the RCCL gather uses, and the two wire encodings are the same bytes; malformed input is refused"""
+    import torch
+    from oracle import oracle_ctypes as oc
+    from plaac_amd import dist as pdist
+    from plaac_amd import native, synth
+    c1, o1 = _adversarial(native)
+    c2, o2 = synth.make_batch(2, nprot=1500, seed=4, stop_fraction=0.3)
+    codes = np.concatenate([c1, c2])
+    offs = np.concatenate([o1, o2[1:] + o1[-1]]).astype(np.uint64)
+    lens = torch.from_numpy(np.diff(offs.astype(np.int64)))
+    for c in (60, 25, 7, 500):
+        want = oc.score_batch(oc.build_params(corelength=c), codes, offs, nthreads=4)
+        wire = native.rows_to_wire(want, offs)
+        assert len(wire) == 136 * len(want)
+        assert native.rows_from_wire(wire, offs, c).tobytes() == want.tobytes()
+        wt = pdist.rows_to_wire_torch(torch.from_numpy(want.view(np.uint8).reshape(-1).copy()), lens)
+        assert wt.numpy().tobytes() == wire.tobytes()
+        back = pdist.rows_from_wire_torch(wt, lens, c)
+        assert back.numpy().tobytes() == want.tobytes()
+    bad = want.copy()
+    bad["prot_len"][5] += 7  # not the record's length, trimmed or not
+    with pytest.raises(native.PlaacError):
+        native.rows_to_wire(bad, offs)
 
 
 def test_two_rank_shard_histogram_and_gather(tmp_path):

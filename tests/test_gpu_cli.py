@@ -81,6 +81,31 @@ def test_background_tools_roundtrip(oracle, io, tmp_path):
     assert [l for l in a[1:] if l] == want
 
 
+def test_config3_the_way_baseline_words_it_reference_written_human_background(oracle, io, native, tmp_path):
+    """BASELINE config 3: "-a 0.5 mixed background" = the web app's real invocation `-i <fasta> -c 60 -a 0.5 -B
+    bg_freqs_HUMAN.txt` (web/lib/server.rb:152-155) with the background file the reference itself wrote (plaac.jar -b,
+    tests/golden/bg_freqs/, make_bg_freqs.py). A human-proteome-shaped synthetic FASTA (incl. a 34,350-residue record)
+    through bin/plaac against the oracle-formatted table; the parameter block echoes the file's frequencies."""
+    from plaac_amd import synth
+    bgfile = os.path.join(GOLDEN, "bg_freqs", "bg_freqs_HUMAN.txt")
+    bgcounts = io.read_aa_params(bgfile)[0]
+    P = native.make_params(alpha=0.5, bgcounts=bgcounts)
+    codes, offs = synth.make_batch(3, nprot=2000, seed=33, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+    fa = tmp_path / "human_like.fa"
+    _write_fasta(fa, codes, offs)
+    lines = run("-i", fa, "-c", 60, "-a", "0.5", "-B", bgfile)
+    body = [l for l in lines if l and not l.startswith("#")]
+    want, _ = expected_rows(oracle, io, str(fa), alpha=0.5, bgcounts=bgcounts)
+    assert body[0] == io.summary_header() and body[1:] == want
+    head = [l for l in lines if l.startswith("## ")]
+    assert head[0].startswith("## alpha=0.5; corelength=60;")
+    c = bgcounts.copy()
+    c[0] = c[21] = 0
+    bg_line = [l for l in head if l.startswith("## bg_input")][0]
+    assert "A=%.5f;" % (c[1] / c.sum()) in bg_line and "L=%.5f;" % (c[10] / c.sum()) in bg_line
+    # the same background through -b <fasta> would need the proteome; the file IS what the reference counted from it
+
+
 def test_fg_override_reproduces_kat28(io, kat28):
     """-F prd_freq_scer_04.txt (fixed: the reference reads the -B file here) -> the 28 annotated PrDs"""
     lines = run("-i", KAT, "-F", os.path.join(GOLDEN, "prd_freq_scer_04.txt"), "-p", "all", "-s")

@@ -1130,3 +1130,17 @@ def test_sweep_group_of_more_than_256_core_lengths(native, oracle, monkeypatch, 
     for (a, cl), rows in zip(points, got):
         want = oracle.score_batch(oracle.build_params(alpha=a, corelength=cl, bgcounts=bg), codes, offs, nthreads=8)
         assert_rows_equal(rows, want, "alpha=%s c=%d mode=%s" % (a, cl, mode))
+
+
+def test_result_breaking_switches_change_nothing_in_the_release_library(native, oracle, monkeypatch):
+    """PLAAC_DEBUG_SKIP / PLAAC_VIT_STOP in a host's environment: the library that ships does not read them (VERDICT r04 #4)"""
+    from plaac_amd import synth
+    monkeypatch.setenv("PLAAC_DEBUG_SKIP", "k_win,k_fwd,k_vit,k_tracksL,k_refine_centres,k_tracks20f,k_core_list,k_long")
+    monkeypatch.setenv("PLAAC_DEBUG_SKIP_FROM", "0")
+    monkeypatch.setenv("PLAAC_VIT_STOP", "1")
+    codes, offs = synth.make_batch(2, nprot=900, seed=3, stop_fraction=0.1)
+    want = oracle.score_batch(oracle.build_params(), codes, offs, nthreads=8)
+    with native.Context(native.make_params()) as c:
+        for _ in range(4):  # (the switch used to act from the third call on)
+            rows = c.score(codes, offs)
+            assert_rows_equal(rows, want)

@@ -133,6 +133,27 @@ def test_read_aa_params(io, tmp_path, oracle):
     assert np.array_equal(io.read_aa_params(p)[0], np.arange(22) * 1000.5)
 
 
+def test_reference_written_background_files_round_trip_byte_for_byte(io, oracle):
+    """tests/golden/bg_freqs/*.txt are the reference's OWN output (`plaac.jar -b`, print_aa_params plaac.java:2665-2669,
+    copied by tests/golden/make_bg_freqs.py): plaac_read_aa_params (the -B reader, :2684-2713) followed by
+    plaac_format_aa_params (the -b writer) must reproduce every file byte for byte; the counts are integers, the stop bin
+    counts the terminal stops (countaas does not trim them, :1698-1706); and the oracle's table setup accepts them."""
+    import glob
+    files = sorted(glob.glob(os.path.join(GOLDEN, "bg_freqs", "bg_freqs_*.txt")))
+    assert len(files) == 12
+    for f in files:
+        raw = open(f, "rb").read()
+        vec, warn = io.read_aa_params(f)
+        assert not warn.any(), f
+        assert io.format_aa_params(vec).encode() == raw, f
+        assert np.array_equal(vec, np.round(vec)) and vec[1:21].min() > 0
+        Po = oracle.build_params(alpha=0.5, bgcounts=vec)
+        bg = np.array(Po.bg)
+        assert abs(bg.sum() - 1.0) < 1e-12 and bg[0] > 0 and bg[21] > 0  # eps on X and * (:490-495)
+    human = io.read_aa_params(os.path.join(GOLDEN, "bg_freqs", "bg_freqs_HUMAN.txt"))[0]
+    assert human[1] == 2428201.0 and human[0] == 6721.0  # (first lines of the file as the reference wrote them)
+
+
 def test_summary_row_text(io, oracle, classic4):
     """format a Sup35p row produced by the oracle (tests may use it) and check every column"""
     codes, offs = oracle.pack([s for _, s in classic4])

@@ -7,7 +7,7 @@ out=gpurun_out/r4/ablate.txt
 F="--steps 12 --warmup 4 --no-cpu-baseline --no-e2e --no-predict --no-clock-probe --no-host-leg"
 for skip in "" k_win k_fwd k_vit k_core_list k_vit,k_core_list,k_finish k_refine_centres k_tracksL,k_refine_centres k_tracksL,k_refine_centres,k_tracks20f k_pack k_win,k_fwd,k_vit,k_core_list,k_finish ""; do
   echo "== skip: [$skip]" >> $out
-  PLAAC_DEBUG_SKIP="$skip" timeout -k 10 300 python3 bench.py $F 2>>gpurun_out/r4/ablate.err | python3 -c "
+  PLAAC_NATIVE_LIB=$PWD/plaac_amd/libplaac_native_diag.so PLAAC_DEBUG_SKIP="$skip" timeout -k 10 300 python3 bench.py --allow-diagnostics $F 2>>gpurun_out/r4/ablate.err | python3 -c "
 import sys,json
 for l in sys.stdin:
     l=l.strip()

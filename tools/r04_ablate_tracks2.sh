@@ -7,7 +7,7 @@ out=gpurun_out/r4/ablate_tracks2.txt
 F="--steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-predict --no-clock-probe --no-host-leg --tracks --nprot 1250000"
 for skip in "" k_tracks20s k_fwd_post k_bwd k_bwd,k_fwd_post k_bwd_pair,k_fwd_pair,k_post k_vit k_win k_pack k_tracks20_whole,k_tracks20_list k_core_list ""; do
   echo "== skip: [$skip]" >> $out
-  PLAAC_DEBUG_SKIP="$skip" timeout -k 10 300 python3 bench.py $F 2>>gpurun_out/r4/ablate_tracks2.err | python3 -c "
+  PLAAC_NATIVE_LIB=$PWD/plaac_amd/libplaac_native_diag.so PLAAC_DEBUG_SKIP="$skip" timeout -k 10 300 python3 bench.py --allow-diagnostics $F 2>>gpurun_out/r4/ablate_tracks2.err | python3 -c "
 import sys,json
 for l in sys.stdin:
     l=l.strip()
