@@ -1067,6 +1067,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         }
         case K_BWD:
         case K_BWD_PAIR:
+        case K_BWD_FWD_POST:
         case K_FWD_POST_LANE: { // (o.b > o.a: the wave-groups [o.a, o.b) of the run instead of all of it)
             const bool part = o.b > o.a;
             const uint32_t g0 = part ? o.a : F.segb[o.run];
@@ -1081,6 +1082,15 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             else if (o.kern == K_BWD_PAIR)
                 hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, s,
                                    PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + g0, ctx->d_bwd);
+            else if (o.kern == K_BWD_FWD_POST)
+                hipLaunchKernelGGL(k_bwd_fwd_post<true>, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+                                   PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, ctx->d_bwd, D.tp);
+            else if (o.sel && K.track_post_form == 1)
+                hipLaunchKernelGGL(k_fwd_post_t<256>, dim3((cnt + 255u) / 256u), dim3(256), 0, s, D.d_offsets, PL.neff,
+                                   PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
+            else if (o.sel && K.track_post_occ3)
+                hipLaunchKernelGGL((k_fwd_post<true, 3>), dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+                                   PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
             else if (o.sel)
                 hipLaunchKernelGGL(k_fwd_post<true>, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
                                    PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
@@ -1172,7 +1182,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             if (o.trk) {
                 // (input order behind the long proteins: see the kernel's segment table)
                 const unsigned na = std::min(kb_grid, K.track_consec);
-                hipLaunchKernelGGL(k_tracks20s<true>, dim3(na + kb_grid), dim3(64), 0, s, D.d_codes, PL.order, nprot, D.total, tab,
+                hipLaunchKernelGGL(k_tracks20s<true>, dim3(na + kb_grid), dim3(64), K.track_kb_lds, s, D.d_codes, PL.order, nprot, D.total, tab,
                                    ctx->d_divtab, rows0, D.tp, D.huge, D.d_offsets, PL.neff, (uint32_t)na);
             } else
                 hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, s, D.d_codes, PL.order, nprot, D.total, tab,

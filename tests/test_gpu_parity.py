@@ -860,7 +860,7 @@ def test_hmm_scores_from_the_chain_kernels_or_from_the_finishing_kernel(native, 
             assert_rows_equal(got, want, what="%s, overlapping call %d" % (knobs, rep))
 
 
-@pytest.mark.parametrize("fused", ["0", "1", "every pair kept"])
+@pytest.mark.parametrize("fused", ["0", "1", "every pair kept", "two kernels, r04 launch order", "one kernel", "window kernel behind the packed copy"])
 @pytest.mark.parametrize("vit_mixed", ["0", "1", "throughput-bound"])
 def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, oracle, monkeypatch, fused, vit_mixed):
     """Chain-bound batches in track mode (round 4): the wave-groups without a long protein run the forward pass BEHIND the
@@ -875,6 +875,19 @@ def test_track_mode_posteriors_from_the_forward_pass_or_from_k_post(native, orac
     if fused == "every pair kept":  # the fused pass reading a full backward array instead of recomputing between checkpoints
         fused = "1"
         monkeypatch.setenv("PLAAC_TRACK_CKPT", "0")
+    # round 5's default: the forward pass stores its posteriors transposed through LDS onto 64-byte sectors (k_fwd_post_t),
+    # the window kernel is enqueued behind the packed copy, the Viterbi bytes ahead of k_finish
+    if fused == "two kernels, r04 launch order":  # round 4's forms: a lane stores its own 16-byte runs
+        fused = "1"
+        monkeypatch.setenv("PLAAC_TRACK_POST_FORM", "0")
+        monkeypatch.setenv("PLAAC_TRACK_POST_OCC", "2")
+        monkeypatch.setenv("PLAAC_TRACK_VIT_EARLY", "0")
+    if fused == "one kernel":  # k_bwd_fwd_post: a lane reads back its own checkpoints (measured slower, kept as a form)
+        fused = "1"
+        monkeypatch.setenv("PLAAC_TRACK_ONE_PASS", "1")
+    if fused == "window kernel behind the packed copy":
+        fused = "1"
+        monkeypatch.setenv("PLAAC_TRACK_KB_LATE", "1")
     latency = "1"
     if vit_mixed == "throughput-bound":  # calls not bound by a chain take the same split, with the Viterbi pass in one form
         vit_mixed, latency = "1", "0"
