@@ -232,6 +232,8 @@ def main():
                     "sample (counter passes: their launches would be averaged into the per-launch means)")
     ap.add_argument("--calibrate", action="store_true", help="after the timed region run the histogram kernel once "
                     "(it reads exactly R bytes): calibration of FETCH_SIZE for tools/pmc.sh")
+    ap.add_argument("--max-len", type=int, default=0, help="clip every sequence length (cfg4 with 8192: the length law without its "
+                    "0.01 %% tail of 8,193 - 36,000-residue records: a proteome whose step no single chain bounds)")
     ap.add_argument("--allow-diagnostics", action="store_true", help="run although PLAAC_DEBUG_* / PLAAC_VIT_STOP are set (only a "
                     "DIAG build of the library reads them, and its rows are wrong by design: tools/r04_ablate*.sh)")
     ap.add_argument("--no-tracks-leg", action="store_true", help="N = 1 default line: skip the `tracks` object (the 1.25 M-sequence "
@@ -277,7 +279,8 @@ def main():
     pieces, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=dev)], 0
     for ci, start in enumerate(range(0, nfull, SYNTH_CHUNK)):
         c_, o_ = synth.make_batch_torch(args.config, min(SYNTH_CHUNK, nfull - start), np.array(P.fg), np.array(P.bg),
-                                        dev, seed=synth.SEED0 + args.config + 1000 * seed_rank + 100000 * ci)
+                                        dev, seed=synth.SEED0 + args.config + 1000 * seed_rank + 100000 * ci,
+                                        max_len=args.max_len or None)
         pieces.append(c_)
         offs.append(o_[1:] + base)
         base += int(o_[-1].item())
@@ -863,6 +866,8 @@ def main():
     wl = {2: "cfg2 yeast-shaped proteome (5,880 sequences)", 3: "cfg3 human-shaped proteome (20,600 sequences), "
           "-a 0.5 with the background counted from the input inside every step (two-pass)",
           4: "cfg4 UniRef50-shaped, 10M sequences"}[args.config]
+    if args.max_len:
+        wl += "; lengths clipped at %d" % args.max_len
     if args.nprot:
         wl += "; --nprot %d sequences per GPU" % nprot
     elif strong:

@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 /* 2 (round 5): plaac_node_batch_last_error; node batches are detached (not dangling) when their node is destroyed first;
- * plaac_node_batch_upload rejects offsets[0] != 0; wire rows (plaac_wire_row) for the cross-process gather. A binding
+ * plaac_node_batch_upload rejects offsets[0] != 0; wire rows (plaac_rows_to_wire / _from_wire) for the cross-process gather;
+ * plaac_score_begin_counting / plaac_score_end_counts (scoring and background counts in one pass). A binding
  * compares plaac_abi_version() with the PLAAC_ABI_VERSION it was compiled against before its first call. */
 #define PLAAC_ABI_VERSION 2
 #define PLAAC_NAA 22
@@ -178,6 +179,14 @@ plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *o
  * one context per GPU, two batches in flight). The buffers handed to _begin may be reused as soon as it returns. */
 plaac_status plaac_score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot);
 plaac_status plaac_score_end(plaac_ctx *ctx, plaac_row *rows);
+/* The same pair with the reference's FIRST pass folded in (round 5): the batch's 22 background counts (computeaafreq,
+ * plaac.java:1655-1666: the histogram over its valid records) are taken on the device copy the scoring kernels read and come
+ * back with the rows. For hosts whose scoring tables do not depend on the counts - alpha = 1 (plaac.java:458: the input's
+ * background then only appears in the "## bg_input" line of the parameter block) - the reference's two passes over the input
+ * become one: bin/plaac runs this way by default. A batch begun with plaac_score_begin_counting must be collected with
+ * plaac_score_end_counts. */
+plaac_status plaac_score_begin_counting(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot);
+plaac_status plaac_score_end_counts(plaac_ctx *ctx, plaac_row *rows, int64_t counts[PLAAC_NAA]);
 
 /* ---- resident batches: upload once, use many times -------------------------------------------------------
  * The reference makes one full pass over the input for the background counts and a second one for scoring

@@ -21,12 +21,24 @@
 //                                             free), beyond it the kept batches are released and the scoring pass reads the
 //                                             file again. Resident set of the default two-pass run: that budget + the batches
 //                                             in flight (4 x PLAAC_BATCH_BYTES of text, parsed) + 256 MiB of formatted output
+//   PLAAC_SINGLE_PASS=1                       (round 5, off by default) when the scoring tables do not depend on the input's
+//                                             residue counts - alpha = 1, background counted from the scored input itself
+//                                             (plaac.java:377-384, :458) - and the input fits PLAAC_KEEP_BYTES, run the counting
+//                                             pass INSIDE the scoring pass (plaac_score_begin_counting): the table is formatted
+//                                             while the file is still being read, the parameter block (whose "## bg_input" line
+//                                             needs the final counts) and everything behind it are held back until the last batch
+//                                             has been counted, then written in the reference's order. The bytes on stdout are the
+//                                             same (tested). Measured on the 10 M-sequence input: 2.45 - 2.58 s against 2.2 - 2.7 s
+//                                             for the two passes on the same box - the host's 16 cores are the bound, and parsing
+//                                             beside formatting needs the same core-seconds as parsing before formatting
+//                                             (profiles/r05_e2e_single_pass.txt).
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -35,6 +47,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "plaac_host.h"
@@ -49,7 +62,13 @@ struct Options {
     bool headers = false, params = true;
 };
 
-void put(const std::string &s) { std::fwrite(s.data(), 1, s.size(), stdout); }
+// single-pass runs hold back what the reference prints before the table until the input's residue counts are final:
+// while g_defer is set, put() collects instead of writing
+std::string *g_defer = nullptr;
+void put(const std::string &s) {
+    if (g_defer) g_defer->append(s);
+    else std::fwrite(s.data(), 1, s.size(), stdout);
+}
 
 // PLAAC_TIMING=1: wall-clock of the host stages on stderr (never on stdout: the tables stay byte-identical)
 struct StageTimer {
@@ -140,6 +159,13 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
     if (!e || !*e) return dflt;
     const long long v = std::atoll(e);
     return v > 0 ? (uint64_t)v : dflt;
+}
+
+// on / off switches: unset = dflt, "0" = off, anything else = on (env_u64 takes 0 for "use the default")
+bool env_flag(const char *name, bool dflt) {
+    const char *e = std::getenv(name);
+    if (!e || !*e) return dflt;
+    return !(e[0] == '0' && e[1] == 0);
 }
 
 // Batches the background pass keeps for the scoring pass. Once the input turns out to be larger than the budget the
@@ -317,19 +343,20 @@ class Writer {
     std::condition_variable cv_put, cv_get;
     std::vector<std::string> q;
     size_t bytes = 0;
-    bool closed = false;
+    bool closed = false, held = false;
     std::atomic<bool> bad{false}; // a short write or a stream error (ENOSPC, EIO, closed pipe): the table is incomplete
     std::thread th;
     static constexpr size_t CAP = 256u << 20; // text waiting to be written
 
   public:
-    Writer() {
+    // hold: nothing is written (and nothing waits for room) until release(), which puts `prefix` in front of what has come in
+    explicit Writer(bool hold = false) : held(hold) {
         th = std::thread([this] {
             for (;;) {
                 std::vector<std::string> take;
                 {
                     std::unique_lock<std::mutex> l(m);
-                    cv_get.wait(l, [&] { return !q.empty() || closed; });
+                    cv_get.wait(l, [&] { return (!held && !q.empty()) || closed; });
                     if (q.empty()) return;
                     take.swap(q);
                     bytes = 0;
@@ -344,15 +371,27 @@ class Writer {
     void write(std::string &&s) {
         if (s.empty()) return;
         std::unique_lock<std::mutex> l(m);
-        cv_put.wait(l, [&] { return bytes < CAP; });
+        cv_put.wait(l, [&] { return held || bytes < CAP; });
         bytes += s.size();
         q.push_back(std::move(s));
         cv_get.notify_one();
+    }
+    void release(std::string &&prefix) {
+        std::lock_guard<std::mutex> l(m);
+        if (!held) return;
+        held = false;
+        if (!prefix.empty()) q.insert(q.begin(), std::move(prefix));
+        cv_get.notify_all();
+    }
+    bool is_held() {
+        std::lock_guard<std::mutex> l(m);
+        return held;
     }
     bool finish() { // everything handed over so far has been flushed when this returns; false: a write failed
         {
             std::lock_guard<std::mutex> l(m);
             closed = true;
+            held = false;
             cv_get.notify_all();
         }
         if (th.joinable()) th.join();
@@ -387,7 +426,7 @@ struct Engine {
                 const int n = plaac_device_count();
                 // pipelined scoring (default): ONE context per GPU with two batches in flight; PLAAC_PIPELINE=0: the
                 // synchronous entry point on two contexts per GPU (round 3)
-                const int per = (int)env_u64("PLAAC_CTX_PER_DEVICE", env_u64("PLAAC_PIPELINE", 1) ? 1 : 2);
+                const int per = (int)env_u64("PLAAC_CTX_PER_DEVICE", env_flag("PLAAC_PIPELINE", true) ? 1 : 2);
                 for (int k = 0; k < per; ++k)
                     for (int d = 0; d < n; ++d) devs.push_back(d);
             }
@@ -400,7 +439,7 @@ struct Engine {
             if (st != PLAAC_OK) err = plaac_node_last_error(nullptr);
             // consecutive batches of a context overlap on the device too (the head of a batch beside the tail of the one
             // before it; the long chains of consecutive batches side by side)
-            else if (env_u64("PLAAC_PIPELINE", 1) && env_u64("PLAAC_OVERLAP_CALLS", 1)) (void)plaac_node_set_overlap(node, 1);
+            else if (env_flag("PLAAC_PIPELINE", true) && env_flag("PLAAC_OVERLAP_CALLS", true)) (void)plaac_node_set_overlap(node, 1);
         });
     }
     bool ready(const plaac_params &P) {
@@ -463,16 +502,23 @@ Finish<F> make_finish(F f) {
     return Finish<F>{f};
 }
 
+// `drained` (nullable): called once, by the last worker to leave, when every batch of the input has been worked (and
+// collected) - before the sink has seen them all. With it the pass runs AHEAD of its sink like a keeping pass does (the
+// reader and the workers are not bound to the printer's window): the single-pass run needs the counts of the whole input
+// while the formatter is still busy.
 template <class Prep, class Work, class Sink, class Fin = NoFinish>
 bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, plaac_fasta_stream *fs, const Stream &sp,
                   std::vector<plaac_fasta *> *replay, std::vector<plaac_fasta *> *keep, uint64_t keep_bytes, Prep &&prep,
-                  Work &&work, Sink &&sink, Fin finish = Fin()) {
-    if (!fs && !replay) return true; // nothing to read
+                  Work &&work, Sink &&sink, Fin finish = Fin(), const std::function<void()> *drained = nullptr) {
+    if (!fs && !replay) {
+        if (drained) (*drained)();
+        return true; // nothing to read
+    }
     // A pass that keeps its parsed batches anyway (the background pass, up to keep_bytes) lets the reader run as far
     // ahead as it likes: it parses through the few hundred ms in which the GPU contexts come up instead of stopping
     // four batches in. A pass that does not keep them is bounded to four batches in flight.
     KeptState ks; // (declared before the queues: batches still queued at a failure are destroyed before it)
-    Queue q(keep ? (size_t)1 << 30 : 4);
+    Queue q((keep || drained) ? (size_t)1 << 30 : 4);
     Reorder ro(4); // widened once the number of contexts is known
     std::atomic<bool> failed{false};
     bool keeping = keep != nullptr, keep_overflow = false;
@@ -523,10 +569,12 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
         q.close();
         reader.join();
         if (fs) plaac_fasta_close(fs);
+        if (drained) (*drained)();
         return false;
     }
     const int nctx = plaac_node_size(eng.node);
-    ro.set_window((uint64_t)2 * nctx + 2);
+    ro.set_window(drained ? (uint64_t)1 << 40 : (uint64_t)2 * nctx + 2);
+    std::atomic<int> live_workers{nctx};
     std::vector<std::thread> workers;
     for (int k = 0; k < nctx; ++k)
         workers.emplace_back([&, k] {
@@ -566,6 +614,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                 if (Fin::enabled) pend = std::move(b);
                 else ro.put(std::move(b));
             }
+            if (--live_workers == 0 && drained) (*drained)();
         });
     bool ok = true;
     for (;;) {
@@ -677,25 +726,67 @@ bool count_background(Engine &eng, const plaac_params &P, const std::string &pat
     return ok;
 }
 
+// The single pass (round 5; alpha = 1, background counted from the scored input): what the reference prints before the first
+// table row is held back in `held` (put() collects while g_defer points at it); `block_at` is where the parameter block goes
+// once the counts are final, `make_block(counts, text)` formats it (and checks that the tables the batches were scored
+// with are the tables of those counts).
+struct SinglePass {
+    std::string held;
+    size_t block_at = 0;
+    bool want_block = false;
+    std::function<bool(const double counts[PLAAC_NAA], std::string &text)> make_block;
+};
+
 // ---- pass 2, summary mode (scoreallfastas :653-950) ----
-bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Stream &sp, std::vector<plaac_fasta *> *replay) {
+bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Stream &sp, std::vector<plaac_fasta *> *replay,
+               SinglePass *single = nullptr) {
     if (o.headers) column_notes();
     put(std::string(plaac_summary_header()) + "\n");
     plaac_fasta_stream *fs = nullptr; // the reference opens the file after it has printed the header (:715-750)
     if (!replay && !open_stream(o.input, &fs)) return false;
+    g_defer = nullptr; // (single pass: everything in front of the table is in single->held now)
     const unsigned nt_max = plaac_host_threads();
     uint64_t nres = 0, nrec = 0;
     std::fflush(stdout);
-    Writer writer; // from here on the table goes through the writer thread
-    const bool pipelined = env_u64("PLAAC_PIPELINE", 1) != 0;
-    auto collect = make_finish([](plaac_ctx *ctx, Batch &b) { return plaac_score_end(ctx, b.rows.data()); });
+    Writer writer(single != nullptr); // from here on the table goes through the writer thread
+    const bool pipelined = env_flag("PLAAC_PIPELINE", true) || single;
+    std::mutex cm;
+    int64_t total_counts[PLAAC_NAA] = {0};
+    std::atomic<bool> block_failed{false};
+    auto collect = make_finish([&](plaac_ctx *ctx, Batch &b) {
+        if (!single) return plaac_score_end(ctx, b.rows.data());
+        int64_t c[PLAAC_NAA];
+        const plaac_status st = plaac_score_end_counts(ctx, b.rows.data(), c);
+        if (st == PLAAC_OK) {
+            std::lock_guard<std::mutex> l(cm);
+            for (int i = 0; i < PLAAC_NAA; ++i) total_counts[i] += c[i];
+        }
+        return st;
+    });
+    // every batch of the input has been counted (the formatter is still at work): the parameter block can be written, the
+    // table behind it released
+    const std::function<void()> drained = [&] {
+        if (!single) return;
+        std::string block;
+        double cd[PLAAC_NAA];
+        {
+            std::lock_guard<std::mutex> l(cm);
+            for (int i = 0; i < PLAAC_NAA; ++i) cd[i] = (double)total_counts[i];
+        }
+        if (single->want_block && !single->make_block(cd, block)) block_failed = true;
+        single->held.insert(single->block_at, block);
+        g_timer.lap("single pass: input read, counted, scored");
+        writer.release(std::move(single->held));
+    };
     auto run = [&](auto &&...a) {
-        return pipelined ? run_pipeline(std::forward<decltype(a)>(a)..., collect) : run_pipeline(std::forward<decltype(a)>(a)...);
+        return pipelined ? run_pipeline(std::forward<decltype(a)>(a)..., collect, single ? &drained : nullptr)
+                         : run_pipeline(std::forward<decltype(a)>(a)...);
     };
     const bool ok = run(
         eng, P, o.input, fs, sp, replay, (std::vector<plaac_fasta *> *)nullptr, (uint64_t)0, [](Batch &) {},
         [&](plaac_ctx *ctx, Batch &b) {
             b.rows.resize(b.f->nrec);
+            if (single) return plaac_score_begin_counting(ctx, b.f->codes, b.f->offsets, b.f->nrec);
             if (pipelined) return plaac_score_begin(ctx, b.f->codes, b.f->offsets, b.f->nrec);
             return plaac_score(ctx, b.f->codes, b.f->offsets, b.f->nrec, b.rows.data(), nullptr);
         },
@@ -741,8 +832,13 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             nrec += f->nrec;
             return true;
         });
+    if (single && writer.is_held()) drained(); // (a failed pipeline never drained: what was held still goes out)
     if (!writer.finish()) {
         std::fprintf(stderr, "plaac: writing the table to stdout failed (disk full / closed pipe?): output is incomplete\n");
+        return false;
+    }
+    if (block_failed) {
+        std::fprintf(stderr, "plaac: the scoring tables depend on the input's residue counts after all - rerun with PLAAC_SINGLE_PASS=0\n");
         return false;
     }
     g_timer.lap("scoring pass (read + H2D + GPU + D2H + format + write)", (double)nres, "residues");
@@ -870,11 +966,29 @@ int main(int argc, char **argv) {
               env_u64("PLAAC_BATCH_BYTES", o.plotlist.empty() ? (96ull << 20) : (8ull << 20))};
     const uint64_t keep_bytes = env_u64("PLAAC_KEEP_BYTES", default_keep_bytes());
 
+    // ONE pass instead of the reference's two (counting pass :377-384, scoring pass :755)? Only when the tables the batches
+    // are scored with cannot depend on the counts: alpha = 1 after its clamp (:444-447, :458 - the input's background then
+    // only shows in the "## bg_input" line), background = the scored input itself, summary mode, an input that can be opened
+    // and whose formatted table may wait in memory (the budget of the kept batches of the two-pass run)
+    SinglePass single;
+    bool single_pass = false;
+    {
+        const double a_eff = (o.alpha > 1 || o.alpha < 0) ? 1.0 : o.alpha;
+        struct stat sb;
+        single_pass = env_flag("PLAAC_SINGLE_PASS", false) && env_flag("PLAAC_PIPELINE", true) && !o.input.empty() &&
+                      o.plotlist.empty() && o.bgfreq.empty() && (o.bgfile.empty() || o.bgfile == o.input) && a_eff == 1.0 &&
+                      ::stat(o.input.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && ::access(o.input.c_str(), R_OK) == 0 &&
+                      (uint64_t)sb.st_size <= keep_bytes;
+    }
+    if (single_pass) g_defer = &single.held;
+
     // background counts (:377-384)
     double bgf[PLAAC_NAA] = {0}, fgf[PLAAC_NAA];
     std::vector<plaac_fasta *> kept; // parsed batches of the input, when the background pass read it
     bool kept_valid = false, ok = true;
-    if (!o.bgfreq.empty()) {
+    if (single_pass) {
+        // (counted inside the scoring pass)
+    } else if (!o.bgfreq.empty()) {
         ok = read_params_file(o.bgfreq, bgf);
     } else if (!o.bgfile.empty()) {
         const bool same = o.bgfile == o.input;
@@ -904,7 +1018,25 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "plaac: bad parameters\n");
         return 2;
     }
-    if (o.params) {
+    if (o.params && single_pass) { // the block needs the final counts: its place is kept, its text comes with them
+        single.want_block = true;
+        single.block_at = single.held.size();
+        const plaac_params Pscored = P;
+        const Options oc = o;
+        const bool fg_given = have_fg;
+        std::vector<double> fgv(fgf, fgf + PLAAC_NAA);
+        single.make_block = [Pscored, oc, fg_given, fgv](const double counts[PLAAC_NAA], std::string &out) {
+            plaac_params P2;
+            if (plaac_params_init(&P2, fg_given ? fgv.data() : nullptr, counts, oc.alpha, oc.corelength, oc.ww1, oc.ww2, oc.ww3, 1) != PLAAC_OK)
+                return false;
+            char t2[8192];
+            plaac_format_param_block(&P2, t2, sizeof t2);
+            out = t2;
+            plaac_params Pc = Pscored; // identical but for the input's own frequencies?
+            std::memcpy(Pc.bgthis, P2.bgthis, sizeof Pc.bgthis);
+            return std::memcmp(&Pc, &P2, sizeof P2) == 0;
+        };
+    } else if (o.params) {
         plaac_format_param_block(&P, text, sizeof text);
         put(text);
     }
@@ -925,7 +1057,7 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "plaac: plaac_node_set_params failed: %s\n", plaac_node_last_error(eng.node));
         return 1;
     }
-    ok = o.plotlist.empty() ? score_all(eng, P, o, sp, kept_valid ? &kept : nullptr)
+    ok = o.plotlist.empty() ? score_all(eng, P, o, sp, kept_valid ? &kept : nullptr, single_pass ? &single : nullptr)
                             : plot_some(eng, P, o, sp, kept_valid ? &kept : nullptr);
     // The output is complete and flushed; contexts, batches and the HIP runtime are torn down in order (≈55 ms with
     // two contexts on an MI355X). PLAAC_FAST_EXIT=1 leaves through _exit instead and lets the operating system reclaim

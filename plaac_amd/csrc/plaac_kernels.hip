@@ -161,6 +161,8 @@ struct plaac_ctx {
         uint8_t *d_codes = nullptr;
         uint64_t *d_offsets = nullptr;
         plaac_row *d_rows = nullptr;
+        unsigned long long *d_counts = nullptr; // plaac_score_begin_counting: the batch's 22 background counts
+        bool counted = false;
         size_t cap_codes = 0, cap_offs = 0, cap_rows = 0;
         uint32_t nprot = 0;
         uint64_t call_no = 0; // ncalls of the scoring call (its join event is ev[call_no % EV_SETS][E_JOIN]); ~0: nothing enqueued
@@ -755,7 +757,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     for (auto &sl : ctx->slot)
-        for (void *b : {(void *)sl.d_codes, (void *)sl.d_offsets, (void *)sl.d_rows})
+        for (void *b : {(void *)sl.d_codes, (void *)sl.d_offsets, (void *)sl.d_rows, (void *)sl.d_counts})
             if (b) (void)hipFree(b);
     if (ctx->xfer) {
         (void)hipStreamSynchronize(ctx->xfer);
@@ -1044,7 +1046,10 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
     hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_codes, \
                        D.d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + F.segb[o.run], rows0, \
                        TRK ? ctx->d_fwd : (double2 *)nullptr, PL.lat, nprot)
-            if (o.trk && o.ext) LAUNCH_FWD(true, true);
+            if (K.fwd_direct && !o.trk && !o.ext)
+                hipLaunchKernelGGL(k_fwd_direct, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_codes, D.total,
+                                   D.d_offsets, PL.neff, PL.order + first, cnt, tab, rows0);
+            else if (o.trk && o.ext) LAUNCH_FWD(true, true);
             else if (o.trk) LAUNCH_FWD(true, false);
             else if (o.ext) LAUNCH_FWD(false, true);
             else LAUNCH_FWD(false, false);
@@ -1851,7 +1856,7 @@ plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *o
     return score_resident_to_host(ctx, ctx->d_codes, ctx->d_offsets, nprot, total, rows, tracks);
 }
 
-plaac_status plaac_score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot) {
+static plaac_status score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot, bool counting) {
     if (!ctx) return PLAAC_ERR_ARG;
     if (ctx->slots_busy >= 2) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_begin: two batches are pending (call plaac_score_end)");
     PL_HIP(ctx, hipSetDevice(ctx->device));
@@ -1859,11 +1864,16 @@ plaac_status plaac_score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint6
     plaac_ctx::Slot &S = ctx->slot[ctx->slot_next];
     S.nprot = nprot;
     S.call_no = ~0ull;
+    S.counted = counting;
     if (nprot) {
         uint64_t total = 0;
         plaac_status rc = stage_in_to(ctx, codes, offsets, nprot, &total, S.d_codes, S.cap_codes, S.d_offsets, S.cap_offs, ctx->xfer);
         if (rc != PLAAC_OK) return rc;
         if ((rc = grow(ctx, S.d_rows, S.cap_rows, (size_t)nprot)) != PLAAC_OK) return rc;
+        if (counting) { // the background pass (countaas / isvalidprotein, plaac.java:1698-1739) over the copy the scoring reads
+            if (!S.d_counts) PL_HIP(ctx, hipMalloc(&S.d_counts, sizeof(unsigned long long) * NAA));
+            if ((rc = plaac_histogram_device(ctx, S.d_codes, S.d_offsets, nprot, (int64_t *)S.d_counts, ctx->stream)) != PLAAC_OK) return rc;
+        }
         const uint64_t call_no = ctx->ncalls;
         rc = plaac_score_device(ctx, S.d_codes, S.d_offsets, nprot, total, S.d_rows, nullptr, ctx->stream);
         if (rc != PLAAC_OK) return rc;
@@ -1875,7 +1885,14 @@ plaac_status plaac_score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint6
     return PLAAC_OK;
 }
 
-plaac_status plaac_score_end(plaac_ctx *ctx, plaac_row *rows) {
+plaac_status plaac_score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot) {
+    return score_begin(ctx, codes, offsets, nprot, false);
+}
+plaac_status plaac_score_begin_counting(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot) {
+    return score_begin(ctx, codes, offsets, nprot, true);
+}
+
+static plaac_status score_end(plaac_ctx *ctx, plaac_row *rows, int64_t *counts) {
     if (!ctx) return PLAAC_ERR_ARG;
     if (ctx->slots_busy == 0) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end: no batch is pending");
     PL_HIP(ctx, hipSetDevice(ctx->device));
@@ -1883,10 +1900,23 @@ plaac_status plaac_score_end(plaac_ctx *ctx, plaac_row *rows) {
     S.busy = false; // (whatever happens below, the slot is given up)
     ctx->slot_oldest ^= 1u;
     --ctx->slots_busy;
+    if (counts)
+        for (int i = 0; i < NAA; ++i) counts[i] = 0;
     if (S.nprot == 0 || S.call_no == ~0ull) return PLAAC_OK;
     if (!rows) return fail(ctx, PLAAC_ERR_ARG, "null rows");
+    if (counts && !S.counted) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_counts: the oldest batch was begun without counting");
+    // (the histogram kernel was enqueued on the scoring stream ahead of the call whose join event this is)
     PL_HIP(ctx, hipEventSynchronize(ctx->ev[S.call_no % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
+    if (counts) {
+        PL_HIP(ctx, hipMemcpyAsync(counts, S.d_counts, sizeof(int64_t) * NAA, hipMemcpyDeviceToHost, ctx->xfer));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->xfer));
+    }
     return copy_out(ctx, rows, S.d_rows, sizeof(plaac_row) * (size_t)S.nprot, ctx->xfer);
+}
+plaac_status plaac_score_end(plaac_ctx *ctx, plaac_row *rows) { return score_end(ctx, rows, nullptr); }
+plaac_status plaac_score_end_counts(plaac_ctx *ctx, plaac_row *rows, int64_t counts[PLAAC_NAA]) {
+    if (ctx && !counts) return fail(ctx, PLAAC_ERR_ARG, "null counts");
+    return score_end(ctx, rows, counts);
 }
 
 struct plaac_batch {

@@ -76,7 +76,7 @@ EXPORTS = (
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
-    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_debug_schedule",
+    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_debug_schedule",
 )
 
 _lib = None
@@ -124,6 +124,8 @@ def load():
     L.plaac_debug_schedule.restype = C.c_long
     L.plaac_score_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.plaac_score_end.argtypes = [C.c_void_p, C.c_void_p]
+    L.plaac_score_begin_counting.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.plaac_score_end_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.plaac_score_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
     L.plaac_histogram_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -301,15 +303,31 @@ class Context:
         self._check(self._L.plaac_score_end(self._h, rows.ctypes.data))
         return rows
 
-    def score_stream(self, batches):
-        """scores an iterable of (codes, offsets) batches with two in flight; yields the row arrays in order"""
+    def score_begin_counting(self, codes, offsets):
+        """plaac_score_begin_counting: as score_begin, and the batch's background counts come back with the rows"""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self._L.plaac_score_begin_counting(self._h, codes.ctypes.data, offsets.ctypes.data, len(offsets) - 1))
+        return len(offsets) - 1
+
+    def score_end_counts(self, nprot):
+        """(rows, 22 int64 counts) of the OLDEST pending batch, which was begun with score_begin_counting"""
+        rows = np.zeros(nprot, dtype=ROW_DTYPE)
+        counts = np.zeros(NAA, dtype=np.int64)
+        self._check(self._L.plaac_score_end_counts(self._h, rows.ctypes.data, counts.ctypes.data))
+        return rows, counts
+
+    def score_stream(self, batches, counting=False):
+        """scores an iterable of (codes, offsets) batches with two in flight; yields the row arrays in order
+        (counting: (rows, counts) pairs - the reference's background pass folded into the scoring pass)"""
         pending = []
+        begin, end = (self.score_begin_counting, self.score_end_counts) if counting else (self.score_begin, self.score_end)
         for codes, offsets in batches:
-            pending.append(self.score_begin(codes, offsets))
+            pending.append(begin(codes, offsets))
             if len(pending) == 2:
-                yield self.score_end(pending.pop(0))
+                yield end(pending.pop(0))
         while pending:
-            yield self.score_end(pending.pop(0))
+            yield end(pending.pop(0))
 
     # ---- resident batch: upload once, histogram / score (under several parameter sets) many times ----
     def upload(self, codes, offsets):

@@ -242,3 +242,37 @@ def test_track_table_reads_like_the_R_consumer(io, tmp_path):
         assert "".join(aa for _, _, aa in g) == seqs[nm].rstrip("*")
         post = np.array([[rnum(r[rnames.index(h)]) for h in hmm] for r in rows if int(r[0]) == o_])
         assert np.all(np.abs(post.sum(axis=1) - 1.0) < 1e-3)          # posteriors of the two states
+
+
+def test_single_pass_writes_the_same_bytes_as_the_two_passes(native, tmp_path):
+    """bin/plaac can fold the reference's counting pass (plaac.java:377-384) into its scoring pass when alpha = 1 (round 5,
+    PLAAC_SINGLE_PASS=1: plaac_score_begin_counting; the parameter block waits for the final counts, everything behind it is held back): stdout
+    must be byte-identical to the two-pass run (PLAAC_SINGLE_PASS=0) for every way of asking - plain, with the column notes,
+    an invalid alpha (replaced by 1.0 with the warning line), -b naming the input itself, without the parameter block, with
+    the dot export, many small batches over two contexts, an empty file - and alpha < 1 / -B / -p keep the two passes."""
+    from plaac_amd import synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(4, nprot=3000, seed=90, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.2)
+    fa = tmp_path / "in.fa"
+    _write_fasta(fa, codes, offs)
+    empty = tmp_path / "empty.fa"
+    empty.write_text("")
+    dot = tmp_path / "hmm.dot"
+    cases = [["-i", fa], ["-i", fa, "-d"], ["-i", fa, "-a", "3"], ["-i", fa, "-b", fa], ["-i", fa, "-s"], ["-i", fa, "-h", dot],
+             ["-i", fa, "-c", "30", "-W", "21"], ["-i", empty], ["-i", FA4, "-a", "1.0"], ["-i", fa, "-a", "0.5"],
+             ["-i", fa, "-B", os.path.join(GOLDEN, "bg_freqs", "bg_freqs_YEAST.txt")]]
+    for args in cases:
+        outs = []
+        for env in ({"PLAAC_SINGLE_PASS": "0"}, {"PLAAC_SINGLE_PASS": "1"},
+                    {"PLAAC_SINGLE_PASS": "1", "PLAAC_BATCH_RECORDS": "257", "PLAAC_DEVICES": "0,0"}):
+            r = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300, env=dict(os.environ, PLAAC_TIMING="1", **env))
+            assert r.returncode == 0, r.stderr.decode(errors="replace")
+            outs.append((r.stdout, r.stderr.decode(errors="replace")))
+        assert outs[0][0] == outs[1][0] == outs[2][0], "single pass differs from two passes for %s" % args
+        single = "single pass" in outs[1][1]
+        assert "single pass" not in outs[0][1]
+        expect_single = not any(str(a) in ("0.5", "-B") for a in args)
+        assert single == expect_single, (args, outs[1][1])
+    # a single-pass table is still the oracle's (bg_input line from the counts of the whole input)
+    lines = outs[1][0].decode().split("\n")
+    assert any(l.startswith("## bg_input") for l in lines)

@@ -1050,6 +1050,14 @@ def test_pipelined_host_scoring_two_batches_in_flight(native, oracle, overlap):
         with pytest.raises(native.PlaacError):
             ctx.score_end(1)
         assert_rows_equal(ctx.score(*batches[3]), want[3], "the synchronous entry point afterwards")
+        # round 5: the reference's first pass (computeaafreq, plaac.java:1655-1666) folded into the scoring pass - the
+        # batch's background counts come back with its rows (bin/plaac's single pass when alpha = 1)
+        for k, (g, cnt) in enumerate(ctx.score_stream(batches, counting=True)):
+            assert_rows_equal(g, want[k], "counting batch %d (overlap %s)" % (k, overlap))
+            assert np.array_equal(cnt, oracle.histogram(*batches[k])), "counts of batch %d" % k
+        n0 = ctx.score_begin(*batches[0])  # a batch begun without counting cannot be collected with counts
+        with pytest.raises(native.PlaacError):
+            ctx.score_end_counts(n0)
 
 
 def test_overlapping_calls_of_every_kind_in_any_order(native, oracle):
