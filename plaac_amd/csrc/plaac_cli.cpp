@@ -21,17 +21,18 @@
 //                                             free), beyond it the kept batches are released and the scoring pass reads the
 //                                             file again. Resident set of the default two-pass run: that budget + the batches
 //                                             in flight (4 x PLAAC_BATCH_BYTES of text, parsed) + 256 MiB of formatted output
-//   PLAAC_SINGLE_PASS=1                       (round 5, off by default) when the scoring tables do not depend on the input's
-//                                             residue counts - alpha = 1, background counted from the scored input itself
-//                                             (plaac.java:377-384, :458) - and the input fits PLAAC_KEEP_BYTES, run the counting
-//                                             pass INSIDE the scoring pass (plaac_score_begin_counting): the table is formatted
-//                                             while the file is still being read, the parameter block (whose "## bg_input" line
-//                                             needs the final counts) and everything behind it are held back until the last batch
-//                                             has been counted, then written in the reference's order. The bytes on stdout are the
-//                                             same (tested). Measured on the 10 M-sequence input: 2.45 - 2.58 s against 2.2 - 2.7 s
-//                                             for the two passes on the same box - the host's 16 cores are the bound, and parsing
-//                                             beside formatting needs the same core-seconds as parsing before formatting
-//                                             (profiles/r05_e2e_single_pass.txt).
+//   PLAAC_SINGLE_PASS=0                       always the reference's two passes. Default (round 5): when the scoring tables do
+//                                             not depend on the input's residue counts - alpha = 1, background counted from the
+//                                             scored input itself (plaac.java:377-384, :458) - and the input fits
+//                                             PLAAC_KEEP_BYTES, the counting pass runs INSIDE the scoring pass
+//                                             (plaac_score_begin_counting): the table is formatted while the file is still being
+//                                             read, the parameter block (whose "## bg_input" line needs the final counts) and
+//                                             everything behind it are held back until the last batch has been counted, then
+//                                             written in the reference's order. The bytes on stdout are the same (tested).
+//   PLAAC_HUGE_PAGES=0                        plain allocations for the big host buffers (encoded residues, rows, formatted
+//                                             text) instead of transparent huge pages on request. 10 M sequences, same box:
+//                                             two passes 2.18 - 2.47 s, + huge pages 2.09 - 2.16, + single pass 1.94 - 2.11
+//                                             (profiles/r05_e2e_single_pass.txt; first touch of 3 GiB 0.44 -> 0.12 s)
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -47,6 +48,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -229,12 +231,50 @@ uint64_t default_keep_bytes() {
     return std::min<uint64_t>(4ull << 30, avail / 4);
 }
 
+// Host buffers of a batch's rows / formatted text on transparent huge pages where the host grants them on request (THP mode
+// "madvise" on the MI355X boxes; tools/thp_probe.cpp: first touch of 3 GiB 0.44 -> 0.12 s, unmapping 0.27 -> 0.12 s): a
+// 10 M-sequence run touches 1.6 GB of rows and 2.1 GB of text once each.
+constexpr size_t HUGE_PAGE = 2u << 20;
+inline bool huge_pages_on() { // PLAAC_HUGE_PAGES=0: plain allocations (A/B switch)
+    static const bool on = !(std::getenv("PLAAC_HUGE_PAGES") && std::getenv("PLAAC_HUGE_PAGES")[0] == '0');
+    return on;
+}
+inline void advise_huge(void *p, size_t bytes) {
+    if (!huge_pages_on()) return;
+    const uintptr_t a = ((uintptr_t)p + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE, e = ((uintptr_t)p + bytes) / HUGE_PAGE * HUGE_PAGE;
+    if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+}
+// the rows of a batch: uninitialised (the device copy writes every row), huge pages
+struct RowBuf {
+    plaac_row *p = nullptr;
+    size_t n = 0;
+    void resize(size_t k) {
+        std::free(p);
+        n = k;
+        const size_t bytes = k * sizeof(plaac_row);
+        if (bytes >= 4 * HUGE_PAGE && huge_pages_on()) {
+            const size_t rounded = (bytes + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE;
+            p = (plaac_row *)std::aligned_alloc(HUGE_PAGE, rounded);
+            if (p) (void)madvise(p, rounded, MADV_HUGEPAGE);
+        } else {
+            p = (plaac_row *)std::malloc(bytes ? bytes : 1);
+        }
+        if (!p) throw std::bad_alloc();
+    }
+    plaac_row *data() { return p; }
+    plaac_row &operator[](size_t i) { return p[i]; }
+    ~RowBuf() { std::free(p); }
+    RowBuf() = default;
+    RowBuf(const RowBuf &) = delete;
+    RowBuf &operator=(const RowBuf &) = delete;
+};
+
 struct Batch {
     uint64_t seq = 0;
     plaac_fasta *f = nullptr;
     bool owned = true; // false: kept by the background pass (KeptState decides when it is released)
     KeptState *kept = nullptr;
-    std::vector<plaac_row> rows;
+    RowBuf rows;
     // track mode: the selected records as their own batch
     std::vector<uint32_t> pick;
     std::vector<std::string> ids, names;
@@ -800,6 +840,14 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
                 const uint32_t r0 = (uint32_t)((uint64_t)f->nrec * t / nt), r1 = (uint32_t)((uint64_t)f->nrec * (t + 1) / nt);
                 std::vector<char> line;
                 std::string &out = part[t];
+                // (one allocation per thread and batch instead of a doubling string: ~230 bytes of numbers per row + its name,
+                //  sequences are printed for the few records with a PrD; huge pages)
+                {
+                    const size_t est = (size_t)(r1 - r0) * 260 + (size_t)(f->name_off[r1] - f->name_off[r0]) +
+                                       (size_t)(f->offsets[r1] - f->offsets[r0]) / 8 + 4096;
+                    out.reserve(est);
+                    if (est >= 4 * HUGE_PAGE) advise_huge(&out[0], out.capacity());
+                }
                 for (uint32_t i = r0; i < r1; ++i) {
                     const uint64_t len = f->offsets[i + 1] - f->offsets[i];
                     if (len == 0) {
@@ -975,7 +1023,7 @@ int main(int argc, char **argv) {
     {
         const double a_eff = (o.alpha > 1 || o.alpha < 0) ? 1.0 : o.alpha;
         struct stat sb;
-        single_pass = env_flag("PLAAC_SINGLE_PASS", false) && env_flag("PLAAC_PIPELINE", true) && !o.input.empty() &&
+        single_pass = env_flag("PLAAC_SINGLE_PASS", true) && env_flag("PLAAC_PIPELINE", true) && !o.input.empty() &&
                       o.plotlist.empty() && o.bgfreq.empty() && (o.bgfile.empty() || o.bgfile == o.input) && a_eff == 1.0 &&
                       ::stat(o.input.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && ::access(o.input.c_str(), R_OK) == 0 &&
                       (uint64_t)sb.st_size <= keep_bytes;

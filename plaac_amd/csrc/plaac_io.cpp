@@ -267,6 +267,20 @@ long emit(const std::string &s, char *buf, size_t cap) {
 double inf2nan(double x) { return std::isinf(x) ? std::nan("") : x; } // (:1008)
 
 // worker threads for parsing / formatting: hardware threads capped by the cgroup CPU quota and PLAAC_THREADS
+// Large host buffers (the encoded residues of a batch: up to gigabytes for an input that is kept for a second pass) on
+// transparent huge pages where the host offers them on request (THP mode "madvise", as on the MI355X boxes): first touch of
+// 3 GiB 0.44 s -> 0.12 s, unmapping 0.27 s -> 0.12 s (tools/thp_probe.cpp). free() releases them like any malloc'ed block.
+void *big_alloc(size_t bytes) {
+    constexpr size_t HUGE = 2u << 20;
+    if (bytes < 4 * HUGE) return std::malloc(bytes);
+    const size_t rounded = (bytes + HUGE - 1) / HUGE * HUGE;
+    static const bool off = std::getenv("PLAAC_HUGE_PAGES") && std::getenv("PLAAC_HUGE_PAGES")[0] == '0'; // (A/B switch)
+    if (off) return std::malloc(bytes);
+    void *p = std::aligned_alloc(HUGE, rounded);
+    if (p) (void)madvise(p, rounded, MADV_HUGEPAGE);
+    return p;
+}
+
 unsigned host_threads() {
     unsigned n = std::thread::hardware_concurrency();
     if (n == 0) n = 1;
@@ -436,7 +450,7 @@ static plaac_status parse_records(const char *d, size_t nbytes, size_t rb0, size
     f->offsets[nrec] = off;
     f->name_off[nrec] = noff;
     f->nres = off;
-    f->codes = (uint8_t *)std::malloc(off + 64);
+    f->codes = (uint8_t *)big_alloc(off + 64);
     f->names = (char *)std::malloc(noff + 1);
     if (!f->codes || !f->names) {
         plaac_fasta_free(f);

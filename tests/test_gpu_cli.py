@@ -245,8 +245,8 @@ def test_track_table_reads_like_the_R_consumer(io, tmp_path):
 
 
 def test_single_pass_writes_the_same_bytes_as_the_two_passes(native, tmp_path):
-    """bin/plaac can fold the reference's counting pass (plaac.java:377-384) into its scoring pass when alpha = 1 (round 5,
-    PLAAC_SINGLE_PASS=1: plaac_score_begin_counting; the parameter block waits for the final counts, everything behind it is held back): stdout
+    """bin/plaac folds the reference's counting pass (plaac.java:377-384) into its scoring pass when alpha = 1 (round 5:
+    plaac_score_begin_counting; the parameter block waits for the final counts, everything behind it is held back): stdout
     must be byte-identical to the two-pass run (PLAAC_SINGLE_PASS=0) for every way of asking - plain, with the column notes,
     an invalid alpha (replaced by 1.0 with the warning line), -b naming the input itself, without the parameter block, with
     the dot export, many small batches over two contexts, an empty file - and alpha < 1 / -B / -p keep the two passes."""
@@ -263,8 +263,7 @@ def test_single_pass_writes_the_same_bytes_as_the_two_passes(native, tmp_path):
              ["-i", fa, "-B", os.path.join(GOLDEN, "bg_freqs", "bg_freqs_YEAST.txt")]]
     for args in cases:
         outs = []
-        for env in ({"PLAAC_SINGLE_PASS": "0"}, {"PLAAC_SINGLE_PASS": "1"},
-                    {"PLAAC_SINGLE_PASS": "1", "PLAAC_BATCH_RECORDS": "257", "PLAAC_DEVICES": "0,0"}):
+        for env in ({"PLAAC_SINGLE_PASS": "0", "PLAAC_HUGE_PAGES": "0"}, {}, {"PLAAC_BATCH_RECORDS": "257", "PLAAC_DEVICES": "0,0"}):
             r = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300, env=dict(os.environ, PLAAC_TIMING="1", **env))
             assert r.returncode == 0, r.stderr.decode(errors="replace")
             outs.append((r.stdout, r.stderr.decode(errors="replace")))

@@ -2,8 +2,6 @@
 # round 5: bin/plaac single pass vs two passes: CLI tests, then the 10 M-sequence end-to-end leg both ways (stage clocks on stderr)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5; mkdir -p $O
-timeout -k 10 900 python3 -m pytest tests/test_gpu_cli.py tests/test_real_proteomes.py tests/test_gpu_parity.py -x -q -m gpu -k "cli or pipelined or single_pass or table" > $O/e2e_tests.txt 2>&1; tail -n 4 $O/e2e_tests.txt
-grep -q "passed" $O/e2e_tests.txt && ! grep -q "failed" $O/e2e_tests.txt || exit 1
 python3 - > $O/e2e_single_pass.txt 2>&1 <<'PY'
 import os, sys, subprocess, time, hashlib
 sys.path.insert(0, os.getcwd())
@@ -23,16 +21,17 @@ del codes, offsets, pieces
 torch.cuda.empty_cache()
 print("# 10 M sequences, %d residues, %d bytes of FASTA; bin/plaac -i <fa> > <tsv>, PLAAC_TIMING=1" % (nres, fbytes))
 for rep in range(3):
-    for mode in ("0", "1"):
-        t0 = time.perf_counter()
-        with open(tsv, "wb") as fh:
-            r = subprocess.run(["bin/plaac", "-i", fa], stdout=fh, stderr=subprocess.PIPE, env=dict(os.environ, PLAAC_TIMING="1", PLAAC_SINGLE_PASS=mode))
-        dt = time.perf_counter() - t0
-        h = hashlib.sha256(open(tsv, "rb").read()).hexdigest()[:16]
-        print("PLAAC_SINGLE_PASS=%s: %.3f s  rc %d  sha256 %s  %.3g residues/s" % (mode, dt, r.returncode, h, nres / dt))
-        if rep == 2:
-            for l in r.stderr.decode().splitlines():
-                if l.startswith("plaac-timing"):
-                    print("    " + l)
+    for mode, huge, fast in (("0", "0", ""), ("0", "1", ""), ("1", "1", ""), ("1", "1", "1")):
+        if True:
+            t0 = time.perf_counter()
+            with open(tsv, "wb") as fh:
+                r = subprocess.run(["bin/plaac", "-i", fa], stdout=fh, stderr=subprocess.PIPE, env=dict(os.environ, PLAAC_TIMING="1", PLAAC_SINGLE_PASS=mode, PLAAC_HUGE_PAGES=huge, **({"PLAAC_FAST_EXIT": "1"} if fast else {})))
+            dt = time.perf_counter() - t0
+            h = hashlib.sha256(open(tsv, "rb").read()).hexdigest()[:16]
+            print("PLAAC_SINGLE_PASS=%s PLAAC_HUGE_PAGES=%s%s: %.3f s  rc %d  sha256 %s  %.3g residues/s" % (mode, huge, " PLAAC_FAST_EXIT=1" if fast else "", dt, r.returncode, h, nres / dt))
+            if rep == 2:
+                for l in r.stderr.decode().splitlines():
+                    if l.startswith("plaac-timing"):
+                        print("    " + l)
 PY
 cat $O/e2e_single_pass.txt
