@@ -647,7 +647,10 @@ def main():
         try:
             with open(pth) as fh:
                 tj = json.load(fh)
-            if tj.get("workload") == [args.config, nprot, bool(args.tracks)] and not args.sweep:
+            wkey = list(tj.get("workload") or [])
+            if len(wkey) == 3:  # (files of rounds 1 - 4: no sweep flag)
+                wkey.append(False)
+            if wkey == [args.config, nprot, bool(args.tracks), bool(args.sweep)]:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import pmc_summary
                 counters_sha, tree_sha = tj.get("kernels_source_sha16"), pmc_summary.kernels_sha()
@@ -678,17 +681,18 @@ def main():
     # the forms the library picks by itself comes from a separate pair of passes (tools/r04_pmc_tracks_default_forms.sh)
     traffic_default_forms = None
     if args.tracks and nprot == 1250000 and not args.sweep:
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import pmc_summary
-            with open(os.path.join(ROOT, "profiles", "r04_pmc_tracks_default_forms.txt")) as fh:
-                txt = fh.read()
-            sha = re.search(r"kernels_source_sha16: (\w+)", txt)
-            tot = re.search(r"all scoring kernels: ([0-9.]+) GB per step", txt)
-            if sha and tot and sha.group(1) == pmc_summary.kernels_sha():
-                traffic_default_forms = int(float(tot.group(1)) * 1e9)
-        except (OSError, ValueError):
-            pass
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_summary
+        for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_tracks_default_forms.txt"))):
+            try:
+                with open(pth) as fh:
+                    txt = fh.read()
+                sha = re.search(r"kernels_source_sha16: (\w+)", txt)
+                tot = re.search(r"all scoring kernels: ([0-9.]+) GB per step", txt)
+                if sha and tot and sha.group(1) == pmc_summary.kernels_sha():
+                    traffic_default_forms = int(float(tot.group(1)) * 1e9)
+            except (OSError, ValueError):
+                pass
     path_ms = ktimes["total"]
     step_ms = dt / args.steps * 1e3
     # (rates are per timed step; with overlapping steps a call's own latency - first planning kernel to join - is longer)

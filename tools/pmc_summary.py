@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-KEYS = ("k_long", "k_core_par", "k_calib_read<16, 0>", "k_calib_read<4, 0>", "k_calib_read<4, 1>", "k_tracksL", "k_tracks20f", "k_refine_centres", "k_core_list", "k_core_chain", "k_core_eval", "k_core_reduce", "k_fwd_pair", "k_finish", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
+KEYS = ("k_bwd_fwd_post", "k_fwd_post", "k_fwd_direct", "k_long", "k_core_par", "k_calib_read<16, 0>", "k_calib_read<4, 0>", "k_calib_read<4, 1>", "k_tracksL", "k_tracks20f", "k_refine_centres", "k_core_list", "k_core_chain", "k_core_eval", "k_core_reduce", "k_fwd_pair", "k_finish", "k_tracks20s", "k_tracks20", "k_tracks<", "k_bwd", "k_post", "k_llr_at_centre", "k_replicate", "k_vit", "k_fwd", "k_win", "k_hist", "k_plan_lengths", "k_plan_scan",
         "k_plan_scatter", "k_pack", "k_group_rows", "k_scan_u32")
 
 
@@ -70,7 +70,7 @@ def main(root):
         per_step[k] = round(sum(n) / len(n), 3) if n and k != "k_hist" and not k.startswith("k_calib") else 1.0
     step = {k: {c: v * per_step[k] for c, v in d.items()} for k, d in mean.items()}
     summary = {"counters_mean_per_launch": mean, "launches_per_step": per_step, "kernel_durations": durations, "bench_lines": bench}
-    cfg = bench.get("trace_serial", {}).get("config", {})
+    cfg = (bench.get("trace_serial", {}).get("config") or bench.get("trace_concurrent", {}).get("config") or {})
     R, P = cfg.get("residues_per_gpu"), cfg.get("sequences_per_gpu")
     traffic = {}
     for k, c in step.items():
@@ -128,7 +128,8 @@ def main(root):
     if R:
         mode = cfg.get("mode") == "tracks"
         wl = {"cfg2": 2, "cfg3": 3, "cfg4": 4}.get(cfg.get("workload", "")[:4], 4)
-        json.dump({"workload": [wl, P, mode], "kernels_source_sha16": kernels_sha(), "source": "tools/pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+        sweep = "sweep" in (cfg.get("mode") or "")
+        json.dump({"workload": [wl, P, mode, sweep], "kernels_source_sha16": kernels_sha(), "source": "tools/pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                    "passes); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md gfx950 correction",
                    "bytes_per_launch": {k: round(v["hbm_bytes_gfx950_corrected"]) for k, v in traffic.items()
                                         if not k.startswith("k_calib")},
