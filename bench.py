@@ -650,7 +650,7 @@ def main():
             wkey = list(tj.get("workload") or [])
             if len(wkey) == 3:  # (files of rounds 1 - 4: no sweep flag)
                 wkey.append(False)
-            if wkey == [args.config, nprot, bool(args.tracks), bool(args.sweep)]:
+            if wkey == [args.config, nprot, bool(args.tracks), bool(args.sweep)] and not args.max_len:  # (clipped lengths: another workload)
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import pmc_summary
                 counters_sha, tree_sha = tj.get("kernels_source_sha16"), pmc_summary.kernels_sha()
@@ -680,7 +680,7 @@ def main():
     # track mode: tools/pmc.sh serialises the streams, which selects the throughput forms of the chain kernels - the traffic of
     # the forms the library picks by itself comes from a separate pair of passes (tools/r04_pmc_tracks_default_forms.sh)
     traffic_default_forms = None
-    if args.tracks and nprot == 1250000 and not args.sweep:
+    if args.tracks and nprot == 1250000 and not args.sweep and not args.max_len:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import pmc_summary
         for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_tracks_default_forms.txt"))):
