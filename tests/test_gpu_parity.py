@@ -485,13 +485,20 @@ def test_log_sum_exp_with_and_without_its_in_range_select(native, oracle, monkey
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["1", "0"])
+@pytest.mark.parametrize("form", ["1", "0", "1, core search behind the whole pass", "1, chains first"])
 def test_chain_bound_sweep_with_long_proteins_in_both_viterbi_forms(native, oracle, monkeypatch, form):
     """a chain-bound sweep over a batch whose first wave-groups hold proteins of >= 2048 residues: those groups are a run of
     their own in the latency form of k_vit, their core windows come from k_core_chain / _eval / _reduce per core length
     with scratch per sweep group (form 1); form 0 keeps the throughput form for every wave-group. Five core lengths per
     alpha: two launches per group. Prion-like long proteins, so that the long groups do have cores."""
     from plaac_amd import synth
+    # round 5: the core search of the long wave-groups runs on the group's forward stream as soon as the latency-form pass over
+    # them is through (default); the older place and the other launch order are forms of their own
+    if "behind the whole pass" in form:
+        monkeypatch.setenv("PLAAC_SWEEP_CORE_ASIDE", "0")
+    if "chains first" in form:
+        monkeypatch.setenv("PLAAC_SWEEP_CHAINS_FIRST", "1")
+    form = form[0]
     monkeypatch.setenv("PLAAC_LATENCY_MODE", "1")
     monkeypatch.setenv("PLAAC_SWEEP_LATENCY", form)
     P = native.make_params()
