@@ -1362,7 +1362,7 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
         if ((rc = grow(ctx, PL.crow, PL.cap_crow, (size_t)nprot)) != PLAAC_OK) return rc;
         if ((rc = grow(ctx, PL.fblist, PL.cap_fblist, (size_t)nprot)) != PLAAC_OK) return rc;
     }
-    while (ctx->gev.size() < 3 * (size_t)sched::MAXG) { // per group: forward pass done / long-run Viterbi pass done / long-run core search done
+    while (ctx->gev.size() < 4 * (size_t)sched::MAXG) { // per group: forward pass done / long-run Viterbi pass done / long-run core search done / the other wave-groups' Viterbi pass done
         hipEvent_t e = nullptr;
         PL_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->gev.push_back(e);

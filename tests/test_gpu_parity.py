@@ -485,7 +485,7 @@ def test_log_sum_exp_with_and_without_its_in_range_select(native, oracle, monkey
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["1", "0", "1, core search behind the whole pass", "1, chains first"])
+@pytest.mark.parametrize("form", ["1", "0", "1, core search behind the whole pass", "1, chains first", "1, own streams", "1, own streams, the other wave-groups aside"])
 def test_chain_bound_sweep_with_long_proteins_in_both_viterbi_forms(native, oracle, monkeypatch, form):
     """a chain-bound sweep over a batch whose first wave-groups hold proteins of >= 2048 residues: those groups are a run of
     their own in the latency form of k_vit, their core windows come from k_core_chain / _eval / _reduce per core length
@@ -498,6 +498,10 @@ def test_chain_bound_sweep_with_long_proteins_in_both_viterbi_forms(native, orac
         monkeypatch.setenv("PLAAC_SWEEP_CORE_ASIDE", "0")
     if "chains first" in form:
         monkeypatch.setenv("PLAAC_SWEEP_CHAINS_FIRST", "1")
+    if "own streams" in form:  # (as with GPU_MAX_HW_QUEUES >= 12: the other wave-groups' Viterbi pass then runs beside the long chains)
+        monkeypatch.setenv("PLAAC_SWEEP_SPREAD", "0")
+    if "wave-groups aside" in form:
+        monkeypatch.setenv("PLAAC_SWEEP_REST_ASIDE", "1")
     form = form[0]
     monkeypatch.setenv("PLAAC_LATENCY_MODE", "1")
     monkeypatch.setenv("PLAAC_SWEEP_LATENCY", form)

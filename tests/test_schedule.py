@@ -172,7 +172,7 @@ def test_no_wait_can_deadlock_and_conflicting_accesses_are_ordered(native, shape
     assert not m.errors, "\n".join(m.errors[:12])
 
 
-KNOBS = [{"PLAAC_SWEEP_CORE_ASIDE": "0"}, {"PLAAC_SWEEP_CHAINS_FIRST": "1"}, {"PLAAC_SWEEP_CORE_ASIDE": "0", "PLAAC_SWEEP_CHAINS_FIRST": "1"}, {"PLAAC_TRACK_ONE_PASS": "1"}, {"PLAAC_TRACK_KB_LATE": "1"}, {"PLAAC_TRACK_VIT_EARLY": "0"}, {"PLAAC_SERIAL_STREAMS": "1"}, {"PLAAC_KB_SIDE": "0"}, {"PLAAC_FINISH_KERNEL": "1"}, {"PLAAC_KB_PRIO": "0"}, {"PLAAC_TRACK_FUSED": "0"}, {"PLAAC_TRACK_VIT_MIXED": "0"}, {"PLAAC_TRACK_CONSEC": "0"}, {"PLAAC_TRACK_CKPT": "0"}, {"PLAAC_TRACK_SEGMENTS": "2"},
+KNOBS = [{"PLAAC_SWEEP_SPREAD": "0", "PLAAC_SWEEP_REST_ASIDE": "1"}, {"PLAAC_SWEEP_SPREAD": "0", "PLAAC_SWEEP_CORE_ASIDE": "0"}, {"PLAAC_SWEEP_CORE_ASIDE": "0"}, {"PLAAC_SWEEP_CHAINS_FIRST": "1"}, {"PLAAC_SWEEP_CORE_ASIDE": "0", "PLAAC_SWEEP_CHAINS_FIRST": "1"}, {"PLAAC_TRACK_ONE_PASS": "1"}, {"PLAAC_TRACK_KB_LATE": "1"}, {"PLAAC_TRACK_VIT_EARLY": "0"}, {"PLAAC_SERIAL_STREAMS": "1"}, {"PLAAC_KB_SIDE": "0"}, {"PLAAC_FINISH_KERNEL": "1"}, {"PLAAC_KB_PRIO": "0"}, {"PLAAC_TRACK_FUSED": "0"}, {"PLAAC_TRACK_VIT_MIXED": "0"}, {"PLAAC_TRACK_CONSEC": "0"}, {"PLAAC_TRACK_CKPT": "0"}, {"PLAAC_TRACK_SEGMENTS": "2"},
          {"PLAAC_MIXED_MIN_REST": "1", "PLAAC_TRACK_SEGMENTS": "4", "PLAAC_SEGMENT_MIN_ROWS": "1"}, {"PLAAC_MIXED": "0"}, {"PLAAC_LATENCY_MODE": "1"}, {"PLAAC_LATENCY_MODE": "0"},
          {"PLAAC_KB_LANE": "0"}, {"PLAAC_KB_FILTER": "0"}, {"PLAAC_CORE_LIST": "0"}, {"PLAAC_MIXED_GROUPS": "3", "PLAAC_MIXED_MIN_REST": "1"},
          {"PLAAC_KB_LANE_MIN_GROUPS": "1"}, {"PLAAC_PIPE_SEGMENTS": "4", "PLAAC_SEGMENT_MIN_ROWS": "1"},
