@@ -49,6 +49,32 @@ plaac_status plaac_fasta_open(const char *path, plaac_fasta_stream **out);
 plaac_status plaac_fasta_next(plaac_fasta_stream *s, uint32_t max_records, uint64_t max_bytes, plaac_fasta **out);
 void plaac_fasta_close(plaac_fasta_stream *s);
 
+/* The stream cut into batches of TEXT for the device-side parser (plaac_score_begin_text, round 5): the same batch boundaries
+ * as plaac_fasta_next, but the records are only LOCATED - starts[i] = offset of record i's '>' inside `text`, starts[nrec] = len -
+ * and their names copied (untrimmed: whether a name is trimmed depends on how the record before it ended, :4362, which the
+ * device reports as blank_end; plaac_fasta_text_trim_names applies it). `text` points into the stream's file image and stays
+ * valid until plaac_fasta_text_free (which also lets the stream release the pages behind it). *out = NULL at the end. */
+typedef struct plaac_fasta_text {
+    const char *text;
+    uint64_t len;
+    uint32_t nrec;
+    uint64_t *starts;   /* nrec + 1 */
+    char *names;        /* all headers, NUL-separated */
+    uint64_t *name_off; /* nrec + 1 offsets into names */
+    void *owner_;       /* the stream (page release bookkeeping) */
+    uint64_t file_off_; /* offset of `text` in the file */
+} plaac_fasta_text;
+plaac_status plaac_fasta_next_text(plaac_fasta_stream *s, uint32_t max_records, uint64_t max_bytes, plaac_fasta_text **out);
+void plaac_fasta_text_free(plaac_fasta_text *t);
+/* trims the names the reference trims: the first record of the file and every record whose predecessor ended in an empty
+ * line. prev_blank: how the record before this batch ended (1 for the first batch); returns the flag for the next batch. */
+int plaac_fasta_text_trim_names(plaac_fasta_text *t, const uint8_t *blank_end, int prev_blank);
+/* Residues [first, first + count) of record i of a text batch, encoded as plaac_encode does, read from the TEXT with the
+ * extents the device reported for the batch (plaac_score_end_text: extents[2i], extents[2i+1]): the host's way to the few
+ * residues a summary row prints without a copy of all codes. Returns how many were written (fewer when the record ends). */
+uint64_t plaac_fasta_text_codes(const char *text, const uint64_t *starts, const uint32_t *extents, uint32_t i, uint64_t first,
+                                uint64_t count, uint8_t *out);
+
 /* Worker threads the host helpers use for parsing / formatting: hardware threads, capped by the cgroup CPU
  * quota, overridable with PLAAC_THREADS. plaac_fasta_read parses records in parallel (they are independent once
  * the header lines are located). */

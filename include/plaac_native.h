@@ -187,6 +187,23 @@ plaac_status plaac_score_end(plaac_ctx *ctx, plaac_row *rows);
  * plaac_score_end_counts. */
 plaac_status plaac_score_begin_counting(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot);
 plaac_status plaac_score_end_counts(plaac_ctx *ctx, plaac_row *rows, int64_t counts[PLAAC_NAA]);
+/* The same pipeline fed with FASTA TEXT (round 5; SURVEY.md section 2, K1 "encode / validate"): the host only finds where the
+ * records begin - text[starts[i]] is the '>' of record i, starts[nrec] = text_len: whole records, as plaac_fasta_next_text
+ * (plaac_host.h) cuts them - and keeps their names; the DEVICE splits the lines, drops the line terminators, stops a record
+ * at an empty line and encodes the residues (fastareader plaac.java:4302-4375, string2aa / aatoint :1764-1769, :1508-1534,
+ * exactly as plaac_fasta_next / plaac_encode do on the host - tested against them). counting != 0: the background counts as
+ * in plaac_score_begin_counting. plaac_score_end_text returns the rows and, for the host's formatter, what the device parsed:
+ * codes (NULLABLE; capacity codes_cap bytes, text_len always suffices), offsets (nrec + 1), blank_end (nrec: 1 = the record's
+ * sequence ended at an empty line, which makes the reference trim the NEXT record's name, :4362), extents (nullable, 2 * nrec:
+ * per record the positions, relative to its start, of the header's line end and of the empty line that ended it - or the
+ * record's length; its residues are the bytes between them that are not line ends), counts (nullable). A host that prints a
+ * few residues per record (the summary table: the PAPA window, the sequences of the records with a PrD) leaves `codes` NULL
+ * and reads them from the text it still holds with plaac_fasta_text_codes (plaac_host.h) - bin/plaac does: a copy of every
+ * code back to the host costs the collecting thread more than the parse it saved. */
+plaac_status plaac_score_begin_text(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
+                                    int counting);
+plaac_status plaac_score_end_text(plaac_ctx *ctx, plaac_row *rows, uint8_t *codes, uint64_t codes_cap, uint64_t *offsets,
+                                  uint8_t *blank_end, uint32_t *extents, int64_t *counts);
 
 /* ---- resident batches: upload once, use many times -------------------------------------------------------
  * The reference makes one full pass over the input for the background counts and a second one for scoring

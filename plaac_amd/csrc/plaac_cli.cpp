@@ -15,7 +15,9 @@
 // scores them, and the main thread formats and prints them in file order while later batches are still being read
 // and scored. Memory is bounded by the batches in flight, whatever the size of the file.
 //   PLAAC_BATCH_RECORDS / PLAAC_BATCH_BYTES   batch size (default 262144 records / 96 MiB of FASTA text)
-//   PLAAC_DEVICES=0,1,...                     devices to use, a device may be repeated (default: all, PLAAC_CTX_PER_DEVICE = 2 each)
+//   PLAAC_DEVICES=0,1,...                     devices to use, a device may be repeated (default: one context on each of the
+//                                             first ceil(input bytes / PLAAC_BYTES_PER_DEVICE) GPUs, 4 GiB per device: a context
+//                                             costs 0.15 s to bring up, and the kernels of 3 GB of FASTA take 0.14 s of ONE GPU)
 //   PLAAC_KEEP_BYTES                          the background pass keeps the parsed batches for the scoring pass up to this many
 //                                             bytes (default: 4 GiB, at most a quarter of the memory the host / cgroup has
 //                                             free), beyond it the kept batches are released and the scoring pass reads the
@@ -29,12 +31,24 @@
 //                                             read, the parameter block (whose "## bg_input" line needs the final counts) and
 //                                             everything behind it are held back until the last batch has been counted, then
 //                                             written in the reference's order. The bytes on stdout are the same (tested).
+//   PLAAC_PLACED_WRITE=0                      single pass with stdout a plain file (not a pipe, not opened for appending): the
+//                                             table is written where it belongs while the block still waits - a placeholder of
+//                                             the block's length (made-up counts) first, the real block over it at the end; if
+//                                             the length differs after all (no valid residue: NaN) the table is moved. 0: hold
+//                                             everything back, as for a pipe. 10 M sequences: 1.40 - 1.50 s -> 1.25 - 1.35 s
+//   PLAAC_DEVICE_PARSE=0                      single pass: the HOST splits lines and encodes (plaac_fasta_next). Default (round
+//                                             5, K1): the host only finds the records and keeps their names, the device parses
+//                                             (plaac_score_begin_text); the few residues a row prints are read from the text
+//   PLAAC_TIMING=1                            stage clock on stderr; with PLAAC_TIMING_T0=<the launcher's CLOCK_MONOTONIC, ns>
+//                                             also since the launch, with PLAAC_TIMING_MAPS=1 the large resident mappings
 //   PLAAC_HUGE_PAGES=0                        plain allocations for the big host buffers (encoded residues, rows, formatted
 //                                             text) instead of transparent huge pages on request. 10 M sequences, same box:
 //                                             two passes 2.18 - 2.47 s, + huge pages 2.09 - 2.16, + single pass 1.94 - 2.11
 //                                             (profiles/r05_e2e_single_pass.txt; first touch of 3 GiB 0.44 -> 0.12 s)
 #include <atomic>
+#include <fcntl.h>
 #include <chrono>
+#include <ctime>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -83,6 +97,39 @@ struct StageTimer {
         if (units > 0) std::fprintf(stderr, "plaac-timing: %-28s %9.3f ms  %.3g %s/s\n", what, s * 1e3, units / s, unit);
         else std::fprintf(stderr, "plaac-timing: %-28s %9.3f ms\n", what, s * 1e3);
         t0 = t1;
+    }
+    // PLAAC_TIMING_T0 = the launcher's CLOCK_MONOTONIC in ns when it started this process: what exec + dynamic loading took
+    // (this object is constructed after the libraries are in), and `mark` = the same clock at a point of interest
+    static double mono_ms() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    }
+    double loaded_ms = mono_ms();
+    void mark(const char *what) const {
+        const char *e = std::getenv("PLAAC_TIMING_T0");
+        if (!on || !e) return;
+        const double t0ms = std::strtod(e, nullptr) * 1e-6;
+        std::fprintf(stderr, "plaac-timing: %-28s %9.3f ms after the launch (libraries loaded at %.3f ms)\n", what, mono_ms() - t0ms,
+                     loaded_ms - t0ms);
+        if (FILE *fp = std::fopen("/proc/self/status", "r")) { // what the operating system will have to take back at exit
+            char line[256];
+            while (std::fgets(line, sizeof line, fp))
+                if (!std::strncmp(line, "VmRSS", 5) || !std::strncmp(line, "Rss", 3) || !std::strncmp(line, "VmPTE", 5) ||
+                    !std::strncmp(line, "VmSize", 6) || !std::strncmp(line, "VmLck", 5) || !std::strncmp(line, "VmPin", 5))
+                    std::fprintf(stderr, "plaac-timing:     %s", line);
+            std::fclose(fp);
+        }
+        if (std::getenv("PLAAC_TIMING_MAPS"))
+            if (FILE *fp = std::fopen("/proc/self/smaps", "r")) { // the mappings with more than 32 MB resident
+                char line[512], head[512] = "";
+                while (std::fgets(line, sizeof line, fp)) {
+                    unsigned long a, b, kb;
+                    if (std::sscanf(line, "%lx-%lx ", &a, &b) == 2 && std::strchr(line, '-') && !std::strstr(line, "kB")) std::strncpy(head, line, sizeof head - 1);
+                    else if (std::sscanf(line, "Rss: %lu kB", &kb) == 1 && kb > 32768) std::fprintf(stderr, "plaac-timing:     %8lu kB resident in %s", kb, head);
+                }
+                std::fclose(fp);
+            }
     }
 } g_timer;
 
@@ -244,30 +291,32 @@ inline void advise_huge(void *p, size_t bytes) {
     const uintptr_t a = ((uintptr_t)p + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE, e = ((uintptr_t)p + bytes) / HUGE_PAGE * HUGE_PAGE;
     if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
 }
-// the rows of a batch: uninitialised (the device copy writes every row), huge pages
-struct RowBuf {
-    plaac_row *p = nullptr;
+// the rows (codes) of a batch: uninitialised (the device copy writes every element), huge pages
+template <class T>
+struct HugeBuf {
+    T *p = nullptr;
     size_t n = 0;
     void resize(size_t k) {
         std::free(p);
         n = k;
-        const size_t bytes = k * sizeof(plaac_row);
+        const size_t bytes = k * sizeof(T);
         if (bytes >= 4 * HUGE_PAGE && huge_pages_on()) {
             const size_t rounded = (bytes + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE;
-            p = (plaac_row *)std::aligned_alloc(HUGE_PAGE, rounded);
+            p = (T *)std::aligned_alloc(HUGE_PAGE, rounded);
             if (p) (void)madvise(p, rounded, MADV_HUGEPAGE);
         } else {
-            p = (plaac_row *)std::malloc(bytes ? bytes : 1);
+            p = (T *)std::malloc(bytes ? bytes : 1);
         }
         if (!p) throw std::bad_alloc();
     }
-    plaac_row *data() { return p; }
-    plaac_row &operator[](size_t i) { return p[i]; }
-    ~RowBuf() { std::free(p); }
-    RowBuf() = default;
-    RowBuf(const RowBuf &) = delete;
-    RowBuf &operator=(const RowBuf &) = delete;
+    T *data() { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    ~HugeBuf() { std::free(p); }
+    HugeBuf() = default;
+    HugeBuf(const HugeBuf &) = delete;
+    HugeBuf &operator=(const HugeBuf &) = delete;
 };
+using RowBuf = HugeBuf<plaac_row>;
 
 struct Batch {
     uint64_t seq = 0;
@@ -286,8 +335,16 @@ struct Batch {
     plaac_status st = PLAAC_OK;
     bool begun = false; // pipelined scoring: plaac_score_begin has taken the batch (plaac_score_end is owed)
     std::string err;
+    // device-side parse (K1): the batch as located text; `view` is what the device made of it (f points at it once the
+    // batch has been collected; the names are the text batch's, trimmed by the sink, which sees the batches in file order)
+    plaac_fasta_text *ft = nullptr;
+    plaac_fasta view{};
+    std::vector<uint64_t> toffs;
+    std::vector<uint8_t> tblank;
+    std::vector<uint32_t> text_ext; // per record: where its header line and its sequence end (plaac_score_end_text)
     ~Batch() {
-        if (f && owned) plaac_fasta_free(f);
+        if (ft) plaac_fasta_text_free(ft);
+        else if (f && owned) plaac_fasta_free(f);
         else if (f && kept) kept->batch_gone(f);
     }
 };
@@ -378,10 +435,79 @@ class Reorder {
 };
 
 // stdout writer on its own thread: the formatter hands over finished text and goes on with the next batch
+// Formatted text on its way to stdout: buffers on huge pages that go back to a pool when they have been written, instead of
+// a std::string per formatter thread and batch. (Those came from malloc arenas - a fresh set of threads per batch, up to 8 x
+// cores arenas - that never shrink: 2.1 GB resident at the end of a 10 M-sequence run, first touched 4 KB at a time and
+// handed back 4 KB at a time by the exit, 0.5 s after the output was complete; profiles/r05_e2e_device_parse.txt.)
+struct TextBuf {
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    void append(const char *s, size_t k) {
+        if (n + k > cap) grow(n + k);
+        std::memcpy(p + n, s, k);
+        n += k;
+    }
+    void push_back(char c) { append(&c, 1); }
+    static char *alloc(size_t &cap) {
+        cap = (cap + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE;
+        char *q = (char *)std::aligned_alloc(HUGE_PAGE, cap);
+        if (!q) throw std::bad_alloc();
+        if (huge_pages_on()) (void)madvise(q, cap, MADV_HUGEPAGE);
+        return q;
+    }
+    void grow(size_t need) {
+        size_t c2 = std::max(need, cap * 2);
+        char *q = alloc(c2);
+        if (n) std::memcpy(q, p, n);
+        std::free(p);
+        p = q;
+        cap = c2;
+    }
+};
+class TextPool {
+    std::mutex m;
+    std::vector<TextBuf> idle;
+    static constexpr size_t KEEP = 96; // buffers kept for reuse (a part of a full batch is ~5 MB)
+
+  public:
+    TextBuf get(size_t cap) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (size_t k = idle.size(); k-- > 0;)
+                if (idle[k].cap >= cap) {
+                    TextBuf b = idle[k];
+                    idle[k] = idle.back();
+                    idle.pop_back();
+                    b.n = 0;
+                    return b;
+                }
+        }
+        TextBuf b;
+        b.cap = cap;
+        b.p = TextBuf::alloc(b.cap);
+        return b;
+    }
+    void put(TextBuf b) {
+        if (!b.p) return;
+        {
+            std::lock_guard<std::mutex> l(m);
+            if (idle.size() < KEEP) {
+                idle.push_back(b);
+                return;
+            }
+        }
+        std::free(b.p);
+    }
+    ~TextPool() {
+        for (TextBuf &b : idle) std::free(b.p);
+    }
+};
+
 class Writer {
     std::mutex m;
     std::condition_variable cv_put, cv_get;
-    std::vector<std::string> q;
+    std::vector<TextBuf> q;
+    TextPool pool;
     size_t bytes = 0;
     bool closed = false, held = false;
     std::atomic<bool> bad{false}; // a short write or a stream error (ENOSPC, EIO, closed pipe): the table is incomplete
@@ -393,7 +519,7 @@ class Writer {
     explicit Writer(bool hold = false) : held(hold) {
         th = std::thread([this] {
             for (;;) {
-                std::vector<std::string> take;
+                std::vector<TextBuf> take;
                 {
                     std::unique_lock<std::mutex> l(m);
                     cv_get.wait(l, [&] { return (!held && !q.empty()) || closed; });
@@ -402,25 +528,44 @@ class Writer {
                     bytes = 0;
                     cv_put.notify_all();
                 }
-                for (const std::string &s : take)
-                    if (!bad && std::fwrite(s.data(), 1, s.size(), stdout) != s.size()) bad = true;
+                for (TextBuf &s : take) {
+                    if (!bad && std::fwrite(s.p, 1, s.n, stdout) != s.n) bad = true;
+                    pool.put(s);
+                }
             }
         });
     }
     bool failed() const { return bad; }
-    void write(std::string &&s) {
-        if (s.empty()) return;
+    TextBuf buffer(size_t cap) { return pool.get(cap); } // for write(): goes back to the pool when it has been written
+    void write(TextBuf s) {
+        if (s.n == 0) {
+            pool.put(s);
+            return;
+        }
         std::unique_lock<std::mutex> l(m);
         cv_put.wait(l, [&] { return held || bytes < CAP; });
-        bytes += s.size();
-        q.push_back(std::move(s));
+        bytes += s.n;
+        q.push_back(s);
         cv_get.notify_one();
     }
-    void release(std::string &&prefix) {
+    void write(const std::string &s) {
+        TextBuf b = pool.get(s.size() + 1);
+        b.append(s.data(), s.size());
+        write(b);
+    }
+    void release(const std::string &prefix) {
+        TextBuf b{};
+        if (!prefix.empty()) {
+            b = pool.get(prefix.size() + 1);
+            b.append(prefix.data(), prefix.size());
+        }
         std::lock_guard<std::mutex> l(m);
-        if (!held) return;
+        if (!held) {
+            pool.put(b);
+            return;
+        }
         held = false;
-        if (!prefix.empty()) q.insert(q.begin(), std::move(prefix));
+        if (b.n) q.insert(q.begin(), b);
         cv_get.notify_all();
     }
     bool is_held() {
@@ -449,9 +594,11 @@ struct Engine {
     plaac_status st = PLAAC_OK;
     std::string err;
     bool started = false, joined = false;
-    void start(const plaac_params &P) { // HIP start-up takes a few hundred ms: it runs beside option handling / parsing
+    // max_devices: how many of the visible GPUs a run of this size is worth (a context costs ~0.15 s to bring up and ~40 ms to
+    // take down, and the summary table of a 3 GB input keeps ONE GPU busy for a tenth of the run: the host formats)
+    void start(const plaac_params &P, int max_devices = 1 << 30) { // HIP start-up takes a few hundred ms: it runs beside option handling / parsing
         started = true;
-        starter = std::thread([this, P] {
+        starter = std::thread([this, P, max_devices] {
             std::vector<int> devs;
             if (const char *e = std::getenv("PLAAC_DEVICES")) {
                 for (const char *p = e; *p;) {
@@ -463,7 +610,7 @@ struct Engine {
                 }
             }
             if (devs.empty()) {
-                const int n = plaac_device_count();
+                const int n = std::min(plaac_device_count(), std::max(1, max_devices));
                 // pipelined scoring (default): ONE context per GPU with two batches in flight; PLAAC_PIPELINE=0: the
                 // synchronous entry point on two contexts per GPU (round 3)
                 const int per = (int)env_u64("PLAAC_CTX_PER_DEVICE", env_flag("PLAAC_PIPELINE", true) ? 1 : 2);
@@ -549,7 +696,8 @@ Finish<F> make_finish(F f) {
 template <class Prep, class Work, class Sink, class Fin = NoFinish>
 bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, plaac_fasta_stream *fs, const Stream &sp,
                   std::vector<plaac_fasta *> *replay, std::vector<plaac_fasta *> *keep, uint64_t keep_bytes, Prep &&prep,
-                  Work &&work, Sink &&sink, Fin finish = Fin(), const std::function<void()> *drained = nullptr) {
+                  Work &&work, Sink &&sink, Fin finish = Fin(), const std::function<void()> *drained = nullptr,
+                  bool as_text = false) {
     if (!fs && !replay) {
         if (drained) (*drained)();
         return true; // nothing to read
@@ -572,6 +720,16 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                 if (seq >= replay->size()) break;
                 b->f = (*replay)[seq];
                 b->owned = false;
+            } else if (as_text) { // K1: the records are only located; the device parses them
+                plaac_fasta_text *t = nullptr;
+                const plaac_status st = plaac_fasta_next_text(fs, sp.batch_records, sp.batch_bytes, &t);
+                if (st != PLAAC_OK) {
+                    std::fprintf(stderr, "plaac: reading %s failed (status %d)\n", path.c_str(), (int)st);
+                    failed = true;
+                    break;
+                }
+                if (!t) break;
+                b->ft = t;
             } else {
                 plaac_fasta *f = nullptr;
                 const plaac_status st = plaac_fasta_next(fs, sp.batch_records, sp.batch_bytes, &f);
@@ -777,6 +935,56 @@ struct SinglePass {
     std::function<bool(const double counts[PLAAC_NAA], std::string &text)> make_block;
 };
 
+// Is stdout a plain file this process may write at offsets of its choosing (not a pipe / terminal, not opened for appending)?
+// *at = where the next byte goes. The single pass then writes the table where it belongs while the parameter block in
+// front of it still waits for the counts (PLAAC_PLACED_WRITE=0: hold everything back, as for a pipe).
+bool stdout_is_plain_file(off_t *at) {
+    struct stat sb;
+    if (::fstat(STDOUT_FILENO, &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
+    const int fl = ::fcntl(STDOUT_FILENO, F_GETFL);
+    if (fl < 0 || (fl & O_APPEND)) return false;
+    const off_t o = ::lseek(STDOUT_FILENO, 0, SEEK_CUR);
+    if (o < 0) return false;
+    *at = o;
+    return true;
+}
+bool pwrite_all(int fd, const char *p, size_t n, off_t at) {
+    while (n) {
+        const ssize_t k = ::pwrite(fd, p, n, at);
+        if (k <= 0) return false;
+        p += k;
+        n -= (size_t)k;
+        at += k;
+    }
+    return true;
+}
+// moves the bytes of stdout's file from `from` to its end by `delta` (the parameter block came out longer or shorter than its
+// placeholder: an input without a single valid residue prints NaN frequencies). stdout is write-only as a rule, so the file
+// is opened a second time through /proc.
+bool shift_tail(off_t from, off_t end, long delta) {
+    if (delta == 0 || end <= from) return true;
+    const int fd = ::open("/proc/self/fd/1", O_RDWR);
+    if (fd < 0) return false;
+    std::vector<char> buf(8u << 20);
+    bool ok = true;
+    if (delta > 0) { // towards the end: last chunk first
+        for (off_t hi = end; ok && hi > from;) {
+            const off_t lo = std::max<off_t>(from, hi - (off_t)buf.size());
+            ok = ::pread(fd, buf.data(), (size_t)(hi - lo), lo) == (ssize_t)(hi - lo) && pwrite_all(fd, buf.data(), (size_t)(hi - lo), lo + delta);
+            hi = lo;
+        }
+    } else {
+        for (off_t lo = from; ok && lo < end;) {
+            const off_t hi = std::min<off_t>(end, lo + (off_t)buf.size());
+            ok = ::pread(fd, buf.data(), (size_t)(hi - lo), lo) == (ssize_t)(hi - lo) && pwrite_all(fd, buf.data(), (size_t)(hi - lo), lo + delta);
+            lo = hi;
+        }
+        if (ok) ok = ::ftruncate(fd, end + delta) == 0;
+    }
+    ::close(fd);
+    return ok;
+}
+
 // ---- pass 2, summary mode (scoreallfastas :653-950) ----
 bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Stream &sp, std::vector<plaac_fasta *> *replay,
                SinglePass *single = nullptr) {
@@ -788,15 +996,55 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
     const unsigned nt_max = plaac_host_threads();
     uint64_t nres = 0, nrec = 0;
     std::fflush(stdout);
-    Writer writer(single != nullptr); // from here on the table goes through the writer thread
+    // single pass into a plain file: the text in front of the table goes out now, with a block of the right length computed
+    // from made-up counts in the block's place; the real block is written over it once the counts are final
+    bool placed = false;
+    off_t placed_at = 0;
+    size_t placeholder_len = 0;
+    std::string final_block;
+    if (single && env_flag("PLAAC_PLACED_WRITE", true) && stdout_is_plain_file(&placed_at)) {
+        placed = true;
+        std::string blk0;
+        if (single->want_block) {
+            double ones[PLAAC_NAA];
+            for (double &v : ones) v = 1.0;
+            (void)single->make_block(ones, blk0);
+        }
+        placeholder_len = blk0.size();
+        placed_at += (off_t)single->block_at;
+        single->held.insert(single->block_at, blk0);
+    }
+    Writer writer(single != nullptr && !placed); // from here on the table goes through the writer thread
+    if (placed) writer.write(single->held);
     const bool pipelined = env_flag("PLAAC_PIPELINE", true) || single;
     std::mutex cm;
     int64_t total_counts[PLAAC_NAA] = {0};
     std::atomic<bool> block_failed{false};
+    // K1: the single pass hands the device the file's text (PLAAC_DEVICE_PARSE=0: the host parses, as in the two passes)
+    const bool as_text = single && !replay && env_flag("PLAAC_DEVICE_PARSE", true);
+    int prev_blank = 1; // (the sink's: how the record before the batch it is looking at ended)
     auto collect = make_finish([&](plaac_ctx *ctx, Batch &b) {
         if (!single) return plaac_score_end(ctx, b.rows.data());
         int64_t c[PLAAC_NAA];
-        const plaac_status st = plaac_score_end_counts(ctx, b.rows.data(), c);
+        plaac_status st;
+        if (b.ft) {
+            const uint32_t n = b.ft->nrec;
+            b.toffs.resize((size_t)n + 1);
+            b.tblank.resize((size_t)n + 1);
+            b.text_ext.resize(2 * (size_t)n + 2);
+            // (no copy of the codes: a summary row prints a few residues, read from the text - plaac_fasta_text_codes)
+            st = plaac_score_end_text(ctx, b.rows.data(), nullptr, 0, b.toffs.data(), b.tblank.data(), b.text_ext.data(), c);
+            b.view.nrec = n;
+            b.view.nres = b.toffs[n];
+            b.view.codes = nullptr;
+            b.view.offsets = b.toffs.data();
+            b.view.names = b.ft->names;
+            b.view.name_off = b.ft->name_off;
+            b.f = &b.view;
+            b.owned = false;
+        } else {
+            st = plaac_score_end_counts(ctx, b.rows.data(), c);
+        }
         if (st == PLAAC_OK) {
             std::lock_guard<std::mutex> l(cm);
             for (int i = 0; i < PLAAC_NAA; ++i) total_counts[i] += c[i];
@@ -814,40 +1062,46 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             for (int i = 0; i < PLAAC_NAA; ++i) cd[i] = (double)total_counts[i];
         }
         if (single->want_block && !single->make_block(cd, block)) block_failed = true;
-        single->held.insert(single->block_at, block);
         g_timer.lap("single pass: input read, counted, scored");
-        writer.release(std::move(single->held));
+        if (placed) {
+            final_block = std::move(block); // (written over its placeholder when the table is out)
+            return;
+        }
+        single->held.insert(single->block_at, block);
+        writer.release(single->held);
     };
     auto run = [&](auto &&...a) {
-        return pipelined ? run_pipeline(std::forward<decltype(a)>(a)..., collect, single ? &drained : nullptr)
+        return pipelined ? run_pipeline(std::forward<decltype(a)>(a)..., collect, single ? &drained : nullptr, as_text)
                          : run_pipeline(std::forward<decltype(a)>(a)...);
     };
     const bool ok = run(
         eng, P, o.input, fs, sp, replay, (std::vector<plaac_fasta *> *)nullptr, (uint64_t)0, [](Batch &) {},
         [&](plaac_ctx *ctx, Batch &b) {
+            if (b.ft) {
+                b.rows.resize(b.ft->nrec);
+                return plaac_score_begin_text(ctx, b.ft->text, b.ft->len, b.ft->starts, b.ft->nrec, 1);
+            }
             b.rows.resize(b.f->nrec);
             if (single) return plaac_score_begin_counting(ctx, b.f->codes, b.f->offsets, b.f->nrec);
             if (pipelined) return plaac_score_begin(ctx, b.f->codes, b.f->offsets, b.f->nrec);
             return plaac_score(ctx, b.f->codes, b.f->offsets, b.f->nrec, b.rows.data(), nullptr);
         },
         [&](Batch &b) {
+            if (b.ft) prev_blank = plaac_fasta_text_trim_names(b.ft, b.tblank.data(), prev_blank);
             const plaac_fasta *f = b.f;
             // format in parallel (contiguous row ranges per thread), print in file order
             const unsigned nt = f->nrec < 2048 ? 1u : nt_max;
-            std::vector<std::string> part(nt);
+            std::vector<TextBuf> part(nt);
             std::vector<int> bad(nt, 0);
             auto fmt = [&](unsigned t) {
                 const uint32_t r0 = (uint32_t)((uint64_t)f->nrec * t / nt), r1 = (uint32_t)((uint64_t)f->nrec * (t + 1) / nt);
                 std::vector<char> line;
-                std::string &out = part[t];
-                // (one allocation per thread and batch instead of a doubling string: ~230 bytes of numbers per row + its name,
-                //  sequences are printed for the few records with a PrD; huge pages)
-                {
-                    const size_t est = (size_t)(r1 - r0) * 260 + (size_t)(f->name_off[r1] - f->name_off[r0]) +
-                                       (size_t)(f->offsets[r1] - f->offsets[r0]) / 8 + 4096;
-                    out.reserve(est);
-                    if (est >= 4 * HUGE_PAGE) advise_huge(&out[0], out.capacity());
-                }
+                std::vector<uint8_t> some; // device-parsed batch: the record's codes where the row prints them
+                // (one buffer per thread and batch, from the writer's pool: ~230 bytes of numbers per row + its name, sequences
+                //  are printed for the few records with a PrD; it grows if that was too little)
+                part[t] = writer.buffer((size_t)(r1 - r0) * 260 + (size_t)(f->name_off[r1] - f->name_off[r0]) +
+                                        (size_t)(f->offsets[r1] - f->offsets[r0]) / 8 + 4096);
+                TextBuf &out = part[t];
                 for (uint32_t i = r0; i < r1; ++i) {
                     const uint64_t len = f->offsets[i + 1] - f->offsets[i];
                     if (len == 0) {
@@ -855,8 +1109,36 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
                         continue;
                     }
                     line.resize(len * 3 + std::strlen(rec_name(f, i)) + 2048);
-                    const long k = plaac_format_summary_row(&b.rows[i], rec_name(f, i), f->codes + f->offsets[i], len,
-                                                            o.corelength, o.ww2, line.data(), line.size());
+                    const uint8_t *rec_codes;
+                    if (b.ft) {
+                        // The residues a row prints (plaac_format_summary_row: the PAPA window; core, PrD and its two ends when
+                        // the PrD is long enough; every range clamped into the protein): one stretch of the record, decoded
+                        // from the text into its place
+                        const plaac_row &r = b.rows[i];
+                        const long n = r.prot_len;
+                        if (some.size() < len) some.resize(len);
+                        if (n > 0) {
+                            long lo = n - 1, hi = 0;
+                            auto want = [&](long v) {
+                                v = std::min(std::max(v, 0l), n - 1);
+                                lo = std::min(lo, v);
+                                hi = std::max(hi, v);
+                            };
+                            want((long)r.papa_cen - o.ww2 / 2);
+                            want((long)r.papa_cen + o.ww2 / 2);
+                            if (r.prd_end - r.prd_start + 1 >= o.corelength)
+                                for (long v : {(long)r.core_start, (long)r.core_end, (long)r.prd_start, (long)r.prd_start + 14,
+                                               (long)r.prd_end - 14, (long)r.prd_end})
+                                    want(v);
+                            (void)plaac_fasta_text_codes(b.ft->text, b.ft->starts, b.text_ext.data(), i, (uint64_t)lo,
+                                                         (uint64_t)(hi - lo + 1), some.data() + lo);
+                        }
+                        rec_codes = some.data();
+                    } else {
+                        rec_codes = f->codes + f->offsets[i];
+                    }
+                    const long k = plaac_format_summary_row(&b.rows[i], rec_name(f, i), rec_codes, len, o.corelength, o.ww2,
+                                                            line.data(), line.size());
                     if (k < 0) {
                         bad[t] = 1;
                         return;
@@ -875,7 +1157,7 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             }
             for (unsigned t = 0; t < nt; ++t)
                 if (bad[t]) return false;
-            for (unsigned t = 0; t < nt; ++t) writer.write(std::move(part[t]));
+            for (unsigned t = 0; t < nt; ++t) writer.write(part[t]);
             nres += f->nres;
             nrec += f->nrec;
             return true;
@@ -884,6 +1166,17 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
     if (!writer.finish()) {
         std::fprintf(stderr, "plaac: writing the table to stdout failed (disk full / closed pipe?): output is incomplete\n");
         return false;
+    }
+    if (placed && single->want_block && ok) {
+        const long delta = (long)final_block.size() - (long)placeholder_len;
+        const off_t end = ::lseek(STDOUT_FILENO, 0, SEEK_CUR);
+        bool done = end >= 0 && shift_tail(placed_at + (off_t)placeholder_len, end, delta) &&
+                    pwrite_all(STDOUT_FILENO, final_block.data(), final_block.size(), placed_at);
+        if (done && delta != 0) done = ::lseek(STDOUT_FILENO, end + delta, SEEK_SET) >= 0;
+        if (!done) {
+            std::fprintf(stderr, "plaac: could not put the parameter block in its place in the output file - rerun with PLAAC_PLACED_WRITE=0\n");
+            return false;
+        }
     }
     if (block_failed) {
         std::fprintf(stderr, "plaac: the scoring tables depend on the input's residue counts after all - rerun with PLAAC_SINGLE_PASS=0\n");
@@ -1008,7 +1301,19 @@ int main(int argc, char **argv) {
     plaac_params_init(&P, nullptr, nullptr, 1.0, o.corelength, o.ww1, o.ww2, o.ww3, 1);
     Engine eng;
     const bool need_gpu = !o.input.empty() || (!o.bgfile.empty() && o.bgfreq.empty());
-    if (need_gpu) eng.start(P); // HIP start-up runs beside the rest of the set-up
+    // One GPU per PLAAC_BYTES_PER_DEVICE of input (default 4 GiB; PLAAC_DEVICES names the devices itself): the kernels of a
+    // 3 GB FASTA take 0.14 s of one MI355X, the host's share of that run 1.2 s - seven more contexts only add their start-up
+    // and teardown (profiles/r05_e2e_device_parse.txt: 1.9 - 2.1 s with eight contexts against 1.25 - 1.35 s with one).
+    int worth = 1;
+    {
+        uint64_t in_bytes = 0;
+        struct stat sb;
+        for (const std::string *f : {&o.input, &o.bgfile})
+            if (!f->empty() && ::stat(f->c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) in_bytes = std::max<uint64_t>(in_bytes, (uint64_t)sb.st_size);
+        const uint64_t per = std::max<uint64_t>(1, env_u64("PLAAC_BYTES_PER_DEVICE", 4ull << 30));
+        worth = (int)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1, (in_bytes + per - 1) / per));
+    }
+    if (need_gpu) eng.start(P, worth); // HIP start-up runs beside the rest of the set-up
     // track mode moves 82 bytes per residue through the host: smaller batches
     Stream sp{(uint32_t)env_u64("PLAAC_BATCH_RECORDS", 262144),
               env_u64("PLAAC_BATCH_BYTES", o.plotlist.empty() ? (96ull << 20) : (8ull << 20))};
@@ -1111,10 +1416,12 @@ int main(int argc, char **argv) {
     // two contexts on an MI355X). PLAAC_FAST_EXIT=1 leaves through _exit instead and lets the operating system reclaim
     // everything.
     std::fflush(stdout);
+    g_timer.mark("output complete");
     std::fflush(stderr);
     if (std::getenv("PLAAC_FAST_EXIT")) ::_exit(ok ? 0 : 1);
     plaac_node_destroy(eng.node);
     g_timer.lap("teardown: GPU contexts");
+    g_timer.mark("contexts destroyed");
     // The parsed input kept for the scoring pass (up to PLAAC_KEEP_BYTES) is handed back by process exit: unmapping
     // gigabytes piecewise costs 0.3 s that the exit path does not have to pay (PLAAC_TEARDOWN=1: free it, for leak checkers)
     if (std::getenv("PLAAC_TEARDOWN")) {

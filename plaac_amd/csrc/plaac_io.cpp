@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <array>
 #include <string>
 #include <thread>
 
@@ -557,6 +558,157 @@ plaac_status plaac_fasta_next(plaac_fasta_stream *s, uint32_t max_records, uint6
 }
 
 void plaac_fasta_close(plaac_fasta_stream *s) { delete s; }
+
+// ---- the stream as batches of text for the device-side parser (K1, round 5) ----
+plaac_status plaac_fasta_next_text(plaac_fasta_stream *s, uint32_t max_records, uint64_t max_bytes, plaac_fasta_text **out) {
+    if (!s || !out) return PLAAC_ERR_ARG;
+    *out = nullptr;
+    const char *d = s->file.data;
+    const size_t nbytes = s->file.size;
+    if (max_records == 0) max_records = 1;
+    if (max_bytes == 0) max_bytes = 1;
+    auto is_start = [&](size_t p) { return d[p] == '>' && (p == 0 || d[p - 1] == '\n' || d[p - 1] == '\r'); };
+    // bytes before the first header of the rest of the file belong to no record (hasmorefastas skips them)
+    while (s->cursor < nbytes && !is_start(s->cursor)) {
+        const char *q = (const char *)memchr(d + s->cursor + 1, '>', nbytes - s->cursor - 1);
+        s->cursor = q ? (size_t)(q - d) : nbytes;
+    }
+    if (s->cursor >= nbytes) return PLAAC_OK;
+    const size_t b0 = s->cursor;
+    // record starts inside [b0, b0 + max_bytes), in parallel over byte ranges, then cut at max_records / the first start at or
+    // after b0 + max_bytes (a record is never split)
+    size_t hard = nbytes;
+    if (nbytes - b0 > max_bytes) {
+        size_t p = b0 + (size_t)max_bytes;
+        hard = nbytes;
+        while (p < nbytes) {
+            const char *q = (const char *)memchr(d + p, '>', nbytes - p);
+            if (!q) break;
+            p = (size_t)(q - d);
+            if (is_start(p)) {
+                hard = p;
+                break;
+            }
+            ++p;
+        }
+    }
+    const size_t span = hard - b0;
+    const unsigned nt = span < (8u << 20) ? 1u : host_threads();
+    std::vector<std::vector<uint64_t>> part(nt);
+    auto scan = [&](unsigned t) {
+        size_t p = b0 + span / nt * t;
+        const size_t e = t + 1 == nt ? hard : b0 + span / nt * (t + 1);
+        while (p < e) {
+            const char *q = (const char *)memchr(d + p, '>', e - p);
+            if (!q) break;
+            p = (size_t)(q - d);
+            if (is_start(p)) part[t].push_back(p);
+            ++p;
+        }
+    };
+    if (nt == 1) {
+        scan(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(scan, t);
+        for (auto &th : pool) th.join();
+    }
+    std::vector<uint64_t> starts;
+    for (auto &v : part) starts.insert(starts.end(), v.begin(), v.end());
+    size_t e = hard;
+    if (starts.size() > max_records) {
+        e = (size_t)starts[max_records];
+        starts.resize(max_records);
+    }
+    const size_t nrec = starts.size();
+    plaac_fasta_text *t = (plaac_fasta_text *)std::calloc(1, sizeof(plaac_fasta_text));
+    if (!t) return PLAAC_ERR_NOMEM;
+    t->text = d + b0;
+    t->len = e - b0;
+    t->nrec = (uint32_t)nrec;
+    t->owner_ = s;
+    t->file_off_ = b0;
+    t->starts = (uint64_t *)std::malloc((nrec + 1) * sizeof(uint64_t));
+    t->name_off = (uint64_t *)std::malloc((nrec + 1) * sizeof(uint64_t));
+    if (!t->starts || !t->name_off) {
+        plaac_fasta_text_free(t);
+        return PLAAC_ERR_NOMEM;
+    }
+    // header extents: from behind the '>' to the first line terminator (or the record's end)
+    std::vector<uint32_t> nlen(nrec);
+    uint64_t noff = 0;
+    for (size_t i = 0; i < nrec; ++i) {
+        const size_t rb = (size_t)starts[i] + 1, re = i + 1 < nrec ? (size_t)starts[i + 1] : e;
+        const char *nl = (const char *)memchr(d + rb, '\n', re - rb);
+        size_t le = nl ? (size_t)(nl - d) : re;
+        if (const char *cr = (const char *)memchr(d + rb, '\r', le - rb)) le = (size_t)(cr - d);
+        nlen[i] = (uint32_t)(le - rb);
+        t->starts[i] = starts[i] - b0;
+        t->name_off[i] = noff;
+        noff += nlen[i] + 1;
+    }
+    t->starts[nrec] = e - b0;
+    t->name_off[nrec] = noff;
+    t->names = (char *)std::malloc(noff + 1);
+    if (!t->names) {
+        plaac_fasta_text_free(t);
+        return PLAAC_ERR_NOMEM;
+    }
+    for (size_t i = 0; i < nrec; ++i) {
+        std::memcpy(t->names + t->name_off[i], d + starts[i] + 1, nlen[i]);
+        t->names[t->name_off[i] + nlen[i]] = '\0';
+    }
+    t->names[noff] = '\0';
+    s->cursor = e;
+    *out = t;
+    return PLAAC_OK;
+}
+
+void plaac_fasta_text_free(plaac_fasta_text *t) {
+    if (!t) return;
+    // (the pages of the file image behind this batch are not needed again: the stream lets them go in file order)
+    plaac_fasta_stream *s = (plaac_fasta_stream *)t->owner_;
+    if (s && s->file.map && t->starts) {
+        const size_t page = 4096, a = (size_t)t->file_off_ & ~(page - 1), b = ((size_t)t->file_off_ + (size_t)t->len) & ~(page - 1);
+        if (b > a) ::madvise((char *)s->file.map + a, b - a, MADV_DONTNEED);
+    }
+    std::free(t->starts);
+    std::free(t->names);
+    std::free(t->name_off);
+    std::free(t);
+}
+
+int plaac_fasta_text_trim_names(plaac_fasta_text *t, const uint8_t *blank_end, int prev_blank) {
+    if (!t || !blank_end) return prev_blank;
+    for (uint32_t i = 0; i < t->nrec; ++i) {
+        if (i == 0 ? prev_blank != 0 : blank_end[i - 1] != 0) { // hasmorefastas: line.trim().substring(1) (:4362)
+            char *b = t->names + t->name_off[i];
+            size_t e = std::strlen(b);
+            while (e > 0 && (unsigned char)b[e - 1] <= ' ') --e;
+            b[e] = '\0';
+        }
+    }
+    return t->nrec ? (blank_end[t->nrec - 1] != 0) : prev_blank;
+}
+
+uint64_t plaac_fasta_text_codes(const char *text, const uint64_t *starts, const uint32_t *extents, uint32_t i, uint64_t first,
+                                uint64_t count, uint8_t *out) {
+    if (!text || !starts || !extents || !out || count == 0) return 0;
+    static const std::array<uint8_t, 256> lut = [] {
+        std::array<uint8_t, 256> l{};
+        char all[256];
+        for (int k = 0; k < 256; ++k) all[k] = (char)k;
+        plaac_encode(all, 256, l.data());
+        return l;
+    }();
+    const unsigned char *p = (const unsigned char *)text + starts[i] + extents[2 * (size_t)i] + 1;
+    const unsigned char *e = (const unsigned char *)text + starts[i] + extents[2 * (size_t)i + 1];
+    uint64_t idx = 0, k = 0;
+    for (; p < e && idx < first; ++p) idx += !(*p == '\n' || *p == '\r'); // (the residues in front of the range)
+    for (; p < e && k < count; ++p)
+        if (!(*p == '\n' || *p == '\r')) out[k++] = lut[*p];
+    return k;
+}
 
 void plaac_fasta_free(plaac_fasta *f) {
     if (!f) return;

@@ -57,6 +57,7 @@ static inline void cpu_relax() {
 #include "kernels_windows_filter.hip.inc"
 #include "kernels_windows_lane.hip.inc"
 #include "kernels_misc.hip.inc"
+#include "fasta_device.hip.inc"
 #include "schedule.hip.inc"
 
 constexpr int E_JOIN_IDX = sched::E_JOIN; // index of a call's join event in its set of timing events
@@ -163,6 +164,16 @@ struct plaac_ctx {
         plaac_row *d_rows = nullptr;
         unsigned long long *d_counts = nullptr; // plaac_score_begin_counting: the batch's 22 background counts
         bool counted = false;
+        // plaac_score_begin_text: the batch's FASTA text, record starts, per-record lengths / blank-line flags (K1)
+        char *d_text = nullptr;
+        uint64_t *d_starts = nullptr;
+        uint32_t *d_len = nullptr;
+        uint8_t *d_blank = nullptr;
+        FaExtent *d_ext = nullptr;
+        unsigned long long *d_total = nullptr, *d_bsum = nullptr;
+        size_t cap_text = 0, cap_starts = 0, cap_len = 0, cap_blank = 0, cap_ext = 0, cap_bsum = 0;
+        uint64_t nres = 0;
+        bool from_text = false;
         size_t cap_codes = 0, cap_offs = 0, cap_rows = 0;
         uint32_t nprot = 0;
         uint64_t call_no = 0; // ncalls of the scoring call (its join event is ev[call_no % EV_SETS][E_JOIN]); ~0: nothing enqueued
@@ -757,7 +768,9 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     for (auto &sl : ctx->slot)
-        for (void *b : {(void *)sl.d_codes, (void *)sl.d_offsets, (void *)sl.d_rows, (void *)sl.d_counts})
+        for (void *b : {(void *)sl.d_codes, (void *)sl.d_offsets, (void *)sl.d_rows, (void *)sl.d_counts, (void *)sl.d_text,
+                        (void *)sl.d_starts, (void *)sl.d_len, (void *)sl.d_blank, (void *)sl.d_total, (void *)sl.d_ext,
+                        (void *)sl.d_bsum})
             if (b) (void)hipFree(b);
     if (ctx->xfer) {
         (void)hipStreamSynchronize(ctx->xfer);
@@ -1865,6 +1878,7 @@ static plaac_status score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint
     S.nprot = nprot;
     S.call_no = ~0ull;
     S.counted = counting;
+    S.from_text = false;
     if (nprot) {
         uint64_t total = 0;
         plaac_status rc = stage_in_to(ctx, codes, offsets, nprot, &total, S.d_codes, S.cap_codes, S.d_offsets, S.cap_offs, ctx->xfer);
@@ -1887,6 +1901,72 @@ static plaac_status score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint
 
 plaac_status plaac_score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot) {
     return score_begin(ctx, codes, offsets, nprot, false);
+}
+
+// K1 (round 5): the same pipeline fed with FASTA TEXT - the records' bytes and where each begins - parsed and encoded on the
+// device (fasta_device.hip.inc) into the slot the scoring kernels read. Upload and parse run on the copy stream, beside the
+// kernels of the batch before; the codes are complete when the scoring call is made (the overlap contract).
+plaac_status plaac_score_begin_text(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
+                                    int counting) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (ctx->slots_busy >= 2) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_begin_text: two batches are pending (call plaac_score_end_text)");
+    if (nrec && (!text || !starts)) return fail(ctx, PLAAC_ERR_ARG, "null text / starts");
+    for (uint32_t i = 0; i < nrec; ++i)
+        if (starts[i + 1] < starts[i] || starts[i + 1] > text_len || starts[i + 1] - starts[i] >= 0x7fffffffull)
+            return fail(ctx, PLAAC_ERR_ARG, "record starts must be non-decreasing and inside the text, records below 2^31 bytes");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->xfer) PL_HIP(ctx, hipStreamCreateWithFlags(&ctx->xfer, hipStreamNonBlocking));
+    plaac_ctx::Slot &S = ctx->slot[ctx->slot_next];
+    S.nprot = nrec;
+    S.call_no = ~0ull;
+    S.counted = counting != 0;
+    S.from_text = true;
+    S.nres = 0;
+    if (nrec) {
+        plaac_status rc;
+        size_t cap_tot = S.d_total ? 1 : 0;
+        if ((rc = grow(ctx, S.d_text, S.cap_text, (size_t)text_len + 16)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, S.d_starts, S.cap_starts, (size_t)nrec + 1)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, S.d_len, S.cap_len, (size_t)nrec)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, S.d_blank, S.cap_blank, (size_t)nrec)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, S.d_total, cap_tot, (size_t)1)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, S.d_codes, S.cap_codes, (size_t)text_len + 64)) != PLAAC_OK) return rc; // (a record's codes are fewer than its bytes)
+        if ((rc = grow(ctx, S.d_offsets, S.cap_offs, (size_t)nrec + 1)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, S.d_rows, S.cap_rows, (size_t)nrec)) != PLAAC_OK) return rc;
+        if ((rc = copy_in(ctx, S.d_text, text, (size_t)text_len, ctx->xfer)) != PLAAC_OK) return rc;
+        if ((rc = copy_in(ctx, S.d_starts, starts, sizeof(uint64_t) * ((size_t)nrec + 1), ctx->xfer)) != PLAAC_OK) return rc;
+        static const FastaLut lut = [] {
+            FastaLut l;
+            char all[256];
+            for (int i = 0; i < 256; ++i) all[i] = (char)i;
+            plaac_encode(all, 256, l.t);
+            return l;
+        }();
+        const unsigned nb = (nrec + FA_RECS - 1u) / FA_RECS, ns = (nrec + FA_SCAN - 1u) / FA_SCAN;
+        if ((rc = grow(ctx, S.d_ext, S.cap_ext, (size_t)nrec)) != PLAAC_OK) return rc;
+        if ((rc = grow(ctx, S.d_bsum, S.cap_bsum, (size_t)ns)) != PLAAC_OK) return rc;
+        hipLaunchKernelGGL(k_fasta_lengths, dim3(nb), dim3(FA_BLOCK), 0, ctx->xfer, S.d_text, S.d_starts, nrec, S.d_len, S.d_blank, S.d_ext);
+        hipLaunchKernelGGL(k_fasta_block_sums, dim3(ns), dim3(FA_SCAN), 0, ctx->xfer, S.d_len, nrec, S.d_bsum);
+        hipLaunchKernelGGL(k_fasta_offsets, dim3(ns), dim3(FA_SCAN), 0, ctx->xfer, S.d_len, nrec, S.d_bsum, S.d_offsets, S.d_total);
+        hipLaunchKernelGGL(k_fasta_encode, dim3(nb), dim3(FA_BLOCK), 0, ctx->xfer, S.d_text, S.d_starts, nrec, S.d_ext, S.d_offsets, lut,
+                           S.d_codes);
+        unsigned long long total = 0;
+        PL_HIP(ctx, hipMemcpyAsync(&total, S.d_total, sizeof total, hipMemcpyDeviceToHost, ctx->xfer));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->xfer));
+        S.nres = total;
+        if (counting) {
+            if (!S.d_counts) PL_HIP(ctx, hipMalloc(&S.d_counts, sizeof(unsigned long long) * NAA));
+            if ((rc = plaac_histogram_device(ctx, S.d_codes, S.d_offsets, nrec, (int64_t *)S.d_counts, ctx->stream)) != PLAAC_OK) return rc;
+        }
+        const uint64_t call_no = ctx->ncalls;
+        rc = plaac_score_device(ctx, S.d_codes, S.d_offsets, nrec, total, S.d_rows, nullptr, ctx->stream);
+        if (rc != PLAAC_OK) return rc;
+        S.call_no = call_no;
+    }
+    S.busy = true;
+    ctx->slot_next ^= 1u;
+    ++ctx->slots_busy;
+    return PLAAC_OK;
 }
 plaac_status plaac_score_begin_counting(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot) {
     return score_begin(ctx, codes, offsets, nprot, true);
@@ -1914,6 +1994,32 @@ static plaac_status score_end(plaac_ctx *ctx, plaac_row *rows, int64_t *counts) 
     return copy_out(ctx, rows, S.d_rows, sizeof(plaac_row) * (size_t)S.nprot, ctx->xfer);
 }
 plaac_status plaac_score_end(plaac_ctx *ctx, plaac_row *rows) { return score_end(ctx, rows, nullptr); }
+
+plaac_status plaac_score_end_text(plaac_ctx *ctx, plaac_row *rows, uint8_t *codes, uint64_t codes_cap, uint64_t *offsets,
+                                  uint8_t *blank_end, uint32_t *extents, int64_t *counts) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (ctx->slots_busy == 0) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text: no batch is pending");
+    plaac_ctx::Slot &S = ctx->slot[ctx->slot_oldest];
+    if (!S.from_text) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text: the oldest batch was not begun from text");
+    const uint32_t nrec = S.nprot;
+    const uint64_t nres = S.nres;
+    if (nrec && (!offsets || !blank_end)) {
+        (void)score_end(ctx, rows, counts); // (the slot is given up whatever happens)
+        return fail(ctx, PLAAC_ERR_ARG, "null output buffer");
+    }
+    if (codes && nres > codes_cap) {
+        (void)score_end(ctx, rows, counts);
+        return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text: the codes buffer is too small (the text's length always suffices)");
+    }
+    if (offsets && nrec == 0) offsets[0] = 0;
+    plaac_status rc = score_end(ctx, rows, counts); // (waits for the batch; the slot's buffers stay until the next begin)
+    if (rc != PLAAC_OK || nrec == 0) return rc;
+    if (codes && nres && (rc = copy_out(ctx, codes, S.d_codes, (size_t)nres, ctx->xfer)) != PLAAC_OK) return rc;
+    static_assert(sizeof(FaExtent) == 2 * sizeof(uint32_t), "extents are (h, b) pairs of uint32");
+    if (extents && (rc = copy_out(ctx, extents, S.d_ext, sizeof(FaExtent) * (size_t)nrec, ctx->xfer)) != PLAAC_OK) return rc;
+    if ((rc = copy_out(ctx, offsets, S.d_offsets, sizeof(uint64_t) * ((size_t)nrec + 1), ctx->xfer)) != PLAAC_OK) return rc;
+    return copy_out(ctx, blank_end, S.d_blank, (size_t)nrec, ctx->xfer);
+}
 plaac_status plaac_score_end_counts(plaac_ctx *ctx, plaac_row *rows, int64_t counts[PLAAC_NAA]) {
     if (ctx && !counts) return fail(ctx, PLAAC_ERR_ARG, "null counts");
     return score_end(ctx, rows, counts);

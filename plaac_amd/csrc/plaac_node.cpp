@@ -171,8 +171,13 @@ void plaac_node_destroy(plaac_node *node) {
         for (plaac_node_batch *nb : node->live) release_parts(nb); // (the shells stay valid until plaac_node_batch_free)
         node->live.clear();
     }
-    for (plaac_ctx *c : node->ctx)
-        if (c) plaac_ctx_destroy(c);
+    // (side by side, as they were created: a context's streams and buffers take tens of ms to hand back)
+    std::vector<plaac_status> st(node->ctx.size(), PLAAC_OK);
+    std::vector<std::string> why(node->ctx.size());
+    if (!node->ctx.empty())
+        run_parts(node->ctx.size(), st, why, [&](size_t k) {
+            if (node->ctx[k]) plaac_ctx_destroy(node->ctx[k]);
+        });
     delete node;
 }
 

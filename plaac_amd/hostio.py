@@ -14,7 +14,7 @@ class _Fasta(C.Structure):
 
 
 HOST_EXPORTS = (
-    "plaac_fasta_read", "plaac_fasta_free", "plaac_read_aa_params", "plaac_format_fixed",
+    "plaac_fasta_read", "plaac_fasta_free", "plaac_fasta_next_text", "plaac_fasta_text_free", "plaac_fasta_text_trim_names", "plaac_fasta_text_codes", "plaac_read_aa_params", "plaac_format_fixed",
     "plaac_format_fixed_reference",
     "plaac_format_double_tostring", "plaac_format_summary_row", "plaac_summary_header", "plaac_tracks_header",
     "plaac_format_track_rows", "plaac_track_rows_bound", "plaac_format_param_block", "plaac_format_aa_params",
@@ -99,6 +99,65 @@ def stream_fasta(path, max_records=262144, max_bytes=128 << 20):
             yield _take(pf)
     finally:
         L.plaac_fasta_close(h)
+
+
+class _FastaText(C.Structure):
+    """plaac_fasta_text"""
+    _fields_ = [("text", C.c_void_p), ("len", C.c_uint64), ("nrec", C.c_uint32), ("starts", C.POINTER(C.c_uint64)),
+                ("names", C.c_void_p), ("name_off", C.POINTER(C.c_uint64)), ("owner_", C.c_void_p), ("file_off_", C.c_uint64)]
+
+
+def stream_fasta_text(path, max_records=262144, max_bytes=128 << 20):
+    """the stream as batches of TEXT for the device-side parser (plaac_fasta_next_text): a generator of
+    (text bytes, starts u64[nrec + 1], trim) where trim(blank_end, prev_blank) -> (names list[bytes], next prev_blank)
+    applies the reference's name trimming once the device has reported how the records ended"""
+    L = _lib()
+    L.plaac_fasta_next_text.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(_FastaText))]
+    L.plaac_fasta_text_free.argtypes = [C.POINTER(_FastaText)]
+    L.plaac_fasta_text_free.restype = None
+    L.plaac_fasta_text_trim_names.argtypes = [C.POINTER(_FastaText), C.c_void_p, C.c_int]
+    h = C.c_void_p()
+    st = L.plaac_fasta_open(str(path).encode(), C.byref(h))
+    if st != native.PLAAC_OK:
+        raise native.PlaacError(st, "cannot read " + str(path))
+    try:
+        while True:
+            pt = C.POINTER(_FastaText)()
+            st = L.plaac_fasta_next_text(h, int(max_records), int(max_bytes), C.byref(pt))
+            if st != native.PLAAC_OK:
+                raise native.PlaacError(st, "plaac_fasta_next_text")
+            if not pt:
+                return
+            t = pt.contents
+            n = t.nrec
+            text = C.string_at(t.text, int(t.len))
+            starts = np.ctypeslib.as_array(t.starts, shape=(n + 1,)).copy()
+
+            def trim(blank_end, prev_blank, pt=pt, n=n):
+                be = np.ascontiguousarray(blank_end, dtype=np.uint8)
+                nxt = L.plaac_fasta_text_trim_names(pt, be.ctypes.data, int(prev_blank))
+                tt = pt.contents
+                noff = np.ctypeslib.as_array(tt.name_off, shape=(n + 1,))
+                names = [C.string_at(tt.names + int(noff[i])) for i in range(n)]
+                return names, int(nxt)
+
+            yield text, starts, trim
+            L.plaac_fasta_text_free(pt)
+    finally:
+        L.plaac_fasta_close(h)
+
+
+def text_codes(text, starts, extents, i, first, count):
+    """plaac_fasta_text_codes: residues [first, first + count) of record i of a text batch, read from the text with the
+    extents the device reported (Context.score_text(..., want_codes=False))"""
+    L = _lib()
+    L.plaac_fasta_text_codes.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.plaac_fasta_text_codes.restype = C.c_uint64
+    starts = np.ascontiguousarray(starts, dtype=np.uint64)
+    extents = np.ascontiguousarray(extents, dtype=np.uint32)
+    out = np.zeros(max(int(count), 1), dtype=np.uint8)
+    k = L.plaac_fasta_text_codes(text, starts.ctypes.data, extents.ctypes.data, int(i), int(first), int(count), out.ctypes.data)
+    return out[:int(k)]
 
 
 def read_aa_params(path):

@@ -76,7 +76,7 @@ EXPORTS = (
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
-    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_debug_schedule",
+    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_score_begin_text", "plaac_score_end_text", "plaac_debug_schedule",
 )
 
 _lib = None
@@ -126,6 +126,8 @@ def load():
     L.plaac_score_end.argtypes = [C.c_void_p, C.c_void_p]
     L.plaac_score_begin_counting.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.plaac_score_end_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.plaac_score_begin_text.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int]
+    L.plaac_score_end_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.plaac_score_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
     L.plaac_histogram_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -316,6 +318,25 @@ class Context:
         counts = np.zeros(NAA, dtype=np.int64)
         self._check(self._L.plaac_score_end_counts(self._h, rows.ctypes.data, counts.ctypes.data))
         return rows, counts
+
+    def score_text(self, text, starts, counting=False, want_codes=True):
+        """plaac_score_begin_text + plaac_score_end_text (K1: FASTA text parsed and encoded on the device): `text` bytes of whole
+        records, starts[i] = where record i begins (starts[-1] = len(text)). Returns (rows, codes, offsets, blank_end[, counts]);
+        want_codes=False: `codes` is the records' extents instead (uint32 [nrec, 2], for hostio.text_codes)."""
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        nrec = len(starts) - 1
+        self._check(self._L.plaac_score_begin_text(self._h, text, len(text), starts.ctypes.data, nrec, 1 if counting else 0))
+        rows = np.zeros(nrec, dtype=ROW_DTYPE)
+        codes = np.zeros(max(len(text), 1), dtype=np.uint8)
+        offsets = np.zeros(nrec + 1, dtype=np.uint64)
+        blank = np.zeros(max(nrec, 1), dtype=np.uint8)
+        counts = np.zeros(NAA, dtype=np.int64)
+        ext = np.zeros((max(nrec, 1), 2), dtype=np.uint32)
+        self._check(self._L.plaac_score_end_text(self._h, rows.ctypes.data, codes.ctypes.data if want_codes else None, len(codes),
+                                                 offsets.ctypes.data, blank.ctypes.data, ext.ctypes.data,
+                                                 counts.ctypes.data if counting else None))
+        out = (rows, codes[:int(offsets[-1])] if want_codes else ext[:nrec], offsets, blank[:nrec])
+        return out + (counts,) if counting else out
 
     def score_stream(self, batches, counting=False):
         """scores an iterable of (codes, offsets) batches with two in flight; yields the row arrays in order

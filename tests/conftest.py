@@ -76,3 +76,24 @@ def runs_of_ones(v):
         else:
             j += 1
     return out
+
+
+def quirky_fasta(seed=5, nrec=1500):
+    """FASTA text with everything fastareader (plaac.java:4302-4375) has a rule for: junk before the first header, \n / \r\n /
+    lone \r line ends (mixed inside a record), empty lines that end a record's sequence (the rest is skipped, the NEXT name is
+    trimmed), blanks / tabs / '>' / '*' / lower case / other bytes inside sequence lines, headers with trailing blanks, records
+    without a sequence, a last line without a terminator"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    aas = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYacdXB* ->\t", dtype=np.uint8)
+    out = [b"leading junk\n>first header after junk  \n"]
+    for r in range(nrec):
+        out.append(b">rec%d text%s" % (r, b" \t " if r % 3 == 0 else b"") + (b"\r\n" if r % 5 == 0 else b"\n"))
+        for _ in range(int(rng.integers(0, 5))):
+            out.append(b"A" + bytes(rng.choice(aas, int(rng.integers(1, 90)))) + (b"\r" if r % 11 == 0 else (b"\r\n" if r % 7 == 0 else b"\n")))
+        if r % 4 == 0:
+            out.append((b"\r\n" if r % 8 == 0 else b"\n") + b"skipped line\n")
+        if r % 97 == 0:
+            out.append(b">\n>only a header\n")
+    out.append(b">last\nMKVLAAGIQQ*")
+    return b"".join(out)

@@ -258,16 +258,22 @@ def test_single_pass_writes_the_same_bytes_as_the_two_passes(native, tmp_path):
     empty = tmp_path / "empty.fa"
     empty.write_text("")
     dot = tmp_path / "hmm.dot"
+    # K1 (round 5): the single pass parses on the device (plaac_score_begin_text); a file with every line-end / blank-line /
+    # name-trimming quirk of fastareader (:4302-4375), cut into batches at any record, must come out the same
+    from conftest import quirky_fasta
+    quirks = tmp_path / "quirks.fa"
+    quirks.write_bytes(quirky_fasta(seed=8, nrec=1200))
     cases = [["-i", fa], ["-i", fa, "-d"], ["-i", fa, "-a", "3"], ["-i", fa, "-b", fa], ["-i", fa, "-s"], ["-i", fa, "-h", dot],
-             ["-i", fa, "-c", "30", "-W", "21"], ["-i", empty], ["-i", FA4, "-a", "1.0"], ["-i", fa, "-a", "0.5"],
+             ["-i", fa, "-c", "30", "-W", "21"], ["-i", empty], ["-i", FA4, "-a", "1.0"], ["-i", quirks], ["-i", fa, "-a", "0.5"],
              ["-i", fa, "-B", os.path.join(GOLDEN, "bg_freqs", "bg_freqs_YEAST.txt")]]
     for args in cases:
         outs = []
-        for env in ({"PLAAC_SINGLE_PASS": "0", "PLAAC_HUGE_PAGES": "0"}, {}, {"PLAAC_BATCH_RECORDS": "257", "PLAAC_DEVICES": "0,0"}):
+        for env in ({"PLAAC_SINGLE_PASS": "0", "PLAAC_HUGE_PAGES": "0"}, {}, {"PLAAC_BATCH_RECORDS": "257", "PLAAC_DEVICES": "0,0"},
+                    {"PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_BATCH_RECORDS": "1"} if args[1] is quirks else {"PLAAC_BATCH_BYTES": "4096"}):
             r = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300, env=dict(os.environ, PLAAC_TIMING="1", **env))
             assert r.returncode == 0, r.stderr.decode(errors="replace")
             outs.append((r.stdout, r.stderr.decode(errors="replace")))
-        assert outs[0][0] == outs[1][0] == outs[2][0], "single pass differs from two passes for %s" % args
+        assert all(o[0] == outs[0][0] for o in outs[1:]), "single pass differs from two passes for %s" % args
         single = "single pass" in outs[1][1]
         assert "single pass" not in outs[0][1]
         expect_single = not any(str(a) in ("0.5", "-B") for a in args)
@@ -275,3 +281,50 @@ def test_single_pass_writes_the_same_bytes_as_the_two_passes(native, tmp_path):
     # a single-pass table is still the oracle's (bg_input line from the counts of the whole input)
     lines = outs[1][0].decode().split("\n")
     assert any(l.startswith("## bg_input") for l in lines)
+
+
+def test_single_pass_into_a_file_writes_the_table_in_place(native, tmp_path):
+    """Single pass with stdout a plain file (round 5): the table is written where it belongs while the parameter block in front
+    of it still waits for the counts - a placeholder of the block's length first, the block over it at the end. Byte-identical
+    to the two-pass run: plain, with column notes, without the block, from an offset inside a file that already has content,
+    appending (no placing then), an input without a single valid residue (the block prints NaN: shorter than its placeholder,
+    the table moves), an input of one residue type (frequency 1.00000), an empty input."""
+    from plaac_amd import synth
+    from conftest import quirky_fasta
+    P = native.make_params()
+    codes, offs = synth.make_batch(4, nprot=5000, seed=91, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.2)
+    fa = tmp_path / "in.fa"
+    _write_fasta(fa, codes, offs)
+    allx = tmp_path / "allx.fa"
+    allx.write_bytes(b"".join(b">x%d\n%s\n" % (i, b"X" * (50 + i) + (b"*" if i % 2 else b"")) for i in range(300)))
+    polyq = tmp_path / "polyq.fa"
+    polyq.write_bytes(b"".join(b">q%d\n%s\n" % (i, b"Q" * (80 + i)) for i in range(100)))
+    quirks = tmp_path / "quirks.fa"
+    quirks.write_bytes(quirky_fasta(seed=9, nrec=900))
+    empty = tmp_path / "empty.fa"
+    empty.write_text("")
+
+    def to_file(args, env, mode="wb", lead=b""):
+        out = tmp_path / "out.tsv"
+        if mode == "ab":
+            out.write_bytes(lead)
+        with open(out, mode) as fh:
+            if mode == "wb" and lead:
+                fh.write(lead)
+                fh.flush()
+            r = subprocess.run([BIN] + [str(a) for a in args], stdout=fh, stderr=subprocess.PIPE, timeout=300,
+                               env=dict(os.environ, PLAAC_TIMING="1", **env))
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        return out.read_bytes(), r.stderr.decode(errors="replace")
+
+    for args in (["-i", fa], ["-i", fa, "-d"], ["-i", fa, "-s"], ["-i", allx], ["-i", allx, "-d"], ["-i", polyq], ["-i", quirks], ["-i", empty]):
+        want, _ = to_file(args, {"PLAAC_SINGLE_PASS": "0"})
+        for env in ({}, {"PLAAC_PLACED_WRITE": "0"}, {"PLAAC_BATCH_RECORDS": "300"}):
+            got, err = to_file(args, env)
+            assert "single pass" in err
+            assert got == want, (args, env)
+        got, _ = to_file(args, {}, lead=b"something the shell wrote before\n")
+        assert got == b"something the shell wrote before\n" + want, args
+        got, _ = to_file(args, {}, mode="ab", lead=b"appended to\n")
+        assert got == b"appended to\n" + want, args
+    assert b"NaN" in to_file(["-i", allx], {})[0]

@@ -1176,3 +1176,48 @@ def test_result_breaking_switches_change_nothing_in_the_release_library(native, 
         for _ in range(4):  # (the switch used to act from the third call on)
             rows = c.score(codes, offs)
             assert_rows_equal(rows, want)
+
+
+@pytest.mark.parametrize("max_records,max_bytes", [(1 << 20, 1 << 30), (257, 1 << 30), (1 << 20, 4096), (1, 1 << 30)])
+def test_fasta_text_parsed_on_the_device_equals_the_host_parser(native, oracle, tmp_path, max_records, max_bytes):
+    """K1 (round 5): plaac_score_begin_text / _end_text - the host only finds the records, the device splits lines, stops at
+    empty lines and encodes. Codes, offsets, names (with the reference's trimming rule across batch boundaries), rows and
+    background counts must equal what the host parser (plaac_fasta_read, itself held against a Python restatement of
+    fastareader in tests/test_host_io.py) + plaac_score give, for any batch cut."""
+    from plaac_amd import hostio
+    from conftest import quirky_fasta
+    data = quirky_fasta()
+    p = tmp_path / "q.fa"
+    p.write_bytes(data)
+    names, codes, offs = hostio.read_fasta(p)
+    want_rows = oracle.score_batch(oracle.build_params(), codes, offs, nthreads=8)
+    want_counts = oracle.histogram(codes, offs)
+    got_names, got_codes, got_rows, lens = [], [], [], []
+    counts = np.zeros(22, dtype=np.int64)
+    prev_blank = 1
+    with native.Context(native.make_params()) as ctx:
+        for text, starts, trim in hostio.stream_fasta_text(p, max_records, max_bytes):
+            rows, c, o, blank, cnt = ctx.score_text(text, starts, counting=True)
+            nm, prev_blank = trim(blank, prev_blank)
+            got_names += nm
+            got_codes.append(c)
+            lens.append(np.diff(o.astype(np.int64)))
+            got_rows.append(rows)
+            counts += cnt
+        # the host's way to a few residues without the copy of all codes: the device's extents + the text
+        rng = np.random.default_rng(1)
+        text, starts, trim = next(iter(hostio.stream_fasta_text(p, 1 << 20, 1 << 30)))
+        rows, ext, o, blank = ctx.score_text(text, starts, want_codes=False)
+        assert_rows_equal(rows, want_rows, "rows without the codes copied back")
+        assert np.array_equal(o, offs)
+        for i in rng.integers(0, len(names), 400):
+            n = int(offs[i + 1] - offs[i])
+            first = int(rng.integers(0, n + 2))
+            cnt = int(rng.integers(0, 60))
+            want = codes[int(offs[i]) + min(first, n):int(offs[i]) + min(first + cnt, n)]
+            assert np.array_equal(hostio.text_codes(text, starts, ext, i, first, cnt), want), (i, first, cnt)
+    assert got_names == names
+    assert np.array_equal(np.concatenate(lens), np.diff(offs.astype(np.int64)))
+    assert np.array_equal(np.concatenate(got_codes), codes)
+    assert_rows_equal(np.concatenate(got_rows), want_rows, "rows of the device-parsed batches")
+    assert np.array_equal(counts, want_counts)

@@ -335,3 +335,30 @@ def test_hmm_dot_export(io, native):
     probs = rec1.split("prob|")[1].split("}")[0].split("|")
     assert len(probs) == 20 and probs[11] == io.format_fixed(P.fg[12] / sum(P.fg), 4)  # N is the 12th code
     assert lines[-4:-2] == ["  n0 -> rec0 [style=dashed];", "  n1 -> rec1 [style=dashed];"]
+
+
+def test_text_batches_locate_the_records_the_parser_finds(io, tmp_path):
+    """plaac_fasta_next_text (the host half of the device-side parse): the same records as plaac_fasta_read - their starts are
+    the '>' of a line, their untrimmed names the header text - for any batch cut; junk before the first header belongs to no
+    batch; the batches tile the file from the first header on."""
+    rng = np.random.default_rng(3)
+    out = [b"junk\r\n>a  \n"]
+    for r in range(800):
+        out.append(b">r%d  \t" % r + (b"\r\n" if r % 3 == 0 else b"\n") + b"ACD>EF\n" * int(rng.integers(0, 3)) + (b"\n" if r % 5 == 0 else b""))
+    data = b"".join(out)
+    p = tmp_path / "t.fa"
+    p.write_bytes(data)
+    names, codes, offs = io.read_fasta(p)
+    for mr, mb in ((1 << 20, 1 << 30), (7, 1 << 30), (1 << 20, 100)):
+        pos, n, untrimmed = data.index(b">"), 0, []
+        for text, starts, trim in io.stream_fasta_text(p, mr, mb):
+            assert data[pos:pos + len(text)] == text and len(starts) - 1 <= mr
+            for i in range(len(starts) - 1):
+                assert text[int(starts[i]):int(starts[i]) + 1] == b">"
+            nm, _ = trim(np.zeros(len(starts) - 1, np.uint8), 0)  # (no trimming: raw header text)
+            untrimmed += nm
+            pos += len(text)
+            n += len(starts) - 1
+        assert pos == len(data) and n == len(names)
+        assert [u.rstrip(bytes(range(33))) if (i == 0) else u for i, u in enumerate(untrimmed)][:1] == names[:1]
+        assert all(u.startswith(nm) for u, nm in zip(untrimmed, names))

@@ -1,0 +1,42 @@
+#!/bin/bash
+# round 5, K1: bin/plaac single pass with the FASTA parsed on the device vs on the host, the table written in place vs held back:
+# the 10 M-sequence leg every way (the output file is removed before each run)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5; mkdir -p $O
+
+
+python3 - > $O/e2e_device_parse.txt 2>&1 <<'PY'
+import os, sys, subprocess, time, hashlib
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import bench
+from plaac_amd import native, synth
+dev = torch.device("cuda", 0)
+P = native.make_params()
+pieces, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=dev)], 0
+for ci, start in enumerate(range(0, 10_000_000, 1_250_000)):
+    c_, o_ = synth.make_batch_torch(4, 1_250_000, np.array(P.fg), np.array(P.bg), dev, seed=synth.SEED0 + 4 + 100000 * ci)
+    pieces.append(c_); offs.append(o_[1:] + base); base += int(o_[-1].item())
+codes = torch.cat(pieces); offsets = torch.cat(offs)
+fa, tsv = "/tmp/e2e.fa", "/tmp/e2e.tsv"
+fbytes, nres = bench.write_fasta(torch, codes, offsets, 10_000_000, fa)
+del codes, offsets, pieces
+torch.cuda.empty_cache()
+print("# 10 M sequences, %d residues, %d bytes of FASTA; bin/plaac -i <fa> > <tsv>, PLAAC_TIMING=1" % (nres, fbytes))
+for rep in range(3):
+    for env in ({"PLAAC_SINGLE_PASS": "0"}, {"PLAAC_PLACED_WRITE": "0", "PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_PLACED_WRITE": "0"}, {},
+                {"PLAAC_FAST_EXIT": "1"}, {"PLAAC_DEVICES": "0,0,0,0,0,0,0,0"}):
+        if os.path.exists(tsv):
+            os.unlink(tsv)  # (the shell's truncation of a stale 2 GB file is not the program's time: 0.3 s)
+        t0 = time.perf_counter()
+        with open(tsv, "wb") as fh:
+            r = subprocess.run(["bin/plaac", "-i", fa], stdout=fh, stderr=subprocess.PIPE, env=dict(os.environ, PLAAC_TIMING="1", PLAAC_TIMING_T0=str(time.clock_gettime_ns(time.CLOCK_MONOTONIC)), **env))
+        dt = time.perf_counter() - t0
+        h = hashlib.sha256(open(tsv, "rb").read()).hexdigest()[:16]
+        print("%-32s %.3f s  rc %d  sha256 %s  %.3g residues/s" % (" ".join("%s=%s" % kv for kv in env.items()) or "(default)", dt, r.returncode, h, nres / dt))
+        if rep == 2:
+            for l in r.stderr.decode().splitlines():
+                if l.startswith("plaac-timing"):
+                    print("    " + l)
+PY
+cat $O/e2e_device_parse.txt
