@@ -50,24 +50,24 @@ plaac_status plaac_fasta_next(plaac_fasta_stream *s, uint32_t max_records, uint6
 void plaac_fasta_close(plaac_fasta_stream *s);
 
 /* The stream cut into batches of TEXT for the device-side parser (plaac_score_begin_text, round 5): the same batch boundaries
- * as plaac_fasta_next, but the records are only LOCATED - starts[i] = offset of record i's '>' inside `text`, starts[nrec] = len -
- * and their names copied (untrimmed: whether a name is trimmed depends on how the record before it ended, :4362, which the
- * device reports as blank_end; plaac_fasta_text_trim_names applies it). `text` points into the stream's file image and stays
- * valid until plaac_fasta_text_free (which also lets the stream release the pages behind it). *out = NULL at the end. */
+ * as plaac_fasta_next, but the records are only LOCATED - starts[i] = offset of record i's '>' inside `text`, starts[nrec] = len;
+ * record i's name is the name_len[i] bytes behind its '>' (NOT copied, not NUL-terminated; untrimmed: whether a name is
+ * trimmed depends on how the record before it ended, :4362, which the device reports as blank_end;
+ * plaac_fasta_text_trim_names applies it to name_len). `text` points into the stream's file image and stays valid until
+ * plaac_fasta_text_free (which also lets the stream release the pages behind it). *out = NULL at the end. */
 typedef struct plaac_fasta_text {
     const char *text;
     uint64_t len;
     uint32_t nrec;
     uint64_t *starts;   /* nrec + 1 */
-    char *names;        /* all headers, NUL-separated */
-    uint64_t *name_off; /* nrec + 1 offsets into names */
+    uint32_t *name_len; /* nrec */
     void *owner_;       /* the stream (page release bookkeeping) */
     uint64_t file_off_; /* offset of `text` in the file */
 } plaac_fasta_text;
 plaac_status plaac_fasta_next_text(plaac_fasta_stream *s, uint32_t max_records, uint64_t max_bytes, plaac_fasta_text **out);
 void plaac_fasta_text_free(plaac_fasta_text *t);
-/* trims the names the reference trims: the first record of the file and every record whose predecessor ended in an empty
- * line. prev_blank: how the record before this batch ended (1 for the first batch); returns the flag for the next batch. */
+/* trims (shortens name_len of) the names the reference trims: the first record of the file and every record whose
+ * predecessor ended in an empty line. prev_blank: how the record before this batch ended (1 for the first batch); returns the flag for the next batch. */
 int plaac_fasta_text_trim_names(plaac_fasta_text *t, const uint8_t *blank_end, int prev_blank);
 /* Residues [first, first + count) of record i of a text batch, encoded as plaac_encode does, read from the TEXT with the
  * extents the device reported for the batch (plaac_score_end_text: extents[2i], extents[2i+1]): the host's way to the few
@@ -98,6 +98,10 @@ int plaac_format_double_tostring(double v, char *buf, size_t cap);
  * Records with row->prot_len == 0 produce no line (returns 0). */
 long plaac_format_summary_row(const plaac_row *row, const char *name, const uint8_t *codes, uint64_t reclen,
                               int corelength, int ww2, char *buf, size_t cap);
+/* The same with the name given by length (not NUL-terminated: the names of a text batch lie in the file's text) and written
+ * without a terminating NUL. cap must cover name_len + 3 * prot_len + ww2 + 8700 (the longest a row can be); -1 otherwise. */
+long plaac_format_summary_row_n(const plaac_row *row, const char *name, size_t name_len, const uint8_t *codes, uint64_t reclen,
+                                int corelength, int ww2, char *buf, size_t cap);
 /* header line of the summary table (:715-719) and of the per-residue table (:603-605), no newline */
 const char *plaac_summary_header(void);
 const char *plaac_tracks_header(void);

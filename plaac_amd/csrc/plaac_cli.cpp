@@ -63,6 +63,7 @@
 #include <vector>
 
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -120,6 +121,18 @@ struct StageTimer {
                     std::fprintf(stderr, "plaac-timing:     %s", line);
             std::fclose(fp);
         }
+        {
+            rusage ru;
+            getrusage(RUSAGE_SELF, &ru);
+            std::fprintf(stderr, "plaac-timing:     cpu used so far: user %.3f s, system %.3f s\n", ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6,
+                         ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6);
+            if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu.stat", "r")) { // (the container's CPU quota: was the process held back?)
+                char line[256];
+                while (std::fgets(line, sizeof line, fp))
+                    if (std::strstr(line, "throttled")) std::fprintf(stderr, "plaac-timing:     cgroup %s", line);
+                std::fclose(fp);
+            }
+        }
         if (std::getenv("PLAAC_TIMING_MAPS"))
             if (FILE *fp = std::fopen("/proc/self/smaps", "r")) { // the mappings with more than 32 MB resident
                 char line[512], head[512] = "";
@@ -132,6 +145,29 @@ struct StageTimer {
             }
     }
 } g_timer;
+
+// PLAAC_TIMING: how long each stage of the pipeline was BUSY (summed over its calls; the stages run side by side)
+struct Busy {
+    std::atomic<long long> ns[10] = {};
+    std::atomic<long long> cpu_fmt{0};
+    const char *name[10] = {"reader: next batch", "worker: begin (upload, parse kernels, enqueue)", "worker: end (wait, download)",
+                           "sink: format a batch (all threads, wall)", "sink: hand parts to the writer (waits for room)",
+                           "writer: fwrite", "writer: waiting for text", "sink: waiting for a scored batch",
+                           "sink: format threads, summed over threads", "sink: the residues a row prints, read from the text (summed)"};
+    struct Scope {
+        Busy &b;
+        int k;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~Scope() { b.ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    };
+    Scope in(int k) { return Scope{*this, k}; }
+    void report() {
+        if (!g_timer.on) return;
+        for (int k = 0; k < 10; ++k)
+            if (ns[k]) std::fprintf(stderr, "plaac-timing:   busy %-52s %9.3f ms\n", name[k], ns[k] * 1e-6);
+        if (cpu_fmt) std::fprintf(stderr, "plaac-timing:   cpu  %-52s %9.3f ms\n", "sink: format threads, CPU time summed", cpu_fmt * 1e-6);
+    }
+} g_busy;
 
 void usage() {
     put("------------------------------------------------------------\n"
@@ -521,6 +557,7 @@ class Writer {
             for (;;) {
                 std::vector<TextBuf> take;
                 {
+                    auto busy = g_busy.in(6);
                     std::unique_lock<std::mutex> l(m);
                     cv_get.wait(l, [&] { return (!held && !q.empty()) || closed; });
                     if (q.empty()) return;
@@ -528,6 +565,7 @@ class Writer {
                     bytes = 0;
                     cv_put.notify_all();
                 }
+                auto busy = g_busy.in(5);
                 for (TextBuf &s : take) {
                     if (!bad && std::fwrite(s.p, 1, s.n, stdout) != s.n) bad = true;
                     pool.put(s);
@@ -722,6 +760,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                 b->owned = false;
             } else if (as_text) { // K1: the records are only located; the device parses them
                 plaac_fasta_text *t = nullptr;
+                auto busy = g_busy.in(0);
                 const plaac_status st = plaac_fasta_next_text(fs, sp.batch_records, sp.batch_bytes, &t);
                 if (st != PLAAC_OK) {
                     std::fprintf(stderr, "plaac: reading %s failed (status %d)\n", path.c_str(), (int)st);
@@ -780,6 +819,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
             BatchPtr pend; // pipelined scoring: the batch begun in the previous round
             auto collect_pending = [&] { // (an end is owed for every begin, whatever has failed since)
                 if (pend->begun) {
+                    auto busy = g_busy.in(2);
                     const plaac_status st = finish(ctx, *pend);
                     if (st != PLAAC_OK && pend->st == PLAAC_OK) {
                         pend->st = st;
@@ -798,6 +838,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                     if (pend && !ro.has_room(b->seq)) collect_pending();
                     ro.wait_room(b->seq);
                     if (!failed) {
+                        auto busy = g_busy.in(1);
                         b->st = work(ctx, *b);
                         if (b->st != PLAAC_OK) {
                             b->err = plaac_last_error(ctx);
@@ -816,7 +857,11 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
         });
     bool ok = true;
     for (;;) {
-        BatchPtr b = ro.take();
+        BatchPtr b;
+        {
+            auto busy = g_busy.in(7);
+            b = ro.take();
+        }
         if (!b) break;
         if (b->st != PLAAC_OK && ok) {
             std::fprintf(stderr, "plaac: scoring failed (status %d): %s\n", (int)b->st, b->err.c_str());
@@ -1038,8 +1083,8 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             b.view.nres = b.toffs[n];
             b.view.codes = nullptr;
             b.view.offsets = b.toffs.data();
-            b.view.names = b.ft->names;
-            b.view.name_off = b.ft->name_off;
+            b.view.names = nullptr; // (a text batch's names lie in its text: name_of below)
+            b.view.name_off = nullptr;
             b.f = &b.view;
             b.owned = false;
         } else {
@@ -1094,21 +1139,48 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             std::vector<TextBuf> part(nt);
             std::vector<int> bad(nt, 0);
             auto fmt = [&](unsigned t) {
+                auto busy_thread = g_busy.in(8);
+                struct CpuClock { // (thread CPU time beside the wall time: the difference is time the thread was not running)
+                    timespec t0;
+                    CpuClock() { clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t0); }
+                    ~CpuClock() {
+                        timespec t1;
+                        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1);
+                        g_busy.cpu_fmt += (t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec);
+                    }
+                } cpu_clock;
                 const uint32_t r0 = (uint32_t)((uint64_t)f->nrec * t / nt), r1 = (uint32_t)((uint64_t)f->nrec * (t + 1) / nt);
-                std::vector<char> line;
+                long long decode_ns = 0;
+                struct AddDecode {
+                    long long &v;
+                    ~AddDecode() { g_busy.ns[9] += v; }
+                } add_decode{decode_ns};
                 std::vector<uint8_t> some; // device-parsed batch: the record's codes where the row prints them
                 // (one buffer per thread and batch, from the writer's pool: ~230 bytes of numbers per row + its name, sequences
                 //  are printed for the few records with a PrD; it grows if that was too little)
-                part[t] = writer.buffer((size_t)(r1 - r0) * 260 + (size_t)(f->name_off[r1] - f->name_off[r0]) +
-                                        (size_t)(f->offsets[r1] - f->offsets[r0]) / 8 + 4096);
+                auto name_of = [&](uint32_t i, size_t &nl) -> const char * {
+                    if (b.ft) {
+                        nl = b.ft->name_len[i];
+                        return b.ft->text + b.ft->starts[i] + 1;
+                    }
+                    const char *nm = rec_name(f, i);
+                    nl = std::strlen(nm);
+                    return nm;
+                };
+                const size_t names_bytes = b.ft ? (size_t)(r1 - r0) * 24 : (size_t)(f->name_off[r1] - f->name_off[r0]);
+                part[t] = writer.buffer((size_t)(r1 - r0) * 260 + names_bytes + (size_t)(f->offsets[r1] - f->offsets[r0]) / 8 + 16384);
                 TextBuf &out = part[t];
                 for (uint32_t i = r0; i < r1; ++i) {
                     const uint64_t len = f->offsets[i + 1] - f->offsets[i];
+                    size_t nl = 0;
+                    const char *nm = name_of(i, nl);
                     if (len == 0) {
-                        std::fprintf(stderr, "plaac: record '%s' has no sequence, skipped\n", rec_name(f, i));
+                        std::fprintf(stderr, "plaac: record '%.*s' has no sequence, skipped\n", (int)nl, nm);
                         continue;
                     }
-                    line.resize(len * 3 + std::strlen(rec_name(f, i)) + 2048);
+                    // (the row goes straight into the part's buffer: room for the longest a row can be)
+                    const size_t need = nl + len * 3 + (size_t)o.ww2 + 8800;
+                    if (out.n + need > out.cap) out.grow(out.n + need);
                     const uint8_t *rec_codes;
                     if (b.ft) {
                         // The residues a row prints (plaac_format_summary_row: the PAPA window; core, PrD and its two ends when
@@ -1130,34 +1202,42 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
                                 for (long v : {(long)r.core_start, (long)r.core_end, (long)r.prd_start, (long)r.prd_start + 14,
                                                (long)r.prd_end - 14, (long)r.prd_end})
                                     want(v);
+                            const auto td0 = std::chrono::steady_clock::now();
                             (void)plaac_fasta_text_codes(b.ft->text, b.ft->starts, b.text_ext.data(), i, (uint64_t)lo,
                                                          (uint64_t)(hi - lo + 1), some.data() + lo);
+                            decode_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - td0).count();
                         }
                         rec_codes = some.data();
                     } else {
                         rec_codes = f->codes + f->offsets[i];
                     }
-                    const long k = plaac_format_summary_row(&b.rows[i], rec_name(f, i), rec_codes, len, o.corelength, o.ww2,
-                                                            line.data(), line.size());
+                    const long k = plaac_format_summary_row_n(&b.rows[i], nm, nl, rec_codes, len, o.corelength, o.ww2, out.p + out.n,
+                                                              out.cap - out.n - 1);
                     if (k < 0) {
                         bad[t] = 1;
                         return;
                     }
                     if (k == 0) continue; // nothing left after the stop trim (:762)
-                    out.append(line.data(), (size_t)k);
-                    out.push_back('\n');
+                    out.n += (size_t)k;
+                    out.p[out.n++] = '\n';
                 }
             };
-            if (nt == 1) {
-                fmt(0);
-            } else {
-                std::vector<std::thread> pool;
-                for (unsigned t = 0; t < nt; ++t) pool.emplace_back(fmt, t);
-                for (auto &th : pool) th.join();
+            {
+                auto busy = g_busy.in(3);
+                if (nt == 1) {
+                    fmt(0);
+                } else {
+                    std::vector<std::thread> pool;
+                    for (unsigned t = 0; t < nt; ++t) pool.emplace_back(fmt, t);
+                    for (auto &th : pool) th.join();
+                }
             }
             for (unsigned t = 0; t < nt; ++t)
                 if (bad[t]) return false;
-            for (unsigned t = 0; t < nt; ++t) writer.write(part[t]);
+            {
+                auto busy = g_busy.in(4);
+                for (unsigned t = 0; t < nt; ++t) writer.write(part[t]);
+            }
             nres += f->nres;
             nrec += f->nrec;
             return true;
@@ -1183,6 +1263,7 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
         return false;
     }
     g_timer.lap("scoring pass (read + H2D + GPU + D2H + format + write)", (double)nres, "residues");
+    g_busy.report();
     return ok;
 }
 

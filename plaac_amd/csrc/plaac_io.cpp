@@ -253,11 +253,6 @@ void clamp_range(int m, int &r1, int &r2) {
     if (r2 >= m) r2 = m - 1;
 }
 
-void append_aa(std::string &out, const uint8_t *aa, int m, int r1, int r2) {
-    clamp_range(m, r1, r2);
-    for (int i = r1; i <= r2; ++i) out.push_back(kAlphabet[aa[i] <= 21 ? aa[i] : 0]);
-}
-
 long emit(const std::string &s, char *buf, size_t cap) {
     if (s.size() + 1 > cap) return -1;
     std::memcpy(buf, s.data(), s.size());
@@ -560,6 +555,9 @@ plaac_status plaac_fasta_next(plaac_fasta_stream *s, uint32_t max_records, uint6
 void plaac_fasta_close(plaac_fasta_stream *s) { delete s; }
 
 // ---- the stream as batches of text for the device-side parser (K1, round 5) ----
+// The reader is the one serial stage of bin/plaac's single pass, so it does as little as it can: it finds the lines that
+// begin with '>' (memchr, the batch's bytes split over the host's threads) and, in the same sweep, where each header line
+// ends; names are NOT copied (a name is text[starts[i] + 1 .. + name_len[i]), the text stays mapped while the batch lives).
 plaac_status plaac_fasta_next_text(plaac_fasta_stream *s, uint32_t max_records, uint64_t max_bytes, plaac_fasta_text **out) {
     if (!s || !out) return PLAAC_ERR_ARG;
     *out = nullptr;
@@ -575,12 +573,10 @@ plaac_status plaac_fasta_next_text(plaac_fasta_stream *s, uint32_t max_records, 
     }
     if (s->cursor >= nbytes) return PLAAC_OK;
     const size_t b0 = s->cursor;
-    // record starts inside [b0, b0 + max_bytes), in parallel over byte ranges, then cut at max_records / the first start at or
-    // after b0 + max_bytes (a record is never split)
+    // the batch ends at the first record start at or after b0 + max_bytes (a record is never split), or at max_records
     size_t hard = nbytes;
     if (nbytes - b0 > max_bytes) {
         size_t p = b0 + (size_t)max_bytes;
-        hard = nbytes;
         while (p < nbytes) {
             const char *q = (const char *)memchr(d + p, '>', nbytes - p);
             if (!q) break;
@@ -593,17 +589,30 @@ plaac_status plaac_fasta_next_text(plaac_fasta_stream *s, uint32_t max_records, 
         }
     }
     const size_t span = hard - b0;
-    const unsigned nt = span < (8u << 20) ? 1u : host_threads();
-    std::vector<std::vector<uint64_t>> part(nt);
+    const unsigned nt = span < (4u << 20) ? 1u : host_threads();
+    struct Found {
+        uint64_t start;
+        uint32_t name_len;
+    };
+    std::vector<std::vector<Found>> part(nt);
     auto scan = [&](unsigned t) {
         size_t p = b0 + span / nt * t;
         const size_t e = t + 1 == nt ? hard : b0 + span / nt * (t + 1);
+        std::vector<Found> &f = part[t];
+        f.reserve((e - p) / 200 + 16);
         while (p < e) {
             const char *q = (const char *)memchr(d + p, '>', e - p);
             if (!q) break;
             p = (size_t)(q - d);
-            if (is_start(p)) part[t].push_back(p);
-            ++p;
+            if (is_start(p)) {
+                // the header line ends at the first \n or \r (or with the file): the next record cannot begin before that
+                size_t le = p + 1;
+                while (le < nbytes && d[le] != '\n' && d[le] != '\r') ++le;
+                f.push_back(Found{(uint64_t)p, (uint32_t)std::min<size_t>(le - p - 1, 0xffffffffu)});
+                p = le;
+            } else {
+                ++p;
+            }
         }
     };
     if (nt == 1) {
@@ -613,52 +622,35 @@ plaac_status plaac_fasta_next_text(plaac_fasta_stream *s, uint32_t max_records, 
         for (unsigned t = 0; t < nt; ++t) pool.emplace_back(scan, t);
         for (auto &th : pool) th.join();
     }
-    std::vector<uint64_t> starts;
-    for (auto &v : part) starts.insert(starts.end(), v.begin(), v.end());
+    size_t nrec = 0;
+    for (auto &v : part) nrec += v.size();
     size_t e = hard;
-    if (starts.size() > max_records) {
-        e = (size_t)starts[max_records];
-        starts.resize(max_records);
-    }
-    const size_t nrec = starts.size();
     plaac_fasta_text *t = (plaac_fasta_text *)std::calloc(1, sizeof(plaac_fasta_text));
     if (!t) return PLAAC_ERR_NOMEM;
+    const size_t keep = std::min<size_t>(nrec, max_records);
+    t->starts = (uint64_t *)std::malloc((keep + 1) * sizeof(uint64_t));
+    t->name_len = (uint32_t *)std::malloc((keep + 1) * sizeof(uint32_t));
+    if (!t->starts || !t->name_len) {
+        plaac_fasta_text_free(t);
+        return PLAAC_ERR_NOMEM;
+    }
+    size_t k = 0;
+    for (auto &v : part)
+        for (const Found &f : v) {
+            if (k == keep) {
+                if (e == hard) e = (size_t)f.start; // the first record that no longer fits: the batch ends where it begins
+                break;
+            }
+            t->starts[k] = f.start - b0;
+            t->name_len[k] = f.name_len;
+            ++k;
+        }
+    t->starts[keep] = e - b0;
     t->text = d + b0;
     t->len = e - b0;
-    t->nrec = (uint32_t)nrec;
+    t->nrec = (uint32_t)keep;
     t->owner_ = s;
     t->file_off_ = b0;
-    t->starts = (uint64_t *)std::malloc((nrec + 1) * sizeof(uint64_t));
-    t->name_off = (uint64_t *)std::malloc((nrec + 1) * sizeof(uint64_t));
-    if (!t->starts || !t->name_off) {
-        plaac_fasta_text_free(t);
-        return PLAAC_ERR_NOMEM;
-    }
-    // header extents: from behind the '>' to the first line terminator (or the record's end)
-    std::vector<uint32_t> nlen(nrec);
-    uint64_t noff = 0;
-    for (size_t i = 0; i < nrec; ++i) {
-        const size_t rb = (size_t)starts[i] + 1, re = i + 1 < nrec ? (size_t)starts[i + 1] : e;
-        const char *nl = (const char *)memchr(d + rb, '\n', re - rb);
-        size_t le = nl ? (size_t)(nl - d) : re;
-        if (const char *cr = (const char *)memchr(d + rb, '\r', le - rb)) le = (size_t)(cr - d);
-        nlen[i] = (uint32_t)(le - rb);
-        t->starts[i] = starts[i] - b0;
-        t->name_off[i] = noff;
-        noff += nlen[i] + 1;
-    }
-    t->starts[nrec] = e - b0;
-    t->name_off[nrec] = noff;
-    t->names = (char *)std::malloc(noff + 1);
-    if (!t->names) {
-        plaac_fasta_text_free(t);
-        return PLAAC_ERR_NOMEM;
-    }
-    for (size_t i = 0; i < nrec; ++i) {
-        std::memcpy(t->names + t->name_off[i], d + starts[i] + 1, nlen[i]);
-        t->names[t->name_off[i] + nlen[i]] = '\0';
-    }
-    t->names[noff] = '\0';
     s->cursor = e;
     *out = t;
     return PLAAC_OK;
@@ -673,8 +665,7 @@ void plaac_fasta_text_free(plaac_fasta_text *t) {
         if (b > a) ::madvise((char *)s->file.map + a, b - a, MADV_DONTNEED);
     }
     std::free(t->starts);
-    std::free(t->names);
-    std::free(t->name_off);
+    std::free(t->name_len);
     std::free(t);
 }
 
@@ -682,10 +673,10 @@ int plaac_fasta_text_trim_names(plaac_fasta_text *t, const uint8_t *blank_end, i
     if (!t || !blank_end) return prev_blank;
     for (uint32_t i = 0; i < t->nrec; ++i) {
         if (i == 0 ? prev_blank != 0 : blank_end[i - 1] != 0) { // hasmorefastas: line.trim().substring(1) (:4362)
-            char *b = t->names + t->name_off[i];
-            size_t e = std::strlen(b);
-            while (e > 0 && (unsigned char)b[e - 1] <= ' ') --e;
-            b[e] = '\0';
+            const unsigned char *b = (const unsigned char *)t->text + t->starts[i] + 1;
+            uint32_t e = t->name_len[i];
+            while (e > 0 && b[e - 1] <= ' ') --e;
+            t->name_len[i] = e;
         }
     }
     return t->nrec ? (blank_end[t->nrec - 1] != 0) : prev_blank;
@@ -778,64 +769,139 @@ const char *plaac_tracks_header(void) {
            "HMM.PrD-like";
 }
 
-long plaac_format_summary_row(const plaac_row *r, const char *name, const uint8_t *codes, uint64_t reclen,
-                              int corelength, int ww2, char *buf, size_t cap) {
+// The row straight into the caller's buffer (round 5: 10 M of these are the longest stage of bin/plaac's run once the parse
+// is the device's): no string object, the integer and the three decimals of a %.3f from one rounded product.
+namespace {
+struct RowOut {
+    char *p;
+    inline void ch(char c) { *p++ = c; }
+    inline void lit(const char *s, size_t n) {
+        std::memcpy(p, s, n);
+        p += n;
+    }
+    inline void u64(unsigned long long v) {
+        char tmp[24];
+        int k = 24;
+        do {
+            tmp[--k] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        lit(tmp + k, (size_t)(24 - k));
+    }
+    inline void I(long v) { // "\t" + decimal
+        ch('\t');
+        if (v < 0) {
+            ch('-');
+            u64(0ull - (unsigned long long)v);
+        } else {
+            u64((unsigned long long)v);
+        }
+    }
+    inline void F(double v) { // "\t" + %.3f of java.util.Formatter (append_fixed's fast path; everything else through it)
+        ch('\t');
+        const double av = std::fabs(v);
+        if (av < 1e9) { // (false for NaN)
+            const double y = av * 1e3;
+            const double fl = std::floor(y), f = y - fl, err = y * 0x1p-51 + 0x1p-60;
+            if (std::fabs(f - 0.5) > err && err < 0.25) {
+                const unsigned long long r = (unsigned long long)fl + (f > 0.5 ? 1ull : 0ull);
+                if (std::signbit(v)) ch('-');
+                u64(r / 1000ull);
+                const unsigned fr = (unsigned)(r % 1000ull);
+                ch('.');
+                ch((char)('0' + fr / 100u));
+                ch((char)('0' + fr / 10u % 10u));
+                ch((char)('0' + fr % 10u));
+                return;
+            }
+        }
+        thread_local std::string s;
+        s.clear();
+        append_fixed(s, v, 3);
+        lit(s.data(), s.size());
+    }
+    inline void aa(const uint8_t *codes, int m, int r1, int r2) {
+        clamp_range(m, r1, r2);
+        for (int i = r1; i <= r2; ++i) *p++ = kAlphabet[codes[i] <= 21 ? codes[i] : 0];
+    }
+};
+} // namespace
+
+long plaac_format_summary_row_n(const plaac_row *r, const char *name, size_t name_len, const uint8_t *codes, uint64_t reclen,
+                                int corelength, int ww2, char *buf, size_t cap) {
     if (!r || !name || !buf) return -1;
     if (r->prot_len <= 0) return 0; // skipped record (:762)
     const int n = r->prot_len;
     (void)reclen;
-    thread_local std::string s; // one buffer per formatter thread: no allocation per row
-    s.assign(name);
-    auto I = [&](long v) { s += '\t'; append_int(s, v); };
-    auto F = [&](double v) { s += '\t'; append_fixed(s, v, 3); };
+    // the longest a row can be: the name, 37 fields of at most 26 characters (a %.3f below 1e9; larger values and the
+    // non-finite ones are at most 330), four sequences inside the protein and the PAPA window
+    if (cap < name_len + 3 * (size_t)n + (size_t)(ww2 > 0 ? ww2 : 0) + 37 * 26 + 23 * 330 + 64) return -1;
+    RowOut o{buf};
+    o.lit(name, name_len);
     // one-based indices; the -1/-2 sentinels are shifted too, as the reference does (:902-913)
-    I(r->mw_score);
-    I(r->mw_start + 1);
-    I(r->mw_end + 1);
-    I(r->mw_end - r->mw_start + 1);
-    F(inf2nan(r->llr_score));
-    I(r->llr_start + 1);
-    I(r->llr_end + 1);
-    I(r->llr_end - r->llr_start + 1);
-    F(inf2nan(r->llr_score) / (double)(r->llr_end - r->llr_start + 1)); // NLLR (:907)
-    I(r->vit_maxrun);
-    F(inf2nan(r->core_score));
-    I(r->core_start + 1);
-    I(r->core_end + 1);
-    I(r->core_end - r->core_start + 1);
-    F(r->prd_score);
-    I(r->prd_start + 1);
-    I(r->prd_end + 1);
-    I(r->prd_end - r->prd_start + 1);
-    I(n);
-    F(r->hmm_all);
-    F(r->hmm_vit);
-    s += '\t';
+    o.I(r->mw_score);
+    o.I(r->mw_start + 1);
+    o.I(r->mw_end + 1);
+    o.I(r->mw_end - r->mw_start + 1);
+    o.F(inf2nan(r->llr_score));
+    o.I(r->llr_start + 1);
+    o.I(r->llr_end + 1);
+    o.I(r->llr_end - r->llr_start + 1);
+    o.F(inf2nan(r->llr_score) / (double)(r->llr_end - r->llr_start + 1)); // NLLR (:907)
+    o.I(r->vit_maxrun);
+    o.F(inf2nan(r->core_score));
+    o.I(r->core_start + 1);
+    o.I(r->core_end + 1);
+    o.I(r->core_end - r->core_start + 1);
+    o.F(r->prd_score);
+    o.I(r->prd_start + 1);
+    o.I(r->prd_end + 1);
+    o.I(r->prd_end - r->prd_start + 1);
+    o.I(n);
+    o.F(r->hmm_all);
+    o.F(r->hmm_vit);
+    o.ch('\t');
     if (r->prd_end - r->prd_start + 1 >= corelength) { // (:915-922)
-        append_aa(s, codes, n, r->core_start, r->core_end);
-        s += '\t';
-        append_aa(s, codes, n, r->prd_start, r->prd_start + 14);
-        s += '\t';
-        append_aa(s, codes, n, r->prd_end - 14, r->prd_end);
-        s += '\t';
-        append_aa(s, codes, n, r->prd_start, r->prd_end);
+        o.aa(codes, n, r->core_start, r->core_end);
+        o.ch('\t');
+        o.aa(codes, n, r->prd_start, r->prd_start + 14);
+        o.ch('\t');
+        o.aa(codes, n, r->prd_end - 14, r->prd_end);
+        o.ch('\t');
+        o.aa(codes, n, r->prd_start, r->prd_end);
     } else {
-        s += "-\t-\t-\t-";
+        o.lit("-\t-\t-\t-", 7);
     }
-    I(r->fi_numaa);
-    F(r->fi_meanhydro);
-    F(r->fi_meancharge);
-    F(r->fi_meancombo);
-    I(r->fi_maxrun);
-    F(inf2nan(r->papa_combo));
-    F(r->papa_prop);
-    F(r->papa_fi);
-    F(r->papa_llr);
-    F(r->papa_llr2);
-    I(r->papa_cen + 1);
-    s += '\t';
-    append_aa(s, codes, n, r->papa_cen - ww2 / 2, r->papa_cen + ww2 / 2); // (:944)
-    return emit(s, buf, cap);
+    o.I(r->fi_numaa);
+    o.F(r->fi_meanhydro);
+    o.F(r->fi_meancharge);
+    o.F(r->fi_meancombo);
+    o.I(r->fi_maxrun);
+    o.F(inf2nan(r->papa_combo));
+    o.F(r->papa_prop);
+    o.F(r->papa_fi);
+    o.F(r->papa_llr);
+    o.F(r->papa_llr2);
+    o.I(r->papa_cen + 1);
+    o.ch('\t');
+    o.aa(codes, n, r->papa_cen - ww2 / 2, r->papa_cen + ww2 / 2); // (:944)
+    return (long)(o.p - buf);
+}
+
+long plaac_format_summary_row(const plaac_row *r, const char *name, const uint8_t *codes, uint64_t reclen,
+                              int corelength, int ww2, char *buf, size_t cap) {
+    if (!name) return -1;
+    // (the bound of the direct writer is generous; a caller with a tight buffer gets the row through a string)
+    const size_t nl = std::strlen(name);
+    const long k = plaac_format_summary_row_n(r, name, nl, codes, reclen, corelength, ww2, buf, cap);
+    if (k >= 0 && buf && cap) buf[(size_t)k < cap ? (size_t)k : cap - 1] = '\0';
+    if (k >= 0 || !r || !buf || r->prot_len <= 0) return k;
+    std::vector<char> big(nl + 3 * (size_t)r->prot_len + (size_t)(ww2 > 0 ? ww2 : 0) + 37 * 26 + 23 * 330 + 64);
+    const long k2 = plaac_format_summary_row_n(r, name, nl, codes, reclen, corelength, ww2, big.data(), big.size());
+    if (k2 < 0 || (size_t)k2 + 1 > cap) return -1;
+    std::memcpy(buf, big.data(), (size_t)k2);
+    buf[k2] = '\0';
+    return k2;
 }
 
 size_t plaac_track_rows_bound(uint32_t n, size_t id_len, size_t name_len) {

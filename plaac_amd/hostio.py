@@ -14,7 +14,7 @@ class _Fasta(C.Structure):
 
 
 HOST_EXPORTS = (
-    "plaac_fasta_read", "plaac_fasta_free", "plaac_fasta_next_text", "plaac_fasta_text_free", "plaac_fasta_text_trim_names", "plaac_fasta_text_codes", "plaac_read_aa_params", "plaac_format_fixed",
+    "plaac_fasta_read", "plaac_fasta_free", "plaac_fasta_next_text", "plaac_fasta_text_free", "plaac_fasta_text_trim_names", "plaac_fasta_text_codes", "plaac_format_summary_row_n", "plaac_read_aa_params", "plaac_format_fixed",
     "plaac_format_fixed_reference",
     "plaac_format_double_tostring", "plaac_format_summary_row", "plaac_summary_header", "plaac_tracks_header",
     "plaac_format_track_rows", "plaac_track_rows_bound", "plaac_format_param_block", "plaac_format_aa_params",
@@ -104,7 +104,7 @@ def stream_fasta(path, max_records=262144, max_bytes=128 << 20):
 class _FastaText(C.Structure):
     """plaac_fasta_text"""
     _fields_ = [("text", C.c_void_p), ("len", C.c_uint64), ("nrec", C.c_uint32), ("starts", C.POINTER(C.c_uint64)),
-                ("names", C.c_void_p), ("name_off", C.POINTER(C.c_uint64)), ("owner_", C.c_void_p), ("file_off_", C.c_uint64)]
+                ("name_len", C.POINTER(C.c_uint32)), ("owner_", C.c_void_p), ("file_off_", C.c_uint64)]
 
 
 def stream_fasta_text(path, max_records=262144, max_bytes=128 << 20):
@@ -133,12 +133,11 @@ def stream_fasta_text(path, max_records=262144, max_bytes=128 << 20):
             text = C.string_at(t.text, int(t.len))
             starts = np.ctypeslib.as_array(t.starts, shape=(n + 1,)).copy()
 
-            def trim(blank_end, prev_blank, pt=pt, n=n):
+            def trim(blank_end, prev_blank, pt=pt, n=n, text=text, starts=starts):
                 be = np.ascontiguousarray(blank_end, dtype=np.uint8)
                 nxt = L.plaac_fasta_text_trim_names(pt, be.ctypes.data, int(prev_blank))
-                tt = pt.contents
-                noff = np.ctypeslib.as_array(tt.name_off, shape=(n + 1,))
-                names = [C.string_at(tt.names + int(noff[i])) for i in range(n)]
+                nlen = np.ctypeslib.as_array(pt.contents.name_len, shape=(max(n, 1),))
+                names = [text[int(starts[i]) + 1:int(starts[i]) + 1 + int(nlen[i])] for i in range(n)]
                 return names, int(nxt)
 
             yield text, starts, trim

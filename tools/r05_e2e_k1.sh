@@ -23,9 +23,9 @@ fbytes, nres = bench.write_fasta(torch, codes, offsets, 10_000_000, fa)
 del codes, offsets, pieces
 torch.cuda.empty_cache()
 print("# 10 M sequences, %d residues, %d bytes of FASTA; bin/plaac -i <fa> > <tsv>, PLAAC_TIMING=1" % (nres, fbytes))
-for rep in range(3):
-    for env in ({"PLAAC_SINGLE_PASS": "0"}, {"PLAAC_PLACED_WRITE": "0", "PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_PLACED_WRITE": "0"}, {},
-                {"PLAAC_FAST_EXIT": "1"}, {"PLAAC_DEVICES": "0,0,0,0,0,0,0,0"}):
+E2E_ENVS = [dict(kv.split("=") for kv in grp.split()) for grp in os.environ.get("E2E_ENVS", "PLAAC_SINGLE_PASS=0;PLAAC_PLACED_WRITE=0 PLAAC_DEVICE_PARSE=0;PLAAC_DEVICE_PARSE=0;PLAAC_PLACED_WRITE=0;;PLAAC_FAST_EXIT=1;PLAAC_DEVICES=0,0,0,0,0,0,0,0").split(";")]
+for rep in range(int(os.environ.get("E2E_REPS", "3"))):
+    for env in E2E_ENVS:
         if os.path.exists(tsv):
             os.unlink(tsv)  # (the shell's truncation of a stale 2 GB file is not the program's time: 0.3 s)
         t0 = time.perf_counter()
@@ -34,7 +34,7 @@ for rep in range(3):
         dt = time.perf_counter() - t0
         h = hashlib.sha256(open(tsv, "rb").read()).hexdigest()[:16]
         print("%-32s %.3f s  rc %d  sha256 %s  %.3g residues/s" % (" ".join("%s=%s" % kv for kv in env.items()) or "(default)", dt, r.returncode, h, nres / dt))
-        if rep == 2:
+        if rep == int(os.environ.get("E2E_REPS", "3")) - 1:
             for l in r.stderr.decode().splitlines():
                 if l.startswith("plaac-timing"):
                     print("    " + l)
