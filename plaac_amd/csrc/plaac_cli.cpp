@@ -153,7 +153,7 @@ struct Busy {
     const char *name[10] = {"reader: next batch", "worker: begin (upload, parse kernels, enqueue)", "worker: end (wait, download)",
                            "sink: format a batch (all threads, wall)", "sink: hand parts to the writer (waits for room)",
                            "writer: fwrite", "writer: waiting for text", "sink: waiting for a scored batch",
-                           "sink: format threads, summed over threads", "sink: the residues a row prints, read from the text (summed)"};
+                           "sink: format threads, summed over threads"};
     struct Scope {
         Busy &b;
         int k;
@@ -163,7 +163,7 @@ struct Busy {
     Scope in(int k) { return Scope{*this, k}; }
     void report() {
         if (!g_timer.on) return;
-        for (int k = 0; k < 10; ++k)
+        for (int k = 0; k < 9; ++k)
             if (ns[k]) std::fprintf(stderr, "plaac-timing:   busy %-52s %9.3f ms\n", name[k], ns[k] * 1e-6);
         if (cpu_fmt) std::fprintf(stderr, "plaac-timing:   cpu  %-52s %9.3f ms\n", "sink: format threads, CPU time summed", cpu_fmt * 1e-6);
     }
@@ -536,6 +536,57 @@ class TextPool {
     }
     ~TextPool() {
         for (TextBuf &b : idle) std::free(b.p);
+    }
+};
+
+// Threads that stay: a batch's rows are formatted by the same threads as the batch before. (A fresh std::thread per batch and
+// range lands on one of the host's 256 CPUs that has been idle - clocked down, caches cold - and is gone after 10 ms: the
+// formatter ran at 480 ns per row inside the run against 205 ns in a loop of its own, profiles/r05_e2e_device_parse.txt.)
+class ThreadTeam {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(unsigned)> *job = nullptr;
+    unsigned long gen = 0;
+    unsigned remaining = 0;
+    bool stop = false;
+
+  public:
+    explicit ThreadTeam(unsigned n) {
+        for (unsigned t = 0; t < n; ++t)
+            th.emplace_back([this, t] {
+                unsigned long seen = 0;
+                for (;;) {
+                    const std::function<void(unsigned)> *f;
+                    {
+                        std::unique_lock<std::mutex> l(m);
+                        cv_work.wait(l, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        f = job;
+                    }
+                    (*f)(t);
+                    std::lock_guard<std::mutex> l(m);
+                    if (--remaining == 0) cv_done.notify_all();
+                }
+            });
+    }
+    unsigned size() const { return (unsigned)th.size(); }
+    void run(const std::function<void(unsigned)> &f) { // f(t) for every t < size(), returns when all are through
+        std::unique_lock<std::mutex> l(m);
+        job = &f;
+        remaining = (unsigned)th.size();
+        ++gen;
+        cv_work.notify_all();
+        cv_done.wait(l, [&] { return remaining == 0; });
+    }
+    ~ThreadTeam() {
+        {
+            std::lock_guard<std::mutex> l(m);
+            stop = true;
+            cv_work.notify_all();
+        }
+        for (auto &t : th) t.join();
     }
 };
 
@@ -1039,6 +1090,8 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
     if (!replay && !open_stream(o.input, &fs)) return false;
     g_defer = nullptr; // (single pass: everything in front of the table is in single->held now)
     const unsigned nt_max = plaac_host_threads();
+    std::unique_ptr<ThreadTeam> team; // (made when the first large batch arrives; PLAAC_FORMAT_TEAM=0: a thread per range and batch)
+    const bool use_team = env_flag("PLAAC_FORMAT_TEAM", true);
     uint64_t nres = 0, nrec = 0;
     std::fflush(stdout);
     // single pass into a plain file: the text in front of the table goes out now, with a block of the right length computed
@@ -1150,11 +1203,6 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
                     }
                 } cpu_clock;
                 const uint32_t r0 = (uint32_t)((uint64_t)f->nrec * t / nt), r1 = (uint32_t)((uint64_t)f->nrec * (t + 1) / nt);
-                long long decode_ns = 0;
-                struct AddDecode {
-                    long long &v;
-                    ~AddDecode() { g_busy.ns[9] += v; }
-                } add_decode{decode_ns};
                 std::vector<uint8_t> some; // device-parsed batch: the record's codes where the row prints them
                 // (one buffer per thread and batch, from the writer's pool: ~230 bytes of numbers per row + its name, sequences
                 //  are printed for the few records with a PrD; it grows if that was too little)
@@ -1202,10 +1250,8 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
                                 for (long v : {(long)r.core_start, (long)r.core_end, (long)r.prd_start, (long)r.prd_start + 14,
                                                (long)r.prd_end - 14, (long)r.prd_end})
                                     want(v);
-                            const auto td0 = std::chrono::steady_clock::now();
                             (void)plaac_fasta_text_codes(b.ft->text, b.ft->starts, b.text_ext.data(), i, (uint64_t)lo,
                                                          (uint64_t)(hi - lo + 1), some.data() + lo);
-                            decode_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - td0).count();
                         }
                         rec_codes = some.data();
                     } else {
@@ -1226,6 +1272,10 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
                 auto busy = g_busy.in(3);
                 if (nt == 1) {
                     fmt(0);
+                } else if (use_team) {
+                    if (!team) team.reset(new ThreadTeam(nt));
+                    const std::function<void(unsigned)> job = fmt;
+                    team->run(job);
                 } else {
                     std::vector<std::thread> pool;
                     for (unsigned t = 0; t < nt; ++t) pool.emplace_back(fmt, t);
