@@ -204,6 +204,17 @@ plaac_status plaac_score_begin_text(plaac_ctx *ctx, const char *text, uint64_t t
                                     int counting);
 plaac_status plaac_score_end_text(plaac_ctx *ctx, plaac_row *rows, uint8_t *codes, uint64_t codes_cap, uint64_t *offsets,
                                   uint8_t *blank_end, uint32_t *extents, int64_t *counts);
+/* The oldest pending TEXT batch's summary rows as the TABLE'S TEXT, made on the device (round 5): scoreallfastas' output line
+ * (plaac.java:899-945) for every record of the batch, exactly the bytes plaac_format_summary_row_n writes on the host (tested
+ * byte for byte), names taken from the text (trimmed where the reference trims them, :4362; prev_blank: how the record before
+ * this batch ended, 1 for the first batch of a file). plaac_score_end_text_table_size waits for the batch and reports the
+ * table's size, how the batch's last record ended, and whether the host must format this batch itself (*needs_host != 0: a
+ * value of 1e9 or more, an infinity the reference prints as such, a record without a sequence, for which the host prints
+ * a note - then collect the batch with plaac_score_end_text and format as before; the device never guesses).
+ * plaac_score_end_text_table copies the text into `table` (capacity >= the reported size) and gives the slot up. */
+plaac_status plaac_score_end_text_table_size(plaac_ctx *ctx, int corelength, int ww2, int prev_blank, uint64_t *table_bytes,
+                                             int *needs_host, int *last_blank, uint64_t *residues /* nullable: the batch's */);
+plaac_status plaac_score_end_text_table(plaac_ctx *ctx, char *table, uint64_t table_cap, int64_t *counts);
 
 /* ---- resident batches: upload once, use many times -------------------------------------------------------
  * The reference makes one full pass over the input for the background counts and a second one for scoring

@@ -39,6 +39,9 @@
 //   PLAAC_DEVICE_PARSE=0                      single pass: the HOST splits lines and encodes (plaac_fasta_next). Default (round
 //                                             5, K1): the host only finds the records and keeps their names, the device parses
 //                                             (plaac_score_begin_text); the few residues a row prints are read from the text
+//   PLAAC_DEVICE_FORMAT=0                     single pass, one context: the HOST formats the rows. Default: the device writes the
+//                                             table's text (plaac_score_end_text_table: the rows never cross PCIe; a batch with
+//                                             a value it will not vouch for comes back the old way). 1.25 - 1.44 s -> 0.60 - 0.78 s
 //   PLAAC_TIMING=1                            stage clock on stderr; with PLAAC_TIMING_T0=<the launcher's CLOCK_MONOTONIC, ns>
 //                                             also since the launch, with PLAAC_TIMING_MAPS=1 the large resident mappings
 //   PLAAC_HUGE_PAGES=0                        plain allocations for the big host buffers (encoded residues, rows, formatted
@@ -354,6 +357,31 @@ struct HugeBuf {
 };
 using RowBuf = HugeBuf<plaac_row>;
 
+struct TextBuf {
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    void append(const char *s, size_t k) {
+        if (n + k > cap) grow(n + k);
+        std::memcpy(p + n, s, k);
+        n += k;
+    }
+    void push_back(char c) { append(&c, 1); }
+    static char *alloc(size_t &cap) {
+        cap = (cap + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE;
+        char *q = (char *)std::aligned_alloc(HUGE_PAGE, cap);
+        if (!q) throw std::bad_alloc();
+        if (huge_pages_on()) (void)madvise(q, cap, MADV_HUGEPAGE);
+        return q;
+    }
+    void grow(size_t need) {
+        size_t c2 = std::max(need, cap * 2);
+        char *q = alloc(c2);
+        if (n) std::memcpy(q, p, n);
+        std::free(p);
+        p = q;
+        cap = c2;
+    }
+};
 struct Batch {
     uint64_t seq = 0;
     plaac_fasta *f = nullptr;
@@ -378,6 +406,10 @@ struct Batch {
     std::vector<uint64_t> toffs;
     std::vector<uint8_t> tblank;
     std::vector<uint32_t> text_ext; // per record: where its header line and its sequence end (plaac_score_end_text)
+    TextBuf table{};                // the batch's rows as text, made on the device (plaac_score_end_text_table)
+    bool have_table = false;
+    int last_blank = 0;
+    uint64_t table_residues = 0;
     ~Batch() {
         if (ft) plaac_fasta_text_free(ft);
         else if (f && owned) plaac_fasta_free(f);
@@ -475,31 +507,6 @@ class Reorder {
 // a std::string per formatter thread and batch. (Those came from malloc arenas - a fresh set of threads per batch, up to 8 x
 // cores arenas - that never shrink: 2.1 GB resident at the end of a 10 M-sequence run, first touched 4 KB at a time and
 // handed back 4 KB at a time by the exit, 0.5 s after the output was complete; profiles/r05_e2e_device_parse.txt.)
-struct TextBuf {
-    char *p = nullptr;
-    size_t n = 0, cap = 0;
-    void append(const char *s, size_t k) {
-        if (n + k > cap) grow(n + k);
-        std::memcpy(p + n, s, k);
-        n += k;
-    }
-    void push_back(char c) { append(&c, 1); }
-    static char *alloc(size_t &cap) {
-        cap = (cap + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE;
-        char *q = (char *)std::aligned_alloc(HUGE_PAGE, cap);
-        if (!q) throw std::bad_alloc();
-        if (huge_pages_on()) (void)madvise(q, cap, MADV_HUGEPAGE);
-        return q;
-    }
-    void grow(size_t need) {
-        size_t c2 = std::max(need, cap * 2);
-        char *q = alloc(c2);
-        if (n) std::memcpy(q, p, n);
-        std::free(p);
-        p = q;
-        cap = c2;
-    }
-};
 class TextPool {
     std::mutex m;
     std::vector<TextBuf> idle;
@@ -1121,10 +1128,36 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
     // K1: the single pass hands the device the file's text (PLAAC_DEVICE_PARSE=0: the host parses, as in the two passes)
     const bool as_text = single && !replay && env_flag("PLAAC_DEVICE_PARSE", true);
     int prev_blank = 1; // (the sink's: how the record before the batch it is looking at ended)
+    // ... and the rows as TEXT from the device as well (plaac_score_end_text_table), when ONE context collects the batches in file
+    // order (the name of a batch's first record is trimmed or not by how the batch before it ended). PLAAC_DEVICE_FORMAT=0: host.
+    const bool device_format = as_text && plaac_node_size(eng.node) == 1 && env_flag("PLAAC_DEVICE_FORMAT", true);
+    int dev_prev_blank = 1; // (the one worker's)
     auto collect = make_finish([&](plaac_ctx *ctx, Batch &b) {
         if (!single) return plaac_score_end(ctx, b.rows.data());
         int64_t c[PLAAC_NAA];
         plaac_status st;
+        if (b.ft && device_format) {
+            // the rows as text, made on the device; a batch it will not vouch for (a value of 1e9 or more, an infinity, a record
+            // without a sequence) comes back the old way and is formatted below
+            uint64_t bytes = 0;
+            int needs_host = 0, lastb = dev_prev_blank;
+            st = plaac_score_end_text_table_size(ctx, o.corelength, o.ww2, dev_prev_blank, &bytes, &needs_host, &lastb, &b.table_residues);
+            if (st != PLAAC_OK) return st;
+            dev_prev_blank = lastb;
+            b.last_blank = lastb;
+            if (!needs_host) {
+                b.table = writer.buffer((size_t)bytes + 1);
+                st = plaac_score_end_text_table(ctx, b.table.p, b.table.cap, c);
+                b.table.n = (size_t)bytes;
+                b.have_table = st == PLAAC_OK;
+                if (st == PLAAC_OK) {
+                    std::lock_guard<std::mutex> l(cm);
+                    for (int i = 0; i < PLAAC_NAA; ++i) total_counts[i] += c[i];
+                }
+                return st;
+            }
+            b.rows.resize(b.ft->nrec);
+        }
         if (b.ft) {
             const uint32_t n = b.ft->nrec;
             b.toffs.resize((size_t)n + 1);
@@ -1176,7 +1209,7 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
         eng, P, o.input, fs, sp, replay, (std::vector<plaac_fasta *> *)nullptr, (uint64_t)0, [](Batch &) {},
         [&](plaac_ctx *ctx, Batch &b) {
             if (b.ft) {
-                b.rows.resize(b.ft->nrec);
+                if (!device_format) b.rows.resize(b.ft->nrec);
                 return plaac_score_begin_text(ctx, b.ft->text, b.ft->len, b.ft->starts, b.ft->nrec, 1);
             }
             b.rows.resize(b.f->nrec);
@@ -1185,6 +1218,15 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             return plaac_score(ctx, b.f->codes, b.f->offsets, b.f->nrec, b.rows.data(), nullptr);
         },
         [&](Batch &b) {
+            if (b.have_table) { // (formatted on the device)
+                prev_blank = b.last_blank;
+                nres += b.table_residues;
+                nrec += b.ft->nrec;
+                auto busy = g_busy.in(4);
+                writer.write(b.table);
+                b.table = TextBuf{};
+                return true;
+            }
             if (b.ft) prev_blank = plaac_fasta_text_trim_names(b.ft, b.tblank.data(), prev_blank);
             const plaac_fasta *f = b.f;
             // format in parallel (contiguous row ranges per thread), print in file order

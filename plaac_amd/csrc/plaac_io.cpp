@@ -117,8 +117,16 @@ void append_fixed(std::string &s, double v, int decimals) {
     if (decimals >= 0 && decimals <= 9 && av < 1e9) { // (false for NaN)
         const double y = av * p10[decimals];
         const double fl = std::floor(y), f = y - fl, err = y * 0x1p-51 + 0x1p-60;
-        if (std::fabs(f - 0.5) > err && err < 0.25) {
-            unsigned long long r = (unsigned long long)fl + (f > 0.5 ? 1ull : 0ull);
+        const bool clear = std::fabs(f - 0.5) > err;
+        if (err < 0.25 && (clear || y < 0x1p51)) {
+            unsigned long long r = (unsigned long long)fl;
+            // Within the noise of the tie t = (k + 1/2) / 10^decimals (means of small integers sit there all the time): the
+            // Formatter rounds the SHORTEST digits D that read back as v. c = the double nearest t (a correctly rounded
+            // quotient of two integers). v == c: D is t itself (no decimal with fewer places lies within half an ulp of c, and
+            // t reads back as c) - HALF_UP goes up. v != c: D lies in v's own rounding interval, which ends before (begins
+            // after) c's, and t lies in c's - D is on v's side of t. Either way: up iff v >= c. (The device's formatter,
+            // format_device.hip.inc, takes the same step; the differential test against the digit-string path covers it.)
+            r += clear ? (f > 0.5 ? 1ull : 0ull) : (av >= (double)(2ull * r + 1ull) / (2.0 * p10[decimals]) ? 1ull : 0ull);
             char tmp[40];
             int k = 40;
             for (int i = 0; i < decimals; ++i) {
@@ -803,8 +811,9 @@ struct RowOut {
         if (av < 1e9) { // (false for NaN)
             const double y = av * 1e3;
             const double fl = std::floor(y), f = y - fl, err = y * 0x1p-51 + 0x1p-60;
-            if (std::fabs(f - 0.5) > err && err < 0.25) {
-                const unsigned long long r = (unsigned long long)fl + (f > 0.5 ? 1ull : 0ull);
+            if (err < 0.25) {
+                unsigned long long r = (unsigned long long)fl;
+                r += std::fabs(f - 0.5) > err ? (f > 0.5 ? 1ull : 0ull) : (av >= (double)(2ull * r + 1ull) / 2000.0 ? 1ull : 0ull); // (append_fixed)
                 if (std::signbit(v)) ch('-');
                 u64(r / 1000ull);
                 const unsigned fr = (unsigned)(r % 1000ull);

@@ -58,6 +58,7 @@ static inline void cpu_relax() {
 #include "kernels_windows_lane.hip.inc"
 #include "kernels_misc.hip.inc"
 #include "fasta_device.hip.inc"
+#include "format_device.hip.inc"
 #include "schedule.hip.inc"
 
 constexpr int E_JOIN_IDX = sched::E_JOIN; // index of a call's join event in its set of timing events
@@ -172,6 +173,13 @@ struct plaac_ctx {
         FaExtent *d_ext = nullptr;
         unsigned long long *d_total = nullptr, *d_bsum = nullptr;
         size_t cap_text = 0, cap_starts = 0, cap_len = 0, cap_blank = 0, cap_ext = 0, cap_bsum = 0;
+        // plaac_score_end_text_table: the batch's rows as text (format_device.hip.inc)
+        uint64_t *d_toffs = nullptr;
+        char *d_table = nullptr;
+        uint32_t *d_fmtflags = nullptr;
+        size_t cap_toffs = 0, cap_table = 0, cap_fmtflags = 0;
+        uint64_t table_bytes = 0;
+        bool table_sized = false;
         uint64_t nres = 0;
         bool from_text = false;
         size_t cap_codes = 0, cap_offs = 0, cap_rows = 0;
@@ -181,6 +189,7 @@ struct plaac_ctx {
     } slot[2];
     unsigned slot_next = 0, slot_oldest = 0, slots_busy = 0;
     hipStream_t xfer = nullptr;
+    int table_corelength = 60, table_ww2 = 41, table_prev_blank = 1; // (plaac_score_end_text_table_size -> _table)
     // staging for the host-buffer entry points
     uint8_t *d_codes = nullptr;
     uint64_t *d_offsets = nullptr;
@@ -770,7 +779,7 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     for (auto &sl : ctx->slot)
         for (void *b : {(void *)sl.d_codes, (void *)sl.d_offsets, (void *)sl.d_rows, (void *)sl.d_counts, (void *)sl.d_text,
                         (void *)sl.d_starts, (void *)sl.d_len, (void *)sl.d_blank, (void *)sl.d_total, (void *)sl.d_ext,
-                        (void *)sl.d_bsum})
+                        (void *)sl.d_bsum, (void *)sl.d_toffs, (void *)sl.d_table, (void *)sl.d_fmtflags})
             if (b) (void)hipFree(b);
     if (ctx->xfer) {
         (void)hipStreamSynchronize(ctx->xfer);
@@ -2023,6 +2032,90 @@ plaac_status plaac_score_end_text(plaac_ctx *ctx, plaac_row *rows, uint8_t *code
 plaac_status plaac_score_end_counts(plaac_ctx *ctx, plaac_row *rows, int64_t counts[PLAAC_NAA]) {
     if (ctx && !counts) return fail(ctx, PLAAC_ERR_ARG, "null counts");
     return score_end(ctx, rows, counts);
+}
+
+// The oldest pending text batch's summary rows AS TEXT (round 5, format_device.hip.inc): _size waits for the batch, runs the
+// length pass and says how many bytes the table takes and whether the host has to format this batch itself (|v| >= 1e9, an
+// infinity the reference prints as such, a record without a sequence: then
+// *needs_host != 0 and the caller collects the batch with plaac_score_end_text as before); _table writes the bytes, copies
+// them to `table` (capacity >= the size reported) and gives the slot up like every other end call.
+plaac_status plaac_score_end_text_table_size(plaac_ctx *ctx, int corelength, int ww2, int prev_blank, uint64_t *table_bytes,
+                                             int *needs_host, int *last_blank, uint64_t *residues) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (!table_bytes || !needs_host || !last_blank) return fail(ctx, PLAAC_ERR_ARG, "null argument");
+    if (ctx->slots_busy == 0) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table_size: no batch is pending");
+    plaac_ctx::Slot &S = ctx->slot[ctx->slot_oldest];
+    if (!S.from_text) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table_size: the oldest batch was not begun from text");
+    *table_bytes = 0, *needs_host = 0, *last_blank = prev_blank;
+    if (residues) *residues = S.nres;
+    S.table_sized = false;
+    const uint32_t nrec = S.nprot;
+    if (nrec == 0 || S.call_no == ~0ull) {
+        S.table_bytes = 0, S.table_sized = true;
+        return PLAAC_OK;
+    }
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PL_HIP(ctx, hipEventSynchronize(ctx->ev[S.call_no % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
+    plaac_status rc;
+    if ((rc = grow(ctx, S.d_toffs, S.cap_toffs, (size_t)nrec + 1)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, S.d_fmtflags, S.cap_fmtflags, (size_t)4)) != PLAAC_OK) return rc;
+    PL_HIP(ctx, hipMemsetAsync(S.d_fmtflags, 0, 4 * sizeof(uint32_t), ctx->xfer));
+    const unsigned nb = (nrec + 255u) / 256u, ns = (nrec + FA_SCAN - 1u) / FA_SCAN;
+    hipLaunchKernelGGL(k_format_rows<false>, dim3(nb), dim3(256), 0, ctx->xfer, S.d_rows, S.d_codes, S.d_offsets, S.d_text, S.d_starts,
+                       S.d_ext, S.d_blank, nrec, prev_blank, corelength, ww2, S.d_len, (const uint64_t *)nullptr, (char *)nullptr,
+                       S.d_fmtflags);
+    hipLaunchKernelGGL(k_fasta_block_sums, dim3(ns), dim3(FA_SCAN), 0, ctx->xfer, S.d_len, nrec, S.d_bsum);
+    hipLaunchKernelGGL(k_fasta_offsets, dim3(ns), dim3(FA_SCAN), 0, ctx->xfer, S.d_len, nrec, S.d_bsum, S.d_toffs, S.d_total);
+    struct {
+        unsigned long long total;
+        uint32_t flags[4];
+        uint8_t lastb;
+    } h{};
+    PL_HIP(ctx, hipMemcpyAsync(&h.total, S.d_total, sizeof h.total, hipMemcpyDeviceToHost, ctx->xfer));
+    PL_HIP(ctx, hipMemcpyAsync(h.flags, S.d_fmtflags, sizeof h.flags, hipMemcpyDeviceToHost, ctx->xfer));
+    PL_HIP(ctx, hipMemcpyAsync(&h.lastb, S.d_blank + (nrec - 1), 1, hipMemcpyDeviceToHost, ctx->xfer));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->xfer));
+    *table_bytes = h.total;
+    *needs_host = (h.flags[0] || h.flags[1]) ? 1 : 0;
+    *last_blank = h.lastb ? 1 : 0;
+    S.table_bytes = h.total;
+    S.table_sized = !*needs_host;
+    ctx->table_corelength = corelength, ctx->table_ww2 = ww2, ctx->table_prev_blank = prev_blank;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_score_end_text_table(plaac_ctx *ctx, char *table, uint64_t table_cap, int64_t *counts) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (ctx->slots_busy == 0) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table: no batch is pending");
+    plaac_ctx::Slot &S = ctx->slot[ctx->slot_oldest];
+    if (!S.from_text || !S.table_sized)
+        return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table: call plaac_score_end_text_table_size first (and plaac_score_end_text when it asks for the host)");
+    if (S.table_bytes > table_cap || (S.table_bytes && !table))
+        return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table: the buffer is smaller than the size reported");
+    const uint32_t nrec = S.nprot;
+    S.table_sized = false;
+    if (nrec && S.call_no != ~0ull && S.table_bytes) {
+        PL_HIP(ctx, hipSetDevice(ctx->device));
+        plaac_status rc;
+        if ((rc = grow(ctx, S.d_table, S.cap_table, (size_t)S.table_bytes + 16)) != PLAAC_OK) return rc;
+        hipLaunchKernelGGL(k_format_rows<true>, dim3((nrec + 255u) / 256u), dim3(256), 0, ctx->xfer, S.d_rows, S.d_codes, S.d_offsets,
+                           S.d_text, S.d_starts, S.d_ext, S.d_blank, nrec, ctx->table_prev_blank, ctx->table_corelength, ctx->table_ww2,
+                           S.d_len, S.d_toffs, S.d_table, S.d_fmtflags);
+        if ((rc = copy_out(ctx, table, S.d_table, (size_t)S.table_bytes, ctx->xfer)) != PLAAC_OK) return rc;
+    }
+    // the slot is given up; the counts come back as with plaac_score_end_counts (no rows are copied)
+    S.busy = false;
+    ctx->slot_oldest ^= 1u;
+    --ctx->slots_busy;
+    if (counts) {
+        for (int i = 0; i < NAA; ++i) counts[i] = 0;
+        if (nrec && S.call_no != ~0ull) {
+            if (!S.counted) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table: the batch was begun without counting");
+            PL_HIP(ctx, hipMemcpyAsync(counts, S.d_counts, sizeof(int64_t) * NAA, hipMemcpyDeviceToHost, ctx->xfer));
+            PL_HIP(ctx, hipStreamSynchronize(ctx->xfer));
+        }
+    }
+    return PLAAC_OK;
 }
 
 struct plaac_batch {

@@ -76,7 +76,7 @@ EXPORTS = (
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
-    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_score_begin_text", "plaac_score_end_text", "plaac_debug_schedule",
+    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_score_begin_text", "plaac_score_end_text", "plaac_score_end_text_table_size", "plaac_score_end_text_table", "plaac_debug_schedule",
 )
 
 _lib = None
@@ -128,6 +128,8 @@ def load():
     L.plaac_score_end_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.plaac_score_begin_text.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int]
     L.plaac_score_end_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.plaac_score_end_text_table_size.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+    L.plaac_score_end_text_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.plaac_score_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
     L.plaac_histogram_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -337,6 +339,35 @@ class Context:
                                                  counts.ctypes.data if counting else None))
         out = (rows, codes[:int(offsets[-1])] if want_codes else ext[:nrec], offsets, blank[:nrec])
         return out + (counts,) if counting else out
+
+    def score_text_table(self, text, starts, corelength=60, ww2=41, prev_blank=1):
+        """plaac_score_begin_text + plaac_score_end_text_table_size / _table: the batch's summary rows as the table's text, made on
+        the device. Returns (table bytes, last_blank, counts) - or (None, last_blank, None) with the batch still pending when the
+        device asks for the host's formatter (collect it with score_text_end)."""
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        nrec = len(starts) - 1
+        self._check(self._L.plaac_score_begin_text(self._h, text, len(text), starts.ctypes.data, nrec, 1))
+        size, needs, lastb = C.c_uint64(), C.c_int(), C.c_int()
+        self._check(self._L.plaac_score_end_text_table_size(self._h, int(corelength), int(ww2), int(prev_blank), C.byref(size),
+                                                            C.byref(needs), C.byref(lastb), None))
+        if needs.value:
+            return None, lastb.value, None
+        buf = C.create_string_buffer(max(int(size.value), 1))
+        counts = np.zeros(NAA, dtype=np.int64)
+        self._check(self._L.plaac_score_end_text_table(self._h, buf, size.value, counts.ctypes.data))
+        return buf.raw[:size.value], lastb.value, counts
+
+    def score_text_end(self, nrec, text_len, counting=True):
+        """plaac_score_end_text for a batch left pending by score_text_table"""
+        rows = np.zeros(nrec, dtype=ROW_DTYPE)
+        codes = np.zeros(max(text_len, 1), dtype=np.uint8)
+        offsets = np.zeros(nrec + 1, dtype=np.uint64)
+        blank = np.zeros(max(nrec, 1), dtype=np.uint8)
+        ext = np.zeros((max(nrec, 1), 2), dtype=np.uint32)
+        counts = np.zeros(NAA, dtype=np.int64)
+        self._check(self._L.plaac_score_end_text(self._h, rows.ctypes.data, codes.ctypes.data, len(codes), offsets.ctypes.data,
+                                                 blank.ctypes.data, ext.ctypes.data, counts.ctypes.data if counting else None))
+        return rows, codes[:int(offsets[-1])], offsets, blank[:nrec], counts
 
     def score_stream(self, batches, counting=False):
         """scores an iterable of (codes, offsets) batches with two in flight; yields the row arrays in order

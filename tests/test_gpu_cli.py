@@ -258,7 +258,8 @@ def test_single_pass_writes_the_same_bytes_as_the_two_passes(native, tmp_path):
     empty = tmp_path / "empty.fa"
     empty.write_text("")
     dot = tmp_path / "hmm.dot"
-    # K1 (round 5): the single pass parses on the device (plaac_score_begin_text); a file with every line-end / blank-line /
+    # K1 (round 5): the single pass parses on the device (plaac_score_begin_text) and, with one context, formats the rows there
+    # too (plaac_score_end_text_table; PLAAC_DEVICE_FORMAT=0: the host's formatter); a file with every line-end / blank-line /
     # name-trimming quirk of fastareader (:4302-4375), cut into batches at any record, must come out the same
     from conftest import quirky_fasta
     quirks = tmp_path / "quirks.fa"
@@ -269,7 +270,8 @@ def test_single_pass_writes_the_same_bytes_as_the_two_passes(native, tmp_path):
     for args in cases:
         outs = []
         for env in ({"PLAAC_SINGLE_PASS": "0", "PLAAC_HUGE_PAGES": "0"}, {}, {"PLAAC_BATCH_RECORDS": "257", "PLAAC_DEVICES": "0,0"},
-                    {"PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_BATCH_RECORDS": "1"} if args[1] is quirks else {"PLAAC_BATCH_BYTES": "4096"}):
+                    {"PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_DEVICE_FORMAT": "0"}, {"PLAAC_DEVICE_FORMAT": "0", "PLAAC_BATCH_RECORDS": "100"},
+                    {"PLAAC_BATCH_RECORDS": "1"} if args[1] is quirks else {"PLAAC_BATCH_BYTES": "4096"}):
             r = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300, env=dict(os.environ, PLAAC_TIMING="1", **env))
             assert r.returncode == 0, r.stderr.decode(errors="replace")
             outs.append((r.stdout, r.stderr.decode(errors="replace")))
@@ -319,7 +321,7 @@ def test_single_pass_into_a_file_writes_the_table_in_place(native, tmp_path):
 
     for args in (["-i", fa], ["-i", fa, "-d"], ["-i", fa, "-s"], ["-i", allx], ["-i", allx, "-d"], ["-i", polyq], ["-i", quirks], ["-i", empty]):
         want, _ = to_file(args, {"PLAAC_SINGLE_PASS": "0"})
-        for env in ({}, {"PLAAC_PLACED_WRITE": "0"}, {"PLAAC_BATCH_RECORDS": "300"}):
+        for env in ({}, {"PLAAC_PLACED_WRITE": "0"}, {"PLAAC_BATCH_RECORDS": "300"}, {"PLAAC_DEVICE_FORMAT": "0"}):
             got, err = to_file(args, env)
             assert "single pass" in err
             assert got == want, (args, env)

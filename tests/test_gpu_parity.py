@@ -1221,3 +1221,53 @@ def test_fasta_text_parsed_on_the_device_equals_the_host_parser(native, oracle, 
     assert np.array_equal(np.concatenate(got_codes), codes)
     assert_rows_equal(np.concatenate(got_rows), want_rows, "rows of the device-parsed batches")
     assert np.array_equal(counts, want_counts)
+
+
+def test_summary_rows_formatted_on_the_device_equal_the_hosts(native, oracle, tmp_path):
+    """Round 5: plaac_score_end_text_table - scoreallfastas' output lines (plaac.java:899-945) written by the device from the
+    rows it has just scored, the codes it has just parsed and the names in the text. Byte for byte the host formatter's
+    (plaac_format_summary_row, itself tested against a restatement of java.util.Formatter in tests/test_host_io.py) over the
+    same records, for any batch cut and both name-trimming states, values on a %.3f tie included (a mean charge of exactly
+    1/16; ratios of small integers sit on ties all the time); a batch with a record without a sequence is handed back to the host."""
+    from plaac_amd import hostio, synth
+    from conftest import quirky_fasta
+    P = native.make_params()
+    codes, offs = synth.make_batch(4, nprot=4000, seed=17, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.2)
+    letters = np.frombuffer(b"XACDEFGHIKLMNPQRSTVWY*", dtype=np.uint8)[codes]
+    recs = [b">prot%05d some words  \n" % i + letters[int(offs[i]):int(offs[i + 1])].tobytes() + b"\n" + (b"\n" if i % 7 == 0 else b"")
+            for i in range(len(offs) - 1) if offs[i + 1] > offs[i]]
+    p = tmp_path / "t.fa"
+    p.write_bytes(b"".join(recs))
+    names, hc, ho = hostio.read_fasta(p)
+    want_rows = oracle.score_batch(oracle.build_params(), hc, ho, nthreads=8)
+    want = [hostio.format_summary_row(want_rows[i], names[i], hc[int(ho[i]):int(ho[i + 1])], corelength=60, ww2=41) for i in range(len(names))]
+    want_text = b"".join((w if isinstance(w, bytes) else w.encode()) + b"\n" for w in want if w)
+    for max_records in (1 << 20, 333):
+        got, prev = [], 1
+        with native.Context(P) as ctx:
+            for text, starts, trim in hostio.stream_fasta_text(p, max_records, 1 << 30):
+                table, prev, counts = ctx.score_text_table(text, starts, 60, 41, prev)
+                assert table is not None, "a batch of ordinary proteins needs no host formatting"
+                got.append(table)
+        assert b"".join(got) == want_text, "device-formatted table, batches of %d records" % max_records
+    # handed back: a record without a sequence (the host prints a note for it); a protein built to put a value on a %.3f tie
+    # (one K in 16 residues: a mean charge of exactly 62.5 thousandths) comes out like the host's
+    tie = tmp_path / "tie.fa"
+    tie.write_bytes(b">tie\n" + b"K" + b"A" * 15 + b"\n" + recs[0])
+    nos = tmp_path / "noseq.fa"
+    nos.write_bytes(recs[0] + b">nothing here\n" + recs[1])
+    with native.Context(P) as ctx:
+        for path in (tie, nos):
+            text, starts, trim = next(iter(hostio.stream_fasta_text(path, 1 << 20, 1 << 30)))
+            n2, hc2, ho2 = hostio.read_fasta(path)
+            rows2 = oracle.score_batch(oracle.build_params(), hc2, ho2, nthreads=8)
+            table, _, _ = ctx.score_text_table(text, starts, 60, 41, 1)
+            if path is nos:
+                assert table is None
+            if table is None:
+                rows, c, o, blank, cnt = ctx.score_text_end(len(starts) - 1, len(text))  # (the batch is still there for the host)
+                assert np.array_equal(c, hc2) and np.array_equal(o, ho2)
+                assert_rows_equal(rows, rows2, "rows of a handed-back batch")
+            else:
+                w2 = [hostio.format_summary_row(rows2[i], n2[i], hc2[int(ho2[i]):int(ho2[i + 1])]) for i in range(len(n2))]
+                assert table == b"".join(w.encode() + b"\n" for w in w2 if w)
