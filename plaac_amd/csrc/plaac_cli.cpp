@@ -1126,15 +1126,19 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
     int64_t total_counts[PLAAC_NAA] = {0};
     std::atomic<bool> block_failed{false};
     // K1: the single pass hands the device the file's text (PLAAC_DEVICE_PARSE=0: the host parses, as in the two passes)
-    const bool as_text = single && !replay && env_flag("PLAAC_DEVICE_PARSE", true);
+    // (round 5, late: also every other pipelined scoring pass that reads the file itself - background from -B / -b another file,
+    //  or an input too large to keep: the web application's own invocation is "-B bg_freqs_X.txt -a 0.5", web/lib/server.rb:152-155)
+    const bool counting = single != nullptr;
+    const bool as_text = pipelined && !replay && env_flag("PLAAC_DEVICE_PARSE", true);
     int prev_blank = 1; // (the sink's: how the record before the batch it is looking at ended)
     // ... and the rows as TEXT from the device as well (plaac_score_end_text_table), when ONE context collects the batches in file
     // order (the name of a batch's first record is trimmed or not by how the batch before it ended). PLAAC_DEVICE_FORMAT=0: host.
     const bool device_format = as_text && plaac_node_size(eng.node) == 1 && env_flag("PLAAC_DEVICE_FORMAT", true);
     int dev_prev_blank = 1; // (the one worker's)
     auto collect = make_finish([&](plaac_ctx *ctx, Batch &b) {
-        if (!single) return plaac_score_end(ctx, b.rows.data());
-        int64_t c[PLAAC_NAA];
+        if (!b.ft && !counting) return plaac_score_end(ctx, b.rows.data());
+        int64_t c[PLAAC_NAA] = {0};
+        int64_t *const cp = counting ? c : nullptr;
         plaac_status st;
         if (b.ft && device_format) {
             // the rows as text, made on the device; a batch it will not vouch for (a value of 1e9 or more, an infinity, a record
@@ -1147,7 +1151,7 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             b.last_blank = lastb;
             if (!needs_host) {
                 b.table = writer.buffer((size_t)bytes + 1);
-                st = plaac_score_end_text_table(ctx, b.table.p, b.table.cap, c);
+                st = plaac_score_end_text_table(ctx, b.table.p, b.table.cap, cp);
                 b.table.n = (size_t)bytes;
                 b.have_table = st == PLAAC_OK;
                 if (st == PLAAC_OK) {
@@ -1164,7 +1168,7 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             b.tblank.resize((size_t)n + 1);
             b.text_ext.resize(2 * (size_t)n + 2);
             // (no copy of the codes: a summary row prints a few residues, read from the text - plaac_fasta_text_codes)
-            st = plaac_score_end_text(ctx, b.rows.data(), nullptr, 0, b.toffs.data(), b.tblank.data(), b.text_ext.data(), c);
+            st = plaac_score_end_text(ctx, b.rows.data(), nullptr, 0, b.toffs.data(), b.tblank.data(), b.text_ext.data(), cp);
             b.view.nrec = n;
             b.view.nres = b.toffs[n];
             b.view.codes = nullptr;
@@ -1210,7 +1214,7 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
         [&](plaac_ctx *ctx, Batch &b) {
             if (b.ft) {
                 if (!device_format) b.rows.resize(b.ft->nrec);
-                return plaac_score_begin_text(ctx, b.ft->text, b.ft->len, b.ft->starts, b.ft->nrec, 1);
+                return plaac_score_begin_text(ctx, b.ft->text, b.ft->len, b.ft->starts, b.ft->nrec, counting ? 1 : 0);
             }
             b.rows.resize(b.f->nrec);
             if (single) return plaac_score_begin_counting(ctx, b.f->codes, b.f->offsets, b.f->nrec);
