@@ -631,7 +631,16 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         return PLAAC_ERR_ARG;
     }
     int ndev = 0;
+    const bool ctx_timing = std::getenv("PLAAC_CTX_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { // PLAAC_CTX_TIMING=1: what bringing a context up is made of (stderr)
+        if (!ctx_timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "plaac-ctx-timing: %-40s %8.3f ms\n", what, std::chrono::duration<double>(t - t_last).count() * 1e3);
+        t_last = t;
+    };
     hipError_t e = hipGetDeviceCount(&ndev);
+    lap("hipGetDeviceCount (HIP comes up)");
     if (e != hipSuccess || ndev <= 0) {
         g_create_err = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count=0");
         return PLAAC_ERR_DEVICE;
@@ -657,6 +666,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    lap("hipSetDevice + properties");
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         g_create_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
         plaac_ctx_destroy(ctx);
@@ -668,11 +678,13 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
         if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
             return bail("hipStreamCreate", e);
         if ((e = hipMalloc((void **)&ctx->d_qprobe, 2 * sizeof(long long))) != hipSuccess) return bail("hipMalloc(qprobe)", e);
+        lap("first stream + first hipMalloc");
         if (const char *why = assign_role_streams(ctx, 1, nullptr)) {
             g_create_err = why;
             plaac_ctx_destroy(ctx);
             return PLAAC_ERR_DEVICE;
         }
+        lap("high-priority role streams (create + probe)");
         for (auto &je : ctx->jev)
             if ((e = hipEventCreateWithFlags(&je, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
@@ -696,6 +708,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     for (auto &set : ctx->ev)
         for (auto &ev : set)
             if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    lap("events");
     if ((e = hipMalloc((void **)&ctx->d_tab, sizeof(DevTables))) != hipSuccess) return bail("hipMalloc(tables)", e);
     for (auto &pb : ctx->pl)
         if ((e = hipMalloc((void **)&pb.hist, sizeof(uint32_t) * (LEN_BINS + 1))) != hipSuccess)
@@ -716,13 +729,16 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
                        ctx->d_divtab);
     hipLaunchKernelGGL(k_check_recip, dim3((RECIP_CHECK_MAX + 255u) / 256u), dim3(256), 0, ctx->stream, RECIP_CHECK_MAX,
                        ctx->d_fbcount);
+    lap("small allocations");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail("k_build_divtab", e);
+    lap("first kernels (code object load) + sync");
     if (const char *why = check_divtab(ctx)) { // SharedDiv is correctly rounded only if every reciprocal is
         g_create_err = why;
         plaac_ctx_destroy(ctx);
         return PLAAC_ERR_DEVICE;
     }
     plaac_status st = plaac_ctx_set_params(ctx, params);
+    lap("tables");
     if (st != PLAAC_OK) {
         g_create_err = ctx->err;
         plaac_ctx_destroy(ctx);
