@@ -61,6 +61,9 @@ typedef struct plaac_fasta_text {
     uint32_t nrec;
     uint64_t *starts;   /* nrec + 1 */
     uint32_t *name_len; /* nrec */
+    int prev_blank;     /* how the record BEFORE this batch ended: 1 = in an empty line (or this is the file's first batch): the
+                           reference trims the first name of this batch then (:4362); the reader looks at that one record itself */
+    int last_blank;     /* the same for this batch's last record (= the next batch's prev_blank) */
     void *owner_;       /* the stream (page release bookkeeping) */
     uint64_t file_off_; /* offset of `text` in the file */
 } plaac_fasta_text;

@@ -39,7 +39,7 @@
 //   PLAAC_DEVICE_PARSE=0                      single pass: the HOST splits lines and encodes (plaac_fasta_next). Default (round
 //                                             5, K1): the host only finds the records and keeps their names, the device parses
 //                                             (plaac_score_begin_text); the few residues a row prints are read from the text
-//   PLAAC_DEVICE_FORMAT=0                     single pass, one context: the HOST formats the rows. Default: the device writes the
+//   PLAAC_DEVICE_FORMAT=0                     the HOST formats the rows of a text batch. Default: the device writes the
 //                                             table's text (plaac_score_end_text_table: the rows never cross PCIe; a batch with
 //                                             a value it will not vouch for comes back the old way). 1.25 - 1.44 s -> 0.60 - 0.78 s
 //   PLAAC_TIMING=1                            stage clock on stderr; with PLAAC_TIMING_T0=<the launcher's CLOCK_MONOTONIC, ns>
@@ -1131,10 +1131,9 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
     const bool counting = single != nullptr;
     const bool as_text = pipelined && !replay && env_flag("PLAAC_DEVICE_PARSE", true);
     int prev_blank = 1; // (the sink's: how the record before the batch it is looking at ended)
-    // ... and the rows as TEXT from the device as well (plaac_score_end_text_table), when ONE context collects the batches in file
-    // order (the name of a batch's first record is trimmed or not by how the batch before it ended). PLAAC_DEVICE_FORMAT=0: host.
-    const bool device_format = as_text && plaac_node_size(eng.node) == 1 && env_flag("PLAAC_DEVICE_FORMAT", true);
-    int dev_prev_blank = 1; // (the one worker's)
+    // ... and the rows as TEXT from the device as well (plaac_score_end_text_table; the name of a batch's first record is trimmed
+    // or not by how the batch before it ended, which the reader finds out itself: any context, any order). PLAAC_DEVICE_FORMAT=0: host.
+    const bool device_format = as_text && env_flag("PLAAC_DEVICE_FORMAT", true);
     auto collect = make_finish([&](plaac_ctx *ctx, Batch &b) {
         if (!b.ft && !counting) return plaac_score_end(ctx, b.rows.data());
         int64_t c[PLAAC_NAA] = {0};
@@ -1144,11 +1143,10 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             // the rows as text, made on the device; a batch it will not vouch for (a value of 1e9 or more, an infinity, a record
             // without a sequence) comes back the old way and is formatted below
             uint64_t bytes = 0;
-            int needs_host = 0, lastb = dev_prev_blank;
-            st = plaac_score_end_text_table_size(ctx, o.corelength, o.ww2, dev_prev_blank, &bytes, &needs_host, &lastb, &b.table_residues);
+            int needs_host = 0, lastb = 0;
+            st = plaac_score_end_text_table_size(ctx, o.corelength, o.ww2, b.ft->prev_blank, &bytes, &needs_host, &lastb, &b.table_residues);
             if (st != PLAAC_OK) return st;
-            dev_prev_blank = lastb;
-            b.last_blank = lastb;
+            b.last_blank = lastb; // (== b.ft->last_blank: the reader's own look at the batch's last record)
             if (!needs_host) {
                 b.table = writer.buffer((size_t)bytes + 1);
                 st = plaac_score_end_text_table(ctx, b.table.p, b.table.cap, cp);
@@ -1223,6 +1221,10 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
         },
         [&](Batch &b) {
             if (b.have_table) { // (formatted on the device)
+                if (b.last_blank != b.ft->last_blank) {
+                    std::fprintf(stderr, "plaac: the reader and the device disagree about how a record ends - rerun with PLAAC_DEVICE_FORMAT=0\n");
+                    return false;
+                }
                 prev_blank = b.last_blank;
                 nres += b.table_residues;
                 nrec += b.ft->nrec;
@@ -1231,7 +1233,7 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
                 b.table = TextBuf{};
                 return true;
             }
-            if (b.ft) prev_blank = plaac_fasta_text_trim_names(b.ft, b.tblank.data(), prev_blank);
+            if (b.ft) prev_blank = plaac_fasta_text_trim_names(b.ft, b.tblank.data(), b.ft->prev_blank);
             const plaac_fasta *f = b.f;
             // format in parallel (contiguous row ranges per thread), print in file order
             const unsigned nt = f->nrec < 2048 ? 1u : nt_max;

@@ -484,6 +484,7 @@ struct plaac_fasta_stream {
     size_t cursor = 0;     // a record start, or 0 before the first batch
     size_t released = 0;   // bytes of the mapping already handed back to the kernel
     bool trim_next = true; // the next record is the file's first or follows a blank-line-terminated one
+    int prev_blank = 1;    // the same for the text batches (plaac_fasta_next_text)
 };
 
 plaac_status plaac_fasta_open(const char *path, plaac_fasta_stream **out) {
@@ -654,6 +655,23 @@ plaac_status plaac_fasta_next_text(plaac_fasta_stream *s, uint32_t max_records, 
             ++k;
         }
     t->starts[keep] = e - b0;
+    // how the batch's last record ends, for the next batch's first name (the device reports it for every record; the reader
+    // needs it for this ONE record so that batches can be collected by any context in any order): the rule of
+    // fasta_device.hip.inc - an empty line behind the header = a terminator preceded by \n, or a \r preceded by \r
+    t->prev_blank = s->prev_blank;
+    t->last_blank = t->prev_blank;
+    if (keep) {
+        const size_t rb = b0 + (size_t)t->starts[keep - 1];
+        size_t h = rb;
+        while (h < e && d[h] != '\n' && d[h] != '\r') ++h;
+        int blank = 0;
+        for (size_t q = h + 1; q < e && !blank; ++q) {
+            const char c = d[q], pc = d[q - 1];
+            blank = (c == '\n' || c == '\r') && (pc == '\n' || (pc == '\r' && c == '\r'));
+        }
+        t->last_blank = blank;
+    }
+    s->prev_blank = t->last_blank;
     t->text = d + b0;
     t->len = e - b0;
     t->nrec = (uint32_t)keep;

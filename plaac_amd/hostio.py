@@ -104,7 +104,8 @@ def stream_fasta(path, max_records=262144, max_bytes=128 << 20):
 class _FastaText(C.Structure):
     """plaac_fasta_text"""
     _fields_ = [("text", C.c_void_p), ("len", C.c_uint64), ("nrec", C.c_uint32), ("starts", C.POINTER(C.c_uint64)),
-                ("name_len", C.POINTER(C.c_uint32)), ("owner_", C.c_void_p), ("file_off_", C.c_uint64)]
+                ("name_len", C.POINTER(C.c_uint32)), ("prev_blank", C.c_int), ("last_blank", C.c_int), ("owner_", C.c_void_p),
+                ("file_off_", C.c_uint64)]
 
 
 def stream_fasta_text(path, max_records=262144, max_bytes=128 << 20):
@@ -133,6 +134,8 @@ def stream_fasta_text(path, max_records=262144, max_bytes=128 << 20):
             text = C.string_at(t.text, int(t.len))
             starts = np.ctypeslib.as_array(t.starts, shape=(n + 1,)).copy()
 
+            trim_flags = (int(t.prev_blank), int(t.last_blank))  # (what the reader itself says about the batch's two ends)
+
             def trim(blank_end, prev_blank, pt=pt, n=n, text=text, starts=starts):
                 be = np.ascontiguousarray(blank_end, dtype=np.uint8)
                 nxt = L.plaac_fasta_text_trim_names(pt, be.ctypes.data, int(prev_blank))
@@ -140,6 +143,7 @@ def stream_fasta_text(path, max_records=262144, max_bytes=128 << 20):
                 names = [text[int(starts[i]) + 1:int(starts[i]) + 1 + int(nlen[i])] for i in range(n)]
                 return names, int(nxt)
 
+            trim.flags = trim_flags
             yield text, starts, trim
             L.plaac_fasta_text_free(pt)
     finally:

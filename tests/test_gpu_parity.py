@@ -1198,6 +1198,8 @@ def test_fasta_text_parsed_on_the_device_equals_the_host_parser(native, oracle, 
     with native.Context(native.make_params()) as ctx:
         for text, starts, trim in hostio.stream_fasta_text(p, max_records, max_bytes):
             rows, c, o, blank, cnt = ctx.score_text(text, starts, counting=True)
+            # (the reader's own look at the batch's two ends - what lets any context format any batch - is the device's)
+            assert trim.flags == (prev_blank, int(blank[-1]) if len(blank) else prev_blank)
             nm, prev_blank = trim(blank, prev_blank)
             got_names += nm
             got_codes.append(c)

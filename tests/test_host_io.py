@@ -360,5 +360,14 @@ def test_text_batches_locate_the_records_the_parser_finds(io, tmp_path):
             pos += len(text)
             n += len(starts) - 1
         assert pos == len(data) and n == len(names)
+        # the reader's own look at each batch's ends: the file's first batch follows "a blank line", a batch's last record ends
+        # in one iff an empty line follows its header before the next record (r % 5 == 0 above), and the flags chain
+        flags = [trim.flags for _, _, trim in io.stream_fasta_text(p, mr, mb)]
+        assert flags[0][0] == 1 and all(a[1] == b[0] for a, b in zip(flags, flags[1:]))
+        k = 0
+        for (text, starts, trim) in io.stream_fasta_text(p, mr, mb):
+            k += len(starts) - 1
+            last = k - 2  # (record k - 1 of the file is ">r<k-2>", the first one is ">a")
+            assert trim.flags[1] == (1 if (last >= 0 and last % 5 == 0) else 0), (k, trim.flags)
         assert [u.rstrip(bytes(range(33))) if (i == 0) else u for i, u in enumerate(untrimmed)][:1] == names[:1]
         assert all(u.startswith(nm) for u, nm in zip(untrimmed, names))
