@@ -19,6 +19,12 @@ with native.Context(P) as ctx:
             t2 = time.perf_counter()
         print("text: locate %.1f ms, begin+end %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
         t0 = time.perf_counter()
+        for text, starts, trim in hostio.stream_fasta_text(fa, 1 << 20, 1 << 30):
+            t1 = time.perf_counter()
+            table, lastb, cnt = ctx.score_text_table(text, starts, 60, 41, 1)
+            t2 = time.perf_counter()
+        print("text -> table: locate %.1f ms, begin + size + table %.1f ms, %d bytes of table" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, len(table)))
+        t0 = time.perf_counter()
         names, codes, offs = hostio.read_fasta(fa)
         t1 = time.perf_counter()
         n = ctx.score_begin_counting(codes, offs)
