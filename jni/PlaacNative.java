@@ -56,4 +56,12 @@ final class PlaacNative {
     static native void batchSweep(long batch, ByteBuffer params, int npoints, ByteBuffer[] rowsOut);
     /** pipelines of batches: consecutive scoring calls of a context may overlap on the device (plaac_ctx_set_overlap) */
     static native void nodeSetOverlap(long node, boolean on);
+
+    // FASTA text in, summary-table text out (round 5): the bytes of whole records ('>' of record i at starts[i], starts[nrec] =
+    // textLen) to context k of the node; the device parses (fastareader), scores and writes scoreallfastas' lines. Two batches
+    // may be pending per context. textTableSize: the table's size, out3 = {needsHost, lastBlank, residues}; prevBlank: how the
+    // record before this batch ended (1 for a file's first batch; lastBlank of the batch before otherwise).
+    static native void textBegin(long node, int k, ByteBuffer text, long textLen, ByteBuffer starts, int nrec, boolean counting);
+    static native long textTableSize(long node, int k, int corelength, int ww2, int prevBlank, long[] out3);
+    static native void textTable(long node, int k, ByteBuffer tableOut, long tableCap, long[] counts22);
 }

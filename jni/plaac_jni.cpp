@@ -239,4 +239,62 @@ JNIEXPORT void JNICALL Java_PlaacNative_nodeSetOverlap(JNIEnv *env, jclass, jlon
     if (plaac_node_set_overlap(node_of(node), on ? 1 : 0) != PLAAC_OK) raise(env, node_error(node));
 }
 
+// ---- FASTA text in, summary-table text out (round 5): fastareader.nextfasta (:4325-4357) in front of the scoring loop and the
+//      output line of scoreallfastas (:899-945) behind it run on the device; a Java host hands over the bytes of whole records
+//      and where each begins, and gets the table's bytes back. Context k of the node; two batches may be pending per context.
+static plaac_ctx *ctx_of(JNIEnv *env, jlong node, jint k) {
+    plaac_ctx *c = plaac_node_ctx(node_of(node), k);
+    if (!c) raise(env, "no such context on this node");
+    return c;
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_textBegin(JNIEnv *env, jclass, jlong node, jint k, jobject text, jlong textLen,
+                                                  jobject starts, jint nrec, jboolean counting) {
+    plaac_ctx *c = ctx_of(env, node, k);
+    if (!c) return;
+    if (nrec < 0 || textLen < 0) return raise(env, "textBegin: negative size");
+    const uint64_t *st = (const uint64_t *)direct(env, starts, 8ull * ((uint64_t)nrec + 1), "starts");
+    if (!st) return;
+    const char *t = (const char *)direct(env, text, (uint64_t)textLen, "text");
+    if (!t) return;
+    if (plaac_score_begin_text(c, t, (uint64_t)textLen, st, (uint32_t)nrec, counting ? 1 : 0) != PLAAC_OK) raise(env, plaac_last_error(c));
+}
+
+// returns the table's size in bytes; out3 = {needsHost, lastBlank, residues}. needsHost != 0: the device will not vouch for a
+// value of this batch - collect it with the row-level natives (not bound here: score / batchScore) after formatting on the host
+JNIEXPORT jlong JNICALL Java_PlaacNative_textTableSize(JNIEnv *env, jclass, jlong node, jint k, jint corelength, jint ww2,
+                                                       jint prevBlank, jlongArray out3) {
+    plaac_ctx *c = ctx_of(env, node, k);
+    if (!c) return -1;
+    if (!out3 || env->GetArrayLength(out3) != 3) {
+        raise(env, "textTableSize: a long[3] is required");
+        return -1;
+    }
+    uint64_t bytes = 0, residues = 0;
+    int needs = 0, lastb = 0;
+    if (plaac_score_end_text_table_size(c, corelength, ww2, prevBlank, &bytes, &needs, &lastb, &residues) != PLAAC_OK) {
+        raise(env, plaac_last_error(c));
+        return -1;
+    }
+    const jlong out[3] = {(jlong)needs, (jlong)lastb, (jlong)residues};
+    env->SetLongArrayRegion(out3, 0, 3, out);
+    return (jlong)bytes;
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_textTable(JNIEnv *env, jclass, jlong node, jint k, jobject tableOut, jlong tableCap,
+                                                  jlongArray counts22) {
+    plaac_ctx *c = ctx_of(env, node, k);
+    if (!c) return;
+    if (tableCap < 0 || (counts22 && env->GetArrayLength(counts22) != PLAAC_NAA)) return raise(env, "textTable: capacity >= 0, counts null or long[22]");
+    char *t = (char *)direct(env, tableOut, (uint64_t)tableCap, "tableOut");
+    if (!t) return;
+    int64_t counts[PLAAC_NAA];
+    if (plaac_score_end_text_table(c, t, (uint64_t)tableCap, counts22 ? counts : nullptr) != PLAAC_OK) return raise(env, plaac_last_error(c));
+    if (counts22) {
+        jlong out[PLAAC_NAA];
+        for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (jlong)counts[i];
+        env->SetLongArrayRegion(counts22, 0, PLAAC_NAA, out);
+    }
+}
+
 } // extern "C"
