@@ -2108,6 +2108,8 @@ plaac_status plaac_score_end_text_table(plaac_ctx *ctx, char *table, uint64_t ta
         return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table: call plaac_score_end_text_table_size first (and plaac_score_end_text when it asks for the host)");
     if (S.table_bytes > table_cap || (S.table_bytes && !table))
         return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table: the buffer is smaller than the size reported");
+    if (counts && S.nprot && S.call_no != ~0ull && !S.counted)
+        return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table: the batch was begun without counting");
     const uint32_t nrec = S.nprot;
     S.table_sized = false;
     if (nrec && S.call_no != ~0ull && S.table_bytes) {
@@ -2126,7 +2128,6 @@ plaac_status plaac_score_end_text_table(plaac_ctx *ctx, char *table, uint64_t ta
     if (counts) {
         for (int i = 0; i < NAA; ++i) counts[i] = 0;
         if (nrec && S.call_no != ~0ull) {
-            if (!S.counted) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table: the batch was begun without counting");
             PL_HIP(ctx, hipMemcpyAsync(counts, S.d_counts, sizeof(int64_t) * NAA, hipMemcpyDeviceToHost, ctx->xfer));
             PL_HIP(ctx, hipStreamSynchronize(ctx->xfer));
         }
