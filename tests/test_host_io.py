@@ -371,3 +371,39 @@ def test_text_batches_locate_the_records_the_parser_finds(io, tmp_path):
             assert trim.flags[1] == (1 if (last >= 0 and last % 5 == 0) else 0), (k, trim.flags)
         assert [u.rstrip(bytes(range(33))) if (i == 0) else u for i, u in enumerate(untrimmed)][:1] == names[:1]
         assert all(u.startswith(nm) for u, nm in zip(untrimmed, names))
+
+
+def test_summary_row_written_straight_into_a_buffer(io):
+    """plaac_format_summary_row_n (round 5: bin/plaac's formatter threads write rows straight into their output buffers): the
+    name by length (not NUL-terminated), no terminating NUL written, -1 unless the buffer covers the longest a row can be,
+    and the same bytes as plaac_format_summary_row - also for NaN / infinite fields and values on a %.3f tie."""
+    import ctypes as C
+    from plaac_amd import native
+    L = native.load()
+    L.plaac_format_summary_row_n.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.plaac_format_summary_row_n.restype = C.c_long
+    rng = np.random.default_rng(12)
+    codes = rng.integers(1, 21, 400).astype(np.uint8)
+    rows = np.zeros(6, dtype=native.ROW_DTYPE)
+    for i, r in enumerate(rows):
+        r["prot_len"] = 400
+        for f in ("llr_score", "core_score", "prd_score", "hmm_all", "hmm_vit", "fi_meanhydro", "fi_meancharge", "fi_meancombo",
+                  "papa_combo", "papa_prop", "papa_fi", "papa_llr", "papa_llr2"):
+            r[f] = rng.normal(0, 30)
+        r["mw_start"], r["mw_end"], r["llr_start"], r["llr_end"] = 5, 84, 10, 69
+        r["core_start"], r["core_end"], r["prd_start"], r["prd_end"], r["papa_cen"] = 20, 79, 15, 140, 100 + i
+    rows[1]["core_score"] = np.nan
+    rows[2]["llr_score"] = -np.inf
+    rows[2]["papa_combo"] = -np.inf
+    rows[3]["fi_meancharge"] = 0.0625      # an exact tie at three decimals
+    rows[4]["fi_meanhydro"] = 0.0475       # the shortest digits sit on the tie, the binary value below it
+    rows[5]["prd_start"], rows[5]["prd_end"] = -1, -2
+    name = b"sp|P1|NAME one two"
+    for r in rows:
+        one = np.array([r], dtype=native.ROW_DTYPE)
+        want = io.format_summary_row(r, name, codes)
+        buf = C.create_string_buffer(b"\xff" * 16384, 16384)
+        k = L.plaac_format_summary_row_n(one.ctypes.data, name + b"JUNK BEHIND THE NAME", len(name), codes.ctypes.data, len(codes), 60, 41, buf, 16384)
+        assert k == len(want.encode()) and buf.raw[:k] == want.encode() and buf.raw[k:k + 1] == b"\xff"
+        assert L.plaac_format_summary_row_n(one.ctypes.data, name, len(name), codes.ctypes.data, len(codes), 60, 41, buf, 2000) == -1
+    assert "0.063" in io.format_summary_row(rows[3], name, codes) and "0.048" in io.format_summary_row(rows[4], name, codes)
