@@ -1904,6 +1904,7 @@ static plaac_status score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint
     S.call_no = ~0ull;
     S.counted = counting;
     S.from_text = false;
+    S.table_sized = false;
     if (nprot) {
         uint64_t total = 0;
         plaac_status rc = stage_in_to(ctx, codes, offsets, nprot, &total, S.d_codes, S.cap_codes, S.d_offsets, S.cap_offs, ctx->xfer);
@@ -1946,6 +1947,7 @@ plaac_status plaac_score_begin_text(plaac_ctx *ctx, const char *text, uint64_t t
     S.call_no = ~0ull;
     S.counted = counting != 0;
     S.from_text = true;
+    S.table_sized = false;
     S.nres = 0;
     if (nrec) {
         plaac_status rc;

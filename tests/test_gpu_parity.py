@@ -1273,3 +1273,70 @@ def test_summary_rows_formatted_on_the_device_equal_the_hosts(native, oracle, tm
             else:
                 w2 = [hostio.format_summary_row(rows2[i], n2[i], hc2[int(ho2[i]):int(ho2[i + 1])]) for i in range(len(n2))]
                 assert table == b"".join(w.encode() + b"\n" for w in w2 if w)
+
+
+def test_text_batches_and_code_batches_share_the_two_slots(native, oracle, tmp_path):
+    """A context's two pending slots taken by text batches (plaac_score_begin_text) and encoded batches (plaac_score_begin /
+    _begin_counting) in any order, each collected by the end call of its kind - and refused by the others without losing
+    the batch: rows, tables and counts of every batch as if it had been alone."""
+    from plaac_amd import hostio, synth
+    P = native.make_params()
+    rng = np.random.default_rng(23)
+    texts, coded = [], []
+    for k in range(4):
+        codes, offs = synth.make_batch(4, nprot=int(rng.integers(300, 3000)), seed=40 + k, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+        keep = [i for i in range(len(offs) - 1) if offs[i + 1] > offs[i]]
+        letters = np.frombuffer(b"XACDEFGHIKLMNPQRSTVWY*", dtype=np.uint8)[codes]
+        p = tmp_path / ("t%d.fa" % k)
+        p.write_bytes(b"".join(b">b%d_%d\n" % (k, i) + letters[int(offs[i]):int(offs[i + 1])].tobytes() + b"\n" for i in keep))
+        text, starts, trim = next(iter(hostio.stream_fasta_text(p, 1 << 20, 1 << 30)))
+        names, hc, ho = hostio.read_fasta(p)
+        rows = oracle.score_batch(oracle.build_params(), hc, ho, nthreads=8)
+        table = b"".join(hostio.format_summary_row(rows[i], names[i], hc[int(ho[i]):int(ho[i + 1])]).encode() + b"\n" for i in range(len(names)))
+        texts.append((text, np.ascontiguousarray(starts, dtype=np.uint64), table, oracle.histogram(hc, ho), rows, hc, ho))
+        coded.append((hc, ho, rows))
+    import ctypes as C
+    with native.Context(P) as ctx:
+        L, h = ctx._L, ctx._h
+
+        def begin_text(k):
+            text, starts = texts[k][0], texts[k][1]
+            ctx._check(L.plaac_score_begin_text(h, text, len(text), starts.ctypes.data, len(starts) - 1, 1))
+
+        def end_table(k):
+            size, needs, lastb = C.c_uint64(), C.c_int(), C.c_int()
+            ctx._check(L.plaac_score_end_text_table_size(h, 60, 41, 1, C.byref(size), C.byref(needs), C.byref(lastb), None))
+            assert not needs.value
+            buf = C.create_string_buffer(max(int(size.value), 1))
+            counts = np.zeros(22, dtype=np.int64)
+            ctx._check(L.plaac_score_end_text_table(h, buf, size.value, counts.ctypes.data))
+            assert buf.raw[:size.value] == texts[k][2] and np.array_equal(counts, texts[k][3]), "table / counts of text batch %d" % k
+
+        for order in ("TcTc", "cTTc", "TTcc", "cTcT"):
+            pending = []
+            it_t, it_c = iter(range(4)), iter(range(4))
+            for kind in order + order:
+                if len(pending) == 2:
+                    what, k = pending.pop(0)
+                    if what == "T":
+                        with pytest.raises(native.PlaacError):  # (an encoded-batch end on a text batch's turn: refused, nothing lost)
+                            ctx._check(L.plaac_score_end_text_table(h, None, 0, None))
+                        end_table(k)
+                    else:
+                        size, needs, lastb = C.c_uint64(), C.c_int(), C.c_int()
+                        assert L.plaac_score_end_text_table_size(h, 60, 41, 1, C.byref(size), C.byref(needs), C.byref(lastb), None) != 0
+                        assert_rows_equal(ctx.score_end(len(coded[k][1]) - 1), coded[k][2], "encoded batch %d between text batches" % k)
+                k = next(it_t, None) if kind == "T" else next(it_c, None)
+                if k is None:
+                    it_t, it_c = iter(range(4)), iter(range(4))
+                    k = next(it_t) if kind == "T" else next(it_c)
+                if kind == "T":
+                    begin_text(k)
+                else:
+                    ctx.score_begin(coded[k][0], coded[k][1])
+                pending.append((kind, k))
+            for what, k in pending:
+                if what == "T":
+                    end_table(k)
+                else:
+                    assert_rows_equal(ctx.score_end(len(coded[k][1]) - 1), coded[k][2], "encoded batch %d at the end" % k)
