@@ -26,7 +26,8 @@
 //   PLAAC_SINGLE_PASS=0                       always the reference's two passes. Default (round 5): when the scoring tables do
 //                                             not depend on the input's residue counts - alpha = 1, background counted from the
 //                                             scored input itself (plaac.java:377-384, :458) - and the input fits
-//                                             PLAAC_KEEP_BYTES, the counting pass runs INSIDE the scoring pass
+//                                             PLAAC_KEEP_BYTES (any size when stdout is a plain file: the table is then written
+//                                             in place and nothing waits in memory), the counting pass runs INSIDE the scoring pass
 //                                             (plaac_score_begin_counting): the table is formatted while the file is still being
 //                                             read, the parameter block (whose "## bg_input" line needs the final counts) and
 //                                             everything behind it are held back until the last batch has been counted, then
@@ -793,7 +794,7 @@ template <class Prep, class Work, class Sink, class Fin = NoFinish>
 bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, plaac_fasta_stream *fs, const Stream &sp,
                   std::vector<plaac_fasta *> *replay, std::vector<plaac_fasta *> *keep, uint64_t keep_bytes, Prep &&prep,
                   Work &&work, Sink &&sink, Fin finish = Fin(), const std::function<void()> *drained = nullptr,
-                  bool as_text = false) {
+                  bool as_text = false, bool run_ahead = true) {
     if (!fs && !replay) {
         if (drained) (*drained)();
         return true; // nothing to read
@@ -802,7 +803,9 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
     // ahead as it likes: it parses through the few hundred ms in which the GPU contexts come up instead of stopping
     // four batches in. A pass that does not keep them is bounded to four batches in flight.
     KeptState ks; // (declared before the queues: batches still queued at a failure are destroyed before it)
-    Queue q((keep || drained) ? (size_t)1 << 30 : 4);
+    // (run_ahead = false: a pass with `drained` whose sink does not hold anything back - the table is being written in place -
+    //  stays within the printer's window like any other: memory bounded whatever the size of the input)
+    Queue q((keep || (drained && run_ahead)) ? (size_t)1 << 30 : 4);
     Reorder ro(4); // widened once the number of contexts is known
     std::atomic<bool> failed{false};
     bool keeping = keep != nullptr, keep_overflow = false;
@@ -868,7 +871,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
         return false;
     }
     const int nctx = plaac_node_size(eng.node);
-    ro.set_window(drained ? (uint64_t)1 << 40 : (uint64_t)2 * nctx + 2);
+    ro.set_window((drained && run_ahead) ? (uint64_t)1 << 40 : (uint64_t)2 * nctx + 2);
     std::atomic<int> live_workers{nctx};
     std::vector<std::thread> workers;
     for (int k = 0; k < nctx; ++k)
@@ -1204,7 +1207,7 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
         writer.release(single->held);
     };
     auto run = [&](auto &&...a) {
-        return pipelined ? run_pipeline(std::forward<decltype(a)>(a)..., collect, single ? &drained : nullptr, as_text)
+        return pipelined ? run_pipeline(std::forward<decltype(a)>(a)..., collect, single ? &drained : nullptr, as_text, !placed)
                          : run_pipeline(std::forward<decltype(a)>(a)...);
     };
     const bool ok = run(
@@ -1509,8 +1512,12 @@ int main(int argc, char **argv) {
         struct stat sb;
         single_pass = env_flag("PLAAC_SINGLE_PASS", true) && env_flag("PLAAC_PIPELINE", true) && !o.input.empty() &&
                       o.plotlist.empty() && o.bgfreq.empty() && (o.bgfile.empty() || o.bgfile == o.input) && a_eff == 1.0 &&
-                      ::stat(o.input.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && ::access(o.input.c_str(), R_OK) == 0 &&
-                      (uint64_t)sb.st_size <= keep_bytes;
+                      ::stat(o.input.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && ::access(o.input.c_str(), R_OK) == 0;
+        // An input of any size when the table can be written in place (nothing waits in memory then); otherwise one whose
+        // table may wait: the budget of the kept batches of the two-pass run
+        off_t at = 0;
+        if (single_pass && (uint64_t)sb.st_size > keep_bytes)
+            single_pass = env_flag("PLAAC_PLACED_WRITE", true) && stdout_is_plain_file(&at);
     }
     if (single_pass) g_defer = &single.held;
 
