@@ -215,6 +215,11 @@ plaac_status plaac_score_end_text(plaac_ctx *ctx, plaac_row *rows, uint8_t *code
 plaac_status plaac_score_end_text_table_size(plaac_ctx *ctx, int corelength, int ww2, int prev_blank, uint64_t *table_bytes,
                                              int *needs_host, int *last_blank, uint64_t *residues /* nullable: the batch's */);
 plaac_status plaac_score_end_text_table(plaac_ctx *ctx, char *table, uint64_t table_cap, int64_t *counts);
+/* The COUNTING pass of a two-pass run fed with text (computeaafreq plaac.java:1655-1666 over nextfasta's records): the batch is
+ * parsed on the device like a scored one and counted (countaas / isvalidprotein :1698-1739), not scored. Shares a context's
+ * two pending slots with the scoring calls; residues (nullable) = the batch's residue count. */
+plaac_status plaac_histogram_begin_text(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec);
+plaac_status plaac_histogram_end_text(plaac_ctx *ctx, int64_t counts[PLAAC_NAA], uint64_t *residues);
 
 /* ---- resident batches: upload once, use many times -------------------------------------------------------
  * The reference makes one full pass over the input for the background counts and a second one for scoring

@@ -1012,6 +1012,31 @@ bool count_background(Engine &eng, const plaac_params &P, const std::string &pat
     uint64_t nres = 0;
     plaac_fasta_stream *fs = nullptr;
     if (!open_stream(path, &fs)) return false; // a missing file: reported, zero counts (:4318-4321)
+    // round 5, late: the counting pass fed with TEXT too (parsed on the device, nothing kept: the scoring pass reads the file
+    // again - it is in the page cache - and parses it on the device as well). PLAAC_DEVICE_PARSE=0 / PLAAC_PIPELINE=0: the
+    // host parses and keeps its batches for the scoring pass, as before.
+    if (env_flag("PLAAC_DEVICE_PARSE", true) && env_flag("PLAAC_PIPELINE", true)) {
+        const bool ok = run_pipeline(
+            eng, P, path, fs, sp, nullptr, nullptr, 0, [](Batch &) {},
+            [&](plaac_ctx *ctx, Batch &b) { return plaac_histogram_begin_text(ctx, b.ft->text, b.ft->len, b.ft->starts, b.ft->nrec); },
+            [](Batch &) { return true; },
+            make_finish([&](plaac_ctx *ctx, Batch &b) {
+                (void)b;
+                int64_t c[PLAAC_NAA];
+                uint64_t r = 0;
+                const plaac_status st = plaac_histogram_end_text(ctx, c, &r);
+                if (st == PLAAC_OK) {
+                    std::lock_guard<std::mutex> l(m);
+                    for (int i = 0; i < PLAAC_NAA; ++i) total[i] += c[i];
+                    nres += r;
+                }
+                return st;
+            }),
+            nullptr, true);
+        for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (double)total[i];
+        g_timer.lap("background pass (read + H2D + parse + histogram on the device)", (double)nres, "residues");
+        return ok;
+    }
     const bool ok = run_pipeline(
         eng, P, path, fs, sp, nullptr, keep, keep_bytes, [](Batch &) {},
         [&](plaac_ctx *ctx, Batch &b) {

@@ -180,6 +180,8 @@ struct plaac_ctx {
         size_t cap_toffs = 0, cap_table = 0, cap_fmtflags = 0;
         uint64_t table_bytes = 0;
         bool table_sized = false;
+        bool hist_only = false;        // plaac_histogram_begin_text: parsed and counted, not scored
+        hipEvent_t hist_ev = nullptr;  // ... its histogram is through
         uint64_t nres = 0;
         bool from_text = false;
         size_t cap_codes = 0, cap_offs = 0, cap_rows = 0;
@@ -792,6 +794,8 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+    for (auto &sl : ctx->slot)
+        if (sl.hist_ev) (void)hipEventDestroy(sl.hist_ev);
     for (auto &sl : ctx->slot)
         for (void *b : {(void *)sl.d_codes, (void *)sl.d_offsets, (void *)sl.d_rows, (void *)sl.d_counts, (void *)sl.d_text,
                         (void *)sl.d_starts, (void *)sl.d_len, (void *)sl.d_blank, (void *)sl.d_total, (void *)sl.d_ext,
@@ -1932,8 +1936,8 @@ plaac_status plaac_score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint6
 // K1 (round 5): the same pipeline fed with FASTA TEXT - the records' bytes and where each begins - parsed and encoded on the
 // device (fasta_device.hip.inc) into the slot the scoring kernels read. Upload and parse run on the copy stream, beside the
 // kernels of the batch before; the codes are complete when the scoring call is made (the overlap contract).
-plaac_status plaac_score_begin_text(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
-                                    int counting) {
+static plaac_status begin_text(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec, int counting,
+                               bool score) {
     if (!ctx) return PLAAC_ERR_ARG;
     if (ctx->slots_busy >= 2) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_begin_text: two batches are pending (call plaac_score_end_text)");
     if (nrec && (!text || !starts)) return fail(ctx, PLAAC_ERR_ARG, "null text / starts");
@@ -1948,6 +1952,7 @@ plaac_status plaac_score_begin_text(plaac_ctx *ctx, const char *text, uint64_t t
     S.counted = counting != 0;
     S.from_text = true;
     S.table_sized = false;
+    S.hist_only = !score;
     S.nres = 0;
     if (nrec) {
         plaac_status rc;
@@ -1985,14 +1990,47 @@ plaac_status plaac_score_begin_text(plaac_ctx *ctx, const char *text, uint64_t t
             if (!S.d_counts) PL_HIP(ctx, hipMalloc(&S.d_counts, sizeof(unsigned long long) * NAA));
             if ((rc = plaac_histogram_device(ctx, S.d_codes, S.d_offsets, nrec, (int64_t *)S.d_counts, ctx->stream)) != PLAAC_OK) return rc;
         }
-        const uint64_t call_no = ctx->ncalls;
-        rc = plaac_score_device(ctx, S.d_codes, S.d_offsets, nrec, total, S.d_rows, nullptr, ctx->stream);
-        if (rc != PLAAC_OK) return rc;
-        S.call_no = call_no;
+        if (score) {
+            const uint64_t call_no = ctx->ncalls;
+            rc = plaac_score_device(ctx, S.d_codes, S.d_offsets, nrec, total, S.d_rows, nullptr, ctx->stream);
+            if (rc != PLAAC_OK) return rc;
+            S.call_no = call_no;
+        } else {
+            if (!S.hist_ev) PL_HIP(ctx, hipEventCreateWithFlags(&S.hist_ev, hipEventDisableTiming));
+            PL_HIP(ctx, hipEventRecord(S.hist_ev, ctx->stream));
+        }
     }
     S.busy = true;
     ctx->slot_next ^= 1u;
     ++ctx->slots_busy;
+    return PLAAC_OK;
+}
+plaac_status plaac_score_begin_text(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
+                                    int counting) {
+    return begin_text(ctx, text, text_len, starts, nrec, counting, true);
+}
+// The counting pass of a two-pass run fed with text (round 5, late): parsed on the device like a scored batch, counted, not
+// scored. Shares the two pending slots with the scoring calls; collected by plaac_histogram_end_text only.
+plaac_status plaac_histogram_begin_text(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec) {
+    return begin_text(ctx, text, text_len, starts, nrec, 1, false);
+}
+plaac_status plaac_histogram_end_text(plaac_ctx *ctx, int64_t counts[PLAAC_NAA], uint64_t *residues) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (!counts) return fail(ctx, PLAAC_ERR_ARG, "null counts");
+    if (ctx->slots_busy == 0) return fail(ctx, PLAAC_ERR_ARG, "plaac_histogram_end_text: no batch is pending");
+    plaac_ctx::Slot &S = ctx->slot[ctx->slot_oldest];
+    if (!S.hist_only) return fail(ctx, PLAAC_ERR_ARG, "plaac_histogram_end_text: the oldest batch was begun for scoring");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    S.busy = false;
+    S.hist_only = false;
+    ctx->slot_oldest ^= 1u;
+    --ctx->slots_busy;
+    for (int i = 0; i < NAA; ++i) counts[i] = 0;
+    if (residues) *residues = S.nres;
+    if (S.nprot == 0) return PLAAC_OK;
+    PL_HIP(ctx, hipEventSynchronize(S.hist_ev));
+    PL_HIP(ctx, hipMemcpyAsync(counts, S.d_counts, sizeof(int64_t) * NAA, hipMemcpyDeviceToHost, ctx->xfer));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->xfer));
     return PLAAC_OK;
 }
 plaac_status plaac_score_begin_counting(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot) {
@@ -2004,6 +2042,7 @@ static plaac_status score_end(plaac_ctx *ctx, plaac_row *rows, int64_t *counts) 
     if (ctx->slots_busy == 0) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end: no batch is pending");
     PL_HIP(ctx, hipSetDevice(ctx->device));
     plaac_ctx::Slot &S = ctx->slot[ctx->slot_oldest];
+    if (S.hist_only) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end: the oldest batch was begun for counting only (plaac_histogram_end_text)");
     S.busy = false; // (whatever happens below, the slot is given up)
     ctx->slot_oldest ^= 1u;
     --ctx->slots_busy;
@@ -2063,7 +2102,7 @@ plaac_status plaac_score_end_text_table_size(plaac_ctx *ctx, int corelength, int
     if (!table_bytes || !needs_host || !last_blank) return fail(ctx, PLAAC_ERR_ARG, "null argument");
     if (ctx->slots_busy == 0) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table_size: no batch is pending");
     plaac_ctx::Slot &S = ctx->slot[ctx->slot_oldest];
-    if (!S.from_text) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table_size: the oldest batch was not begun from text");
+    if (!S.from_text || S.hist_only) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_end_text_table_size: the oldest batch was not begun from text for scoring");
     *table_bytes = 0, *needs_host = 0, *last_blank = prev_blank;
     if (residues) *residues = S.nres;
     S.table_sized = false;

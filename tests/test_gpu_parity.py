@@ -1218,6 +1218,13 @@ def test_fasta_text_parsed_on_the_device_equals_the_host_parser(native, oracle, 
             cnt = int(rng.integers(0, 60))
             want = codes[int(offs[i]) + min(first, n):int(offs[i]) + min(first + cnt, n)]
             assert np.array_equal(hostio.text_codes(text, starts, ext, i, first, cnt), want), (i, first, cnt)
+        # the counting pass alone (plaac_histogram_begin_text / _end_text): parsed on the device, counted, not scored
+        hist, nres = np.zeros(22, dtype=np.int64), 0
+        for text, starts, trim in hostio.stream_fasta_text(p, max_records, max_bytes):
+            c2, r2 = ctx.histogram_text(text, starts)
+            hist += c2
+            nres += r2
+        assert np.array_equal(hist, want_counts) and nres == len(codes)
     assert got_names == names
     assert np.array_equal(np.concatenate(lens), np.diff(offs.astype(np.int64)))
     assert np.array_equal(np.concatenate(got_codes), codes)
