@@ -123,12 +123,17 @@ def run_e2e(torch, codes, offsets, nseq, keep_fasta=False):
         obytes = os.path.getsize(tsv)
         with open(tsv, "rb") as fh:
             nl = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
+        with open(tsv, "rb") as fh:  # the first table rows, for the oracle's check in the cpu_baseline leg
+            head = fh.read(8 << 20).split(b"\n")[:-1]
+        first = next((i for i, l in enumerate(head) if l.startswith(b"SEQid\t")), None)
+        head_rows = head[first + 1:] if first is not None else None
         out = {"value": round(nres / best, 1), "unit": "residues/s", "proteins_per_sec": round(nseq / best, 1),
                "wall_s": runs, "sequences": nseq, "residues": nres, "fasta_bytes": fbytes, "tsv_bytes": obytes,
                "tsv_lines": nl, "fasta_write_s": round(t_write, 3),
                "what": "bin/plaac -i <FASTA> > <TSV>, whole process incl. HIP start-up, best of two runs, 1 GPU"}
         if timing:  # PLAAC_TIMING=1 in the environment: the host's own stage clock of the best run
             out["stages"] = timing
+        out["_head_rows"] = head_rows
         if keep_fasta:
             out["_fasta"] = fa
         return out
@@ -862,6 +867,25 @@ def main():
             finally:
                 if os.path.exists(fa):
                     os.unlink(fa)
+    if e2e is not None and "_head_rows" in e2e:
+        head_rows = e2e.pop("_head_rows")
+        # the table bin/plaac wrote against the oracle's rows pushed through the host formatter (itself held against a
+        # restatement of java.util.Formatter on the CPU): the first rows of the file, byte for byte
+        if cpu is not None and head_rows is not None and not two_pass:
+            from plaac_amd import hostio
+            k_rows = min(len(head_rows), 20000, len(want))
+            exp = []
+            for i in range(len(want)):
+                if len(exp) >= k_rows:
+                    break
+                line = hostio.format_summary_row(want[i], b"s%07d" % i, codes_h[int(off_h[i]):int(off_h[i + 1])])
+                if line:
+                    exp.append(line.encode())
+            ok_rows = [a == b for a, b in zip(head_rows[:k_rows], exp)]
+            e2e["table_rows_checked"] = len(ok_rows)
+            e2e["table_rows_match_oracle"] = bool(ok_rows) and all(ok_rows)
+            if not e2e["table_rows_match_oracle"]:
+                rc = 3
     if cpu is not None and "reference_jar" not in cpu:
         cpu["reference_jar"] = time_reference_jar("", 0) if not os.environ.get("PLAAC_REF_JAR") else "skipped: no e2e leg"
 
