@@ -65,6 +65,25 @@ constexpr int E_JOIN_IDX = sched::E_JOIN; // index of a call's join event in its
 
 } // namespace
 
+// the latency-form chain kernels built a second time under another instruction-scheduling strategy (plaac_kernels_lat.hip)
+namespace plaac_lat {
+void launch_long(dim3 grid, hipStream_t s, const uint64_t *offsets, const uint32_t *neff, const void *order, uint32_t nprot,
+                 const void *tab, const void *packed, const uint32_t *grow, const void *tg_bytes, double *lmarg, double *h0);
+void launch_fwd_pair(dim3 grid, hipStream_t s, const void *order, uint32_t nprot, const void *tab, const void *packed,
+                     const uint32_t *grow, double *lmarg);
+void launch_vit_lat_ext(dim3 grid, hipStream_t s, const uint8_t *codes, const uint64_t *offsets, const uint32_t *neff, const void *order,
+                        uint32_t nprot, const void *tab, const void *packed, const uint32_t *grow, uint32_t *bits, const void *tg_bytes,
+                        double *vend);
+size_t sizeof_sweep_targets();
+size_t sizeof_dev_tables();
+} // namespace plaac_lat
+namespace {
+const bool g_lat_unit = [] { // PLAAC_LAT_UNIT=0: the main unit's copies of those kernels (A/B)
+    const char *e = std::getenv("PLAAC_LAT_UNIT");
+    return !(e && e[0] == '0') && plaac_lat::sizeof_sweep_targets() == sizeof(SweepTargets) && plaac_lat::sizeof_dev_tables() == sizeof(DevTables);
+}();
+} // namespace
+
 // ------------------------------------------------------------------------------------------------
 // C ABI — device half
 // ------------------------------------------------------------------------------------------------
@@ -1005,8 +1024,12 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         }
         case K_LONG: {
             const uint32_t lcnt = (uint32_t)std::min<uint64_t>((uint64_t)F.gl * 64u, nprot);
-            hipLaunchKernelGGL(k_long, dim3(4u * ((lcnt + KA_THREADS - 1) / KA_THREADS)), dim3(KA_THREADS), 0, s, D.d_offsets,
-                               PL.neff, PL.order, lcnt, tab, PL.packed, PL.grow, tg, lmarg, h0);
+            if (g_lat_unit)
+                plaac_lat::launch_long(dim3(4u * ((lcnt + KA_THREADS - 1) / KA_THREADS)), s, D.d_offsets, PL.neff, PL.order, lcnt, tab,
+                                       PL.packed, PL.grow, &tg, lmarg, h0);
+            else
+                hipLaunchKernelGGL(k_long, dim3(4u * ((lcnt + KA_THREADS - 1) / KA_THREADS)), dim3(KA_THREADS), 0, s, D.d_offsets,
+                                   PL.neff, PL.order, lcnt, tab, PL.packed, PL.grow, tg, lmarg, h0);
             break;
         }
         case K_VIT: {
@@ -1032,7 +1055,10 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
     case 3: LAUNCH_VIT(3, LAT, EXT, LIST); break;                                                                  \
     default: LAUNCH_VIT(4, LAT, EXT, LIST); break;                                                                 \
     }
-            if (o.lat && o.ext) LAUNCH_VIT(1, true, true, false);
+            if (o.lat && o.ext && g_lat_unit && !C.tracks)
+                plaac_lat::launch_vit_lat_ext(dim3(abk), s, D.d_codes, D.d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed,
+                                              PL.grow + g0, gbits, &tg, vend);
+            else if (o.lat && o.ext) LAUNCH_VIT(1, true, true, false);
             else if (o.lat) LAUNCH_VIT_NC(true, false, false)
             else if (o.ext && o.list) LAUNCH_VIT(1, false, true, true);
             else if (o.list) LAUNCH_VIT_NC(false, false, true)
@@ -1104,7 +1130,9 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             const uint32_t first = part ? o.a * 64u : seg_first(F.segb, o.run);
             const uint32_t cnt = part ? (uint32_t)(std::min<uint64_t>((uint64_t)o.b * 64u, nprot) - first) : seg_count(F.segb, o.run);
             const dim3 grid((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2));
-            if (o.trk)
+            if (g_lat_unit && !o.trk)
+                plaac_lat::launch_fwd_pair(grid, s, PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat);
+            else if (o.trk)
                 hipLaunchKernelGGL(k_fwd_pair<true>, grid, dim3(KA_THREADS), 0, s, PL.order + first, cnt, tab, PL.packed,
                                    PL.grow + g0, PL.lat, ctx->d_fwd);
             else
