@@ -215,6 +215,16 @@ plaac_status plaac_score_end_text(plaac_ctx *ctx, plaac_row *rows, uint8_t *code
 plaac_status plaac_score_end_text_table_size(plaac_ctx *ctx, int corelength, int ww2, int prev_blank, uint64_t *table_bytes,
                                              int *needs_host, int *last_blank, uint64_t *residues /* nullable: the batch's */);
 plaac_status plaac_score_end_text_table(plaac_ctx *ctx, char *table, uint64_t table_cap, int64_t *counts);
+/* A text batch uploaded and parsed AHEAD of its scoring call by ANOTHER host thread (round 5, late): plaac_text_upload may run
+ * beside the scoring calls of the same context (one upload at a time per context; own stream, own pinned and device buffers),
+ * plaac_score_begin_uploaded takes the batch over (what plaac_score_begin_text does minus the upload and the parse; the batch
+ * object is consumed) and is collected like any text batch (plaac_score_end_text / _end_text_table*). bin/plaac runs an
+ * uploader thread per context: the upload of batch k + 1 beside the download of batch k. */
+typedef struct plaac_text_batch plaac_text_batch;
+plaac_status plaac_text_upload(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
+                               plaac_text_batch **out);
+plaac_status plaac_score_begin_uploaded(plaac_ctx *ctx, plaac_text_batch *batch, int counting);
+void plaac_text_batch_free(plaac_text_batch *batch); /* an uploaded batch that will not be scored */
 /* The COUNTING pass of a two-pass run fed with text (computeaafreq plaac.java:1655-1666 over nextfasta's records): the batch is
  * parsed on the device like a scored one and counted (countaas / isvalidprotein :1698-1739), not scored. Shares a context's
  * two pending slots with the scoring calls; residues (nullable) = the batch's residue count. */

@@ -154,10 +154,10 @@ struct StageTimer {
 struct Busy {
     std::atomic<long long> ns[10] = {};
     std::atomic<long long> cpu_fmt{0};
-    const char *name[10] = {"reader: next batch", "worker: begin (upload, parse kernels, enqueue)", "worker: end (wait, download)",
+    const char *name[10] = {"reader: next batch", "begin: upload + parse kernels (+ enqueue without an uploader thread)", "worker: end (wait, download)",
                            "sink: format a batch (all threads, wall)", "sink: hand parts to the writer (waits for room)",
                            "writer: fwrite", "writer: waiting for text", "sink: waiting for a scored batch",
-                           "sink: format threads, summed over threads"};
+                           "sink: format threads, summed over threads", "worker: begin of an uploaded batch (enqueue)"};
     struct Scope {
         Busy &b;
         int k;
@@ -167,7 +167,7 @@ struct Busy {
     Scope in(int k) { return Scope{*this, k}; }
     void report() {
         if (!g_timer.on) return;
-        for (int k = 0; k < 9; ++k)
+        for (int k = 0; k < 10; ++k)
             if (ns[k]) std::fprintf(stderr, "plaac-timing:   busy %-52s %9.3f ms\n", name[k], ns[k] * 1e-6);
         if (cpu_fmt) std::fprintf(stderr, "plaac-timing:   cpu  %-52s %9.3f ms\n", "sink: format threads, CPU time summed", cpu_fmt * 1e-6);
     }
@@ -407,11 +407,13 @@ struct Batch {
     std::vector<uint64_t> toffs;
     std::vector<uint8_t> tblank;
     std::vector<uint32_t> text_ext; // per record: where its header line and its sequence end (plaac_score_end_text)
+    plaac_text_batch *tb = nullptr; // the batch uploaded and parsed ahead of its scoring call (plaac_text_upload), until that call
     TextBuf table{};                // the batch's rows as text, made on the device (plaac_score_end_text_table)
     bool have_table = false;
     int last_blank = 0;
     uint64_t table_residues = 0;
     ~Batch() {
+        if (tb) plaac_text_batch_free(tb);
         if (ft) plaac_fasta_text_free(ft);
         else if (f && owned) plaac_fasta_free(f);
         else if (f && kept) kept->batch_gone(f);
@@ -794,7 +796,8 @@ template <class Prep, class Work, class Sink, class Fin = NoFinish>
 bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, plaac_fasta_stream *fs, const Stream &sp,
                   std::vector<plaac_fasta *> *replay, std::vector<plaac_fasta *> *keep, uint64_t keep_bytes, Prep &&prep,
                   Work &&work, Sink &&sink, Fin finish = Fin(), const std::function<void()> *drained = nullptr,
-                  bool as_text = false, bool run_ahead = true) {
+                  bool as_text = false, bool run_ahead = true,
+                  const std::function<plaac_status(plaac_ctx *, Batch &)> *upload = nullptr) {
     if (!fs && !replay) {
         if (drained) (*drained)();
         return true; // nothing to read
@@ -873,7 +876,29 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
     const int nctx = plaac_node_size(eng.node);
     ro.set_window((drained && run_ahead) ? (uint64_t)1 << 40 : (uint64_t)2 * nctx + 2);
     std::atomic<int> live_workers{nctx};
-    std::vector<std::thread> workers;
+    std::vector<std::thread> workers, uploaders;
+    // `upload` (text batches): an uploader thread per context takes the batches off the reader's queue, uploads and parses them
+    // (plaac_text_upload) and hands them to the context's worker - the upload of batch k + 1 beside the download of batch k
+    std::vector<std::unique_ptr<Queue>> uq;
+    for (int k = 0; upload && k < nctx; ++k) uq.emplace_back(new Queue(1));
+    for (int k = 0; upload && k < nctx; ++k)
+        uploaders.emplace_back([&, k] {
+            plaac_ctx *ctx = plaac_node_ctx(eng.node, k);
+            for (;;) {
+                BatchPtr b = q.get();
+                if (!b) break;
+                if (!failed) {
+                    auto busy = g_busy.in(1);
+                    b->st = (*upload)(ctx, *b);
+                    if (b->st != PLAAC_OK) {
+                        b->err = plaac_last_error(ctx);
+                        failed = true;
+                    }
+                }
+                uq[k]->put(std::move(b));
+            }
+            uq[k]->close();
+        });
     for (int k = 0; k < nctx; ++k)
         workers.emplace_back([&, k] {
             plaac_ctx *ctx = plaac_node_ctx(eng.node, k);
@@ -891,15 +916,15 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                 ro.put(std::move(pend));
             };
             for (;;) {
-                BatchPtr b = q.get();
+                BatchPtr b = upload ? uq[k]->get() : q.get();
                 if (b) {
                     // A worker never waits for room while it holds a begun batch: that batch may be the very one the printer
                     // is waiting for (a slow worker - the first call of a context measures its streams - sits on the oldest
                     // batch while the others run the window full of finished ones).
                     if (pend && !ro.has_room(b->seq)) collect_pending();
                     ro.wait_room(b->seq);
-                    if (!failed) {
-                        auto busy = g_busy.in(1);
+                    if (!failed && b->st == PLAAC_OK) {
+                        auto busy = g_busy.in(upload ? 9 : 1);
                         b->st = work(ctx, *b);
                         if (b->st != PLAAC_OK) {
                             b->err = plaac_last_error(ctx);
@@ -934,6 +959,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
         }
     }
     reader.join();
+    for (auto &u : uploaders) u.join();
     for (auto &w : workers) w.join();
     if (fs) plaac_fasta_close(fs);
     if (keep && (keep_overflow || !ok || failed)) ks.release_rest(*keep);
@@ -1231,8 +1257,12 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
         single->held.insert(single->block_at, block);
         writer.release(single->held);
     };
+    const std::function<plaac_status(plaac_ctx *, Batch &)> upload = [&](plaac_ctx *ctx, Batch &b) {
+        return plaac_text_upload(ctx, b.ft->text, b.ft->len, b.ft->starts, b.ft->nrec, &b.tb);
+    };
     auto run = [&](auto &&...a) {
-        return pipelined ? run_pipeline(std::forward<decltype(a)>(a)..., collect, single ? &drained : nullptr, as_text, !placed)
+        return pipelined ? run_pipeline(std::forward<decltype(a)>(a)..., collect, single ? &drained : nullptr, as_text, !placed,
+                                        (as_text && env_flag("PLAAC_UPLOAD_THREAD", true)) ? &upload : nullptr)
                          : run_pipeline(std::forward<decltype(a)>(a)...);
     };
     const bool ok = run(
@@ -1240,6 +1270,11 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
         [&](plaac_ctx *ctx, Batch &b) {
             if (b.ft) {
                 if (!device_format) b.rows.resize(b.ft->nrec);
+                if (b.tb) { // (uploaded and parsed by the context's uploader thread already)
+                    plaac_text_batch *t = b.tb;
+                    b.tb = nullptr;
+                    return plaac_score_begin_uploaded(ctx, t, counting ? 1 : 0);
+                }
                 return plaac_score_begin_text(ctx, b.ft->text, b.ft->len, b.ft->starts, b.ft->nrec, counting ? 1 : 0);
             }
             b.rows.resize(b.f->nrec);

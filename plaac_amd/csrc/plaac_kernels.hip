@@ -37,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -87,6 +88,22 @@ const bool g_lat_unit = [] { // PLAAC_LAT_UNIT=0: the main unit's copies of thos
 // ------------------------------------------------------------------------------------------------
 // C ABI — device half
 // ------------------------------------------------------------------------------------------------
+// a text batch uploaded and parsed ahead of its scoring call (plaac_text_upload): the device buffers a pending slot would hold
+struct plaac_text_batch {
+    plaac_ctx *ctx = nullptr;
+    char *d_text = nullptr;
+    uint64_t *d_starts = nullptr;
+    uint32_t *d_len = nullptr;
+    uint8_t *d_blank = nullptr;
+    FaExtent *d_ext = nullptr;
+    unsigned long long *d_total = nullptr, *d_bsum = nullptr;
+    uint8_t *d_codes = nullptr;
+    uint64_t *d_offsets = nullptr;
+    size_t cap_text = 0, cap_starts = 0, cap_len = 0, cap_blank = 0, cap_ext = 0, cap_bsum = 0, cap_codes = 0, cap_offs = 0;
+    uint32_t nrec = 0;
+    uint64_t total = 0;
+};
+
 struct plaac_ctx {
     int device = 0;
     int num_cus = 256;
@@ -140,6 +157,13 @@ struct plaac_ctx {
     static constexpr size_t STAGE_BYTES = 16u << 20;
     uint8_t *h_stage[2] = {nullptr, nullptr};
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    // plaac_text_upload (an uploader thread of the host beside the thread that scores): its own stream, pinned buffers and
+    // recycled sets of device buffers
+    hipStream_t up = nullptr;
+    uint8_t *h_stage_up[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev_up[2] = {nullptr, nullptr};
+    std::mutex up_mu;
+    std::vector<plaac_text_batch *> up_pool;
     uint32_t *d_flag = nullptr;
     KbDivTab *d_divtab = nullptr; // reciprocal tables of the window kernel
     uint32_t *d_kbcnt = nullptr;   // four sets of list counters, used in turn (see CallData::counters)
@@ -815,6 +839,20 @@ void plaac_ctx_destroy(plaac_ctx *ctx) {
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     for (auto &sl : ctx->slot)
         if (sl.hist_ev) (void)hipEventDestroy(sl.hist_ev);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->h_stage_up[i]) (void)hipHostFree(ctx->h_stage_up[i]);
+        if (ctx->stage_ev_up[i]) (void)hipEventDestroy(ctx->stage_ev_up[i]);
+    }
+    for (plaac_text_batch *tb : ctx->up_pool) {
+        for (void *b : {(void *)tb->d_text, (void *)tb->d_starts, (void *)tb->d_len, (void *)tb->d_blank, (void *)tb->d_ext, (void *)tb->d_total,
+                        (void *)tb->d_bsum, (void *)tb->d_codes, (void *)tb->d_offsets})
+            if (b) (void)hipFree(b);
+        delete tb;
+    }
+    if (ctx->up) {
+        (void)hipStreamSynchronize(ctx->up);
+        (void)hipStreamDestroy(ctx->up);
+    }
     for (auto &sl : ctx->slot)
         for (void *b : {(void *)sl.d_codes, (void *)sl.d_offsets, (void *)sl.d_rows, (void *)sl.d_counts, (void *)sl.d_text,
                         (void *)sl.d_starts, (void *)sl.d_len, (void *)sl.d_blank, (void *)sl.d_total, (void *)sl.d_ext,
@@ -1750,25 +1788,36 @@ static plaac_status ensure_stage(plaac_ctx *ctx) {
 
 // host (pageable) -> device through two pinned buffers: the copy into pinned memory of chunk k+1 overlaps the
 // DMA of chunk k. Small copies go directly.
+static plaac_status copy_in_through(plaac_ctx *ctx, uint8_t *(&hs)[2], hipEvent_t (&evs)[2], void *dst, const void *src, size_t bytes,
+                                    hipStream_t st) {
+    if (bytes < (1u << 20)) {
+        PL_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        PL_HIP(ctx, hipStreamSynchronize(st)); // (pageable source: the caller may let go of it)
+        return PLAAC_OK;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (!hs[i]) PL_HIP(ctx, hipHostMalloc((void **)&hs[i], plaac_ctx::STAGE_BYTES, hipHostMallocDefault));
+        if (!evs[i]) PL_HIP(ctx, hipEventCreateWithFlags(&evs[i], hipEventDisableTiming));
+    }
+    size_t done = 0;
+    for (int k = 0; done < bytes; ++k) {
+        const int b = k & 1;
+        const size_t n = std::min(plaac_ctx::STAGE_BYTES, bytes - done);
+        if (k >= 2) PL_HIP(ctx, hipEventSynchronize(evs[b])); // DMA out of this buffer has finished
+        parallel_memcpy(hs[b], (const char *)src + done, n);
+        PL_HIP(ctx, hipMemcpyAsync((char *)dst + done, hs[b], n, hipMemcpyHostToDevice, st));
+        PL_HIP(ctx, hipEventRecord(evs[b], st));
+        done += n;
+    }
+    PL_HIP(ctx, hipStreamSynchronize(st)); // the staging buffers are free again when this returns
+    return PLAAC_OK;
+}
 static plaac_status copy_in(plaac_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st) {
     if (bytes < (1u << 20)) {
         PL_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
         return PLAAC_OK;
     }
-    plaac_status rc = ensure_stage(ctx);
-    if (rc != PLAAC_OK) return rc;
-    size_t done = 0;
-    for (int k = 0; done < bytes; ++k) {
-        const int b = k & 1;
-        const size_t n = std::min(plaac_ctx::STAGE_BYTES, bytes - done);
-        if (k >= 2) PL_HIP(ctx, hipEventSynchronize(ctx->stage_ev[b])); // DMA out of this buffer has finished
-        parallel_memcpy(ctx->h_stage[b], (const char *)src + done, n);
-        PL_HIP(ctx, hipMemcpyAsync((char *)dst + done, ctx->h_stage[b], n, hipMemcpyHostToDevice, st));
-        PL_HIP(ctx, hipEventRecord(ctx->stage_ev[b], st));
-        done += n;
-    }
-    PL_HIP(ctx, hipStreamSynchronize(st)); // the staging buffers are free again when this returns
-    return PLAAC_OK;
+    return copy_in_through(ctx, ctx->h_stage, ctx->stage_ev, dst, src, bytes, st);
 }
 
 // device -> host (pageable), same scheme; returns with the data in place
@@ -2037,6 +2086,130 @@ plaac_status plaac_score_begin_text(plaac_ctx *ctx, const char *text, uint64_t t
                                     int counting) {
     return begin_text(ctx, text, text_len, starts, nrec, counting, true);
 }
+// ---- a text batch uploaded and parsed AHEAD of its scoring call, by another host thread (round 5, late) ----
+// The thread that scores (plaac_score_begin_* / _end_*) spends 4.5 ms of a 262,144-record batch's 7.5 ms inside the upload;
+// with plaac_text_upload an uploader thread of the host does that part for batch k + 1 while the scoring thread collects
+// batch k (H2D beside D2H: the link is full duplex). One upload at a time per context; it touches nothing the scoring calls
+// use (its own stream, pinned buffers and device buffers). plaac_score_begin_uploaded takes the batch over: the pending slot
+// and the batch swap their device buffers.
+static const FastaLut &fasta_lut() {
+    static const FastaLut lut = [] {
+        FastaLut l;
+        char all[256];
+        for (int i = 0; i < 256; ++i) all[i] = (char)i;
+        plaac_encode(all, 256, l.t);
+        return l;
+    }();
+    return lut;
+}
+plaac_status plaac_text_upload(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
+                               plaac_text_batch **out) {
+    if (!ctx || !out) return PLAAC_ERR_ARG;
+    *out = nullptr;
+    if (nrec && (!text || !starts)) return PLAAC_ERR_ARG;
+    for (uint32_t i = 0; i < nrec; ++i)
+        if (starts[i + 1] < starts[i] || starts[i + 1] > text_len || starts[i + 1] - starts[i] >= 0x7fffffffull) return PLAAC_ERR_ARG;
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    plaac_text_batch *tb = nullptr;
+    {
+        std::lock_guard<std::mutex> l(ctx->up_mu);
+        if (!ctx->up) PL_HIP(ctx, hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
+        if (!ctx->up_pool.empty()) {
+            tb = ctx->up_pool.back();
+            ctx->up_pool.pop_back();
+        }
+    }
+    if (!tb) tb = new (std::nothrow) plaac_text_batch();
+    if (!tb) return PLAAC_ERR_NOMEM;
+    tb->ctx = ctx;
+    tb->nrec = nrec;
+    tb->total = 0;
+    auto give_back = [&](plaac_status rc) {
+        std::lock_guard<std::mutex> l(ctx->up_mu);
+        ctx->up_pool.push_back(tb);
+        return rc;
+    };
+    if (nrec) {
+        plaac_status rc;
+        size_t cap_tot = tb->d_total ? 1 : 0;
+        const unsigned nb = (nrec + FA_RECS - 1u) / FA_RECS, ns = (nrec + FA_SCAN - 1u) / FA_SCAN;
+        if ((rc = grow(ctx, tb->d_text, tb->cap_text, (size_t)text_len + 16)) != PLAAC_OK) return give_back(rc);
+        if ((rc = grow(ctx, tb->d_starts, tb->cap_starts, (size_t)nrec + 1)) != PLAAC_OK) return give_back(rc);
+        if ((rc = grow(ctx, tb->d_len, tb->cap_len, (size_t)nrec)) != PLAAC_OK) return give_back(rc);
+        if ((rc = grow(ctx, tb->d_blank, tb->cap_blank, (size_t)nrec)) != PLAAC_OK) return give_back(rc);
+        if ((rc = grow(ctx, tb->d_total, cap_tot, (size_t)1)) != PLAAC_OK) return give_back(rc);
+        if ((rc = grow(ctx, tb->d_codes, tb->cap_codes, (size_t)text_len + 64)) != PLAAC_OK) return give_back(rc);
+        if ((rc = grow(ctx, tb->d_offsets, tb->cap_offs, (size_t)nrec + 1)) != PLAAC_OK) return give_back(rc);
+        if ((rc = grow(ctx, tb->d_ext, tb->cap_ext, (size_t)nrec)) != PLAAC_OK) return give_back(rc);
+        if ((rc = grow(ctx, tb->d_bsum, tb->cap_bsum, (size_t)ns)) != PLAAC_OK) return give_back(rc);
+        if ((rc = copy_in_through(ctx, ctx->h_stage_up, ctx->stage_ev_up, tb->d_text, text, (size_t)text_len, ctx->up)) != PLAAC_OK) return give_back(rc);
+        if ((rc = copy_in_through(ctx, ctx->h_stage_up, ctx->stage_ev_up, tb->d_starts, starts, sizeof(uint64_t) * ((size_t)nrec + 1), ctx->up)) != PLAAC_OK)
+            return give_back(rc);
+        hipLaunchKernelGGL(k_fasta_lengths, dim3(nb), dim3(FA_BLOCK), 0, ctx->up, tb->d_text, tb->d_starts, nrec, tb->d_len, tb->d_blank, tb->d_ext);
+        hipLaunchKernelGGL(k_fasta_block_sums, dim3(ns), dim3(FA_SCAN), 0, ctx->up, tb->d_len, nrec, tb->d_bsum);
+        hipLaunchKernelGGL(k_fasta_offsets, dim3(ns), dim3(FA_SCAN), 0, ctx->up, tb->d_len, nrec, tb->d_bsum, tb->d_offsets, tb->d_total);
+        hipLaunchKernelGGL(k_fasta_encode, dim3(nb), dim3(FA_BLOCK), 0, ctx->up, tb->d_text, tb->d_starts, nrec, tb->d_ext, tb->d_offsets, fasta_lut(),
+                           tb->d_codes);
+        unsigned long long total = 0;
+        hipError_t e = hipMemcpyAsync(&total, tb->d_total, sizeof total, hipMemcpyDeviceToHost, ctx->up);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->up);
+        if (e != hipSuccess) return give_back(PLAAC_ERR_DEVICE);
+        tb->total = total;
+    }
+    *out = tb;
+    return PLAAC_OK;
+}
+
+void plaac_text_batch_free(plaac_text_batch *tb) { // (an uploaded batch that will not be scored: its buffers go back to the context)
+    if (!tb || !tb->ctx) return;
+    std::lock_guard<std::mutex> l(tb->ctx->up_mu);
+    tb->ctx->up_pool.push_back(tb);
+}
+
+plaac_status plaac_score_begin_uploaded(plaac_ctx *ctx, plaac_text_batch *tb, int counting) {
+    if (!ctx || !tb || tb->ctx != ctx) return ctx ? fail(ctx, PLAAC_ERR_ARG, "plaac_score_begin_uploaded: not a batch of this context") : PLAAC_ERR_ARG;
+    if (ctx->slots_busy >= 2) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_begin_uploaded: two batches are pending (call plaac_score_end_text)");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->xfer) PL_HIP(ctx, hipStreamCreateWithFlags(&ctx->xfer, hipStreamNonBlocking));
+    plaac_ctx::Slot &S = ctx->slot[ctx->slot_next];
+    // the slot is free (its last batch has been collected): its buffers and the uploaded batch's change places
+    std::swap(S.d_text, tb->d_text), std::swap(S.cap_text, tb->cap_text);
+    std::swap(S.d_starts, tb->d_starts), std::swap(S.cap_starts, tb->cap_starts);
+    std::swap(S.d_len, tb->d_len), std::swap(S.cap_len, tb->cap_len);
+    std::swap(S.d_blank, tb->d_blank), std::swap(S.cap_blank, tb->cap_blank);
+    std::swap(S.d_ext, tb->d_ext), std::swap(S.cap_ext, tb->cap_ext);
+    std::swap(S.d_bsum, tb->d_bsum), std::swap(S.cap_bsum, tb->cap_bsum);
+    std::swap(S.d_total, tb->d_total);
+    std::swap(S.d_codes, tb->d_codes), std::swap(S.cap_codes, tb->cap_codes);
+    std::swap(S.d_offsets, tb->d_offsets), std::swap(S.cap_offs, tb->cap_offs);
+    const uint32_t nrec = tb->nrec;
+    const uint64_t total = tb->total;
+    plaac_text_batch_free(tb); // (with the slot's old buffers, for the next upload)
+    S.nprot = nrec;
+    S.call_no = ~0ull;
+    S.counted = counting != 0;
+    S.from_text = true;
+    S.table_sized = false;
+    S.hist_only = false;
+    S.nres = total;
+    if (nrec) {
+        plaac_status rc;
+        if ((rc = grow(ctx, S.d_rows, S.cap_rows, (size_t)nrec)) != PLAAC_OK) return rc;
+        if (counting) {
+            if (!S.d_counts) PL_HIP(ctx, hipMalloc(&S.d_counts, sizeof(unsigned long long) * NAA));
+            if ((rc = plaac_histogram_device(ctx, S.d_codes, S.d_offsets, nrec, (int64_t *)S.d_counts, ctx->stream)) != PLAAC_OK) return rc;
+        }
+        const uint64_t call_no = ctx->ncalls;
+        rc = plaac_score_device(ctx, S.d_codes, S.d_offsets, nrec, total, S.d_rows, nullptr, ctx->stream);
+        if (rc != PLAAC_OK) return rc;
+        S.call_no = call_no;
+    }
+    S.busy = true;
+    ctx->slot_next ^= 1u;
+    ++ctx->slots_busy;
+    return PLAAC_OK;
+}
+
 // The counting pass of a two-pass run fed with text (round 5, late): parsed on the device like a scored batch, counted, not
 // scored. Shares the two pending slots with the scoring calls; collected by plaac_histogram_end_text only.
 plaac_status plaac_histogram_begin_text(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec) {

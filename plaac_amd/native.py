@@ -76,7 +76,7 @@ EXPORTS = (
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
-    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_score_begin_text", "plaac_score_end_text", "plaac_score_end_text_table_size", "plaac_score_end_text_table", "plaac_histogram_begin_text", "plaac_histogram_end_text", "plaac_debug_schedule",
+    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_score_begin_text", "plaac_score_end_text", "plaac_score_end_text_table_size", "plaac_score_end_text_table", "plaac_histogram_begin_text", "plaac_histogram_end_text", "plaac_text_upload", "plaac_score_begin_uploaded", "plaac_text_batch_free", "plaac_debug_schedule",
 )
 
 _lib = None
@@ -130,6 +130,10 @@ def load():
     L.plaac_score_end_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.plaac_score_end_text_table_size.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
     L.plaac_score_end_text_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.plaac_text_upload.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.plaac_score_begin_uploaded.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.plaac_text_batch_free.argtypes = [C.c_void_p]
+    L.plaac_text_batch_free.restype = None
     L.plaac_histogram_begin_text.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32]
     L.plaac_histogram_end_text.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.plaac_score_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
@@ -341,6 +345,16 @@ class Context:
                                                  counts.ctypes.data if counting else None))
         out = (rows, codes[:int(offsets[-1])] if want_codes else ext[:nrec], offsets, blank[:nrec])
         return out + (counts,) if counting else out
+
+    def text_upload(self, text, starts):
+        """plaac_text_upload: the batch uploaded and parsed ahead of its scoring call (may run on another thread than the scoring calls)"""
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        tb = C.c_void_p()
+        self._check(self._L.plaac_text_upload(self._h, text, len(text), starts.ctypes.data, len(starts) - 1, C.byref(tb)))
+        return tb
+
+    def score_begin_uploaded(self, tb, counting=True):
+        self._check(self._L.plaac_score_begin_uploaded(self._h, tb, 1 if counting else 0))
 
     def histogram_text(self, text, starts):
         """plaac_histogram_begin_text + _end_text: the residue counts of a text batch (parsed on the device) and its residue count"""

@@ -1347,3 +1347,66 @@ def test_text_batches_and_code_batches_share_the_two_slots(native, oracle, tmp_p
                     end_table(k)
                 else:
                     assert_rows_equal(ctx.score_end(len(coded[k][1]) - 1), coded[k][2], "encoded batch %d at the end" % k)
+
+
+def test_text_batches_uploaded_ahead_by_another_thread(native, oracle, tmp_path):
+    """plaac_text_upload on a second host thread beside the scoring calls of the same context (bin/plaac's uploader thread):
+    batch k + 1 is uploaded and parsed while batch k is scored and collected; plaac_score_begin_uploaded takes it over. The
+    tables and counts of every batch as if it had gone through plaac_score_begin_text."""
+    import ctypes as C
+    import threading
+    from plaac_amd import hostio, synth
+    P = native.make_params()
+    batches = []
+    for k in range(6):
+        codes, offs = synth.make_batch(4, nprot=1500 + 700 * k, seed=70 + k, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+        keep = [i for i in range(len(offs) - 1) if offs[i + 1] > offs[i]]
+        letters = np.frombuffer(b"XACDEFGHIKLMNPQRSTVWY*", dtype=np.uint8)[codes]
+        p = tmp_path / ("u%d.fa" % k)
+        p.write_bytes(b"".join(b">u%d_%d\n" % (k, i) + letters[int(offs[i]):int(offs[i + 1])].tobytes() + b"\n" for i in keep))
+        text, starts, trim = next(iter(hostio.stream_fasta_text(p, 1 << 20, 1 << 30)))
+        names, hc, ho = hostio.read_fasta(p)
+        rows = oracle.score_batch(oracle.build_params(), hc, ho, nthreads=8)
+        table = b"".join(hostio.format_summary_row(rows[i], names[i], hc[int(ho[i]):int(ho[i + 1])]).encode() + b"\n" for i in range(len(names)))
+        batches.append((text, np.ascontiguousarray(starts, dtype=np.uint64), table, oracle.histogram(hc, ho)))
+    with native.Context(P) as ctx:
+        L, h = ctx._L, ctx._h
+        handed, errors = [None] * len(batches), []
+        ready = [threading.Event() for _ in batches]
+
+        def uploader():
+            try:
+                for k, (text, starts, _, _) in enumerate(batches):
+                    handed[k] = ctx.text_upload(text, starts)
+                    ready[k].set()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+                for ev in ready:
+                    ev.set()
+
+        th = threading.Thread(target=uploader)
+        th.start()
+        pending = []
+
+        def collect(k):
+            size, needs, lastb = C.c_uint64(), C.c_int(), C.c_int()
+            ctx._check(L.plaac_score_end_text_table_size(h, 60, 41, 1, C.byref(size), C.byref(needs), C.byref(lastb), None))
+            assert not needs.value
+            buf = C.create_string_buffer(max(int(size.value), 1))
+            counts = np.zeros(22, dtype=np.int64)
+            ctx._check(L.plaac_score_end_text_table(h, buf, size.value, counts.ctypes.data))
+            assert buf.raw[:size.value] == batches[k][2] and np.array_equal(counts, batches[k][3]), "uploaded batch %d" % k
+
+        for k in range(len(batches)):
+            ready[k].wait(60)
+            assert not errors, errors
+            ctx.score_begin_uploaded(handed[k], counting=True)
+            pending.append(k)
+            if len(pending) == 2:
+                collect(pending.pop(0))
+        while pending:
+            collect(pending.pop(0))
+        th.join()
+        # an uploaded batch that is not scored goes back to the context
+        tb = ctx.text_upload(batches[0][0], batches[0][1])
+        L.plaac_text_batch_free(tb)
