@@ -1436,6 +1436,10 @@ bool plot_some(Engine &eng, const plaac_params &P, const Options &o, const Strea
     plaac_fasta_stream *fs = nullptr;
     if (!replay && !open_stream(o.input, &fs)) return false;
     put(std::string(plaac_tracks_header()) + "\n");
+    std::fflush(stdout);
+    const unsigned nt_max = plaac_host_threads();
+    std::unique_ptr<ThreadTeam> team;
+    Writer writer; // (from here on the table goes through the writer thread)
     int genecount = 1; // advanced by the reader thread only (records are selected in file order, :617)
     const bool ok = run_pipeline(
         eng, P, o.input, fs, sp, replay, nullptr, 0,
@@ -1482,17 +1486,59 @@ bool plot_some(Engine &eng, const plaac_params &P, const Options &o, const Strea
             return plaac_score(ctx, b.pcodes.data(), b.poffs.data(), (uint32_t)b.pick.size(), b.rows.data(), &b.tr);
         },
         [&](Batch &b) {
-            std::vector<char> buf;
-            for (size_t k = 0; k < b.pick.size(); ++k) {
-                const uint32_t n = (uint32_t)b.rows[k].prot_len;
-                buf.resize(plaac_track_rows_bound(n, b.ids[k].size(), b.names[k].size()));
-                const long len = plaac_format_track_rows(&b.tr, b.poffs[k], b.pcodes.data() + b.poffs[k], n,
-                                                         b.ids[k].c_str(), b.names[k].c_str(), buf.data(), buf.size());
-                if (len < 0) return false;
-                std::fwrite(buf.data(), 1, (size_t)len, stdout);
+            // The proteins of a batch formatted side by side (round 5, late: one thread formatted 112 bytes per residue at 6 M
+            // residues/s - 4.7 s of a 5.1 s run over 100,000 sequences): contiguous ranges of proteins with about the same
+            // number of residues per thread, each into a buffer of its own; the writer thread prints them in file order.
+            const size_t K = b.pick.size();
+            if (K == 0) return true;
+            const uint64_t total = b.poffs[K];
+            const unsigned nt = total < 65536 ? 1u : nt_max;
+            std::vector<size_t> cut(nt + 1, K);
+            cut[0] = 0;
+            for (unsigned t = 1; t < nt; ++t) // first protein whose offset reaches the t-th share of the residues
+                cut[t] = (size_t)(std::lower_bound(b.poffs.begin(), b.poffs.begin() + K, total * t / nt) - b.poffs.begin());
+            std::vector<TextBuf> part(nt);
+            std::vector<int> bad(nt, 0);
+            auto fmt = [&](unsigned t) {
+                // (a line is the two labels + ~110 bytes of numbers; plaac_track_rows_bound - 400 per residue - is what a line can
+                //  be at most: the buffer starts at the usual size and grows to the bound only if a protein asks for it)
+                size_t need = 4096;
+                for (size_t k = cut[t]; k < cut[t + 1]; ++k)
+                    need += (size_t)b.rows[k].prot_len * (b.ids[k].size() + b.names[k].size() + 130) + 64;
+                part[t] = writer.buffer(need);
+                TextBuf &out = part[t];
+                for (size_t k = cut[t]; k < cut[t + 1]; ++k) {
+                    const uint32_t n = (uint32_t)b.rows[k].prot_len;
+                    long len = plaac_format_track_rows(&b.tr, b.poffs[k], b.pcodes.data() + b.poffs[k], n, b.ids[k].c_str(),
+                                                       b.names[k].c_str(), out.p + out.n, out.cap - out.n);
+                    if (len < 0) {
+                        out.grow(out.n + plaac_track_rows_bound(n, b.ids[k].size(), b.names[k].size()));
+                        len = plaac_format_track_rows(&b.tr, b.poffs[k], b.pcodes.data() + b.poffs[k], n, b.ids[k].c_str(),
+                                                      b.names[k].c_str(), out.p + out.n, out.cap - out.n);
+                    }
+                    if (len < 0) {
+                        bad[t] = 1;
+                        return;
+                    }
+                    out.n += (size_t)len;
+                }
+            };
+            if (nt == 1) {
+                fmt(0);
+            } else {
+                if (!team) team.reset(new ThreadTeam(nt));
+                const std::function<void(unsigned)> job = fmt;
+                team->run(job);
             }
+            for (unsigned t = 0; t < nt; ++t)
+                if (bad[t]) return false;
+            for (unsigned t = 0; t < nt; ++t) writer.write(part[t]);
             return true;
         });
+    if (!writer.finish()) {
+        std::fprintf(stderr, "plaac: writing the tracks to stdout failed (disk full / closed pipe?): output is incomplete\n");
+        return false;
+    }
     if (std::fflush(stdout) != 0 || std::ferror(stdout)) {
         std::fprintf(stderr, "plaac: writing the tracks to stdout failed (disk full / closed pipe?): output is incomplete\n");
         return false;
