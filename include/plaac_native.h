@@ -215,6 +215,16 @@ plaac_status plaac_score_end_text(plaac_ctx *ctx, plaac_row *rows, uint8_t *code
 plaac_status plaac_score_end_text_table_size(plaac_ctx *ctx, int corelength, int ww2, int prev_blank, uint64_t *table_bytes,
                                              int *needs_host, int *last_blank, uint64_t *residues /* nullable: the batch's */);
 plaac_status plaac_score_end_text_table(plaac_ctx *ctx, char *table, uint64_t table_cap, int64_t *counts);
+/* plotsomefastas' PER-RESIDUE table (plaac.java:587-649; the lines of :635-645) for a batch of selected records, made on the
+ * device (round 5, late): scored in track mode like plaac_score with tracks, but the twelve arrays stay on the device and the
+ * table's text comes back - for record k the residues 1 .. prot_len, each "label_k \t AANUM \t AA \t VIT \t MAP \t" + the eight
+ * window tracks with the decimals of :638 + the two posteriors, then the closing line of 56 '#'. labels: for record k the
+ * bytes of "ORDER \t SEQid" at label_off[k] .. label_off[k+1]. rows (nullable): the batch's summary rows as well. *table is
+ * malloc'ed (plaac_table_free) - or NULL with *needs_host != 0 when a value needs the host's formatter (>= 1e9, an infinity):
+ * then plaac_score with tracks and plaac_format_track_rows as before. No batch may be pending on the context. */
+plaac_status plaac_score_tracks_table(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot, const char *labels,
+                                      const uint64_t *label_off, plaac_row *rows, char **table, uint64_t *table_len, int *needs_host);
+void plaac_table_free(char *table);
 /* A text batch uploaded and parsed AHEAD of its scoring call by ANOTHER host thread (round 5, late): plaac_text_upload may run
  * beside the scoring calls of the same context (one upload at a time per context; own stream, own pinned and device buffers),
  * plaac_score_begin_uploaded takes the batch over (what plaac_score_begin_text does minus the upload and the parse; the batch

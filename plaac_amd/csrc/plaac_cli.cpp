@@ -1440,6 +1440,7 @@ bool plot_some(Engine &eng, const plaac_params &P, const Options &o, const Strea
     const unsigned nt_max = plaac_host_threads();
     std::unique_ptr<ThreadTeam> team;
     Writer writer; // (from here on the table goes through the writer thread)
+    const bool device_table = env_flag("PLAAC_DEVICE_FORMAT", true);
     int genecount = 1; // advanced by the reader thread only (records are selected in file order, :617)
     const bool ok = run_pipeline(
         eng, P, o.input, fs, sp, replay, nullptr, 0,
@@ -1478,6 +1479,29 @@ bool plot_some(Engine &eng, const plaac_params &P, const Options &o, const Strea
             if (b.pick.empty()) return PLAAC_OK;
             const uint64_t total = b.poffs.back();
             b.rows.resize(b.pick.size());
+            if (device_table && total < 0xfffffff0ull) {
+                // the batch's lines from the device (plaac_score_tracks_table): the twelve track arrays never cross PCIe, the
+                // text does; a batch with a value the device will not vouch for takes the old way below
+                std::string labels;
+                std::vector<uint64_t> loff(b.pick.size() + 1, 0);
+                for (size_t k = 0; k < b.pick.size(); ++k) {
+                    labels += b.ids[k];
+                    labels += '\t';
+                    labels += b.names[k];
+                    loff[k + 1] = labels.size();
+                }
+                char *table = nullptr;
+                uint64_t len = 0;
+                int needs_host = 0;
+                const plaac_status st = plaac_score_tracks_table(ctx, b.pcodes.data(), b.poffs.data(), (uint32_t)b.pick.size(), labels.data(),
+                                                                 loff.data(), b.rows.data(), &table, &len, &needs_host);
+                if (st != PLAAC_OK) return st;
+                if (!needs_host) {
+                    b.table = TextBuf{table, (size_t)len, (size_t)len};
+                    b.have_table = true;
+                    return PLAAC_OK;
+                }
+            }
             b.t8.resize(2 * total + 2);
             b.t64.resize(10 * total + 10);
             double *d = b.t64.data();
@@ -1491,6 +1515,11 @@ bool plot_some(Engine &eng, const plaac_params &P, const Options &o, const Strea
             // number of residues per thread, each into a buffer of its own; the writer thread prints them in file order.
             const size_t K = b.pick.size();
             if (K == 0) return true;
+            if (b.have_table) { // (formatted on the device)
+                writer.write(b.table);
+                b.table = TextBuf{};
+                return true;
+            }
             const uint64_t total = b.poffs[K];
             const unsigned nt = total < 65536 ? 1u : nt_max;
             std::vector<size_t> cut(nt + 1, K);

@@ -26,6 +26,7 @@
 //   kernels_misc.hip.inc            k_hist (countaas / isvalidprotein :1698-1739), k_validate
 // Below them: the device half of the C ABI (contexts, streams, the scheduling of a scoring call).
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1901,6 +1902,39 @@ plaac_status plaac_histogram(plaac_ctx *ctx, const uint8_t *codes, const uint64_
     return PLAAC_OK;
 }
 
+// the context's device track arrays, sized for `total` residues; trimmed stops' entries made deterministic (0 / NaN)
+static plaac_status device_tracks(plaac_ctx *ctx, uint64_t total, plaac_tracks &dt) {
+    const size_t need = (size_t)total + 8;
+    if (need > ctx->cap_trk || !ctx->d_trk8) {
+        if (ctx->d_trk8) PL_HIP(ctx, hipFree(ctx->d_trk8));
+        if (ctx->d_trk64) PL_HIP(ctx, hipFree(ctx->d_trk64));
+        ctx->d_trk8 = nullptr;
+        ctx->d_trk64 = nullptr;
+        ctx->cap_trk = 0;
+        PL_HIP(ctx, hipMalloc((void **)&ctx->d_trk8, 2 * need));
+        PL_HIP(ctx, hipMalloc((void **)&ctx->d_trk64, 10 * need * sizeof(double)));
+        ctx->cap_trk = need;
+    }
+    const size_t s = ctx->cap_trk;
+    dt.vit = ctx->d_trk8;
+    dt.map = ctx->d_trk8 + s;
+    double *b = ctx->d_trk64;
+    dt.charge = b;
+    dt.hydro = b + s;
+    dt.fi = b + 2 * s;
+    dt.plaacllr = b + 3 * s;
+    dt.papa = b + 4 * s;
+    dt.fix2 = b + 5 * s;
+    dt.plaacllrx2 = b + 6 * s;
+    dt.papax2 = b + 7 * s;
+    dt.post0 = b + 8 * s;
+    dt.post1 = b + 9 * s;
+    // entries of trimmed stops are unspecified: make them deterministic (0 / NaN)
+    PL_HIP(ctx, hipMemsetAsync(ctx->d_trk8, 0, 2 * s, ctx->stream));
+    PL_HIP(ctx, hipMemsetAsync(ctx->d_trk64, 0xff, 10 * s * sizeof(double), ctx->stream));
+    return PLAAC_OK;
+}
+
 // score device-resident codes/offsets and bring rows (+ tracks) back to host buffers
 static plaac_status score_resident_to_host(plaac_ctx *ctx, const uint8_t *d_codes, const uint64_t *d_offsets,
                                            uint32_t nprot, uint64_t total, plaac_row *rows,
@@ -1914,34 +1948,7 @@ static plaac_status score_resident_to_host(plaac_ctx *ctx, const uint8_t *d_code
         for (double *q : hd)
             if (!q) return fail(ctx, PLAAC_ERR_ARG, "tracks struct has a null array");
         if (!tracks->vit || !tracks->map) return fail(ctx, PLAAC_ERR_ARG, "tracks struct has a null array");
-        const size_t need = (size_t)total + 8;
-        if (need > ctx->cap_trk || !ctx->d_trk8) {
-            if (ctx->d_trk8) PL_HIP(ctx, hipFree(ctx->d_trk8));
-            if (ctx->d_trk64) PL_HIP(ctx, hipFree(ctx->d_trk64));
-            ctx->d_trk8 = nullptr;
-            ctx->d_trk64 = nullptr;
-            ctx->cap_trk = 0;
-            PL_HIP(ctx, hipMalloc((void **)&ctx->d_trk8, 2 * need));
-            PL_HIP(ctx, hipMalloc((void **)&ctx->d_trk64, 10 * need * sizeof(double)));
-            ctx->cap_trk = need;
-        }
-        const size_t s = ctx->cap_trk;
-        dt.vit = ctx->d_trk8;
-        dt.map = ctx->d_trk8 + s;
-        double *b = ctx->d_trk64;
-        dt.charge = b;
-        dt.hydro = b + s;
-        dt.fi = b + 2 * s;
-        dt.plaacllr = b + 3 * s;
-        dt.papa = b + 4 * s;
-        dt.fix2 = b + 5 * s;
-        dt.plaacllrx2 = b + 6 * s;
-        dt.papax2 = b + 7 * s;
-        dt.post0 = b + 8 * s;
-        dt.post1 = b + 9 * s;
-        // entries of trimmed stops are unspecified: make them deterministic (0 / NaN)
-        PL_HIP(ctx, hipMemsetAsync(ctx->d_trk8, 0, 2 * s, ctx->stream));
-        PL_HIP(ctx, hipMemsetAsync(ctx->d_trk64, 0xff, 10 * s * sizeof(double), ctx->stream));
+        if ((rc = device_tracks(ctx, total, dt)) != PLAAC_OK) return rc;
     }
     rc = plaac_score_device(ctx, d_codes, d_offsets, nprot, total, ctx->d_rows, tracks ? &dt : nullptr, ctx->stream);
     if (rc != PLAAC_OK) return rc;
@@ -1974,6 +1981,82 @@ plaac_status plaac_score(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *o
     if (rc != PLAAC_OK) return rc;
     return score_resident_to_host(ctx, ctx->d_codes, ctx->d_offsets, nprot, total, rows, tracks);
 }
+
+// plotsomefastas' per-residue table for a batch of selected records, made on the device (round 5, late; format_device.hip.inc):
+// scored in track mode like plaac_score with tracks, but the twelve arrays stay on the device and the table's TEXT comes back.
+// *table: malloc'ed (plaac_table_free), or NULL with *needs_host != 0 when a value is one the host's formatter has to take
+// (>= 1e9, an infinity) - then score the batch with plaac_score and format on the host as before.
+plaac_status plaac_score_tracks_table(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot, const char *labels,
+                                      const uint64_t *label_off, plaac_row *rows, char **table, uint64_t *table_len, int *needs_host) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    if (!table || !table_len || !needs_host) return fail(ctx, PLAAC_ERR_ARG, "null argument");
+    *table = nullptr, *table_len = 0, *needs_host = 0;
+    if (nprot == 0) return PLAAC_OK;
+    if (!labels || !label_off) return fail(ctx, PLAAC_ERR_ARG, "null labels");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->slots_busy) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_tracks_table: batches are pending on this context");
+    uint64_t total = 0;
+    plaac_status rc = stage_in(ctx, codes, offsets, nprot, &total);
+    if (rc != PLAAC_OK) return rc;
+    if (total >= 0xffffffffull) return fail(ctx, PLAAC_ERR_ARG, "plaac_score_tracks_table: a batch of at most 2^32 - 2 residues");
+    if ((rc = grow(ctx, ctx->d_rows, ctx->cap_rows, (size_t)nprot)) != PLAAC_OK) return rc;
+    plaac_tracks dt{};
+    if ((rc = device_tracks(ctx, total, dt)) != PLAAC_OK) return rc;
+    if ((rc = plaac_score_device(ctx, ctx->d_codes, ctx->d_offsets, nprot, total, ctx->d_rows, &dt, ctx->stream)) != PLAAC_OK) return rc;
+    if (rows && (rc = copy_out(ctx, rows, ctx->d_rows, sizeof(plaac_row) * (size_t)nprot, ctx->stream)) != PLAAC_OK) return rc;
+    if (total == 0) return PLAAC_OK;
+    // the text: the slot buffers of the text pipeline serve (no batch is pending): labels -> d_text, label_off -> d_starts,
+    // line lengths -> d_len, line offsets -> d_toffs
+    plaac_ctx::Slot &S = ctx->slot[0];
+    const uint64_t lab_bytes = label_off[nprot];
+    const uint32_t nres = (uint32_t)total;
+    const unsigned ns = (nres + FA_SCAN - 1u) / FA_SCAN;
+    size_t cap_tot = S.d_total ? 1 : 0;
+    if ((rc = grow(ctx, S.d_text, S.cap_text, (size_t)lab_bytes + 16)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, S.d_starts, S.cap_starts, (size_t)nprot + 1)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, S.d_len, S.cap_len, (size_t)nres)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, S.d_toffs, S.cap_toffs, (size_t)nres + 1)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, S.d_bsum, S.cap_bsum, (size_t)ns)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, S.d_total, cap_tot, (size_t)1)) != PLAAC_OK) return rc;
+    if ((rc = grow(ctx, S.d_fmtflags, S.cap_fmtflags, (size_t)4)) != PLAAC_OK) return rc;
+    if ((rc = copy_in(ctx, S.d_text, labels, (size_t)lab_bytes, ctx->stream)) != PLAAC_OK) return rc;
+    if ((rc = copy_in(ctx, S.d_starts, label_off, sizeof(uint64_t) * ((size_t)nprot + 1), ctx->stream)) != PLAAC_OK) return rc;
+    PL_HIP(ctx, hipMemsetAsync(S.d_fmtflags, 0, 4 * sizeof(uint32_t), ctx->stream));
+    const FmtTrackPtrs T{dt.vit, dt.map, {dt.charge, dt.hydro, dt.fi, dt.plaacllr, dt.papa, dt.fix2, dt.plaacllrx2, dt.papax2}, dt.post0, dt.post1};
+    const unsigned nb = (unsigned)((total + 255u) / 256u);
+    hipLaunchKernelGGL(k_format_track_lines<false>, dim3(nb), dim3(256), 0, ctx->stream, ctx->d_codes, ctx->d_offsets, nprot, total, ctx->d_rows, T,
+                       S.d_text, S.d_starts, S.d_len, (const uint64_t *)nullptr, (char *)nullptr, S.d_fmtflags);
+    hipLaunchKernelGGL(k_fasta_block_sums, dim3(ns), dim3(FA_SCAN), 0, ctx->stream, S.d_len, nres, S.d_bsum);
+    hipLaunchKernelGGL(k_fasta_offsets, dim3(ns), dim3(FA_SCAN), 0, ctx->stream, S.d_len, nres, S.d_bsum, S.d_toffs, S.d_total);
+    struct {
+        unsigned long long total;
+        uint32_t flags[4];
+    } h{};
+    PL_HIP(ctx, hipMemcpyAsync(&h.total, S.d_total, sizeof h.total, hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(h.flags, S.d_fmtflags, sizeof h.flags, hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h.flags[0]) {
+        *needs_host = 1;
+        return PLAAC_OK;
+    }
+    if ((rc = grow(ctx, S.d_table, S.cap_table, (size_t)h.total + 16)) != PLAAC_OK) return rc;
+    hipLaunchKernelGGL(k_format_track_lines<true>, dim3(nb), dim3(256), 0, ctx->stream, ctx->d_codes, ctx->d_offsets, nprot, total, ctx->d_rows, T,
+                       S.d_text, S.d_starts, S.d_len, S.d_toffs, S.d_table, S.d_fmtflags);
+    // (hundreds of MB per batch, touched once: huge pages where the host grants them on request)
+    const size_t huge = 2u << 20, out_bytes = ((size_t)h.total + 1 + huge - 1) / huge * huge;
+    char *out = (char *)std::aligned_alloc(huge, out_bytes);
+    if (!out) return fail(ctx, PLAAC_ERR_NOMEM, "out of host memory");
+    (void)madvise(out, out_bytes, MADV_HUGEPAGE);
+    if ((rc = copy_out(ctx, out, S.d_table, (size_t)h.total, ctx->stream)) != PLAAC_OK) {
+        std::free(out);
+        return rc;
+    }
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *table = out;
+    *table_len = h.total;
+    return PLAAC_OK;
+}
+void plaac_table_free(char *table) { std::free(table); }
 
 static plaac_status score_begin(plaac_ctx *ctx, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot, bool counting) {
     if (!ctx) return PLAAC_ERR_ARG;

@@ -76,7 +76,7 @@ EXPORTS = (
     "plaac_node_set_params", "plaac_node_histogram", "plaac_node_score", "plaac_node_last_error",
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
-    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_score_begin_text", "plaac_score_end_text", "plaac_score_end_text_table_size", "plaac_score_end_text_table", "plaac_histogram_begin_text", "plaac_histogram_end_text", "plaac_text_upload", "plaac_score_begin_uploaded", "plaac_text_batch_free", "plaac_debug_schedule",
+    "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_score_begin_text", "plaac_score_end_text", "plaac_score_end_text_table_size", "plaac_score_end_text_table", "plaac_histogram_begin_text", "plaac_histogram_end_text", "plaac_text_upload", "plaac_score_begin_uploaded", "plaac_text_batch_free", "plaac_score_tracks_table", "plaac_table_free", "plaac_debug_schedule",
 )
 
 _lib = None
@@ -130,6 +130,10 @@ def load():
     L.plaac_score_end_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.plaac_score_end_text_table_size.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
     L.plaac_score_end_text_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.plaac_score_tracks_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    L.plaac_table_free.argtypes = [C.c_void_p]
+    L.plaac_table_free.restype = None
     L.plaac_text_upload.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.plaac_score_begin_uploaded.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.plaac_text_batch_free.argtypes = [C.c_void_p]
@@ -345,6 +349,25 @@ class Context:
                                                  counts.ctypes.data if counting else None))
         out = (rows, codes[:int(offsets[-1])] if want_codes else ext[:nrec], offsets, blank[:nrec])
         return out + (counts,) if counting else out
+
+    def score_tracks_table(self, codes, offsets, labels):
+        """plaac_score_tracks_table: the per-residue table of a batch as text from the device; labels = list of b"ORDER\tSEQid" per
+        record. Returns (table bytes or None when the host's formatter is needed, rows)."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        blob = b"".join(labels)
+        loff = np.zeros(n + 1, dtype=np.uint64)
+        loff[1:] = np.cumsum([len(x) for x in labels])
+        rows = np.zeros(n, dtype=ROW_DTYPE)
+        tab, tlen, needs = C.c_void_p(), C.c_uint64(), C.c_int()
+        self._check(self._L.plaac_score_tracks_table(self._h, codes.ctypes.data, offsets.ctypes.data, n, blob, loff.ctypes.data, rows.ctypes.data,
+                                                     C.byref(tab), C.byref(tlen), C.byref(needs)))
+        if needs.value or not tab.value:
+            return (None if needs.value else b""), rows
+        out = C.string_at(tab.value, tlen.value)
+        self._L.plaac_table_free(tab)
+        return out, rows
 
     def text_upload(self, text, starts):
         """plaac_text_upload: the batch uploaded and parsed ahead of its scoring call (may run on another thread than the scoring calls)"""

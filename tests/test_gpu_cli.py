@@ -330,3 +330,27 @@ def test_single_pass_into_a_file_writes_the_table_in_place(native, tmp_path):
         got, _ = to_file(args, {}, mode="ab", lead=b"appended to\n")
         assert got == b"appended to\n" + want, args
     assert b"NaN" in to_file(["-i", allx], {})[0]
+
+
+def test_per_residue_table_from_the_device_is_the_hosts(native, tmp_path):
+    """bin/plaac -p: the lines come from the device (plaac_score_tracks_table) unless PLAAC_DEVICE_FORMAT=0 - the same bytes either
+    way, for -p all and for a list with display names and an order column, over files with stops, short records, records
+    without a sequence, and small batches."""
+    from plaac_amd import synth
+    from conftest import quirky_fasta
+    P = native.make_params()
+    codes, offs = synth.make_batch(4, nprot=400, seed=93, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.3)
+    fa = tmp_path / "in.fa"
+    _write_fasta(fa, codes, offs)
+    quirks = tmp_path / "quirks.fa"
+    quirks.write_bytes(quirky_fasta(seed=10, nrec=300))
+    lst = tmp_path / "list.txt"
+    lst.write_text("rec00007 some description\tShown as seven\nrec00003 some description\nnot-there\nrec00100 some description\tA hundred\n")
+    for args in (["-i", fa, "-p", "all"], ["-i", fa, "-p", lst], ["-i", quirks, "-p", "all", "-s"], ["-i", fa, "-p", "all", "-a", "0.5"]):
+        outs = []
+        for env in ({"PLAAC_DEVICE_FORMAT": "0"}, {}, {"PLAAC_BATCH_BYTES": "20000"}, {"PLAAC_DEVICES": "0,0", "PLAAC_BATCH_RECORDS": "50"}):
+            r = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr.decode(errors="replace")
+            outs.append(r.stdout)
+        assert all(o == outs[0] for o in outs[1:]), args
+        assert outs[0].count(b"#" * 56 + b"\n") >= 1

@@ -1410,3 +1410,29 @@ def test_text_batches_uploaded_ahead_by_another_thread(native, oracle, tmp_path)
         # an uploaded batch that is not scored goes back to the context
         tb = ctx.text_upload(batches[0][0], batches[0][1])
         L.plaac_text_batch_free(tb)
+
+
+def test_per_residue_table_from_the_device_equals_the_hosts(native, oracle):
+    """plaac_score_tracks_table (round 5, late): plotsomefastas' lines (plaac.java:635-645) written by the device from the track
+    arrays it has just filled - byte for byte the host's plaac_format_track_rows over the tracks plaac_score brings back (those
+    are held against the oracle elsewhere): labels with tabs and odd bytes, proteins with a trimmed stop, short and long ones,
+    the closing line after every protein."""
+    from plaac_amd import hostio, synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(4, nprot=700, seed=31, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.3)
+    keep = [i for i in range(len(offs) - 1) if offs[i + 1] - offs[i] > 1]
+    c2 = np.concatenate([codes[int(offs[i]):int(offs[i + 1])] for i in keep])
+    o2 = np.zeros(len(keep) + 1, dtype=np.uint64)
+    o2[1:] = np.cumsum([int(offs[i + 1] - offs[i]) for i in keep])
+    ids = [str(k + 1) if k % 5 else "7%d" % k for k in range(len(keep))]
+    names = [("prot_%d" % k) if k % 3 else ("sp|Q%d|name with blanks, [brackets] & more" % k) for k in range(len(keep))]
+    labels = [(a + "\t" + b).encode() for a, b in zip(ids, names)]
+    with native.Context(P) as ctx:
+        rows, tr = ctx.score(c2, o2, tracks=True)
+        want = b"".join(hostio.format_track_rows(tr, int(o2[k]), c2[int(o2[k]):int(o2[k + 1])], int(rows[k]["prot_len"]), ids[k], names[k]).encode()
+                        for k in range(len(keep)) if rows[k]["prot_len"] > 0)
+        table, rows2 = ctx.score_tracks_table(c2, o2, labels)
+        assert table is not None
+        assert_rows_equal(rows2, rows, "rows beside the table")
+        assert table == want, "per-residue table from the device (%d / %d bytes)" % (len(table), len(want))
+        assert table.count(b"#" * 56 + b"\n") == int((rows["prot_len"] > 0).sum())

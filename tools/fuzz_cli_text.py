@@ -70,6 +70,8 @@ with tempfile.TemporaryDirectory() as tmp:
             args += ["-a", "0.5"]
         elif mode < 0.45:
             args += ["-a", str(rng.choice(["0.5", "1.0", "0.0"])), "-B", os.path.join(ROOT, "tests", "golden", "bg_freqs", "bg_freqs_HUMAN.txt")]
+        if rng.random() < 0.15 and os.path.getsize(fa) < 400000:
+            args += ["-p", "all"]  # (the per-residue table: device lines against the host's)
         if rng.random() < 0.2:
             args += ["-d"]
         if rng.random() < 0.2:
