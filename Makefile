@@ -7,9 +7,12 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-f
 CSRC      = plaac_amd/csrc
 LIB       = plaac_amd/libplaac_native.so
 
-# make DIAG=1: the same library with the result-breaking ablation switches compiled in (PLAAC_DEBUG_SKIP / _SKIP_FROM: named
-# kernels are not launched, rows stale; PLAAC_VIT_STOP; PLAAC_DEBUG_COUNTER) as plaac_amd/libplaac_native_diag.so, which
-# tools/r04_ablate*.sh load through PLAAC_NATIVE_LIB. The release library does not read them.
+# make DIAG=1 (or `make diag`): the DIAGNOSTIC build, plaac_amd/libplaac_native_diag.so, loaded through PLAAC_NATIVE_LIB - the
+# forms that were measured slower and are no longer selected (k_fwd_direct, k_bwd_fwd_post, the lane-store forms of the
+# forward pass with the posteriors, the launch-order and segment switches: EXPERIMENTS.md) and the result-breaking ablation
+# switches (DEBUG_SKIP / _SKIP_FROM: named kernels are not launched, rows stale; VIT_STOP; DEBUG_COUNTER), all read from the
+# environment as PLAAC_<KEY>. The release library contains neither the kernels nor the names (include/plaac_native.h,
+# "environment and test hooks").
 DIAGLIB   = plaac_amd/libplaac_native_diag.so
 ifeq ($(DIAG),1)
 all: $(DIAGLIB)
@@ -17,19 +20,37 @@ endif
 
 all: $(LIB) oracle $(if $(wildcard $(CSRC)/plaac_cli.cpp),cli) $(if $(JNI_H),jni)
 
-LIBSRC    = $(CSRC)/plaac_kernels.hip $(CSRC)/plaac_host.cpp $(CSRC)/plaac_node.cpp $(wildcard $(CSRC)/plaac_io.cpp)
+# One object per source, so that `make -j` compiles the two device units (plaac_kernels.hip: 60 s, plaac_kernels_lat.hip: 20 s)
+# and the host sources side by side; build() runs `make -j4 all`.
+DEPS      = $(wildcard $(CSRC)/*.hip.inc) $(wildcard include/*.h)
+HOSTSRC   = plaac_host plaac_node $(if $(wildcard $(CSRC)/plaac_io.cpp),plaac_io)
+OBJS      = build/plaac_kernels.o build/plaac_kernels_lat.o $(patsubst %,build/%.o,$(HOSTSRC))
+DIAGOBJS  = build/diag/plaac_kernels.o build/diag/plaac_kernels_lat.o $(patsubst %,build/%.o,$(HOSTSRC))
 # The latency-form chain kernels a second time, as a unit of their own under the compiler's max-ilp instruction scheduling
 # (plaac_kernels_lat.hip: chain-bound calls 6 % faster with it, the throughput-bound headline 3.7 % slower - so only there)
-LATOBJ    = build/plaac_kernels_lat.o
-$(LATOBJ): $(CSRC)/plaac_kernels_lat.hip $(wildcard $(CSRC)/*.hip.inc) $(wildcard include/*.h)
-	mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -Wno-unused-function -mllvm -amdgpu-sched-strategy=max-ilp -Iinclude -c -o $@ $(CSRC)/plaac_kernels_lat.hip
+LATFLAGS  = -Wno-unused-function -mllvm -amdgpu-sched-strategy=max-ilp
 
-$(LIB): $(LIBSRC) $(LATOBJ) $(wildcard $(CSRC)/*.hip.inc) $(wildcard include/*.h)
-	$(HIPCC) $(HIPFLAGS) -Iinclude -shared -o $@ $(LIBSRC) -Wl,$(LATOBJ) -Wl,-rpath,/opt/rocm/lib
+build/plaac_kernels.o: $(CSRC)/plaac_kernels.hip $(DEPS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -Iinclude -c -o $@ $<
+build/plaac_kernels_lat.o: $(CSRC)/plaac_kernels_lat.hip $(DEPS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) $(LATFLAGS) -Iinclude -c -o $@ $<
+build/diag/plaac_kernels.o: $(CSRC)/plaac_kernels.hip $(DEPS)
+	@mkdir -p build/diag
+	$(HIPCC) $(HIPFLAGS) -DPLAAC_DIAG=1 -Iinclude -c -o $@ $<
+build/diag/plaac_kernels_lat.o: $(CSRC)/plaac_kernels_lat.hip $(DEPS)
+	@mkdir -p build/diag
+	$(HIPCC) $(HIPFLAGS) $(LATFLAGS) -DPLAAC_DIAG=1 -Iinclude -c -o $@ $<
+build/%.o: $(CSRC)/%.cpp $(wildcard include/*.h)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -Iinclude -c -o $@ $<
 
-$(DIAGLIB): $(LIBSRC) $(LATOBJ) $(wildcard $(CSRC)/*.hip.inc) $(wildcard include/*.h)
-	$(HIPCC) $(HIPFLAGS) -DPLAAC_DIAG=1 -Iinclude -shared -o $@ $(LIBSRC) -Wl,$(LATOBJ) -Wl,-rpath,/opt/rocm/lib
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(OBJS) -Wl,-rpath,/opt/rocm/lib
+
+$(DIAGLIB): $(DIAGOBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(DIAGOBJS) -Wl,-rpath,/opt/rocm/lib
 diag: $(DIAGLIB)
 
 cli: bin/plaac

@@ -72,40 +72,101 @@ def time_reference_jar(fasta_path, nres):
             "sample": "%s, parse+score+format, second of two runs" % os.path.basename(fasta_path)}
 
 
-def write_fasta(torch, codes, offsets, nseq, path):
-    """FASTA text of the first nseq records of the resident batch, assembled in HBM (10-byte header
-    '>s%07d\\n', one sequence line per record) and written with one tofile(). Returns (bytes, residues)."""
+HDR_ALPHABET = b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789 =_-"
+HDR_MIN, HDR_MAX = 80, 160   # bytes of a 'uniref' header line incl. '>' (UniRef50 deflines: cluster id, name, n=, Tax=, TaxID=, RepID=)
+WRAP = 60                    # residues per sequence line of the 'uniref' shape (the reference's own inputs: cli/example/Scer.fasta)
+
+
+def header_len(i):
+    """length law of the 'uniref' header lines: 80 .. 160 bytes incl. '>', a fixed function of the record index (numpy or torch)"""
+    return HDR_MIN + (i * 37 + (i >> 5) * 11) % (HDR_MAX - HDR_MIN + 1)
+
+
+def header_name(i):
+    """SEQid of record i of the 'uniref' shape (the header line without '>'), rebuilt on the host for the table check"""
+    n = int(header_len(np.int64(i))) - 1
+    fixed = b"UniRef50_%010d " % i
+    j = np.arange(len(fixed), n, dtype=np.int64)
+    body = np.frombuffer(HDR_ALPHABET, np.uint8)[(i * 131 + j * 7 + (i >> 3)) % len(HDR_ALPHABET)].tobytes()
+    return fixed + body[:-1] + b"x"  # (never ends in a blank: only the first record's name is trimmed by the reference, :4362)
+
+
+def write_fasta(torch, codes, offsets, nseq, path, shape="single"):
+    """FASTA text of the first nseq records of the resident batch, assembled in HBM and written with one tofile().
+    shape 'single': 10-byte header '>s%07d\n', ONE sequence line per record (the least text a FASTA file can be);
+    shape 'uniref': header lines of 80 - 160 bytes (header_len / header_name) and sequence lines wrapped at 60 columns, as
+    the reference's own inputs and UniRef releases are (fastareader concatenates the lines, plaac.java:4325-4340; SEQid is
+    the whole header, :805). Returns (bytes, residues)."""
     dev = codes.device
     off = offsets[:nseq + 1]
     nres = int(off[-1].item())
     lens = off[1:] - off[:-1]
     letters = torch.tensor(list(b"XACDEFGHIKLMNPQRSTVWY*"), dtype=torch.uint8, device=dev)
-    out = torch.full((nres + 11 * nseq,), 10, dtype=torch.uint8, device=dev)  # '\n' everywhere first
-    rec = torch.repeat_interleave(torch.arange(nseq, device=dev, dtype=torch.int64), lens)
-    dst = torch.arange(nres, device=dev, dtype=torch.int64) + 11 * rec + 10
-    out[dst] = letters[codes[:nres].long()]
-    del rec, dst
-    hdr0 = off[:-1] + 11 * torch.arange(nseq, device=dev, dtype=torch.int64)
-    out[hdr0] = ord(">")
-    out[hdr0 + 1] = ord("s")
     idx = torch.arange(nseq, device=dev, dtype=torch.int64)
-    for d in range(7):
-        out[hdr0 + 2 + d] = (48 + (idx // 10 ** (6 - d)) % 10).to(torch.uint8)
+    if shape == "single":
+        out = torch.full((nres + 11 * nseq,), 10, dtype=torch.uint8, device=dev)  # '\n' everywhere first
+        rec = torch.repeat_interleave(idx, lens)
+        dst = torch.arange(nres, device=dev, dtype=torch.int64) + 11 * rec + 10
+        out[dst] = letters[codes[:nres].long()]
+        del rec, dst
+        hdr0 = off[:-1] + 11 * idx
+        out[hdr0] = ord(">")
+        out[hdr0 + 1] = ord("s")
+        for d in range(7):
+            out[hdr0 + 2 + d] = (48 + (idx // 10 ** (6 - d)) % 10).to(torch.uint8)
+        out.cpu().numpy().tofile(path)
+        return int(out.numel()), nres
+    assert shape == "uniref"
+    hl = header_len(idx)                                   # header bytes incl. '>' (the newline behind it is extra)
+    rec_bytes = hl + 1 + lens + (lens + WRAP - 1) // WRAP  # header + '\n' + residues + one '\n' per sequence line
+    rec0 = torch.cumsum(rec_bytes, 0) - rec_bytes
+    nbytes = int((rec0[-1] + rec_bytes[-1]).item())
+    out = torch.full((nbytes,), 10, dtype=torch.uint8, device=dev)
+    # residues, in pieces (index arrays of 8 bytes per residue)
+    step = 1 << 28
+    for r0 in range(0, nres, step):
+        r1 = min(nres, r0 + step)
+        g = torch.arange(r0, r1, device=dev, dtype=torch.int64)
+        rec = torch.searchsorted(off, g, right=True) - 1
+        t = g - off[rec]
+        out[rec0[rec] + hl[rec] + 1 + t + t // WRAP] = letters[codes[r0:r1].long()]
+        del g, rec, t
+    # headers: '>UniRef50_%010d ' then the filler of header_name()
+    alph = torch.tensor(list(HDR_ALPHABET), dtype=torch.uint8, device=dev)
+    FIX = 1 + len(b"UniRef50_%010d " % 0)
+    out[rec0] = ord(">")
+    for d, ch in enumerate(b"UniRef50_"):
+        out[rec0 + 1 + d] = ch
+    for d in range(10):
+        out[rec0 + 10 + d] = (48 + (idx // 10 ** (9 - d)) % 10).to(torch.uint8)
+    out[rec0 + 20] = ord(" ")
+    for i0 in range(0, nseq, 1 << 21):
+        i1 = min(nseq, i0 + (1 << 21))
+        fl = hl[i0:i1] - FIX                               # filler bytes of these records
+        ri = torch.repeat_interleave(idx[i0:i1], fl)
+        fstart = torch.cumsum(fl, 0) - fl
+        j = torch.arange(int(fl.sum().item()), device=dev, dtype=torch.int64) - torch.repeat_interleave(fstart, fl) + (FIX - 1)
+        out[rec0[ri] + 1 + j] = alph[(ri * 131 + j * 7 + (ri >> 3)) % len(HDR_ALPHABET)]
+        del ri, j, fstart, fl
+    out[rec0 + hl - 1] = ord("x")
     out.cpu().numpy().tofile(path)
-    return int(out.numel()), nres
+    return nbytes, nres
 
 
-def run_e2e(torch, codes, offsets, nseq, keep_fasta=False):
+def run_e2e(torch, codes, offsets, nseq, shape="uniref", keep=False):
     """FASTA bytes in -> TSV bytes out through bin/plaac (the C++ host above the C ABI), wall clock around the
-    whole process (HIP start-up, parse, upload, kernels, download, formatting, write)."""
+    whole process (HIP start-up, parse, upload, kernels, download, formatting, write). keep: the FASTA and the TSV of the
+    last run stay on disk (paths under _fasta / _tsv) for the table check; the caller removes them."""
     exe = os.path.join(ROOT, "bin", "plaac")
     if not os.path.exists(exe):
         return {"skipped": "bin/plaac not built"}
     tmp = os.environ.get("TMPDIR", "/tmp")
-    fa, tsv = os.path.join(tmp, "plaac_bench_%d.fa" % os.getpid()), os.path.join(tmp, "plaac_bench_%d.tsv" % os.getpid())
+    fa = os.path.join(tmp, "plaac_bench_%d_%s.fa" % (os.getpid(), shape))
+    tsv = os.path.join(tmp, "plaac_bench_%d_%s.tsv" % (os.getpid(), shape))
+    ok = False
     try:
         t0 = time.perf_counter()
-        fbytes, nres = write_fasta(torch, codes, offsets, nseq, fa)
+        fbytes, nres = write_fasta(torch, codes, offsets, nseq, fa, shape)
         t_write = time.perf_counter() - t0
         best, runs, timing = None, [], []
         for _ in range(2):
@@ -121,28 +182,76 @@ def run_e2e(torch, codes, offsets, nseq, keep_fasta=False):
             if best is None or dt < best:
                 best, timing = dt, [l for l in r.stderr.decode(errors="replace").splitlines() if l.startswith("plaac-timing")]
         obytes = os.path.getsize(tsv)
-        with open(tsv, "rb") as fh:
-            nl = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
-        with open(tsv, "rb") as fh:  # the first table rows, for the oracle's check in the cpu_baseline leg
-            head = fh.read(8 << 20).split(b"\n")[:-1]
-        first = next((i for i, l in enumerate(head) if l.startswith(b"SEQid\t")), None)
-        head_rows = head[first + 1:] if first is not None else None
         out = {"value": round(nres / best, 1), "unit": "residues/s", "proteins_per_sec": round(nseq / best, 1),
                "wall_s": runs, "sequences": nseq, "residues": nres, "fasta_bytes": fbytes, "tsv_bytes": obytes,
-               "tsv_lines": nl, "fasta_write_s": round(t_write, 3),
-               "what": "bin/plaac -i <FASTA> > <TSV>, whole process incl. HIP start-up, best of two runs, 1 GPU"}
+               "fasta_shape": shape, "fasta_write_s": round(t_write, 3),
+               "what": "bin/plaac -i <FASTA> > <TSV>, whole process incl. HIP start-up, best of two runs, 1 GPU; FASTA text: "
+                       + ("header lines of %d - %d bytes (UniRef-style deflines; SEQid = the whole header, plaac.java:805), "
+                          "sequence lines wrapped at %d columns (fastareader joins them, :4325-4340)" % (HDR_MIN, HDR_MAX, WRAP)
+                          if shape == "uniref" else "10-byte headers, ONE sequence line per record (the least text a FASTA "
+                          "file can be: no line joins, 10 bytes of SEQid)")}
         if timing:  # PLAAC_TIMING=1 in the environment: the host's own stage clock of the best run
             out["stages"] = timing
-        out["_head_rows"] = head_rows
-        if keep_fasta:
-            out["_fasta"] = fa
+        if keep:
+            out["_fasta"], out["_tsv"] = fa, tsv
+        ok = True
         return out
     finally:
-        for p in ((tsv,) if keep_fasta else (fa, tsv)):
+        for p in (() if (keep and ok) else (fa, tsv)):
             try:
                 os.unlink(p)
             except OSError:
                 pass
+
+
+def file_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 24), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def tsv_line_starts(path):
+    """byte offset of every line of the file (+ the file size as the last entry)"""
+    starts, base = [np.zeros(1, np.int64)], 0
+    with open(path, "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 26), b""):
+            nl = np.flatnonzero(np.frombuffer(chunk, np.uint8) == 10)
+            starts.append(nl.astype(np.int64) + (base + 1))
+            base += len(chunk)
+    out = np.concatenate(starts)
+    if out[-1] != base:  # (no newline at the very end)
+        out = np.append(out, base)
+    return out
+
+
+def check_table(tsv, checks, name_of, corelength=60, ww2=41):
+    """The table bin/plaac wrote against the oracle's rows: `checks` = [(first record, oracle rows, codes, offsets)], every
+    record's line rebuilt from the ORACLE's row by the library's host formatter (plaac_format_summary_row_n - itself held
+    against a restatement of java.util.Formatter in tests/test_host_io.py) under the name name_of(record) and compared, byte
+    for byte, with the line of that record in the file. The synthetic records are all scored (none is empty), so record i
+    is line i behind the column header. Returns (lines checked, [mismatching (first, count) slices], total table lines)."""
+    from plaac_amd import hostio
+    starts = tsv_line_starts(tsv)
+    nlines = len(starts) - 1
+    with open(tsv, "rb") as fh:
+        head = fh.read(1 << 20)
+    hl = head.split(b"\n")
+    first = next(i for i, l in enumerate(hl) if l.startswith(b"SEQid\t"))
+    checked, bad = 0, []
+    with open(tsv, "rb") as fh:
+        for (s, rows, codes, offs) in checks:
+            n = len(rows)
+            a, b = int(starts[first + 1 + s]), int(starts[first + 1 + s + n])
+            fh.seek(a)
+            got = fh.read(b - a)
+            exp = hostio.format_summary_rows(rows, [name_of(s + i) for i in range(n)], codes, offs, corelength, ww2)
+            checked += n
+            if got != exp:
+                bad.append([s, n])
+    return checked, bad, nlines - first - 1
 
 
 def check_slices(nfull):
@@ -242,7 +351,7 @@ def main():
     ap.add_argument("--max-len", type=int, default=0, help="clip every sequence length (cfg4 with 8192: the length law without its "
                     "0.01 %% tail of 8,193 - 36,000-residue records: a proteome whose step no single chain bounds)")
     ap.add_argument("--allow-diagnostics", action="store_true", help="run although PLAAC_DEBUG_* / PLAAC_VIT_STOP are set (only a "
-                    "DIAG build of the library reads them, and its rows are wrong by design: tools/r04_ablate*.sh)")
+                    "DIAG build of the library reads them, and its rows are wrong by design: tools/archive/r04_ablate*.sh)")
     ap.add_argument("--no-tracks-leg", action="store_true", help="N = 1 default line: skip the `tracks` object (the 1.25 M-sequence "
                     "share scored in per-residue track mode - the HBM-bound regime of the path - in the same run)")
     args = ap.parse_args()
@@ -641,10 +750,12 @@ def main():
     # [+ 82 B/residue of tracks] [+ 1 B/residue for the background pass of cfg3]; `achieved` divides them by the
     # average launch duration of the longest kernel (the four scoring kernels overlap, see kernels_overlap)
     path_bytes = total * (1 + tb + (1 if two_pass else 0)) + nprot * 168
+    # No one kernel carries the path's bytes (four to six kernel streams share every step), so the headline figure is the
+    # STEP's: algorithmic bytes / wall-clock step (VERDICT r04 for track mode, r05 for summary mode). The longest kernel
+    # stream stays beside it for the record.
+    longest, longest_ms = dom, dom_ms
+    dom, dom_ms = "step", dt / args.steps * 1e3
     achieved = path_bytes / (dom_ms * 1e-3) / 1e9
-    if args.tracks:  # track mode: no one kernel stream carries the path's bytes - the figure is the step's
-        dom, dom_ms = "step", dt / args.steps * 1e3
-        achieved = path_bytes / (dom_ms * 1e-3) / 1e9
     # HBM traffic and executed instruction counts: PMC counters cannot be read from inside this process;
     # tools/pmc.sh collects them for this same workload and leaves the per-launch figures under profiles/
     traffic, traffic_all, exec_ops, issue_instr, traffic_cal, traffic_all_cal, fetch_cal, issue_classes = (None,) * 8
@@ -685,7 +796,7 @@ def main():
     if traffic_all is not None:  # (older rounds' files of the same workload are still under profiles/: not this line's concern)
         stale_counters = None
     # track mode: tools/pmc.sh serialises the streams, which selects the throughput forms of the chain kernels - the traffic of
-    # the forms the library picks by itself comes from a separate pair of passes (tools/r04_pmc_tracks_default_forms.sh)
+    # the forms the library picks by itself comes from a separate pair of passes (tools/archive/r04_pmc_tracks_default_forms.sh)
     traffic_default_forms = None
     if args.tracks and nprot == 1250000 and not args.sweep and not args.max_len:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -707,6 +818,10 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_all_kernels": traffic_all,
+        "what": "algorithmic bytes of one pass (SURVEY 8d M4) / wall-clock step (fence - steps - fence); traffic = counted "
+                "HBM bytes of all kernels of a step",
+        "longest_kernel_stream": {"name": longest, "ms": round(longest_ms, 4),
+                                  "algorithmic_GBps": round(path_bytes / (longest_ms * 1e-3) / 1e9, 3)},
         "traffic_all_kernels_default_forms": traffic_default_forms,
         "traffic_calibrated": traffic_cal, "traffic_all_kernels_calibrated": traffic_all_cal,
         "fetch_calibration": fetch_cal,
@@ -756,7 +871,7 @@ def main():
 
     # ---- rank 0: CPU baseline = the oracle (a port, not the Java reference: no JVM on this box), and the parity check of
     # this run's rows: slices spread over the WHOLE batch (strong scaling: over the gathered, re-ordered table)
-    cpu, rc = None, 0
+    cpu, rc, oracle_keep = None, 0, []
     if not args.no_cpu_baseline:
         from oracle import oracle_ctypes as oc
         nthreads = usable_cores()
@@ -786,6 +901,7 @@ def main():
         want = oc.score_batch(Po, codes_h, off_h, nthreads=nthreads)
         dtn = time.perf_counter() - t1
         checked, max_off, bad = 0, 0, []
+        oracle_keep = []  # (first record, oracle rows, codes, offsets) of every slice: the e2e leg checks the table with them
         if sweep_params:  # every point of the sweep against the oracle run with that point's parameters
             n_c = min(n_s, 20000)
             for k, (a, c) in enumerate((a, c) for a in (0.0, 0.5, 1.0) for c in (30, 60, 90)):
@@ -800,10 +916,12 @@ def main():
                 if s == 0:
                     w = want
                     max_off = max(max_off, int(off_h[-1]))
+                    oracle_keep.append((s, w, codes_h, off_h))
                 else:
                     c_h, o_h, end = host_slice(s, n)
                     w = oc.score_batch(Po, c_h, o_h, nthreads=nthreads)
                     max_off = max(max_off, end)
+                    oracle_keep.append((s, w, c_h, o_h))
                 got = chk_rows[s * RB:(s + n) * RB].cpu().numpy()
                 if got.tobytes() != w.tobytes():
                     bad.append([s, n])
@@ -854,38 +972,65 @@ def main():
             rc = 3
 
     # ---- rank 0, N = 1: end to end through the C++ host (FASTA bytes in -> TSV bytes out), SURVEY 8(d) M1 ----
-    e2e = None
+    # `e2e` = UniRef-shaped TEXT (long headers, 60-column lines) - the metric's "UniRef50-shaped FASTA"; `e2e_single_line` =
+    # the same records as the least text a FASTA file can be (rounds 4 - 5 quoted this one). The uniref table is then checked
+    # against the oracle over every slice the cpu_baseline leg scored (1.05 M records across all batches of the run, the last
+    # 100 k among them) and, as a whole, by sha256 against one run of the host route (host parser + host formatter).
+    e2e = e2e_single = None
     if world == 1 and not args.no_e2e and not args.tracks and not args.sweep:
-        e2e = run_e2e(torch, main_work.codes, main_work.offsets, min(nprot, args.e2e_nprot or nprot))
+        n_e2e = min(nprot, args.e2e_nprot or nprot)
+        e2e_single = run_e2e(torch, main_work.codes, main_work.offsets, n_e2e, "single")
+        e2e = run_e2e(torch, main_work.codes, main_work.offsets, n_e2e, "uniref", keep=True)
+        fa, tsv = e2e.pop("_fasta", None), e2e.pop("_tsv", None)
+        try:
+            if tsv and cpu is not None and oracle_keep and not two_pass:
+                checks = [(s_, w_, c_, o_) for (s_, w_, c_, o_) in oracle_keep if s_ + len(w_) <= n_e2e]
+                t0 = time.perf_counter()
+                nchk, tbad, nlines = check_table(tsv, checks, header_name, P.corelength, P.ww2)
+                e2e.update(table_rows_checked=nchk, table_rows_match_oracle=not tbad, table_mismatching_slices=tbad,
+                           tsv_lines=nlines, table_lines_expected=n_e2e, table_check_s=round(time.perf_counter() - t0, 2),
+                           table_check="every record of the cpu_baseline slices (incl. the last 100 k): the oracle's row "
+                                       "through the library's host formatter under the record's own header, byte for byte "
+                                       "against that record's line of the TSV")
+                if tbad or nlines != n_e2e:
+                    rc = 3
+            if tsv and fa:
+                # the whole table once more through the host route (host FASTA parser, host formatter; same kernels)
+                t0 = time.perf_counter()
+                sha_dev = file_sha256(tsv)
+                tsv2 = tsv + ".hostroute"
+                env = dict(os.environ, PLAAC_DEVICE_PARSE="0", PLAAC_DEVICE_FORMAT="0")
+                with open(tsv2, "wb") as fh:
+                    t1 = time.perf_counter()
+                    r = subprocess.run([os.path.join(ROOT, "bin", "plaac"), "-i", fa], stdout=fh, stderr=subprocess.PIPE, timeout=1800, env=env)
+                    host_s = time.perf_counter() - t1
+                if r.returncode == 0:
+                    sha_host = file_sha256(tsv2)
+                    e2e.update(table_sha256=sha_dev, table_sha_matches_host_route=sha_dev == sha_host,
+                               host_route_wall_s=round(host_s, 4), sha_check_s=round(time.perf_counter() - t0, 2),
+                               host_route="PLAAC_DEVICE_PARSE=0 PLAAC_DEVICE_FORMAT=0 bin/plaac -i <the same FASTA>: host parser "
+                                          "and host formatter, one run")
+                    if sha_dev != sha_host:
+                        rc = 3
+                else:
+                    e2e["host_route_error"] = r.stderr.decode(errors="replace")[-300:]
+                    rc = 3
+                if os.path.exists(tsv2):
+                    os.unlink(tsv2)
+        finally:
+            for p_ in (fa, tsv):
+                if p_ and os.path.exists(p_):
+                    os.unlink(p_)
         # when the operator supplies the real reference (a JVM on PATH and
         # PLAAC_REF_JAR=/path/plaac.jar) time it too, single-threaded as it is, on a bounded sample
         if cpu is not None and os.environ.get("PLAAC_REF_JAR"):
             fa = os.path.join(os.environ.get("TMPDIR", "/tmp"), "plaac_bench_ref_%d.fa" % os.getpid())
             try:
-                _, nres_s = write_fasta(torch, main_work.codes, main_work.offsets, min(nprot, 8000), fa)
+                _, nres_s = write_fasta(torch, main_work.codes, main_work.offsets, min(nprot, 8000), fa, "uniref")
                 cpu["reference_jar"] = time_reference_jar(fa, nres_s)
             finally:
                 if os.path.exists(fa):
                     os.unlink(fa)
-    if e2e is not None and "_head_rows" in e2e:
-        head_rows = e2e.pop("_head_rows")
-        # the table bin/plaac wrote against the oracle's rows pushed through the host formatter (itself held against a
-        # restatement of java.util.Formatter on the CPU): the first rows of the file, byte for byte
-        if cpu is not None and head_rows is not None and not two_pass:
-            from plaac_amd import hostio
-            k_rows = min(len(head_rows), 20000, len(want))
-            exp = []
-            for i in range(len(want)):
-                if len(exp) >= k_rows:
-                    break
-                line = hostio.format_summary_row(want[i], b"s%07d" % i, codes_h[int(off_h[i]):int(off_h[i + 1])])
-                if line:
-                    exp.append(line.encode())
-            ok_rows = [a == b for a, b in zip(head_rows[:k_rows], exp)]
-            e2e["table_rows_checked"] = len(ok_rows)
-            e2e["table_rows_match_oracle"] = bool(ok_rows) and all(ok_rows)
-            if not e2e["table_rows_match_oracle"]:
-                rc = 3
     if cpu is not None and "reference_jar" not in cpu:
         cpu["reference_jar"] = time_reference_jar("", 0) if not os.environ.get("PLAAC_REF_JAR") else "skipped: no e2e leg"
 
@@ -940,6 +1085,7 @@ def main():
         "tracks": tracks_leg,
         "cpu_baseline": cpu,
         "e2e": e2e,
+        "e2e_single_line": e2e_single,
     }
     if weak:
         out["weak"] = weak

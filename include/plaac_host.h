@@ -47,7 +47,7 @@ void plaac_fasta_free(plaac_fasta *f);
 typedef struct plaac_fasta_stream plaac_fasta_stream;
 plaac_status plaac_fasta_open(const char *path, plaac_fasta_stream **out);
 plaac_status plaac_fasta_next(plaac_fasta_stream *s, uint32_t max_records, uint64_t max_bytes, plaac_fasta **out);
-void plaac_fasta_close(plaac_fasta_stream *s);
+void plaac_fasta_close(plaac_fasta_stream *s); /* text batches still alive keep the file image mapped until the last is freed */
 
 /* The stream cut into batches of TEXT for the device-side parser (plaac_score_begin_text, round 5): the same batch boundaries
  * as plaac_fasta_next, but the records are only LOCATED - starts[i] = offset of record i's '>' inside `text`, starts[nrec] = len;

@@ -42,7 +42,8 @@ typedef enum plaac_status {
     PLAAC_ERR_ARG = 1,    /* bad argument (null pointer, non-monotone offsets, code > 21 ...) */
     PLAAC_ERR_DEVICE = 2, /* HIP runtime / kernel failure, or no gfx950 device                */
     PLAAC_ERR_NOMEM = 3,  /* host or device allocation failed                                 */
-    PLAAC_ERR_IO = 4      /* file could not be read (host helpers only)                       */
+    PLAAC_ERR_IO = 4,     /* file could not be read (host helpers only)                       */
+    PLAAC_ERR_UNSUPPORTED = 5 /* a diagnostic-build switch asked of the release library (plaac_debug_set_knob) */
 } plaac_status;
 
 /* Log-space 2-state HMM as hmm.initialize leaves it (plaac.java:2893-2935). */
@@ -235,6 +236,9 @@ plaac_status plaac_text_upload(plaac_ctx *ctx, const char *text, uint64_t text_l
                                plaac_text_batch **out);
 plaac_status plaac_score_begin_uploaded(plaac_ctx *ctx, plaac_text_batch *batch, int counting);
 void plaac_text_batch_free(plaac_text_batch *batch); /* an uploaded batch that will not be scored */
+/* message of the last failing plaac_text_upload on this context: the uploader thread has a slot of its own (plaac_last_error
+ * belongs to the thread that scores) */
+const char *plaac_text_upload_error(const plaac_ctx *ctx);
 /* The COUNTING pass of a two-pass run fed with text (computeaafreq plaac.java:1655-1666 over nextfasta's records): the batch is
  * parsed on the device like a scored one and counted (countaas / isvalidprotein :1698-1739), not scored. Shares a context's
  * two pending slots with the scoring calls; residues (nullable) = the batch's residue count. */
@@ -318,6 +322,53 @@ plaac_status plaac_node_score(plaac_node *node, const uint8_t *codes, const uint
 const char *plaac_node_last_error(const plaac_node *node);
 /* plaac_ctx_set_overlap on every context of the node (for hosts that feed the contexts' device entry points themselves) */
 plaac_status plaac_node_set_overlap(plaac_node *node, int on);
+
+/* ---- FASTA text through a node (round 6): the text entry points of a context, dealt over the node's contexts ---------------
+ * A host that reads a FASTA file (fastareader, plaac.java:4302-4375) and prints scoreallfastas' table (:755-948) hands the
+ * node BATCHES OF TEXT in file order (whole records, text[starts[i]] = the '>' of record i, starts[nrec] = text_len, as
+ * plaac_fasta_next_text cuts them) and takes the table's text back in the same order; which context scores a batch is the
+ * node's business (round robin; every context holds two pending batches, so 2 x plaac_node_size batches may be in flight).
+ * Every "end" call below serves the OLDEST pending batch of the node, whatever context it went to. The node itself keeps
+ * how the record before a batch ended (the reference trims the NEXT name behind an empty line, :4362); plaac_node_text_reset
+ * starts a new file. Results are byte for byte those of a single context fed the same batches.
+ *   plaac_node_text_begin          score (counting != 0: and count, as plaac_score_begin_counting) the batch
+ *   plaac_node_text_table_size     wait for the oldest batch; its table's size, its residues, and *needs_host != 0 when the
+ *                                  device will not vouch for a value of it (>= 1e9, an infinity, a record without a sequence)
+ *   plaac_node_text_table          the table's bytes (capacity >= the size reported); gives the batch up
+ *   plaac_node_text_rows           the oldest batch as rows + what the device parsed (plaac_score_end_text), for a host that
+ *                                  formats it itself - the way out when needs_host != 0; gives the batch up
+ *   plaac_node_text_discard        gives the oldest batch up without collecting anything
+ *   plaac_node_text_pending        batches in flight
+ * The COUNTING pass of a two-pass run (computeaafreq, :1655-1666): plaac_node_histogram_text_begin per batch, then
+ * plaac_node_histogram_text_end once per batch in the same order (counts and *residues are ADDED to what the caller passes
+ * in, so a loop over a file ends with the file's totals; zero them first).
+ * An uploader thread of the host may run plaac_node_text_upload beside the scoring calls (plaac_text_upload: one upload at
+ * a time per context - the node serialises them per context); plaac_node_text_begin_uploaded then takes the batch over. */
+typedef struct plaac_node_text_batch plaac_node_text_batch;
+plaac_status plaac_node_text_begin(plaac_node *node, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
+                                   int counting);
+plaac_status plaac_node_text_upload(plaac_node *node, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
+                                    plaac_node_text_batch **out);
+plaac_status plaac_node_text_begin_uploaded(plaac_node *node, plaac_node_text_batch *batch, int counting);
+void plaac_node_text_batch_free(plaac_node_text_batch *batch); /* an uploaded batch that will not be scored */
+plaac_status plaac_node_text_table_size(plaac_node *node, int corelength, int ww2, uint64_t *table_bytes, int *needs_host,
+                                        uint64_t *residues /* nullable */);
+plaac_status plaac_node_text_table(plaac_node *node, char *table, uint64_t table_cap, int64_t *counts /* nullable */);
+plaac_status plaac_node_text_rows(plaac_node *node, plaac_row *rows, uint8_t *codes /* nullable */, uint64_t codes_cap,
+                                  uint64_t *offsets, uint8_t *blank_end, uint32_t *extents /* nullable */,
+                                  int64_t *counts /* nullable */);
+plaac_status plaac_node_text_discard(plaac_node *node);
+int plaac_node_text_pending(const plaac_node *node);
+uint32_t plaac_node_text_oldest_records(const plaac_node *node); /* records of the oldest pending batch (0: none pending) */
+void plaac_node_text_reset(plaac_node *node); /* a new file begins: the next batch's first name is trimmed (:4362) */
+plaac_status plaac_node_histogram_text_begin(plaac_node *node, const char *text, uint64_t text_len, const uint64_t *starts,
+                                             uint32_t nrec);
+plaac_status plaac_node_histogram_text_end(plaac_node *node, int64_t counts[PLAAC_NAA], uint64_t *residues /* nullable */);
+/* plotsomefastas' per-residue table (plaac.java:587-649) for a batch of selected records on one of the node's contexts
+ * (plaac_score_tracks_table; round robin). No text batch may be pending on the node. */
+plaac_status plaac_node_score_tracks_table(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                                           const char *labels, const uint64_t *label_off, plaac_row *rows, char **table,
+                                           uint64_t *table_len, int *needs_host);
 
 /* THE partitioner of every multi-GPU layer (plaac_node_*, plaac_amd/dist.py, bench.py): SURVEY.md 8(e) G1's "sort by
  * length, deal". The records are sorted by length (descending, stable) and dealt to `parts` shards boustrophedon
@@ -422,6 +473,31 @@ typedef struct plaac_sched_query {
     int32_t last_chain_bound, last_mixed, last_single_summary, old_tail;
 } plaac_sched_query;
 long plaac_debug_schedule(const plaac_sched_query *q, char *buf, size_t cap);
+
+/* ---- environment and test hooks ---------------------------------------------------------------------------------------
+ * The release library reads NINE environment variables of its own - eight when a context is created, one in the host I/O
+ * helpers (and nothing else of the host's environment but the HIP runtime's GPU_MAX_HW_QUEUES):
+ *   PLAAC_LATENCY_MODE=0|1   force the throughput / the latency forms of the chain kernels (default: chosen per batch)
+ *   PLAAC_KB_FILTER=0        summary mode scores every window track with the exact kernel (no filter tier)
+ *   PLAAC_OVERLAP=1          contexts start with plaac_ctx_set_overlap on
+ *   PLAAC_SERIAL_STREAMS=1   every kernel of a call on one stream (profilers that serialise dispatches anyway)
+ *   PLAAC_SWEEP_SPREAD=0|1   a sweep's groups on streams of their own / spread over the call's streams (default: by
+ *                            GPU_MAX_HW_QUEUES)
+ *   PLAAC_STREAM_DEBUG=1     print the role streams' hardware queues at context creation (stderr)
+ *   PLAAC_CTX_TIMING=1       print what bringing a context up is made of (stderr)
+ *   PLAAC_THREADS=n          host threads of plaac_score's staging copies
+ *   PLAAC_HUGE_PAGES=0       plain allocations for the large host buffers of the FASTA / table helpers (plaac_host.h) instead
+ *                            of transparent huge pages on request
+ * None changes a result. Every other switch of earlier rounds is a TEST HOOK: plaac_debug_set_knob(key, value) - key without
+ * the PLAAC_ prefix, value NULL removes it - sets a process-wide table the contexts created afterwards read. The hooks force
+ * a form the library selects by itself for other batch shapes or tables (KB_LANE_MIN_GROUPS, MIXED_GROUPS, GENERIC_TRACKS,
+ * FI_INT, LSE_CLAMP ...: plaac_amd/csrc/schedule.hip.inc lists them), so that parity tests reach it with small batches;
+ * plaac_amd/native.py turns PLAAC_<KEY> of its own process environment into these calls. Keys of forms that were measured
+ * slower and are no longer selected at all (TRACK_ONE_PASS, FWD_DIRECT, TRACK_CKPT ...; EXPERIMENTS.md) and the result-breaking
+ * ablation switches exist in the diagnostic build only (`make DIAG=1`): the release library answers PLAAC_ERR_UNSUPPORTED and
+ * does not contain their kernels. plaac_diag_build() != 0: this library is the diagnostic build. */
+plaac_status plaac_debug_set_knob(const char *key, const char *value);
+int plaac_diag_build(void);
 
 #ifdef __cplusplus
 }

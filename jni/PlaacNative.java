@@ -57,11 +57,34 @@ final class PlaacNative {
     /** pipelines of batches: consecutive scoring calls of a context may overlap on the device (plaac_ctx_set_overlap) */
     static native void nodeSetOverlap(long node, boolean on);
 
-    // FASTA text in, summary-table text out (round 5): the bytes of whole records ('>' of record i at starts[i], starts[nrec] =
-    // textLen) to context k of the node; the device parses (fastareader), scores and writes scoreallfastas' lines. Two batches
-    // may be pending per context. textTableSize: the table's size, out3 = {needsHost, lastBlank, residues}; prevBlank: how the
-    // record before this batch ended (1 for a file's first batch; lastBlank of the batch before otherwise).
-    static native void textBegin(long node, int k, ByteBuffer text, long textLen, ByteBuffer starts, int nrec, boolean counting);
-    static native long textTableSize(long node, int k, int corelength, int ww2, int prevBlank, long[] out3);
-    static native void textTable(long node, int k, ByteBuffer tableOut, long tableCap, long[] counts22);
+    // ---- FASTA text in, table text out (plaac_node_text_*): the bytes of whole records ('>' of record i at starts[i],
+    // starts[nrec] = textLen) in FILE ORDER; the device parses (fastareader, plaac.java:4302-4375), scores and writes
+    // scoreallfastas' lines (:899-945). The node deals the batches over its devices (2 x devices may be in flight) and every
+    // collecting native serves the OLDEST pending batch, so the table comes back in file order. textReset() before a new file.
+    static native void textBegin(long node, ByteBuffer text, long textLen, ByteBuffer starts, int nrec, boolean counting);
+    /** waits for the oldest batch; returns its table's size; out2 = {needsHost, residues} */
+    static native long textTableSize(long node, int corelength, int ww2, long[] out2);
+    /** the oldest batch's table text (after textTableSize said needsHost == 0); gives the batch up */
+    static native void textTable(long node, ByteBuffer tableOut, long tableCap, long[] counts22);
+    /** needsHost != 0 (a value >= 1e9, an infinity, a record without a sequence): the oldest batch as rows + what the device
+     *  parsed, for the host's own formatter (plaac_score_end_text); gives the batch up. textOldestRecords() sizes the buffers. */
+    static native void textRows(long node, ByteBuffer rowsOut, ByteBuffer codesOut, ByteBuffer offsetsOut, ByteBuffer blankEndOut,
+                                ByteBuffer extentsOut, long[] counts22);
+    /** gives the oldest batch up without collecting it */
+    static native void textDiscard(long node);
+    static native int textPending(long node);
+    static native int textOldestRecords(long node);
+    static native void textReset(long node);
+    /** an uploader thread's half of textBegin: upload + parse now, score later (returns the uploaded batch's handle) */
+    static native long textUpload(long node, ByteBuffer text, long textLen, ByteBuffer starts, int nrec);
+    static native void textBeginUploaded(long node, long uploadedBatch, boolean counting);
+    static native void textBatchFree(long uploadedBatch);
+    // the counting pass of a two-pass run over text (computeaafreq, plaac.java:1655-1666): one begin and, in the same order,
+    // one end per batch; counts22 / residues1 are added to
+    static native void histogramTextBegin(long node, ByteBuffer text, long textLen, ByteBuffer starts, int nrec);
+    static native void histogramTextEnd(long node, long[] counts22, long[] residues1);
+    /** plotsomefastas (plaac.java:587-649): the per-residue table of the selected records, made on the device; labels = for
+     *  record k the bytes "ORDER\tSEQid" at labelOff[k] .. labelOff[k+1]; null when a value needs the host's formatter */
+    static native byte[] tracksTable(long node, ByteBuffer codes, ByteBuffer offsets, int nprot, ByteBuffer labels,
+                                     ByteBuffer labelOff, ByteBuffer rowsOut);
 }

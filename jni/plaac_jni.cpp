@@ -239,62 +239,184 @@ JNIEXPORT void JNICALL Java_PlaacNative_nodeSetOverlap(JNIEnv *env, jclass, jlon
     if (plaac_node_set_overlap(node_of(node), on ? 1 : 0) != PLAAC_OK) raise(env, node_error(node));
 }
 
-// ---- FASTA text in, summary-table text out (round 5): fastareader.nextfasta (:4325-4357) in front of the scoring loop and the
-//      output line of scoreallfastas (:899-945) behind it run on the device; a Java host hands over the bytes of whole records
-//      and where each begins, and gets the table's bytes back. Context k of the node; two batches may be pending per context.
-static plaac_ctx *ctx_of(JNIEnv *env, jlong node, jint k) {
-    plaac_ctx *c = plaac_node_ctx(node_of(node), k);
-    if (!c) raise(env, "no such context on this node");
-    return c;
-}
-
-JNIEXPORT void JNICALL Java_PlaacNative_textBegin(JNIEnv *env, jclass, jlong node, jint k, jobject text, jlong textLen,
-                                                  jobject starts, jint nrec, jboolean counting) {
-    plaac_ctx *c = ctx_of(env, node, k);
-    if (!c) return;
+// ---- FASTA text in, table text out (plaac_node_text_*): fastareader.nextfasta (:4325-4357) in front of the scoring loop and
+//      the output line of scoreallfastas (:899-945) behind it run on the device. A Java host hands over the bytes of whole
+//      records and where each begins, in file order, and collects the batches in the same order; which device scores a batch
+//      is the node's business. Every collecting native serves the OLDEST pending batch.
+JNIEXPORT void JNICALL Java_PlaacNative_textBegin(JNIEnv *env, jclass, jlong node, jobject text, jlong textLen, jobject starts,
+                                                  jint nrec, jboolean counting) {
     if (nrec < 0 || textLen < 0) return raise(env, "textBegin: negative size");
     const uint64_t *st = (const uint64_t *)direct(env, starts, 8ull * ((uint64_t)nrec + 1), "starts");
     if (!st) return;
     const char *t = (const char *)direct(env, text, (uint64_t)textLen, "text");
     if (!t) return;
-    if (plaac_score_begin_text(c, t, (uint64_t)textLen, st, (uint32_t)nrec, counting ? 1 : 0) != PLAAC_OK) raise(env, plaac_last_error(c));
+    if (plaac_node_text_begin(node_of(node), t, (uint64_t)textLen, st, (uint32_t)nrec, counting ? 1 : 0) != PLAAC_OK)
+        raise(env, node_error(node));
 }
 
-// returns the table's size in bytes; out3 = {needsHost, lastBlank, residues}. needsHost != 0: the device will not vouch for a
-// value of this batch - collect it with the row-level natives (not bound here: score / batchScore) after formatting on the host
-JNIEXPORT jlong JNICALL Java_PlaacNative_textTableSize(JNIEnv *env, jclass, jlong node, jint k, jint corelength, jint ww2,
-                                                       jint prevBlank, jlongArray out3) {
-    plaac_ctx *c = ctx_of(env, node, k);
-    if (!c) return -1;
-    if (!out3 || env->GetArrayLength(out3) != 3) {
-        raise(env, "textTableSize: a long[3] is required");
+// returns the table's size in bytes; out2 = {needsHost, residues}. needsHost != 0: the device will not vouch for a value of
+// this batch (>= 1e9, an infinity, a record without a sequence) - collect it with textRows and format it on the host, or
+// give it up with textDiscard; textTable refuses it.
+JNIEXPORT jlong JNICALL Java_PlaacNative_textTableSize(JNIEnv *env, jclass, jlong node, jint corelength, jint ww2, jlongArray out2) {
+    if (!out2 || env->GetArrayLength(out2) != 2) {
+        raise(env, "textTableSize: a long[2] is required");
         return -1;
     }
     uint64_t bytes = 0, residues = 0;
-    int needs = 0, lastb = 0;
-    if (plaac_score_end_text_table_size(c, corelength, ww2, prevBlank, &bytes, &needs, &lastb, &residues) != PLAAC_OK) {
-        raise(env, plaac_last_error(c));
+    int needs = 0;
+    if (plaac_node_text_table_size(node_of(node), corelength, ww2, &bytes, &needs, &residues) != PLAAC_OK) {
+        raise(env, node_error(node));
         return -1;
     }
-    const jlong out[3] = {(jlong)needs, (jlong)lastb, (jlong)residues};
-    env->SetLongArrayRegion(out3, 0, 3, out);
+    const jlong out[2] = {(jlong)needs, (jlong)residues};
+    env->SetLongArrayRegion(out2, 0, 2, out);
     return (jlong)bytes;
 }
 
-JNIEXPORT void JNICALL Java_PlaacNative_textTable(JNIEnv *env, jclass, jlong node, jint k, jobject tableOut, jlong tableCap,
+static void put_counts(JNIEnv *env, jlongArray counts22, const int64_t *counts) {
+    jlong out[PLAAC_NAA];
+    for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (jlong)counts[i];
+    env->SetLongArrayRegion(counts22, 0, PLAAC_NAA, out);
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_textTable(JNIEnv *env, jclass, jlong node, jobject tableOut, jlong tableCap,
                                                   jlongArray counts22) {
-    plaac_ctx *c = ctx_of(env, node, k);
-    if (!c) return;
     if (tableCap < 0 || (counts22 && env->GetArrayLength(counts22) != PLAAC_NAA)) return raise(env, "textTable: capacity >= 0, counts null or long[22]");
     char *t = (char *)direct(env, tableOut, (uint64_t)tableCap, "tableOut");
     if (!t) return;
     int64_t counts[PLAAC_NAA];
-    if (plaac_score_end_text_table(c, t, (uint64_t)tableCap, counts22 ? counts : nullptr) != PLAAC_OK) return raise(env, plaac_last_error(c));
-    if (counts22) {
-        jlong out[PLAAC_NAA];
-        for (int i = 0; i < PLAAC_NAA; ++i) out[i] = (jlong)counts[i];
-        env->SetLongArrayRegion(counts22, 0, PLAAC_NAA, out);
+    if (plaac_node_text_table(node_of(node), t, (uint64_t)tableCap, counts22 ? counts : nullptr) != PLAAC_OK) return raise(env, node_error(node));
+    if (counts22) put_counts(env, counts22, counts);
+}
+
+// the oldest batch as rows and what the device parsed (plaac_score_end_text): rowsOut nrec * ROW_BYTES, offsetsOut nrec + 1
+// longs, blankEndOut nrec bytes, extentsOut null or 2 * nrec ints, codesOut null or textLen bytes; counts22 null or long[22]
+JNIEXPORT void JNICALL Java_PlaacNative_textRows(JNIEnv *env, jclass, jlong node, jobject rowsOut, jobject codesOut, jobject offsetsOut,
+                                                 jobject blankEndOut, jobject extentsOut, jlongArray counts22) {
+    if (counts22 && env->GetArrayLength(counts22) != PLAAC_NAA) return raise(env, "textRows: counts null or long[22]");
+    const uint64_t nrec = plaac_node_text_oldest_records(node_of(node));
+    plaac_row *rows = (plaac_row *)direct(env, rowsOut, nrec * sizeof(plaac_row), "rowsOut");
+    if (!rows) return;
+    uint64_t *offs = (uint64_t *)direct(env, offsetsOut, 8ull * (nrec + 1), "offsetsOut");
+    if (!offs) return;
+    uint8_t *blank = (uint8_t *)direct(env, blankEndOut, nrec, "blankEndOut");
+    if (!blank) return;
+    uint32_t *ext = nullptr;
+    if (extentsOut && !(ext = (uint32_t *)direct(env, extentsOut, 8ull * nrec, "extentsOut"))) return;
+    uint8_t *codes = nullptr;
+    uint64_t cap = 0;
+    if (codesOut) {
+        codes = (uint8_t *)direct(env, codesOut, 0, "codesOut");
+        if (!codes) return;
+        cap = (uint64_t)env->GetDirectBufferCapacity(codesOut);
     }
+    int64_t counts[PLAAC_NAA];
+    if (plaac_node_text_rows(node_of(node), rows, codes, cap, offs, blank, ext, counts22 ? counts : nullptr) != PLAAC_OK)
+        return raise(env, node_error(node));
+    if (counts22) put_counts(env, counts22, counts);
+}
+
+JNIEXPORT void JNICALL Java_PlaacNative_textDiscard(JNIEnv *env, jclass, jlong node) {
+    if (plaac_node_text_discard(node_of(node)) != PLAAC_OK) raise(env, node_error(node));
+}
+JNIEXPORT jint JNICALL Java_PlaacNative_textPending(JNIEnv *, jclass, jlong node) { return plaac_node_text_pending(node_of(node)); }
+JNIEXPORT jint JNICALL Java_PlaacNative_textOldestRecords(JNIEnv *, jclass, jlong node) {
+    return (jint)plaac_node_text_oldest_records(node_of(node));
+}
+JNIEXPORT void JNICALL Java_PlaacNative_textReset(JNIEnv *, jclass, jlong node) { plaac_node_text_reset(node_of(node)); }
+
+// an uploader thread's half of textBegin (plaac_node_text_upload): returns the uploaded batch's handle
+JNIEXPORT jlong JNICALL Java_PlaacNative_textUpload(JNIEnv *env, jclass, jlong node, jobject text, jlong textLen, jobject starts, jint nrec) {
+    if (nrec < 0 || textLen < 0) {
+        raise(env, "textUpload: negative size");
+        return 0;
+    }
+    const uint64_t *st = (const uint64_t *)direct(env, starts, 8ull * ((uint64_t)nrec + 1), "starts");
+    if (!st) return 0;
+    const char *t = (const char *)direct(env, text, (uint64_t)textLen, "text");
+    if (!t) return 0;
+    plaac_node_text_batch *b = nullptr;
+    if (plaac_node_text_upload(node_of(node), t, (uint64_t)textLen, st, (uint32_t)nrec, &b) != PLAAC_OK) {
+        raise(env, "textUpload failed (out of memory on the host or the device, or a malformed batch)");
+        return 0;
+    }
+    return (jlong)reinterpret_cast<intptr_t>(b);
+}
+JNIEXPORT void JNICALL Java_PlaacNative_textBeginUploaded(JNIEnv *env, jclass, jlong node, jlong batch, jboolean counting) {
+    plaac_node_text_batch *b = reinterpret_cast<plaac_node_text_batch *>(static_cast<intptr_t>(batch));
+    if (plaac_node_text_begin_uploaded(node_of(node), b, counting ? 1 : 0) != PLAAC_OK) raise(env, node_error(node));
+}
+JNIEXPORT void JNICALL Java_PlaacNative_textBatchFree(JNIEnv *, jclass, jlong batch) {
+    plaac_node_text_batch_free(reinterpret_cast<plaac_node_text_batch *>(static_cast<intptr_t>(batch)));
+}
+
+// the counting pass of a two-pass run over text (computeaafreq, :1655-1666): begin per batch, end per batch in the same
+// order; counts22 / residues1 are ADDED to (zero them before a file)
+JNIEXPORT void JNICALL Java_PlaacNative_histogramTextBegin(JNIEnv *env, jclass, jlong node, jobject text, jlong textLen, jobject starts,
+                                                           jint nrec) {
+    if (nrec < 0 || textLen < 0) return raise(env, "histogramTextBegin: negative size");
+    const uint64_t *st = (const uint64_t *)direct(env, starts, 8ull * ((uint64_t)nrec + 1), "starts");
+    if (!st) return;
+    const char *t = (const char *)direct(env, text, (uint64_t)textLen, "text");
+    if (!t) return;
+    if (plaac_node_histogram_text_begin(node_of(node), t, (uint64_t)textLen, st, (uint32_t)nrec) != PLAAC_OK) raise(env, node_error(node));
+}
+JNIEXPORT void JNICALL Java_PlaacNative_histogramTextEnd(JNIEnv *env, jclass, jlong node, jlongArray counts22, jlongArray residues1) {
+    if (!counts22 || env->GetArrayLength(counts22) != PLAAC_NAA || (residues1 && env->GetArrayLength(residues1) != 1))
+        return raise(env, "histogramTextEnd: a long[22] (and null or a long[1]) are required");
+    jlong cur[PLAAC_NAA], res[1] = {0};
+    env->GetLongArrayRegion(counts22, 0, PLAAC_NAA, cur);
+    if (residues1) env->GetLongArrayRegion(residues1, 0, 1, res);
+    int64_t counts[PLAAC_NAA];
+    for (int i = 0; i < PLAAC_NAA; ++i) counts[i] = (int64_t)cur[i];
+    uint64_t r = (uint64_t)res[0];
+    if (plaac_node_histogram_text_end(node_of(node), counts, &r) != PLAAC_OK) return raise(env, node_error(node));
+    put_counts(env, counts22, counts);
+    if (residues1) {
+        res[0] = (jlong)r;
+        env->SetLongArrayRegion(residues1, 0, 1, res);
+    }
+}
+
+// plotsomefastas' per-residue table (:587-649) made on the device (plaac_node_score_tracks_table): returns the table as a
+// byte[] - or null when a value needs the host's formatter (then score(..., tracks) and format on the host as before).
+// labels = for record k the bytes "ORDER \t SEQid" at labelOff[k] .. labelOff[k+1]; rowsOut null or nprot * ROW_BYTES.
+JNIEXPORT jbyteArray JNICALL Java_PlaacNative_tracksTable(JNIEnv *env, jclass, jlong node, jobject codes, jobject offsets, jint nprot,
+                                                          jobject labels, jobject labelOff, jobject rowsOut) {
+    if (nprot < 0) {
+        raise(env, "tracksTable: negative nprot");
+        return nullptr;
+    }
+    const uint64_t *off = (const uint64_t *)direct(env, offsets, 8ull * ((uint64_t)nprot + 1), "offsets");
+    if (!off) return nullptr;
+    const uint8_t *c = (const uint8_t *)direct(env, codes, off[nprot], "codes");
+    if (!c) return nullptr;
+    const uint64_t *lo = (const uint64_t *)direct(env, labelOff, 8ull * ((uint64_t)nprot + 1), "labelOff");
+    if (!lo) return nullptr;
+    const char *lb = (const char *)direct(env, labels, lo[nprot], "labels");
+    if (!lb) return nullptr;
+    plaac_row *rows = nullptr;
+    if (rowsOut && !(rows = (plaac_row *)direct(env, rowsOut, (uint64_t)nprot * sizeof(plaac_row), "rowsOut"))) return nullptr;
+    char *table = nullptr;
+    uint64_t len = 0;
+    int needs = 0;
+    if (plaac_node_score_tracks_table(node_of(node), c, off, (uint32_t)nprot, lb, lo, rows, &table, &len, &needs) != PLAAC_OK) {
+        raise(env, node_error(node));
+        return nullptr;
+    }
+    if (needs || !table) {
+        plaac_table_free(table);
+        return nullptr;
+    }
+    if (len > 0x7fffffffull) {
+        plaac_table_free(table);
+        raise(env, "tracksTable: the table exceeds a Java array (select fewer records per call)");
+        return nullptr;
+    }
+    jbyteArray out = env->NewByteArray((jsize)len);
+    if (out) env->SetByteArrayRegion(out, 0, (jsize)len, (const jbyte *)table);
+    plaac_table_free(table);
+    return out;
 }
 
 } // extern "C"

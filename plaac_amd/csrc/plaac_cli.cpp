@@ -361,6 +361,12 @@ using RowBuf = HugeBuf<plaac_row>;
 struct TextBuf {
     char *p = nullptr;
     size_t n = 0, cap = 0;
+    bool foreign = false; // the library's buffer (plaac_score_tracks_table): released with plaac_table_free, never reused or grown
+    void release() {
+        if (foreign) plaac_table_free(p);
+        else std::free(p);
+        p = nullptr, n = cap = 0, foreign = false;
+    }
     void append(const char *s, size_t k) {
         if (n + k > cap) grow(n + k);
         std::memcpy(p + n, s, k);
@@ -413,6 +419,7 @@ struct Batch {
     int last_blank = 0;
     uint64_t table_residues = 0;
     ~Batch() {
+        if (table.p) table.release(); // (a batch that never reached the sink: its table is still here)
         if (tb) plaac_text_batch_free(tb);
         if (ft) plaac_fasta_text_free(ft);
         else if (f && owned) plaac_fasta_free(f);
@@ -535,6 +542,7 @@ class TextPool {
     }
     void put(TextBuf b) {
         if (!b.p) return;
+        if (b.foreign) return b.release(); // (not the pool's to recycle)
         {
             std::lock_guard<std::mutex> l(m);
             if (idle.size() < KEEP) {
@@ -891,7 +899,7 @@ bool run_pipeline(Engine &eng, const plaac_params &P0, const std::string &path, 
                     auto busy = g_busy.in(1);
                     b->st = (*upload)(ctx, *b);
                     if (b->st != PLAAC_OK) {
-                        b->err = plaac_last_error(ctx);
+                        b->err = plaac_text_upload_error(ctx); // (the uploader's own slot: plaac_last_error is the scoring thread's)
                         failed = true;
                     }
                 }
@@ -1168,6 +1176,15 @@ bool score_all(Engine &eng, const plaac_params &P, const Options &o, const Strea
             double ones[PLAAC_NAA];
             for (double &v : ones) v = 1.0;
             (void)single->make_block(ones, blk0);
+            // Only the block's LENGTH is wanted: what stands in its place until the counts are final must not pass for output
+            // if the run dies first (a block of made-up frequencies would) - comment lines of '#' with the reason up front.
+            const char note[] = "## INCOMPLETE RUN: the parameter block is written here when the run ends ";
+            size_t at = 0;
+            for (char &ch : blk0) {
+                if (ch == '\n') continue;
+                ch = at < sizeof note - 1 ? note[at] : '#';
+                ++at;
+            }
         }
         placeholder_len = blk0.size();
         placed_at += (off_t)single->block_at;
@@ -1497,7 +1514,7 @@ bool plot_some(Engine &eng, const plaac_params &P, const Options &o, const Strea
                                                                  loff.data(), b.rows.data(), &table, &len, &needs_host);
                 if (st != PLAAC_OK) return st;
                 if (!needs_host) {
-                    b.table = TextBuf{table, (size_t)len, (size_t)len};
+                    b.table = TextBuf{table, (size_t)len, (size_t)len, true};
                     b.have_table = true;
                     return PLAAC_OK;
                 }

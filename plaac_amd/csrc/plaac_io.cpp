@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <string>
 #include <thread>
@@ -485,7 +486,14 @@ struct plaac_fasta_stream {
     size_t released = 0;   // bytes of the mapping already handed back to the kernel
     bool trim_next = true; // the next record is the file's first or follows a blank-line-terminated one
     int prev_blank = 1;    // the same for the text batches (plaac_fasta_next_text)
+    // Text batches point into the file image and let its pages go when they are freed: the stream outlives them. live counts
+    // the batches handed out and not yet freed (+ 1 for the handle itself until plaac_fasta_close); whoever brings it to zero
+    // deletes the stream - a close with batches still queued somewhere (bin/plaac's no-GPU exit) defers the unmapping.
+    std::atomic<long> live{1};
 };
+static void fasta_stream_release(plaac_fasta_stream *s) {
+    if (s && s->live.fetch_sub(1, std::memory_order_acq_rel) == 1) delete s;
+}
 
 plaac_status plaac_fasta_open(const char *path, plaac_fasta_stream **out) {
     if (!path || !out) return PLAAC_ERR_ARG;
@@ -561,7 +569,7 @@ plaac_status plaac_fasta_next(plaac_fasta_stream *s, uint32_t max_records, uint6
     return PLAAC_OK; // end of file: *out stays NULL
 }
 
-void plaac_fasta_close(plaac_fasta_stream *s) { delete s; }
+void plaac_fasta_close(plaac_fasta_stream *s) { fasta_stream_release(s); } // (deferred while text batches are alive)
 
 // ---- the stream as batches of text for the device-side parser (K1, round 5) ----
 // The reader is the one serial stage of bin/plaac's single pass, so it does as little as it can: it finds the lines that
@@ -676,6 +684,7 @@ plaac_status plaac_fasta_next_text(plaac_fasta_stream *s, uint32_t max_records, 
     t->len = e - b0;
     t->nrec = (uint32_t)keep;
     t->owner_ = s;
+    s->live.fetch_add(1, std::memory_order_relaxed);
     t->file_off_ = b0;
     s->cursor = e;
     *out = t;
@@ -693,6 +702,7 @@ void plaac_fasta_text_free(plaac_fasta_text *t) {
     std::free(t->starts);
     std::free(t->name_len);
     std::free(t);
+    fasta_stream_release(s);
 }
 
 int plaac_fasta_text_trim_names(plaac_fasta_text *t, const uint8_t *blank_end, int prev_blank) {

@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -80,10 +81,12 @@ size_t sizeof_sweep_targets();
 size_t sizeof_dev_tables();
 } // namespace plaac_lat
 namespace {
-const bool g_lat_unit = [] { // PLAAC_LAT_UNIT=0: the main unit's copies of those kernels (A/B)
-    const char *e = std::getenv("PLAAC_LAT_UNIT");
-    return !(e && e[0] == '0') && plaac_lat::sizeof_sweep_targets() == sizeof(SweepTargets) && plaac_lat::sizeof_dev_tables() == sizeof(DevTables);
-}();
+// (test hook LAT_UNIT=0, read when a context is created: the main unit's copies of those kernels - A/B)
+bool lat_unit_usable() {
+    std::string v;
+    const bool off = sched::knob_value("LAT_UNIT", v) && !v.empty() && v[0] == '0';
+    return !off && plaac_lat::sizeof_sweep_targets() == sizeof(SweepTargets) && plaac_lat::sizeof_dev_tables() == sizeof(DevTables);
+}
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -108,6 +111,7 @@ struct plaac_text_batch {
 struct plaac_ctx {
     int device = 0;
     int num_cus = 256;
+    bool lat_unit = true;         // the latency-form chain kernels of the max-ilp unit (plaac_kernels_lat.hip) are usable
     hipStream_t stream = nullptr;
     DevTables *d_tab = nullptr;   // tables of ctx->params
     DevTables *d_tabs = nullptr;  // tables of the groups of a sweep
@@ -164,6 +168,7 @@ struct plaac_ctx {
     uint8_t *h_stage_up[2] = {nullptr, nullptr};
     hipEvent_t stage_ev_up[2] = {nullptr, nullptr};
     std::mutex up_mu;
+    std::string up_err;           // message of the last failing plaac_text_upload (written by the uploader thread only)
     std::vector<plaac_text_batch *> up_pool;
     uint32_t *d_flag = nullptr;
     KbDivTab *d_divtab = nullptr; // reciprocal tables of the window kernel
@@ -278,17 +283,29 @@ namespace {
 
 thread_local std::string g_create_err;
 
+// Where a failing call leaves its message: the context's slot (plaac_last_error) - or, inside plaac_text_upload, which may run
+// on a second host thread beside the scoring calls of the same context, the uploader's own slot (plaac_text_upload_error):
+// two threads never write one std::string.
+thread_local std::string *t_err_redirect = nullptr;
+struct ErrRedirect {
+    std::string *prev;
+    explicit ErrRedirect(std::string *to) : prev(t_err_redirect) { t_err_redirect = to; }
+    ~ErrRedirect() { t_err_redirect = prev; }
+};
+inline std::string &err_slot(plaac_ctx *ctx);
 #define PL_HIP(ctx, call)                                                                              \
     do {                                                                                               \
         hipError_t e_ = (call);                                                                        \
         if (e_ != hipSuccess) {                                                                        \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            err_slot(ctx) = std::string(#call) + ": " + hipGetErrorString(e_);                         \
             return e_ == hipErrorOutOfMemory ? PLAAC_ERR_NOMEM : PLAAC_ERR_DEVICE;                     \
         }                                                                                              \
     } while (0)
 
+plaac_status fail(plaac_ctx *ctx, plaac_status st, const char *msg);
+inline std::string &err_slot(plaac_ctx *ctx) { return t_err_redirect ? *t_err_redirect : ctx->err; }
 plaac_status fail(plaac_ctx *ctx, plaac_status st, const char *msg) {
-    if (ctx) ctx->err = msg;
+    if (ctx) err_slot(ctx) = msg;
     return st;
 }
 
@@ -298,10 +315,12 @@ void derive_fi_int(const plaac_params &P, DevTables &D, int32_t *info = nullptr)
 // operand of every log-sum-exp of the recurrences is a sum of transition / initial / final log-probabilities (all <= 0
 // here) and at least one emission log-probability (all <= -0.125 here), so it is <= -0.125, and the table's last entry
 // (the most a difference in [40, 40.01) can add) is below half the spacing of the doubles there, 2^-57.
-// PLAAC_LSE_CLAMP=0: never.
+// Test hook LSE_CLAMP=0: never.
 bool lse_clamp_ok(const plaac_params &P) {
-    if (const char *e = std::getenv("PLAAC_LSE_CLAMP")) // (read whenever tables are built: the tests switch it)
-        if (e[0] == '0') return false;
+    {
+        std::string v; // (test hook LSE_CLAMP, read whenever tables are built: the tests switch it)
+        if (sched::knob_value("LSE_CLAMP", v) && !v.empty() && v[0] == '0') return false;
+    }
     auto nonpos = [](double v) { return v <= 0.0; }; // (false for NaN)
     for (int i = 0; i < 2; ++i) {
         if (!nonpos(P.hmm1.li[i]) || !nonpos(P.hmm1.lf[i])) return false;
@@ -324,10 +343,12 @@ bool lse_clamp_ok(const plaac_params &P) {
 //   backward: b_i(t) = LSE_j((lt[i][j] + b_j(t+1)) + le_j(x_{t+1})): |b_0 - b_1| <= Db := max_j |lt[0][j] - lt[1][j]| + ln 2
 //             (also at the end: |lf_0 - lf_1|); the operands differ by at most max_i |lt[i][0] - lt[i][1]| + Db + E.
 // One unit of slack covers the table's interpolation error (3e-6 per step, not accumulating: the bound is per step) and
-// the roundings. The reference's tables: 18.1 / 18.0. PLAAC_LSE_CLAMP=0 or 1: never.
+// the roundings. The reference's tables: 18.1 / 18.0. test hook LSE_CLAMP=0 or 1: never.
 bool lse_range_ok(const plaac_params &P) {
-    if (const char *e = std::getenv("PLAAC_LSE_CLAMP"))
-        if (e[0] == '0' || e[0] == '1') return false;
+    {
+        std::string v;
+        if (sched::knob_value("LSE_CLAMP", v) && !v.empty() && (v[0] == '0' || v[0] == '1')) return false;
+    }
     const plaac_hmm &H = P.hmm1;
     double E = 0.0;
     for (int k = 0; k < NAA; ++k) {
@@ -660,6 +681,7 @@ plaac_status grow(plaac_ctx *ctx, Tp *&ptr, size_t &cap, size_t need) {
 extern "C" {
 
 const char *plaac_last_error(const plaac_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+const char *plaac_text_upload_error(const plaac_ctx *ctx) { return ctx ? ctx->up_err.c_str() : ""; }
 
 int plaac_device_count(void) {
     int n = 0;
@@ -712,6 +734,7 @@ plaac_status plaac_ctx_create(const plaac_params *params, int device_id, plaac_c
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->lat_unit = lat_unit_usable();
     lap("hipSetDevice + properties");
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         g_create_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
@@ -1063,7 +1086,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
         }
         case K_LONG: {
             const uint32_t lcnt = (uint32_t)std::min<uint64_t>((uint64_t)F.gl * 64u, nprot);
-            if (g_lat_unit)
+            if (ctx->lat_unit)
                 plaac_lat::launch_long(dim3(4u * ((lcnt + KA_THREADS - 1) / KA_THREADS)), s, D.d_offsets, PL.neff, PL.order, lcnt, tab,
                                        PL.packed, PL.grow, &tg, lmarg, h0);
             else
@@ -1094,7 +1117,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
     case 3: LAUNCH_VIT(3, LAT, EXT, LIST); break;                                                                  \
     default: LAUNCH_VIT(4, LAT, EXT, LIST); break;                                                                 \
     }
-            if (o.lat && o.ext && g_lat_unit && !C.tracks)
+            if (o.lat && o.ext && ctx->lat_unit && !C.tracks)
                 plaac_lat::launch_vit_lat_ext(dim3(abk), s, D.d_codes, D.d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed,
                                               PL.grow + g0, gbits, &tg, vend);
             else if (o.lat && o.ext) LAUNCH_VIT(1, true, true, false);
@@ -1153,10 +1176,13 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
     hipLaunchKernelGGL((k_fwd<TRK, EXTF>), dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_codes, \
                        D.d_offsets, PL.neff, PL.order + first, cnt, tab, PL.packed, PL.grow + F.segb[o.run], rows0, \
                        TRK ? ctx->d_fwd : (double2 *)nullptr, PL.lat, nprot)
+#ifdef PLAAC_DIAG
             if (K.fwd_direct && !o.trk && !o.ext)
                 hipLaunchKernelGGL(k_fwd_direct, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_codes, D.total,
                                    D.d_offsets, PL.neff, PL.order + first, cnt, tab, rows0);
-            else if (o.trk && o.ext) LAUNCH_FWD(true, true);
+            else
+#endif
+            if (o.trk && o.ext) LAUNCH_FWD(true, true);
             else if (o.trk) LAUNCH_FWD(true, false);
             else if (o.ext) LAUNCH_FWD(false, true);
             else LAUNCH_FWD(false, false);
@@ -1169,7 +1195,7 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             const uint32_t first = part ? o.a * 64u : seg_first(F.segb, o.run);
             const uint32_t cnt = part ? (uint32_t)(std::min<uint64_t>((uint64_t)o.b * 64u, nprot) - first) : seg_count(F.segb, o.run);
             const dim3 grid((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2));
-            if (g_lat_unit && !o.trk)
+            if (ctx->lat_unit && !o.trk)
                 plaac_lat::launch_fwd_pair(grid, s, PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat);
             else if (o.trk)
                 hipLaunchKernelGGL(k_fwd_pair<true>, grid, dim3(KA_THREADS), 0, s, PL.order + first, cnt, tab, PL.packed,
@@ -1196,20 +1222,22 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             else if (o.kern == K_BWD_PAIR)
                 hipLaunchKernelGGL(k_bwd_pair, dim3((cnt + KA_THREADS / 2 - 1) / (KA_THREADS / 2)), dim3(KA_THREADS), 0, s,
                                    PL.order + first, cnt, D.gtab0, PL.packed, PL.grow + g0, ctx->d_bwd);
+#ifdef PLAAC_DIAG // (forms measured slower, EXPERIMENTS.md: the one-pass kernel, the lane-store forms of the forward pass)
             else if (o.kern == K_BWD_FWD_POST)
                 hipLaunchKernelGGL(k_bwd_fwd_post<true>, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
                                    PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, ctx->d_bwd, D.tp);
-            else if (o.sel && K.track_post_form == 1)
-                hipLaunchKernelGGL(k_fwd_post_t<256>, dim3((cnt + 255u) / 256u), dim3(256), 0, s, D.d_offsets, PL.neff,
-                                   PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
-            else if (o.sel && K.track_post_occ3)
+            else if (o.sel && K.track_post_form == 0 && K.track_post_occ3)
                 hipLaunchKernelGGL((k_fwd_post<true, 3>), dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
                                    PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
-            else if (o.sel)
+            else if (o.sel && K.track_post_form == 0)
                 hipLaunchKernelGGL(k_fwd_post<true>, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
                                    PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
-            else
+            else if (!o.sel)
                 hipLaunchKernelGGL(k_fwd_post<false>, dim3((cnt + KF_THREADS - 1) / KF_THREADS), dim3(KF_THREADS), 0, s, D.d_offsets, PL.neff,
+                                   PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
+#endif
+            else // (the forward pass with the posteriors behind a checkpointed backward pass: the one form the release library has)
+                hipLaunchKernelGGL(k_fwd_post_t<256>, dim3((cnt + 255u) / 256u), dim3(256), 0, s, D.d_offsets, PL.neff,
                                    PL.order + first, cnt, tab, PL.packed, PL.grow + g0, PL.lat, h0, (const double2 *)ctx->d_bwd, D.tp);
             break;
         }
@@ -1580,6 +1608,33 @@ static plaac_status score_points(plaac_ctx *ctx, const uint8_t *d_codes, const u
     return PLAAC_OK;
 }
 
+// Test hook (see schedule.hip.inc, read_knobs): key without the PLAAC_ prefix; value == NULL removes it. Read by the contexts
+// created afterwards. The release library knows the form-forcing keys only; the diagnostic build every key.
+plaac_status plaac_debug_set_knob(const char *key, const char *value) {
+    if (!key) return PLAAC_ERR_ARG;
+    bool diag_only = false;
+    if (!sched::knob_key_known(key, &diag_only)) return PLAAC_ERR_ARG;
+#ifndef PLAAC_DIAG
+    if (diag_only) return PLAAC_ERR_UNSUPPORTED; // (a form that only `make DIAG=1` compiles)
+#endif
+    try {
+        sched::KnobHook &h = sched::knob_hook();
+        std::lock_guard<std::mutex> lock(h.mu);
+        if (value) h.v[key] = value;
+        else h.v.erase(key);
+    } catch (...) {
+        return PLAAC_ERR_NOMEM;
+    }
+    return PLAAC_OK;
+}
+int plaac_diag_build(void) {
+#ifdef PLAAC_DIAG
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 long plaac_debug_schedule(const plaac_sched_query *q, char *buf, size_t cap) {
     using namespace sched;
     if (!q || !buf || q->nprot == 0 || q->npoints == 0 || q->ngroups_sweep == 0 || q->ngroups_sweep > (uint32_t)MAXG) return -1;
@@ -1735,7 +1790,10 @@ plaac_status plaac_last_exact_fallbacks(plaac_ctx *ctx, uint32_t *count) {
     PL_HIP(ctx, hipEventSynchronize(ctx->ev[(ctx->ncalls - 1) % plaac_ctx::EV_SETS][10 /* E_JOIN */]));
     size_t word = 0;
 #ifdef PLAAC_DIAG // (diagnostic build only: PLAAC_DEBUG_COUNTER=16 reads another word of the call's counter set - 16: the core list's length)
-    if (const char *dbg = std::getenv("PLAAC_DEBUG_COUNTER")) word = (size_t)std::min(31L, std::max(0L, std::atol(dbg)));
+    {
+        std::string dbg;
+        if (sched::knob_value("DEBUG_COUNTER", dbg)) word = (size_t)std::min(31L, std::max(0L, std::atol(dbg.c_str())));
+    }
 #endif
     PL_HIP(ctx, hipMemcpy(count, ctx->d_kbcnt + (size_t)KB_COUNTER_WORDS * ((ctx->ncalls - 1) & 3u) + word, sizeof(uint32_t),
                           hipMemcpyDeviceToHost));
@@ -2188,10 +2246,12 @@ static const FastaLut &fasta_lut() {
 plaac_status plaac_text_upload(plaac_ctx *ctx, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
                                plaac_text_batch **out) {
     if (!ctx || !out) return PLAAC_ERR_ARG;
+    ErrRedirect own_slot(&ctx->up_err); // (every message below goes to plaac_text_upload_error, not to the scoring thread's slot)
     *out = nullptr;
-    if (nrec && (!text || !starts)) return PLAAC_ERR_ARG;
+    if (nrec && (!text || !starts)) return fail(ctx, PLAAC_ERR_ARG, "plaac_text_upload: null text or starts");
     for (uint32_t i = 0; i < nrec; ++i)
-        if (starts[i + 1] < starts[i] || starts[i + 1] > text_len || starts[i + 1] - starts[i] >= 0x7fffffffull) return PLAAC_ERR_ARG;
+        if (starts[i + 1] < starts[i] || starts[i + 1] > text_len || starts[i + 1] - starts[i] >= 0x7fffffffull)
+            return fail(ctx, PLAAC_ERR_ARG, "plaac_text_upload: record starts must ascend inside the text, a record below 2^31 bytes");
     PL_HIP(ctx, hipSetDevice(ctx->device));
     plaac_text_batch *tb = nullptr;
     {
@@ -2203,7 +2263,7 @@ plaac_status plaac_text_upload(plaac_ctx *ctx, const char *text, uint64_t text_l
         }
     }
     if (!tb) tb = new (std::nothrow) plaac_text_batch();
-    if (!tb) return PLAAC_ERR_NOMEM;
+    if (!tb) return fail(ctx, PLAAC_ERR_NOMEM, "plaac_text_upload: out of host memory");
     tb->ctx = ctx;
     tb->nrec = nrec;
     tb->total = 0;
@@ -2236,7 +2296,7 @@ plaac_status plaac_text_upload(plaac_ctx *ctx, const char *text, uint64_t text_l
         unsigned long long total = 0;
         hipError_t e = hipMemcpyAsync(&total, tb->d_total, sizeof total, hipMemcpyDeviceToHost, ctx->up);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->up);
-        if (e != hipSuccess) return give_back(PLAAC_ERR_DEVICE);
+        if (e != hipSuccess) return give_back(fail(ctx, PLAAC_ERR_DEVICE, hipGetErrorString(e)));
         tb->total = total;
     }
     *out = tb;

@@ -34,6 +34,26 @@ struct plaac_node {
     // use-after-free of the contexts
     std::mutex live_mu;
     std::vector<plaac_node_batch *> live;
+    // text batches in flight (plaac_node_text_*): which context each went to, oldest first
+    struct TextJob {
+        int ctx;
+        uint32_t nrec;
+        bool hist;
+        bool sized;
+    };
+    std::vector<TextJob> text_fifo;
+    std::vector<int> text_busy;  // pending batches per context (at most two: the contexts' rule)
+    int text_next = 0;           // round robin
+    int text_prev_blank = 1;     // how the record before the next collected batch ended (1: a file's first batch)
+    int text_last_blank = 1;     // ... as reported by the size call of the oldest batch
+    std::vector<std::unique_ptr<std::mutex>> upload_mu; // one upload at a time per context
+};
+
+struct plaac_node_text_batch {
+    plaac_node *node;
+    int ctx;
+    uint32_t nrec;
+    plaac_text_batch *tb;
 };
 
 // a batch whose shards are resident on the devices of a node
@@ -158,6 +178,14 @@ plaac_status plaac_node_create(const plaac_params *params, const int *device_ids
             plaac_node_destroy(node);
             return bad;
         }
+    try {
+        node->text_busy.assign(devs.size(), 0);
+        for (size_t k = 0; k < devs.size(); ++k) node->upload_mu.emplace_back(new std::mutex());
+    } catch (...) {
+        g_node_create_err = "out of host memory";
+        plaac_node_destroy(node);
+        return PLAAC_ERR_NOMEM;
+    }
     *out = node;
     return PLAAC_OK;
 }
@@ -498,6 +526,226 @@ plaac_status plaac_node_score(plaac_node *node, const uint8_t *codes, const uint
     st = plaac_node_batch_score(nb, rows, tracks);
     plaac_node_batch_free(nb);
     return st;
+}
+
+
+// ---- FASTA text through a node (round 6): the contexts' text entry points, dealt round robin, collected in order -----------
+namespace {
+plaac_status ctx_fail(plaac_node *node, int k, plaac_status st) {
+    node->err = std::string("device ") + std::to_string(node->device[(size_t)k]) + ": " + plaac_last_error(node->ctx[(size_t)k]);
+    return st;
+}
+// the context the next batch goes to: round robin over those with a free slot
+int text_pick(plaac_node *node) {
+    const int n = (int)node->ctx.size();
+    for (int i = 0; i < n; ++i) {
+        const int k = (node->text_next + i) % n;
+        if (node->text_busy[(size_t)k] < 2) {
+            node->text_next = (k + 1) % n;
+            return k;
+        }
+    }
+    return -1;
+}
+plaac_status text_push(plaac_node *node, int k, uint32_t nrec, bool hist) {
+    try {
+        node->text_fifo.push_back(plaac_node::TextJob{k, nrec, hist, false});
+    } catch (...) {
+        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+    }
+    ++node->text_busy[(size_t)k];
+    return PLAAC_OK;
+}
+void text_pop(plaac_node *node) {
+    --node->text_busy[(size_t)node->text_fifo.front().ctx];
+    node->text_fifo.erase(node->text_fifo.begin());
+}
+} // namespace
+
+plaac_status plaac_node_text_begin(plaac_node *node, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
+                                   int counting) {
+    if (!node) return PLAAC_ERR_ARG;
+    const int k = text_pick(node);
+    if (k < 0) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_begin: every context holds two pending batches (collect the oldest first)");
+    try {
+        node->text_fifo.reserve(node->text_fifo.size() + 1);
+    } catch (...) {
+        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+    }
+    const plaac_status st = plaac_score_begin_text(node->ctx[(size_t)k], text, text_len, starts, nrec, counting);
+    if (st != PLAAC_OK) return ctx_fail(node, k, st);
+    return text_push(node, k, nrec, false);
+}
+
+plaac_status plaac_node_text_upload(plaac_node *node, const char *text, uint64_t text_len, const uint64_t *starts, uint32_t nrec,
+                                    plaac_node_text_batch **out) {
+    if (!node || !out) return PLAAC_ERR_ARG;
+    *out = nullptr;
+    // (may run on another host thread than the scoring calls: touches nothing of the node but the per-context upload lock and
+    //  an atomic-free round robin of its own - the context is chosen by the batch's turn, which only this thread advances)
+    static thread_local int turn = 0;
+    const int n = (int)node->ctx.size();
+    if (n == 0) return PLAAC_ERR_ARG;
+    const int k = turn++ % n;
+    plaac_node_text_batch *b = new (std::nothrow) plaac_node_text_batch{node, k, nrec, nullptr};
+    if (!b) return PLAAC_ERR_NOMEM;
+    plaac_status st;
+    {
+        std::lock_guard<std::mutex> lock(*node->upload_mu[(size_t)k]);
+        st = plaac_text_upload(node->ctx[(size_t)k], text, text_len, starts, nrec, &b->tb);
+    }
+    if (st != PLAAC_OK) {
+        delete b;
+        return st; // (the message: plaac_text_upload_error(plaac_node_ctx(node, k)); node->err belongs to the scoring thread)
+    }
+    *out = b;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_node_text_begin_uploaded(plaac_node *node, plaac_node_text_batch *batch, int counting) {
+    if (!node || !batch || batch->node != node) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_begin_uploaded: not a batch of this node");
+    const int k = batch->ctx;
+    if (node->text_busy[(size_t)k] >= 2)
+        return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_begin_uploaded: the batch's context holds two pending batches (collect the oldest first)");
+    try {
+        node->text_fifo.reserve(node->text_fifo.size() + 1);
+    } catch (...) {
+        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+    }
+    const plaac_status st = plaac_score_begin_uploaded(node->ctx[(size_t)k], batch->tb, counting);
+    if (st != PLAAC_OK) return ctx_fail(node, k, st); // (the batch is still the caller's)
+    const uint32_t nrec = batch->nrec;
+    delete batch; // (the context consumed the upload)
+    return text_push(node, k, nrec, false);
+}
+
+void plaac_node_text_batch_free(plaac_node_text_batch *batch) {
+    if (!batch) return;
+    if (batch->tb) plaac_text_batch_free(batch->tb);
+    delete batch;
+}
+
+plaac_status plaac_node_text_table_size(plaac_node *node, int corelength, int ww2, uint64_t *table_bytes, int *needs_host,
+                                        uint64_t *residues) {
+    if (!node) return PLAAC_ERR_ARG;
+    if (!table_bytes || !needs_host) return node_fail(node, PLAAC_ERR_ARG, "null argument");
+    if (node->text_fifo.empty()) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_table_size: no batch is pending");
+    plaac_node::TextJob &J = node->text_fifo.front();
+    if (J.hist) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_table_size: the oldest batch was begun for counting only");
+    int lastb = node->text_prev_blank;
+    const plaac_status st = plaac_score_end_text_table_size(node->ctx[(size_t)J.ctx], corelength, ww2, node->text_prev_blank, table_bytes,
+                                                            needs_host, &lastb, residues);
+    if (st != PLAAC_OK) return ctx_fail(node, J.ctx, st);
+    node->text_last_blank = lastb;
+    J.sized = true;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_node_text_table(plaac_node *node, char *table, uint64_t table_cap, int64_t *counts) {
+    if (!node) return PLAAC_ERR_ARG;
+    if (node->text_fifo.empty()) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_table: no batch is pending");
+    const plaac_node::TextJob J = node->text_fifo.front();
+    if (!J.sized) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_table: call plaac_node_text_table_size first");
+    const plaac_status st = plaac_score_end_text_table(node->ctx[(size_t)J.ctx], table, table_cap, counts);
+    if (st != PLAAC_OK) return ctx_fail(node, J.ctx, st); // (the context keeps the batch: a larger buffer, or plaac_node_text_rows)
+    node->text_prev_blank = node->text_last_blank;
+    text_pop(node);
+    return PLAAC_OK;
+}
+
+plaac_status plaac_node_text_rows(plaac_node *node, plaac_row *rows, uint8_t *codes, uint64_t codes_cap, uint64_t *offsets,
+                                  uint8_t *blank_end, uint32_t *extents, int64_t *counts) {
+    if (!node) return PLAAC_ERR_ARG;
+    if (node->text_fifo.empty()) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_rows: no batch is pending");
+    const plaac_node::TextJob J = node->text_fifo.front();
+    if (J.hist) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_rows: the oldest batch was begun for counting only");
+    const plaac_status st = plaac_score_end_text(node->ctx[(size_t)J.ctx], rows, codes, codes_cap, offsets, blank_end, extents, counts);
+    text_pop(node); // (plaac_score_end_text gives the slot up whatever happens)
+    if (st != PLAAC_OK) return ctx_fail(node, J.ctx, st);
+    if (J.nrec && blank_end) node->text_prev_blank = blank_end[J.nrec - 1] ? 1 : 0;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_node_text_discard(plaac_node *node) {
+    if (!node) return PLAAC_ERR_ARG;
+    if (node->text_fifo.empty()) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_text_discard: no batch is pending");
+    const plaac_node::TextJob J = node->text_fifo.front();
+    plaac_status st;
+    if (J.hist) {
+        int64_t counts[PLAAC_NAA];
+        st = plaac_histogram_end_text(node->ctx[(size_t)J.ctx], counts, nullptr);
+    } else {
+        // how the batch's last record ended is still owed to the batch behind it
+        std::vector<plaac_row> rows;
+        std::vector<uint64_t> offs;
+        std::vector<uint8_t> blank;
+        try {
+            rows.resize(J.nrec);
+            offs.resize((size_t)J.nrec + 1);
+            blank.resize(J.nrec);
+        } catch (...) {
+            return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+        }
+        st = plaac_score_end_text(node->ctx[(size_t)J.ctx], rows.data(), nullptr, 0, offs.data(), blank.data(), nullptr, nullptr);
+        if (st == PLAAC_OK && J.nrec) node->text_prev_blank = blank[J.nrec - 1] ? 1 : 0;
+    }
+    text_pop(node);
+    if (st != PLAAC_OK) return ctx_fail(node, J.ctx, st);
+    return PLAAC_OK;
+}
+
+int plaac_node_text_pending(const plaac_node *node) { return node ? (int)node->text_fifo.size() : 0; }
+uint32_t plaac_node_text_oldest_records(const plaac_node *node) {
+    return (node && !node->text_fifo.empty()) ? node->text_fifo.front().nrec : 0u;
+}
+void plaac_node_text_reset(plaac_node *node) {
+    if (node) node->text_prev_blank = node->text_last_blank = 1;
+}
+
+plaac_status plaac_node_histogram_text_begin(plaac_node *node, const char *text, uint64_t text_len, const uint64_t *starts,
+                                             uint32_t nrec) {
+    if (!node) return PLAAC_ERR_ARG;
+    const int k = text_pick(node);
+    if (k < 0) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_histogram_text_begin: every context holds two pending batches");
+    try {
+        node->text_fifo.reserve(node->text_fifo.size() + 1);
+    } catch (...) {
+        return node_fail(node, PLAAC_ERR_NOMEM, "out of host memory");
+    }
+    const plaac_status st = plaac_histogram_begin_text(node->ctx[(size_t)k], text, text_len, starts, nrec);
+    if (st != PLAAC_OK) return ctx_fail(node, k, st);
+    return text_push(node, k, nrec, true);
+}
+
+plaac_status plaac_node_histogram_text_end(plaac_node *node, int64_t counts[PLAAC_NAA], uint64_t *residues) {
+    if (!node) return PLAAC_ERR_ARG;
+    if (!counts) return node_fail(node, PLAAC_ERR_ARG, "null counts");
+    if (node->text_fifo.empty()) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_histogram_text_end: no batch is pending");
+    const plaac_node::TextJob J = node->text_fifo.front();
+    if (!J.hist) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_histogram_text_end: the oldest batch was begun for scoring");
+    int64_t c[PLAAC_NAA];
+    uint64_t r = 0;
+    const plaac_status st = plaac_histogram_end_text(node->ctx[(size_t)J.ctx], c, &r);
+    text_pop(node);
+    if (st != PLAAC_OK) return ctx_fail(node, J.ctx, st);
+    for (int i = 0; i < PLAAC_NAA; ++i) counts[i] += c[i];
+    if (residues) *residues += r;
+    return PLAAC_OK;
+}
+
+plaac_status plaac_node_score_tracks_table(plaac_node *node, const uint8_t *codes, const uint64_t *offsets, uint32_t nprot,
+                                           const char *labels, const uint64_t *label_off, plaac_row *rows, char **table,
+                                           uint64_t *table_len, int *needs_host) {
+    if (!node) return PLAAC_ERR_ARG;
+    if (!node->text_fifo.empty()) return node_fail(node, PLAAC_ERR_ARG, "plaac_node_score_tracks_table: text batches are pending");
+    const int n = (int)node->ctx.size();
+    if (n == 0) return PLAAC_ERR_ARG;
+    const int k = node->text_next % n;
+    node->text_next = (k + 1) % n;
+    const plaac_status st = plaac_score_tracks_table(node->ctx[(size_t)k], codes, offsets, nprot, labels, label_off, rows, table, table_len,
+                                                     needs_host);
+    if (st != PLAAC_OK) return ctx_fail(node, k, st);
+    return PLAAC_OK;
 }
 
 } // extern "C"

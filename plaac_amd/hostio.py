@@ -211,6 +211,34 @@ def format_summary_row(row, name, codes, corelength=60, ww2=41):
     return buf.raw[:k].decode()
 
 
+def format_summary_rows(rows, names, codes, offsets, corelength=60, ww2=41):
+    """The table lines (newline-terminated) of a whole slice as one bytes object: rows = ROW_DTYPE array, names = list of
+    bytes, codes / offsets = the slice's untrimmed residue codes and its n + 1 offsets (relative to codes). One
+    plaac_format_summary_row_n call per record into one buffer; records without a line (prot_len 0) add nothing."""
+    L = _lib()
+    rows = np.ascontiguousarray(rows, dtype=native.ROW_DTYPE)
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    offs = np.asarray(offsets, dtype=np.int64)
+    n = len(rows)
+    f = L.plaac_format_summary_row_n
+    f.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    f.restype = C.c_long
+    lens = np.diff(offs)
+    cap = int(3 * lens.sum() + sum(len(x) for x in names) + n * (ww2 + 8701) + 1)
+    buf = np.empty(cap, dtype=np.uint8)
+    base, at = buf.ctypes.data, 0
+    rbase, cbase, rb = rows.ctypes.data, codes.ctypes.data, rows.dtype.itemsize
+    for i in range(n):
+        nm = names[i]
+        k = f(rbase + i * rb, nm, len(nm), cbase + int(offs[i]), int(lens[i]), corelength, ww2, base + at, cap - at)
+        if k < 0:
+            raise RuntimeError("summary row buffer too small")
+        if k:
+            buf[at + k] = 10
+            at += k + 1
+    return buf[:at].tobytes()
+
+
 def format_track_rows(tracks, first, codes, n, order_id, name):
     T = native.Tracks(**{k: tracks[k].ctypes.data for k in native.TRACK_U8 + native.TRACK_F64})
     codes = np.ascontiguousarray(codes, dtype=np.uint8)

@@ -18,7 +18,34 @@ NAA = 22
 LUTLEN = 4001
 ABI_VERSION = 2
 
-PLAAC_OK, PLAAC_ERR_ARG, PLAAC_ERR_DEVICE, PLAAC_ERR_NOMEM, PLAAC_ERR_IO = range(5)
+PLAAC_OK, PLAAC_ERR_ARG, PLAAC_ERR_DEVICE, PLAAC_ERR_NOMEM, PLAAC_ERR_IO, PLAAC_ERR_UNSUPPORTED = range(6)
+
+# Test hooks of the library (plaac_debug_set_knob; include/plaac_native.h "environment and test hooks"): the library itself
+# reads eight documented environment variables and nothing else; THIS binding turns PLAAC_<KEY> of its own process
+# environment into hook calls whenever a Context / Node is created, so that tests and tools/ keep their switches.
+HOOK_KEYS = ("KB_LANE", "KB_LANE_MIN_GROUPS", "MIXED", "MIXED_GROUPS", "MIXED_MIN_REST", "TRACK_CONSEC", "KB_PER_PROTEIN",
+             "GENERIC_TRACKS", "CORE_PAR", "CORE_LIST", "FI_INT", "LSE_CLAMP", "SWEEP_LATENCY", "SWEEP_CORE_ASIDE", "KB_PRIO",
+             "KB_SIDE", "SEGMENT_MIN_ROWS", "RF_GRID", "LAT_UNIT", "POLL_PLAN", "STREAM_PROBE")
+# forms that only the diagnostic build (`make DIAG=1` -> libplaac_native_diag.so, PLAAC_NATIVE_LIB) compiles
+DIAG_KEYS = ("SWEEP_REST_ASIDE", "SWEEP_CHAINS_FIRST", "CORE_LONG_LIST", "PIPE_SEGMENTS", "TRACK_SEGMENTS", "TRACK_FUSED",
+             "TRACK_VIT_MIXED", "TRACK_CKPT", "FWD_DIRECT", "TRACK_KB_LDS", "TRACK_POST_FORM", "TRACK_POST_OCC", "TRACK_ONE_PASS",
+             "TRACK_KB_LATE", "TRACK_VIT_EARLY", "FINISH_KERNEL", "VIT_STOP", "DEBUG_SKIP", "DEBUG_SKIP_FROM", "DEBUG_COUNTER")
+
+
+class DiagKnob(RuntimeError):
+    """the environment asks for a form that only the diagnostic build of the library has (tests: skipped, see conftest.py)"""
+
+
+def apply_env_knobs(L=None):
+    L = L or load()
+    for key in HOOK_KEYS + DIAG_KEYS:
+        v = os.environ.get("PLAAC_" + key)
+        st = L.plaac_debug_set_knob(key.encode(), None if v is None else v.encode())
+        if st == PLAAC_ERR_UNSUPPORTED:
+            if v is not None:
+                raise DiagKnob("PLAAC_%s needs the diagnostic build of the library (make DIAG=1; PLAAC_NATIVE_LIB)" % key)
+        elif st != PLAAC_OK:
+            raise PlaacError(st, "plaac_debug_set_knob(%s) failed" % key)
 
 
 class PlaacError(RuntimeError):
@@ -77,6 +104,10 @@ EXPORTS = (
     "plaac_node_set_overlap", "plaac_shard_plan", "plaac_node_batch_upload", "plaac_node_batch_histogram",
     "plaac_node_batch_score", "plaac_node_batch_sweep", "plaac_node_batch_free", "plaac_node_batch_records",
     "plaac_node_batch_residues", "plaac_node_batch_last_error", "plaac_rows_to_wire", "plaac_rows_from_wire", "plaac_score_begin", "plaac_score_end", "plaac_score_begin_counting", "plaac_score_end_counts", "plaac_score_begin_text", "plaac_score_end_text", "plaac_score_end_text_table_size", "plaac_score_end_text_table", "plaac_histogram_begin_text", "plaac_histogram_end_text", "plaac_text_upload", "plaac_score_begin_uploaded", "plaac_text_batch_free", "plaac_score_tracks_table", "plaac_table_free", "plaac_debug_schedule",
+    "plaac_node_text_begin", "plaac_node_text_upload", "plaac_node_text_begin_uploaded", "plaac_node_text_batch_free",
+    "plaac_node_text_table_size", "plaac_node_text_table", "plaac_node_text_rows", "plaac_node_text_discard",
+    "plaac_node_text_pending", "plaac_node_text_oldest_records", "plaac_node_text_reset", "plaac_node_histogram_text_begin",
+    "plaac_node_histogram_text_end", "plaac_node_score_tracks_table", "plaac_debug_set_knob", "plaac_diag_build", "plaac_text_upload_error",
 )
 
 _lib = None
@@ -188,6 +219,28 @@ def load():
     L.plaac_batch_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.plaac_score_sweep_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
                                            C.c_uint32, C.c_void_p, C.c_void_p]
+    L.plaac_node_text_begin.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int]
+    L.plaac_node_text_upload.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.plaac_node_text_begin_uploaded.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.plaac_node_text_batch_free.argtypes = [C.c_void_p]
+    L.plaac_node_text_batch_free.restype = None
+    L.plaac_node_text_table_size.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    L.plaac_node_text_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.plaac_node_text_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.plaac_node_text_discard.argtypes = [C.c_void_p]
+    L.plaac_node_text_pending.argtypes = [C.c_void_p]
+    L.plaac_node_text_oldest_records.argtypes = [C.c_void_p]
+    L.plaac_node_text_oldest_records.restype = C.c_uint32
+    L.plaac_node_text_reset.argtypes = [C.c_void_p]
+    L.plaac_node_text_reset.restype = None
+    L.plaac_node_histogram_text_begin.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32]
+    L.plaac_node_histogram_text_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.plaac_node_score_tracks_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p,
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    L.plaac_text_upload_error.argtypes = [C.c_void_p]
+    L.plaac_text_upload_error.restype = C.c_char_p
+    L.plaac_debug_set_knob.argtypes = [C.c_char_p, C.c_char_p]
+    L.plaac_diag_build.restype = C.c_int
     _lib = L
     return L
 
@@ -253,6 +306,8 @@ class Context:
     def __init__(self, params=None, device=0):
         self._L = load()
         self._h = C.c_void_p()
+        apply_env_knobs(self._L)
+        self._h = C.c_void_p()
         self.params = params if params is not None else make_params()
         st = self._L.plaac_ctx_create(C.addressof(self.params), int(device), C.byref(self._h))
         if st != PLAAC_OK:
@@ -279,6 +334,7 @@ class Context:
         self.close()
 
     def set_params(self, params):
+        apply_env_knobs(self._L)  # (LSE_CLAMP is read whenever tables are built)
         self._check(self._L.plaac_ctx_set_params(self._h, C.addressof(params)))
         self.params = params
 
@@ -495,6 +551,8 @@ class Node:
     def __init__(self, params=None, devices=None):
         self._L = load()
         self._h = C.c_void_p()
+        apply_env_knobs(self._L)
+        self._h = C.c_void_p()
         self.params = params if params is not None else make_params()
         ids = None if devices is None else (C.c_int * len(devices))(*[int(d) for d in devices])
         st = self._L.plaac_node_create(C.addressof(self.params), ids, 0 if devices is None else len(devices),
@@ -532,6 +590,7 @@ class Node:
         self.close()
 
     def set_params(self, params):
+        apply_env_knobs(self._L)
         self._check(self._L.plaac_node_set_params(self._h, C.addressof(params)))
         self.params = params
 
@@ -560,6 +619,87 @@ class Node:
 
     def set_overlap(self, on=True):
         self._check(self._L.plaac_node_set_overlap(self._h, 1 if on else 0))
+
+    # ---- FASTA text through the node (plaac_node_text_*): batches in file order, collected oldest first ----
+    def text_begin(self, text, starts, counting=False):
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        self._check(self._L.plaac_node_text_begin(self._h, text, len(text), starts.ctypes.data, len(starts) - 1, 1 if counting else 0))
+
+    def text_upload(self, text, starts):
+        """plaac_node_text_upload (may run on another thread than the scoring calls); returns the uploaded batch's handle"""
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        tb = C.c_void_p()
+        st = self._L.plaac_node_text_upload(self._h, text, len(text), starts.ctypes.data, len(starts) - 1, C.byref(tb))
+        if st != PLAAC_OK:
+            raise PlaacError(st, "plaac_node_text_upload failed")
+        return tb
+
+    def text_begin_uploaded(self, tb, counting=False):
+        self._check(self._L.plaac_node_text_begin_uploaded(self._h, tb, 1 if counting else 0))
+
+    def text_pending(self):
+        return int(self._L.plaac_node_text_pending(self._h))
+
+    def text_reset(self):
+        self._L.plaac_node_text_reset(self._h)
+
+    def text_discard(self):
+        self._check(self._L.plaac_node_text_discard(self._h))
+
+    def text_table(self, corelength=60, ww2=41, counting=False):
+        """the oldest pending batch's table text: (bytes, residues[, counts]) - or (None, residues) with the batch still pending when
+        the device asks for the host's formatter (collect it with text_rows, or text_discard)"""
+        size, needs, nres = C.c_uint64(), C.c_int(), C.c_uint64()
+        self._check(self._L.plaac_node_text_table_size(self._h, int(corelength), int(ww2), C.byref(size), C.byref(needs), C.byref(nres)))
+        if needs.value:
+            return None, int(nres.value)
+        buf = C.create_string_buffer(max(int(size.value), 1))
+        counts = np.zeros(NAA, dtype=np.int64)
+        self._check(self._L.plaac_node_text_table(self._h, buf, size.value, counts.ctypes.data if counting else None))
+        out = (buf.raw[:size.value], int(nres.value))
+        return out + (counts,) if counting else out
+
+    def text_rows(self, text_len, counting=False):
+        """plaac_node_text_rows: the oldest pending batch as (rows, codes, offsets, blank_end, extents[, counts])"""
+        nrec = int(self._L.plaac_node_text_oldest_records(self._h))
+        rows = np.zeros(nrec, dtype=ROW_DTYPE)
+        codes = np.zeros(max(text_len, 1), dtype=np.uint8)
+        offsets = np.zeros(nrec + 1, dtype=np.uint64)
+        blank = np.zeros(max(nrec, 1), dtype=np.uint8)
+        ext = np.zeros((max(nrec, 1), 2), dtype=np.uint32)
+        counts = np.zeros(NAA, dtype=np.int64)
+        self._check(self._L.plaac_node_text_rows(self._h, rows.ctypes.data, codes.ctypes.data, len(codes), offsets.ctypes.data,
+                                                 blank.ctypes.data, ext.ctypes.data, counts.ctypes.data if counting else None))
+        out = (rows, codes[:int(offsets[-1])], offsets, blank[:nrec], ext[:nrec])
+        return out + (counts,) if counting else out
+
+    def histogram_text_begin(self, text, starts):
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        self._check(self._L.plaac_node_histogram_text_begin(self._h, text, len(text), starts.ctypes.data, len(starts) - 1))
+
+    def histogram_text_end(self, counts, residues=0):
+        """adds the oldest counting batch's counts to `counts` (int64[22]); returns the residue total so far"""
+        r = C.c_uint64(int(residues))
+        self._check(self._L.plaac_node_histogram_text_end(self._h, counts.ctypes.data, C.byref(r)))
+        return int(r.value)
+
+    def score_tracks_table(self, codes, offsets, labels):
+        """plaac_node_score_tracks_table: (table bytes or None when the host's formatter is needed, rows)"""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        blob = b"".join(labels)
+        loff = np.zeros(n + 1, dtype=np.uint64)
+        loff[1:] = np.cumsum([len(x) for x in labels])
+        rows = np.zeros(n, dtype=ROW_DTYPE)
+        tab, tlen, needs = C.c_void_p(), C.c_uint64(), C.c_int()
+        self._check(self._L.plaac_node_score_tracks_table(self._h, codes.ctypes.data, offsets.ctypes.data, n, blob, loff.ctypes.data,
+                                                          rows.ctypes.data, C.byref(tab), C.byref(tlen), C.byref(needs)))
+        if needs.value or not tab.value:
+            return (None if needs.value else b""), rows
+        out = C.string_at(tab.value, tlen.value)
+        self._L.plaac_table_free(tab)
+        return out, rows
 
     def upload(self, codes, offsets):
         """plaac_node_batch_upload: the batch cut with plaac_shard_plan, every shard resident on its device"""
@@ -644,6 +784,7 @@ class SchedQuery(C.Structure):
 
 def debug_schedule(q):
     """plaac_debug_schedule: the schedule of a described scoring call as text (host only; no device needed)"""
+    apply_env_knobs()
     for cap in (1 << 18, 1 << 25):  # (a sweep of thousands of points prints thousands of launches)
         buf = C.create_string_buffer(cap)
         n = load().plaac_debug_schedule(C.addressof(q), buf, len(buf))

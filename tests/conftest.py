@@ -14,6 +14,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    """A test that forces a form only the diagnostic build of the library compiles (`make DIAG=1`; forms measured slower and
+    no longer selected, EXPERIMENTS.md) is SKIPPED against the release library - plaac_amd.native raises DiagKnob when the
+    environment asks for such a form. Run those tests with PLAAC_NATIVE_LIB=plaac_amd/libplaac_native_diag.so."""
+    outcome = yield
+    if outcome.excinfo is not None:
+        from plaac_amd import native as nv
+        if isinstance(outcome.excinfo[1], nv.DiagKnob):
+            try:
+                pytest.skip(str(outcome.excinfo[1]))
+            except pytest.skip.Exception:
+                outcome.force_exception(sys.exc_info()[1])
+
+
 def read_fasta_simple(path):
     """plain reader for the committed fixtures (no blank lines / quirks in them)"""
     recs, name, buf = [], None, []

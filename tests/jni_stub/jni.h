@@ -11,6 +11,7 @@ typedef int32_t jint;
 typedef int64_t jlong;
 typedef double jdouble;
 typedef uint8_t jboolean;
+typedef int8_t jbyte;
 typedef jint jsize;
 class _jobject {};
 typedef _jobject *jobject;
@@ -20,6 +21,7 @@ typedef jarray jintArray;
 typedef jarray jlongArray;
 typedef jarray jdoubleArray;
 typedef jarray jobjectArray;
+typedef jarray jbyteArray;
 struct JNIEnv_ {
     jclass FindClass(const char *name);
     jint ThrowNew(jclass cls, const char *msg);
@@ -29,6 +31,9 @@ struct JNIEnv_ {
     void GetIntArrayRegion(jintArray a, jsize start, jsize len, jint *buf);
     void GetDoubleArrayRegion(jdoubleArray a, jsize start, jsize len, jdouble *buf);
     void SetLongArrayRegion(jlongArray a, jsize start, jsize len, const jlong *buf);
+    void GetLongArrayRegion(jlongArray a, jsize start, jsize len, jlong *buf);
+    jbyteArray NewByteArray(jsize len);
+    void SetByteArrayRegion(jbyteArray a, jsize start, jsize len, const jbyte *buf);
     jobject GetObjectArrayElement(jobjectArray a, jsize index);
 };
 typedef JNIEnv_ JNIEnv;

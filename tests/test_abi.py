@@ -153,6 +153,29 @@ def test_cli_fails_loudly_without_a_gpu(tmp_path):
     assert r.returncode == 0 and r.stdout.splitlines()[0] == "0.000000 # X" and len(r.stdout.splitlines()) == 22
 
 
+def test_release_library_reads_only_the_documented_environment():
+    """every PLAAC_ name inside the release library is one of the environment variables include/plaac_native.h
+    documents ("environment and test hooks": at most twelve, none changes a result); every other switch of earlier rounds is a
+    test hook (plaac_debug_set_knob) or exists in the diagnostic build only - whose keys the release library refuses."""
+    import ctypes as C
+    blob = open(os.path.join(ROOT, "plaac_amd", "libplaac_native.so"), "rb").read()
+    found = set(m.decode() for m in re.findall(rb"PLAAC_[A-Z][A-Z0-9_]+", blob))
+    header = open(os.path.join(ROOT, "include", "plaac_native.h")).read()
+    sect = header[header.index("---- environment and test hooks"):]
+    documented = set(re.findall(r"^ \*   (PLAAC_[A-Z0-9_]+)", sect, flags=re.M))
+    assert 1 <= len(documented) <= 12, documented
+    assert found <= documented, found - documented
+    from plaac_amd import native
+    L = native.load()
+    if L.plaac_diag_build():
+        pytest.skip("PLAAC_NATIVE_LIB points at the diagnostic build")
+    assert L.plaac_debug_set_knob(b"KB_LANE_MIN_GROUPS", b"1") == native.PLAAC_OK
+    assert L.plaac_debug_set_knob(b"KB_LANE_MIN_GROUPS", None) == native.PLAAC_OK
+    assert L.plaac_debug_set_knob(b"TRACK_ONE_PASS", b"1") == native.PLAAC_ERR_UNSUPPORTED
+    assert L.plaac_debug_set_knob(b"NO_SUCH_KEY", b"1") == native.PLAAC_ERR_ARG
+    assert set(native.HOOK_KEYS) & set(native.DIAG_KEYS) == set()
+
+
 def test_release_library_does_not_contain_the_result_breaking_switches():
     """PLAAC_DEBUG_SKIP / _SKIP_FROM (kernels not launched, rows stale), PLAAC_VIT_STOP and PLAAC_DEBUG_COUNTER are
     compiled only into the diagnostic build (`make DIAG=1` -> libplaac_native_diag.so); a host's environment cannot switch
@@ -160,4 +183,4 @@ def test_release_library_does_not_contain_the_result_breaking_switches():
     blob = open(os.path.join(ROOT, "plaac_amd", "libplaac_native.so"), "rb").read()
     for name in (b"PLAAC_DEBUG_SKIP", b"PLAAC_VIT_STOP", b"PLAAC_DEBUG_COUNTER"):
         assert name not in blob, name
-    assert b"PLAAC_LATENCY_MODE" in blob  # (the form-selecting knobs, which change no result, are still read)
+    assert b"PLAAC_LATENCY_MODE" in blob  # (a documented environment switch, which changes no result, is still read)

@@ -267,12 +267,21 @@ def test_single_pass_writes_the_same_bytes_as_the_two_passes(native, tmp_path):
     cases = [["-i", fa], ["-i", fa, "-d"], ["-i", fa, "-a", "3"], ["-i", fa, "-b", fa], ["-i", fa, "-s"], ["-i", fa, "-h", dot],
              ["-i", fa, "-c", "30", "-W", "21"], ["-i", empty], ["-i", FA4, "-a", "1.0"], ["-i", quirks], ["-i", fa, "-a", "0.5"],
              ["-i", fa, "-B", os.path.join(GOLDEN, "bg_freqs", "bg_freqs_YEAST.txt")]]
+    from concurrent.futures import ThreadPoolExecutor
     for args in cases:
+        envs = ({"PLAAC_SINGLE_PASS": "0", "PLAAC_HUGE_PAGES": "0"}, {}, {"PLAAC_BATCH_RECORDS": "257", "PLAAC_DEVICES": "0,0"},
+                {"PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_DEVICE_FORMAT": "0"}, {"PLAAC_DEVICE_FORMAT": "0", "PLAAC_BATCH_RECORDS": "100"},
+                {"PLAAC_BATCH_RECORDS": "1"} if args[1] is quirks else {"PLAAC_BATCH_BYTES": "4096"})
+
+        def run(env, args=args):
+            return subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300, env=dict(os.environ, PLAAC_TIMING="1", **env))
+
+        # (the variants of a case side by side, four processes on the card at a time: a run is mostly HIP start-up;
+        #  -h writes a file, so those go one by one)
+        with ThreadPoolExecutor(max_workers=1 if "-h" in args else 4) as pool:
+            rs = list(pool.map(run, envs))
         outs = []
-        for env in ({"PLAAC_SINGLE_PASS": "0", "PLAAC_HUGE_PAGES": "0"}, {}, {"PLAAC_BATCH_RECORDS": "257", "PLAAC_DEVICES": "0,0"},
-                    {"PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_DEVICE_FORMAT": "0"}, {"PLAAC_DEVICE_FORMAT": "0", "PLAAC_BATCH_RECORDS": "100"},
-                    {"PLAAC_BATCH_RECORDS": "1"} if args[1] is quirks else {"PLAAC_BATCH_BYTES": "4096"}):
-            r = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300, env=dict(os.environ, PLAAC_TIMING="1", **env))
+        for r in rs:
             assert r.returncode == 0, r.stderr.decode(errors="replace")
             outs.append((r.stdout, r.stderr.decode(errors="replace")))
         assert all(o[0] == outs[0][0] for o in outs[1:]), "single pass differs from two passes for %s" % args
@@ -306,8 +315,11 @@ def test_single_pass_into_a_file_writes_the_table_in_place(native, tmp_path):
     empty = tmp_path / "empty.fa"
     empty.write_text("")
 
+    import itertools
+    serial = itertools.count()
+
     def to_file(args, env, mode="wb", lead=b""):
-        out = tmp_path / "out.tsv"
+        out = tmp_path / ("out%d.tsv" % next(serial))
         if mode == "ab":
             out.write_bytes(lead)
         with open(out, mode) as fh:
@@ -320,15 +332,20 @@ def test_single_pass_into_a_file_writes_the_table_in_place(native, tmp_path):
         return out.read_bytes(), r.stderr.decode(errors="replace")
 
     for args in (["-i", fa], ["-i", fa, "-d"], ["-i", fa, "-s"], ["-i", allx], ["-i", allx, "-d"], ["-i", polyq], ["-i", quirks], ["-i", empty]):
-        want, _ = to_file(args, {"PLAAC_SINGLE_PASS": "0"})
-        for env in ({}, {"PLAAC_PLACED_WRITE": "0"}, {"PLAAC_BATCH_RECORDS": "300"}, {"PLAAC_DEVICE_FORMAT": "0"}):
-            got, err = to_file(args, env)
-            assert "single pass" in err
-            assert got == want, (args, env)
-        got, _ = to_file(args, {}, lead=b"something the shell wrote before\n")
-        assert got == b"something the shell wrote before\n" + want, args
-        got, _ = to_file(args, {}, mode="ab", lead=b"appended to\n")
-        assert got == b"appended to\n" + want, args
+        from concurrent.futures import ThreadPoolExecutor
+        envs = ({}, {"PLAAC_PLACED_WRITE": "0"}, {"PLAAC_BATCH_RECORDS": "300"}, {"PLAAC_DEVICE_FORMAT": "0"})
+        with ThreadPoolExecutor(max_workers=4) as pool:  # (four processes on the card at a time; every run its own output file)
+            f_want = pool.submit(to_file, args, {"PLAAC_SINGLE_PASS": "0"})
+            f_envs = [pool.submit(to_file, args, env) for env in envs]
+            f_lead = pool.submit(to_file, args, {}, "wb", b"something the shell wrote before\n")
+            f_app = pool.submit(to_file, args, {}, "ab", b"appended to\n")
+            want, _ = f_want.result()
+            for env, f in zip(envs, f_envs):
+                got, err = f.result()
+                assert "single pass" in err
+                assert got == want, (args, env)
+            assert f_lead.result()[0] == b"something the shell wrote before\n" + want, args
+            assert f_app.result()[0] == b"appended to\n" + want, args
     assert b"NaN" in to_file(["-i", allx], {})[0]
 
 

@@ -1436,3 +1436,117 @@ def test_per_residue_table_from_the_device_equals_the_hosts(native, oracle):
         assert_rows_equal(rows2, rows, "rows beside the table")
         assert table == want, "per-residue table from the device (%d / %d bytes)" % (len(table), len(want))
         assert table.count(b"#" * 56 + b"\n") == int((rows["prot_len"] > 0).sum())
+
+
+def test_node_text_api_deals_batches_over_contexts_and_returns_the_table_in_file_order(native, oracle, tmp_path):
+    """Round 6: plaac_node_text_* - FASTA text batches in file order through a node of two contexts (devices
+    {0, 0}), the table collected oldest first: byte for byte the oracle's rows through the host formatter, whatever the batch
+    cut (name trimming behind an empty line crosses batches and contexts); a batch the device will not vouch for (a record
+    without a sequence) is refused by text_table and comes back through text_rows - or is given up with text_discard - and the
+    node goes on; the counting pass (histogram_text) and the uploader-thread entry points; the per-residue table."""
+    import threading
+    from plaac_amd import hostio, synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(4, nprot=3000, seed=23, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.2)
+    letters = np.frombuffer(b"XACDEFGHIKLMNPQRSTVWY*", dtype=np.uint8)[codes]
+    recs = [b">prot%05d some words  \n" % i + b"".join(letters[int(offs[i]) + k:min(int(offs[i]) + k + 60, int(offs[i + 1]))].tobytes() + b"\n"
+                                                       for k in range(0, int(offs[i + 1] - offs[i]), 60)) + (b"\n" if i % 7 == 0 else b"")
+            for i in range(len(offs) - 1) if offs[i + 1] > offs[i]]
+    p = tmp_path / "t.fa"
+    p.write_bytes(b"".join(recs))
+    names, hc, ho = hostio.read_fasta(p)
+    want_rows = oracle.score_batch(oracle.build_params(), hc, ho, nthreads=8)
+    want_text = hostio.format_summary_rows(want_rows, [n.encode() if isinstance(n, str) else n for n in names], hc, ho.astype(np.int64))
+    want_counts = oracle.histogram(hc, ho)
+    with native.Node(P, devices=[0, 0]) as node:
+        assert len(node) == 2
+        for max_records in (1 << 20, 211):
+            node.text_reset()
+            got, counts, nres = [], np.zeros(22, dtype=np.int64), 0
+            for text, starts, trim in hostio.stream_fasta_text(p, max_records, 1 << 30):
+                if node.text_pending() == 4:  # two per context
+                    with pytest.raises(native.PlaacError):
+                        node.text_begin(text, starts, counting=True)
+                    t, r, c = node.text_table(60, 41, counting=True)
+                    got.append(t); counts += c; nres += r
+                node.text_begin(text, starts, counting=True)
+            while node.text_pending():
+                t, r, c = node.text_table(60, 41, counting=True)
+                got.append(t); counts += c; nres += r
+            assert b"".join(got) == want_text, "node table, batches of %d records" % max_records
+            assert np.array_equal(counts, want_counts) and nres == len(hc)
+        # the counting pass by itself, four batches in flight
+        node.text_reset()
+        counts, nres, inflight = np.zeros(22, dtype=np.int64), 0, 0
+        for text, starts, trim in hostio.stream_fasta_text(p, 500, 1 << 30):
+            if inflight == 4:
+                nres = node.histogram_text_end(counts, nres)
+                inflight -= 1
+            node.histogram_text_begin(text, starts)
+            inflight += 1
+        while inflight:
+            nres = node.histogram_text_end(counts, nres)
+            inflight -= 1
+        assert np.array_equal(counts, want_counts) and nres == len(hc)
+        # a batch the device hands back: refused as a table, collected as rows; the next one discarded; then business as usual
+        nos = tmp_path / "noseq.fa"
+        nos.write_bytes(recs[0] + b">nothing here\n" + recs[1])
+        text, starts, trim = next(iter(hostio.stream_fasta_text(nos, 1 << 20, 1 << 30)))
+        n2, hc2, ho2 = hostio.read_fasta(nos)
+        rows2 = oracle.score_batch(oracle.build_params(), hc2, ho2, nthreads=4)
+        node.text_reset()
+        for _ in range(3):
+            node.text_begin(text, starts)
+        t, r = node.text_table()
+        assert t is None and node.text_pending() == 3
+        with pytest.raises(native.PlaacError):
+            node._check(node._L.plaac_node_text_table(node._h, None, 0, None))  # (refused: not sized as a table)
+        rows, c, o, blank, ext = node.text_rows(len(text))
+        assert np.array_equal(c, hc2) and np.array_equal(o, ho2)
+        assert_rows_equal(rows, rows2, "rows of a handed-back batch through the node")
+        node.text_discard()
+        node.text_discard()
+        assert node.text_pending() == 0
+        with pytest.raises(native.PlaacError):
+            node.text_discard()
+        # the uploader-thread entry points: uploads on another thread, begun and collected here
+        node.text_reset()
+        batches = list(hostio.stream_fasta_text(p, 400, 1 << 30))
+        handed, ready, errors = [None] * len(batches), [threading.Event() for _ in batches], []
+
+        def uploader():
+            try:
+                for k, (text, starts, _) in enumerate(batches):
+                    handed[k] = node.text_upload(text, starts)
+                    ready[k].set()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+                for ev in ready:
+                    ev.set()
+
+        th = threading.Thread(target=uploader)
+        th.start()
+        got = []
+        for k in range(len(batches)):
+            ready[k].wait(60)
+            assert not errors, errors
+            if node.text_pending() == 4:
+                got.append(node.text_table()[0])
+            node.text_begin_uploaded(handed[k])
+        while node.text_pending():
+            got.append(node.text_table()[0])
+        th.join()
+        assert b"".join(got) == want_text, "node table from batches uploaded by another thread"
+        tb = node.text_upload(batches[0][0], batches[0][1])
+        node._L.plaac_node_text_batch_free(tb)
+        # plotsomefastas' table through the node = a context's
+        sel = [i for i in range(40) if ho[i + 1] - ho[i] > 1]
+        c3 = np.concatenate([hc[int(ho[i]):int(ho[i + 1])] for i in sel])
+        o3 = np.zeros(len(sel) + 1, dtype=np.uint64)
+        o3[1:] = np.cumsum([int(ho[i + 1] - ho[i]) for i in sel])
+        labels = [b"%d\t" % (k + 1) + (names[i].encode() if isinstance(names[i], str) else names[i]) for k, i in enumerate(sel)]
+        t_node, r_node = node.score_tracks_table(c3, o3, labels)
+    with native.Context(P) as ctx:
+        t_ctx, r_ctx = ctx.score_tracks_table(c3, o3, labels)
+    assert t_node is not None and t_node == t_ctx
+    assert_rows_equal(r_node, r_ctx, "rows beside the node's per-residue table")
