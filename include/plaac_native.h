@@ -430,7 +430,7 @@ plaac_status plaac_calibration_reads(plaac_ctx *ctx, const uint8_t *d_codes, uin
  * same buffer only when they score the same batch with the same parameters (every row field is written once per call,
  * with its final value; the long runs of consecutive chain-bound calls run side by side, so the LATER call is not
  * always the last writer). Results are unchanged; a lone call is unchanged. (bench.py switches it on: its steps are back to back on one
- * resident batch. Measured: DESIGN.md 4.9.) */
+ * resident batch. Measured: EXPERIMENTS.md 4.9.) */
 plaac_status plaac_ctx_set_overlap(plaac_ctx *ctx, int on);
 
 /* DIAGNOSTIC (bench.py --clock-probe): the shader clock the chip actually holds while the scoring kernels run. One wave

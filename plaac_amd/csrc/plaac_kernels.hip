@@ -380,6 +380,7 @@ void fill_tables(const plaac_params &P, DevTables &D) {
         D.row[k][R_LLR] = P.llr[k];
         D.row[k][R_HYD] = P.hydro2[k];
         D.row[k][R_LE0H] = P.hmm0.le[0][k];
+        D.row[k][R_PAD] = win_row_words(k, (int)P.charge[k]); // (two integers: what k_win's packed counters add / take off)
         D.lod[k] = P.lodpapa[k];
         D.hyd[k] = P.hydro2[k];
         D.llr[k] = P.llr[k];
@@ -1326,6 +1327,8 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
                 const unsigned na = std::min(kb_grid, K.track_consec);
                 hipLaunchKernelGGL(k_tracks20s<true>, dim3(na + kb_grid), dim3(64), K.track_kb_lds, s, D.d_codes, PL.order, nprot, D.total, tab,
                                    ctx->d_divtab, rows0, D.tp, D.huge, D.d_offsets, PL.neff, (uint32_t)na);
+                // (PAPAfi / PAPAllr / PAPAllr2 = the tracks' values at the centre the kernel above has just found)
+                hipLaunchKernelGGL(k_papa_from_tracks, dim3((nprot + 255u) / 256u), dim3(256), 0, s, D.d_offsets, PL.neff, nprot, rows0, D.tp, D.huge);
             } else
                 hipLaunchKernelGGL(k_tracks20s<false>, dim3(kb_grid), dim3(64), 0, s, D.d_codes, PL.order, nprot, D.total, tab,
                                    ctx->d_divtab, rows0, D.tp, D.huge, D.d_offsets, PL.neff, 0u);

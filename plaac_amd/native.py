@@ -38,6 +38,8 @@ class DiagKnob(RuntimeError):
 
 def apply_env_knobs(L=None):
     L = L or load()
+    if not hasattr(L, "plaac_debug_set_knob"):  # (an older build: it reads its switches from the environment itself)
+        return
     for key in HOOK_KEYS + DIAG_KEYS:
         v = os.environ.get("PLAAC_" + key)
         st = L.plaac_debug_set_knob(key.encode(), None if v is None else v.encode())
@@ -219,6 +221,9 @@ def load():
     L.plaac_batch_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.plaac_score_sweep_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
                                            C.c_uint32, C.c_void_p, C.c_void_p]
+    if not hasattr(L, "plaac_debug_set_knob"):  # an older build loaded through PLAAC_NATIVE_LIB for an A/B: no round-6 entry points
+        _lib = L
+        return L
     L.plaac_node_text_begin.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int]
     L.plaac_node_text_upload.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.plaac_node_text_begin_uploaded.argtypes = [C.c_void_p, C.c_void_p, C.c_int]

@@ -407,3 +407,32 @@ def test_summary_row_written_straight_into_a_buffer(io):
         assert k == len(want.encode()) and buf.raw[:k] == want.encode() and buf.raw[k:k + 1] == b"\xff"
         assert L.plaac_format_summary_row_n(one.ctypes.data, name, len(name), codes.ctypes.data, len(codes), 60, 41, buf, 2000) == -1
     assert "0.063" in io.format_summary_row(rows[3], name, codes) and "0.048" in io.format_summary_row(rows[4], name, codes)
+
+
+def test_text_batches_outlive_the_close_of_their_stream(tmp_path):
+    """bin/plaac's no-GPU exit closed the FASTA stream while text batches were still queued; freeing them then read
+    the deleted stream (and told the kernel to drop pages of a mapping that was gone). The stream now counts the batches it has
+    handed out: plaac_fasta_close only gives up the handle, the file image stays mapped until the last batch is freed - the
+    batch's text stays readable in between."""
+    import ctypes as C
+    from plaac_amd import hostio
+    L = hostio._lib()
+    L.plaac_fasta_next_text.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(hostio._FastaText))]
+    L.plaac_fasta_text_free.argtypes = [C.POINTER(hostio._FastaText)]
+    L.plaac_fasta_text_free.restype = None
+    p = tmp_path / "big.fa"
+    rec = b">name of record %07d\n" + b"ACDEFGHIKLMNPQRSTVWY" * 30 + b"\n"
+    p.write_bytes(b"".join(rec % i for i in range(40000)))  # 25 MB: mapped, several pages per batch
+    h = C.c_void_p()
+    assert L.plaac_fasta_open(str(p).encode(), C.byref(h)) == 0
+    batches = []
+    for _ in range(3):
+        pt = C.POINTER(hostio._FastaText)()
+        assert L.plaac_fasta_next_text(h, 5000, 1 << 30, C.byref(pt)) == 0 and pt
+        batches.append(pt)
+    L.plaac_fasta_close(h)  # (the handle is gone; three batches are still alive)
+    for k, pt in enumerate(batches):
+        t = pt.contents
+        text = C.string_at(t.text, int(t.len))
+        assert t.nrec == 5000 and text.startswith(b">name of record %07d\n" % (5000 * k))
+        L.plaac_fasta_text_free(pt)  # (the last one unmaps the file)
