@@ -863,7 +863,7 @@ def main():
             "frac_at_measured_clock": None if not (issue_classes and clock and clock.get("under_load_MHz_mean")) else round(
                 issue_classes["cycles_per_step"] / 1024 / (clock["under_load_MHz_mean"] * 1e6) * 1e3 / step_ms, 4),
             "source": "SQ_INSTS_VALU (fp64 / other) + SQ_INSTS_LDS over all kernels of a step, profiles/*pmc_traffic*.json "
-                      "collected for the kernel sources of this tree (sha checked); costs: profiles/r04_issue_classes.json"},
+                      "collected for the kernel sources of this tree (sha checked); per-class costs + the class shares of this tree's listing: the newest profiles/r0*_issue_classes.json"},
         "pmc_counters_stale": stale_counters,
         "shader_clock": clock,
         "host_buffers_pcie_inclusive": host_io,

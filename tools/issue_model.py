@@ -38,7 +38,7 @@ FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xo
         "v_add_f32", "v_sub_f32", "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_subrev_co_u32",
         "v_xnor_b32", "v_accvgpr")
 SLOW45 = ("v_cmp", "v_readlane", "v_readfirstlane")
-KERNELS = ("k_long", "k_tracksL", "k_tracks20f", "k_refine_centres", "k_fwd_pair", "k_fwd", "k_win", "k_vit", "k_core_list", "k_pack",
+KERNELS = ("k_fwd_post_t", "k_bwd_pair", "k_long", "k_tracksL", "k_tracks20f", "k_refine_centres", "k_fwd_pair", "k_fwd", "k_win", "k_vit", "k_core_list", "k_pack",
            "k_finish", "k_tracks20s", "k_tracks20", "k_bwd", "k_post", "k_hist", "k_core_par", "k_core_eval", "k_core_reduce",
            "k_core_chain", "k_llr_at_centre", "k_plan_lengths", "k_plan_scatter")
 
@@ -88,7 +88,9 @@ def kernel_mix(asm_path):
         l = lines[i]
         if l.startswith("_ZN") and not l.startswith("\t") and ":" in l:
             name = l.split(":")[0]
-            end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+            end = next((k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end")), None)
+            if end is None:  # (a data symbol behind the last function: the 2^(j/64) table of the posteriors' exp)
+                break
             key = next((k for k in KERNELS if ("%d%s" % (len(k), k)) in name), None)
             if key:
                 blocks, cur = [], []
@@ -128,6 +130,12 @@ def kernel_mix(asm_path):
     return out
 
 
+def kernels_sha():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    return pmc_summary.kernels_sha()
+
+
 def main():
     asm = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "build", "plaac_kernels.s")
     probe = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04_issue_probe.txt")
@@ -149,9 +157,11 @@ def main():
         "spread_over_2_3_4_waves_per_simd": spread,
         "kernels": kernel_mix(asm),
         "class_shares": "static: per kernel, the instruction classes of its loop blocks (>= 60 instructions) in the `make asm` listing",
-        "source": "tools/issue_model.py: profiles/r04_issue_probe.txt (MI355X) + the `make asm` listing of this tree",
+        "source": "tools/issue_model.py: profiles/r04_issue_probe.txt (MI355X; the per-class issue costs are the machine's, measured in round 4) + the `make asm` listing of this tree (kernel sources sha16 " + kernels_sha() + ")",
     }
-    out = os.path.join(ROOT, "profiles", "r04_issue_classes.json")
+    # (round 6: the class shares of THIS tree's listing go into a file of their own; tools/pmc_summary.py takes the newest
+    #  profiles/r0*_issue_classes.json, so counters collected for this tree meet the shares of this tree)
+    out = os.path.join(ROOT, "profiles", os.environ.get("ISSUE_CLASSES_OUT", "r06_issue_classes.json"))
     with open(out, "w") as fh:
         json.dump(model, fh, indent=1, sort_keys=True)
         fh.write("\n")

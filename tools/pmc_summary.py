@@ -97,8 +97,9 @@ def main(root):
     # instruction-issue roof with measured per-class costs
     issue = None
     try:
-        cls = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                                          "r04_issue_classes.json")))
+        import glob
+        cls = json.load(open(sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                                                           "r0*_issue_classes.json")))[-1]))  # (the newest tree's class shares)
         cost = cls["cost_cycles"]
         per, tot = {}, 0.0
         for k, c in step.items():
