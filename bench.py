@@ -352,6 +352,7 @@ def main():
                     "0.01 %% tail of 8,193 - 36,000-residue records: a proteome whose step no single chain bounds)")
     ap.add_argument("--allow-diagnostics", action="store_true", help="run although PLAAC_DEBUG_* / PLAAC_VIT_STOP are set (only a "
                     "DIAG build of the library reads them, and its rows are wrong by design: tools/archive/r04_ablate*.sh)")
+    ap.add_argument("--no-tolerance-leg", action="store_true", help="N = 1 default line: skip the `summary_value_tolerance` object")
     ap.add_argument("--no-tracks-leg", action="store_true", help="N = 1 default line: skip the `tracks` object (the 1.25 M-sequence "
                     "share scored in per-residue track mode - the HBM-bound regime of the path - in the same run)")
     args = ap.parse_args()
@@ -646,6 +647,22 @@ def main():
                      "what": "plaac_ctx_set_overlap off: every step behind the whole previous step (extra untimed steps)"}
         for c in ctxs:
             c.set_overlap(True)
+    # The same step with plaac_ctx_set_value_tolerance on (OFF in every other number of this line): the five floats at the PAPA
+    # centre from sliding first-level sums - what the north star's own bar for floats (1e-6) buys. Its rows are checked below:
+    # every index and every other field bit-identical to the oracle, the five floats within 1e-9.
+    tol_leg = None
+    if rank == 0 and world == 1 and not args.tracks and not args.sweep and not two_pass and not args.no_tolerance_leg:
+        for c in ctxs:
+            c.set_value_tolerance(True)
+        tsteps_ = max(5, min(args.steps, 20))
+        vdt, vb = run_region(main_work, tsteps_, 2, False, verify=True)
+        for c in ctxs:
+            c.set_value_tolerance(False)
+        tol_leg = {"ms_per_step": round(vdt / tsteps_ * 1e3, 4), "residues_per_sec": round(total * tsteps_ / vdt, 1), "steps": tsteps_,
+                   "what": "plaac_ctx_set_value_tolerance(1): PAPAcombo / PAPAprop / PAPAfi / PAPAllr / PAPAllr2 from first-level "
+                           "window sums that slide over six neighbouring positions (k_refine_centres<., SLIDE>) instead of 41 "
+                           "fixed-order taps per position; NOT the default and not in `value`", "_rows": vb["rows"]}
+        del vb
     # What one GPU of an 8-GPU strong-scaling run would take: the share plaac_shard_plan deals rank 0 of 8 (1.25 M sequences
     # of the 10 M), timed like the main region (overlapping steps, no gather). efficiency = full step / (8 x share step):
     # the ceiling of the 8-GPU curve before any exchange - a single GPU can measure it, the curve itself needs the node.
@@ -927,6 +944,29 @@ def main():
                     bad.append([s, n])
                 checked += n
         match = not bad
+        if tol_leg is not None:  # the tolerance leg's verified step: first slice against the oracle's rows, field by field
+            trows = np.frombuffer(tol_leg.pop("_rows")[:n_s * RB].cpu().numpy().tobytes(), dtype=native.ROW_DTYPE)
+            loose = ("papa_combo", "papa_prop", "papa_fi", "papa_llr", "papa_llr2")
+            tbad, worst = [], 0.0
+            for name in want.dtype.names:
+                g_, w_ = trows[name], want[name]
+                if name in loose:
+                    fin = np.isfinite(w_)
+                    same_special = np.array_equal(np.isnan(g_), np.isnan(w_)) and np.array_equal(np.isinf(g_), np.isinf(w_))
+                    err = float((np.abs(g_[fin] - w_[fin]) / np.maximum(1.0, np.abs(w_[fin]))).max()) if fin.any() else 0.0
+                    worst = max(worst, err)
+                    if not same_special or err > 1e-9:
+                        tbad.append(name)
+                elif g_.dtype.kind == "f":
+                    if not np.array_equal(g_.view(np.uint64), w_.view(np.uint64)):
+                        tbad.append(name)
+                elif not np.array_equal(g_, w_):
+                    tbad.append(name)
+            tol_leg.update(rows_checked=int(n_s), fields_outside_tolerance=tbad, max_relative_deviation_of_the_five_floats=worst,
+                           tolerance="indices and every other field bit-identical to the oracle; the five floats within 1e-9 "
+                                     "(relative, floor 1)", matches_oracle_within_tolerance=not tbad)
+            if tbad:
+                rc = 3
         if tracks_leg is not None:  # the track-mode leg: rows and all twelve tracks of its verified step against the oracle
             tw, tb_ = tracks_leg.pop("_work"), tracks_leg.pop("_bufs")
             n_t = min(tw.nprot, 4000)
@@ -1034,6 +1074,8 @@ def main():
     if cpu is not None and "reference_jar" not in cpu:
         cpu["reference_jar"] = time_reference_jar("", 0) if not os.environ.get("PLAAC_REF_JAR") else "skipped: no e2e leg"
 
+    if tol_leg is not None:
+        tol_leg.pop("_rows", None)
     if tracks_leg is not None:  # (--no-cpu-baseline: nothing was checked)
         tracks_leg.pop("_work", None)
         tracks_leg.pop("_bufs", None)
@@ -1083,6 +1125,7 @@ def main():
         "predicted_strong_efficiency": None if not predicted else predicted["efficiency"],
         "roofline": roofline,
         "tracks": tracks_leg,
+        "summary_value_tolerance": tol_leg,
         "cpu_baseline": cpu,
         "e2e": e2e,
         "e2e_single_line": e2e_single,

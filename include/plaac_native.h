@@ -432,6 +432,12 @@ plaac_status plaac_calibration_reads(plaac_ctx *ctx, const uint8_t *d_codes, uin
  * always the last writer). Results are unchanged; a lone call is unchanged. (bench.py switches it on: its steps are back to back on one
  * resident batch. Measured: EXPERIMENTS.md 4.9.) */
 plaac_status plaac_ctx_set_overlap(plaac_ctx *ctx, int on);
+/* OFF by default. on != 0: summary mode forms the five floats reported AT the PAPA centre (PAPAcombo = PAPAprop, PAPAfi,
+ * PAPAllr, PAPAllr2; disorderreport :4986-4997) from first-level window sums that SLIDE over six neighbouring positions instead
+ * of 41 fixed-order taps per position: they then differ from the reference-order values by less than 1e-12 (the north star's
+ * bar for floats is 1e-6; tested at 1e-9), and the summary step is about 8 % shorter. Every index (PAPAcen included), every
+ * decision and every other float of the row stay exactly the reference-order results. Track mode is not affected. */
+plaac_status plaac_ctx_set_value_tolerance(plaac_ctx *ctx, int on);
 
 /* DIAGNOSTIC (bench.py --clock-probe): the shader clock the chip actually holds while the scoring kernels run. One wave
  * on a stream of its own sleeps in s_sleep 127 steps (64 x 127 shader cycles each) for `micros` microseconds of the

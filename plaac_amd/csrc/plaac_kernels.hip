@@ -111,6 +111,7 @@ struct plaac_text_batch {
 struct plaac_ctx {
     int device = 0;
     int num_cus = 256;
+    bool value_tolerance = false; // plaac_ctx_set_value_tolerance: k_refine_centres<., SLIDE>
     bool lat_unit = true;         // the latency-form chain kernels of the max-ilp unit (plaac_kernels_lat.hip) are usable
     hipStream_t stream = nullptr;
     DevTables *d_tab = nullptr;   // tables of ctx->params
@@ -1356,7 +1357,14 @@ plaac_status run_ops(plaac_ctx *ctx, const CallData &D, const sched::CallKind &C
             // list is through - 7 per CU when the next call may plan beside this kernel (its planning kernels take 8 / 16 KB
             // per block; with 32 KB they waited for this kernel's end: 3.3 ms)
             const unsigned rounds = (o.b + RF_SLOTS - 1) / RF_SLOTS;
-            if (o.sel)
+            if (ctx->value_tolerance && o.sel)
+                hipLaunchKernelGGL((k_refine_centres<true, true>), dim3(std::min(rounds, K.rf_grid)), dim3(64), 0, s, D.d_codes, D.total, tab,
+                                   ctx->d_divtab, rows0, D.huge, PL.clist + o.a, PL.crow + o.a, D.ccount + o.seg, F.kb_prio_refine);
+            else if (ctx->value_tolerance)
+                hipLaunchKernelGGL((k_refine_centres<false, true>), dim3(std::min(rounds, F.tail_allowed ? K.rf_grid / 8u * 7u : K.rf_grid)),
+                                   dim3(64), 0, s, D.d_codes, D.total, tab, ctx->d_divtab, rows0, D.huge, PL.clist + o.a,
+                                   PL.crow + o.a, D.ccount + o.seg, F.kb_prio_refine);
+            else if (o.sel)
                 hipLaunchKernelGGL(k_refine_centres<true>, dim3(std::min(rounds, K.rf_grid)), dim3(64), 0, s, D.d_codes, D.total, tab,
                                    ctx->d_divtab, rows0, D.huge, PL.clist + o.a, PL.crow + o.a, D.ccount + o.seg, F.kb_prio_refine);
             else
@@ -1726,6 +1734,12 @@ plaac_status plaac_timings_mean(plaac_ctx *ctx, uint32_t ncalls, float ms[8]) {
 }
 
 plaac_status plaac_last_timings(plaac_ctx *ctx, float ms[8]) { return plaac_timings_mean(ctx, 1, ms); }
+
+plaac_status plaac_ctx_set_value_tolerance(plaac_ctx *ctx, int on) {
+    if (!ctx) return PLAAC_ERR_ARG;
+    ctx->value_tolerance = on != 0;
+    return PLAAC_OK;
+}
 
 plaac_status plaac_ctx_set_overlap(plaac_ctx *ctx, int on) {
     if (!ctx) return PLAAC_ERR_ARG;

@@ -109,7 +109,7 @@ EXPORTS = (
     "plaac_node_text_begin", "plaac_node_text_upload", "plaac_node_text_begin_uploaded", "plaac_node_text_batch_free",
     "plaac_node_text_table_size", "plaac_node_text_table", "plaac_node_text_rows", "plaac_node_text_discard",
     "plaac_node_text_pending", "plaac_node_text_oldest_records", "plaac_node_text_reset", "plaac_node_histogram_text_begin",
-    "plaac_node_histogram_text_end", "plaac_node_score_tracks_table", "plaac_debug_set_knob", "plaac_diag_build", "plaac_text_upload_error",
+    "plaac_node_histogram_text_end", "plaac_node_score_tracks_table", "plaac_debug_set_knob", "plaac_diag_build", "plaac_text_upload_error", "plaac_ctx_set_value_tolerance",
 )
 
 _lib = None
@@ -244,6 +244,7 @@ def load():
                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L.plaac_text_upload_error.argtypes = [C.c_void_p]
     L.plaac_text_upload_error.restype = C.c_char_p
+    L.plaac_ctx_set_value_tolerance.argtypes = [C.c_void_p, C.c_int]
     L.plaac_debug_set_knob.argtypes = [C.c_char_p, C.c_char_p]
     L.plaac_diag_build.restype = C.c_int
     _lib = L
@@ -520,6 +521,11 @@ class Context:
         """diagnostic: three known-size streaming reads of the residue buffer (FETCH_SIZE calibration, tools/pmc.sh)"""
         self._check(self._L.plaac_calibration_reads(self._h, int(d_codes), int(total_residues),
                                                     None if stream is None else int(stream)))
+
+    def set_value_tolerance(self, on=True):
+        """plaac_ctx_set_value_tolerance: the five floats at the PAPA centre from sliding first-level sums (< 1e-12 from the
+        reference-order values; indices and every other field unchanged); off by default"""
+        self._check(self._L.plaac_ctx_set_value_tolerance(self._h, 1 if on else 0))
 
     def set_overlap(self, on=True):
         """consecutive calls may overlap (the next call plans beside the last window kernels of this one); see the header

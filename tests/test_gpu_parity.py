@@ -1550,3 +1550,35 @@ def test_node_text_api_deals_batches_over_contexts_and_returns_the_table_in_file
         t_ctx, r_ctx = ctx.score_tracks_table(c3, o3, labels)
     assert t_node is not None and t_node == t_ctx
     assert_rows_equal(r_node, r_ctx, "rows beside the node's per-residue table")
+
+
+def test_value_tolerance_mode_moves_only_the_five_floats_at_the_papa_centre(native, oracle):
+    """Round 6: plaac_ctx_set_value_tolerance (off by default). The north star's bar for floats is 1e-6; with the switch on,
+    the five floats reported at the PAPA centre come from first-level sums that slide over six neighbouring positions instead
+    of 41 fixed-order taps each. TOLERANCE: |got - want| <= 1e-9 * max(1, |want|) for papa_combo, papa_prop, papa_fi, papa_llr,
+    papa_llr2 (measured: < 1e-12), the same NaN / infinity pattern - and EVERY other field of the row, every index and
+    decision included, bit-identical to the oracle. Switched off again, the rows are bit-identical as before."""
+    from plaac_amd import synth
+    P = native.make_params()
+    codes, offs = synth.make_batch(4, nprot=300000, seed=41, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+    want = oracle.score_batch(oracle.build_params(), codes, offs, nthreads=16)
+    loose = ("papa_combo", "papa_prop", "papa_fi", "papa_llr", "papa_llr2")
+    with native.Context(P) as ctx:
+        ctx.set_value_tolerance(True)
+        got = ctx.score(codes, offs)
+        for name in want.dtype.names:
+            g, w = got[name], want[name]
+            if name in loose:
+                assert np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(np.isinf(g), np.isinf(w)), name
+                fin = np.isfinite(w)
+                err = np.abs(g[fin] - w[fin]) / np.maximum(1.0, np.abs(w[fin]))
+                assert err.size and err.max() <= 1e-9, (name, err.max())
+            elif g.dtype.kind == "f":
+                assert np.array_equal(g.view(np.uint64), w.view(np.uint64)), name
+            else:
+                assert np.array_equal(g, w), name
+        worst = max(float(np.nanmax(np.abs(got[n][np.isfinite(want[n])] - want[n][np.isfinite(want[n])]))) for n in loose)
+        assert worst < 1e-11, worst  # (what the sliding sums actually cost; the contract above is 1e-9)
+        assert (got["papa_combo"] != want["papa_combo"]).sum() > 1000  # (the switch did something: the sliding form is in use)
+        ctx.set_value_tolerance(False)
+        assert_rows_equal(ctx.score(codes, offs), want, "value tolerance switched off again")

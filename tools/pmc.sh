@@ -9,7 +9,7 @@
 #   sweeps over it, track mode - then run the kernel forms the library picks by itself instead of the throughput forms that the
 #   serialised mode selects; the serial trace is skipped.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; D=${PMC_DIR:-gpurun_out/pmc}; rm -rf $D; mkdir -p $D
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-clock-probe --no-host-leg --no-predict --no-tracks-leg --calibrate $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-clock-probe --no-host-leg --no-predict --no-tracks-leg --no-tolerance-leg --calibrate $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace_concurrent -- python3 bench.py $ARGS > $D/trace_concurrent.json 2> $D/trace_concurrent.err || echo "FAILED trace_concurrent"
 if [ -z "$PMC_DEFAULT_FORMS" ]; then
 export PLAAC_SERIAL_STREAMS=1

@@ -97,7 +97,6 @@ def main(root):
     # instruction-issue roof with measured per-class costs
     issue = None
     try:
-        import glob
         cls = json.load(open(sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
                                                            "r0*_issue_classes.json")))[-1]))  # (the newest tree's class shares)
         cost = cls["cost_cycles"]

@@ -15,7 +15,7 @@ pmcrest)
 sq)
   bash tools/r06_pmc_tracks_sq.sh > /dev/null 2>&1; head -c 3000 $O/pmc_tracks_sq.txt ;;
 lines)
-  Q="--no-e2e --no-predict --no-tracks-leg"
+  Q="--no-e2e --no-predict --no-tracks-leg --no-tolerance-leg"
   python3 bench.py > $O/bench_cfg4_full.json 2> $O/bench_cfg4_full.err; echo "cfg4 rc=$?"
   python3 bench.py --config 2 $Q > $O/bench_cfg2.json 2>> $O/lines.err; echo "cfg2 rc=$?"
   python3 bench.py --config 3 $Q > $O/bench_cfg3_two_pass.json 2>> $O/lines.err; echo "cfg3 rc=$?"

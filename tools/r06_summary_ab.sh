@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r6; mkdir -p $O; TAG=${TAG:-sum}
 out=$O/summary_${TAG}.txt; : > $out
-F="--steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-predict --no-clock-probe --no-host-leg --no-tracks-leg"
+F="--steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-predict --no-clock-probe --no-host-leg --no-tracks-leg --no-tolerance-leg"
 run() { L=$1; shift
   env "$@" timeout -k 10 300 python3 bench.py $F 2>>$O/summary_${TAG}.err | python3 -c "
 import json,sys

@@ -8,7 +8,7 @@ timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "${
 grep -q "passed" $O/${TAG}_tests.txt && ! grep -q "failed" $O/${TAG}_tests.txt || exit 1
 fi
 out=$O/tracks_${TAG}.txt; : > $out
-F="--steps 16 --warmup 4 --no-cpu-baseline --no-e2e --no-predict --no-clock-probe --no-host-leg --no-tracks-leg ${BENCH_ARGS:---tracks --nprot 1250000}"
+F="--steps 16 --warmup 4 --no-cpu-baseline --no-e2e --no-predict --no-clock-probe --no-host-leg --no-tracks-leg --no-tolerance-leg ${BENCH_ARGS:---tracks --nprot 1250000}"
 for rep in 1 2 3; do
   for spec in "$@"; do
     L=${spec%%:*}; E=${spec#*:}
