@@ -244,7 +244,8 @@ def load():
                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L.plaac_text_upload_error.argtypes = [C.c_void_p]
     L.plaac_text_upload_error.restype = C.c_char_p
-    L.plaac_ctx_set_value_tolerance.argtypes = [C.c_void_p, C.c_int]
+    if hasattr(L, "plaac_ctx_set_value_tolerance"):  # (absent from builds of the first half of round 6, loaded for an A/B)
+        L.plaac_ctx_set_value_tolerance.argtypes = [C.c_void_p, C.c_int]
     L.plaac_debug_set_knob.argtypes = [C.c_char_p, C.c_char_p]
     L.plaac_diag_build.restype = C.c_int
     _lib = L
