@@ -20,6 +20,7 @@ gather]) over the resident proteome (reference loop replaced: cli/src/plaac.java
 Inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import re
 import os
@@ -636,6 +637,7 @@ def main():
             ev[1].record(st)
         st.synchronize()
         hist_ms = ev[0].elapsed_time(ev[1]) / 3
+        hist_sha = hashlib.sha256(cnt.cpu().numpy().tobytes()).hexdigest()[:16]
     # the same step with every call ordered behind the whole previous one (plaac_ctx_set_overlap off): untimed extra steps
     by_itself = None
     if overlap and world == 1 and not args.tracks and not args.sweep:
@@ -854,7 +856,7 @@ def main():
         "path_achieved_GBps": round(path_bytes / (step_ms * 1e-3) / 1e9, 3),
         "step_latency_ms": round(path_ms, 4),
         "histogram_pass": None if hist_ms is None else {
-            "kernel": "k_hist", "ms": round(hist_ms, 4), "bytes": total + 8 * nprot,
+            "kernel": "k_hist", "ms": round(hist_ms, 4), "bytes": total + 8 * nprot, "counts_sha16": hist_sha,
             "achieved_GBps": round((total + 8 * nprot) / (hist_ms * 1e-3) / 1e9, 1),
             "frac_of_peak": round((total + 8 * nprot) / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "what": "background pass (countaas / isvalidprotein, plaac.java:1698-1739) over the resident batch, the one "

@@ -217,6 +217,12 @@ def test_histogram_streaming_kernel_random_sets(native, oracle, ctx):
     assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs))
     codes, offs = _random_records(rng, 40, 0.5, maxlen=400_000)                 # records longer than a wave's share
     assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs))
+    codes, offs = _random_records(rng, 30_000, 0.5, maxlen=200, x_rate=0.5)     # every other byte flagged: the ring of
+    assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs))  # flagged positions fills within a row
+    codes, offs = _random_records(rng, 2_000, 0.0, maxlen=40_000, x_rate=0.3, stop_fraction=0.0)  # long records full of X
+    assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs))
+    codes, offs = _random_records(rng, 400_000, 1.0, maxlen=40, stop_fraction=1.0)  # a flagged byte or two in EVERY record,
+    assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs))  # about half of them invalid
     for seqs in (["X" * 5000], ["A" * 70000 + "X" + "A" * 3], ["*" * 40, "X", "AX", "XA", "A*", "*A", "AXA", "A*A", "A**"],
                  ["A" * 17] * 1000 + ["AXA"] + ["C" * 15] * 1000, [""] * 100 + ["MKV"] + [""] * 100, [""], []):
         codes, offs = native.pack(seqs)
