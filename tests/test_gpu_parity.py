@@ -229,6 +229,33 @@ def test_histogram_streaming_kernel_random_sets(native, oracle, ctx):
         assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs)), seqs[:3]
 
 
+def _sparse_records(rng, nrec, maxlen, x_rate, stop_fraction, last_x_fraction=0.0):
+    """like _random_records for tens of MB: X at x_rate of the residues (positions drawn, not a mask over every residue), a
+    stop as the last residue of stop_fraction of the records, an X there for last_x_fraction"""
+    lens = rng.integers(1, maxlen, nrec)
+    offs = np.zeros(nrec + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    n = int(offs[-1])
+    codes = rng.integers(1, 21, n, dtype=np.uint8)
+    codes[rng.integers(0, n, int(n * x_rate))] = 0
+    last = (offs[1:] - 1).astype(np.int64)
+    codes[last[rng.random(nrec) < stop_fraction]] = 21
+    codes[last[rng.random(nrec) < last_x_fraction]] = 0
+    return codes, offs
+
+
+def test_histogram_window_path_on_large_sets(native, oracle, ctx):
+    """k_hist's deciding-before-counting path needs whole 4 KiB groups per wave (tens of MB per batch): records much shorter
+    than a group (the window of 64 record starts falls short inside a group: both paths in one group), X-rich text (several
+    invalid records per group, records straddling groups), records of megabytes (blanked over hundreds of groups), and an X or
+    a stop as the LAST residue of every other record (the one place where the two flagged codes differ)."""
+    rng = np.random.default_rng(20261005)
+    for nrec, maxlen, x_rate, stops, last_x in ((2_000_000, 60, 0.01, 0.5, 0.1), (200_000, 600, 0.02, 0.3, 0.0),
+                                                (60, 2_000_000, 1e-5, 0.5, 0.3), (600_000, 200, 0.0, 0.3, 0.3)):
+        codes, offs = _sparse_records(rng, nrec, maxlen, x_rate, stops, last_x)
+        assert np.array_equal(ctx.histogram(codes, offs), oracle.histogram(codes, offs)), (nrec, maxlen)
+
+
 def test_histogram_device_entry_any_alignment(native, oracle, ctx):
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(7)
