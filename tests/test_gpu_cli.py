@@ -268,10 +268,14 @@ def test_single_pass_writes_the_same_bytes_as_the_two_passes(native, tmp_path):
              ["-i", fa, "-c", "30", "-W", "21"], ["-i", empty], ["-i", FA4, "-a", "1.0"], ["-i", quirks], ["-i", fa, "-a", "0.5"],
              ["-i", fa, "-B", os.path.join(GOLDEN, "bg_freqs", "bg_freqs_YEAST.txt")]]
     from concurrent.futures import ThreadPoolExecutor
-    for args in cases:
+    for ci, args in enumerate(cases):
         envs = ({"PLAAC_SINGLE_PASS": "0", "PLAAC_HUGE_PAGES": "0"}, {}, {"PLAAC_BATCH_RECORDS": "257", "PLAAC_DEVICES": "0,0"},
                 {"PLAAC_DEVICE_PARSE": "0"}, {"PLAAC_DEVICE_FORMAT": "0"}, {"PLAAC_DEVICE_FORMAT": "0", "PLAAC_BATCH_RECORDS": "100"},
                 {"PLAAC_BATCH_RECORDS": "1"} if args[1] is quirks else {"PLAAC_BATCH_BYTES": "4096"})
+        # (every way of running it for the plain call, the column notes, the classic four, the quirky file and the two-pass
+        #  alpha; for the other options the two-pass run, the default and the host's formatter: a run is mostly HIP start-up)
+        if ci not in (0, 1, 8, 9, 10):
+            envs = (envs[0], envs[1], envs[4])
 
         def run(env, args=args):
             return subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300, env=dict(os.environ, PLAAC_TIMING="1", **env))
