@@ -4,7 +4,10 @@ Proteins are independent given the parameter tables, so th
 collective. The only exchanges are
   (i)  an all-reduce(sum) of the 22 x int64 background histogram, needed when the background comes
        from the scored input (plaac.java:377-384 -> one full pass over the input), and
-  (ii) the final gather of 160-byte summary rows to rank 0 (plaac.java:755-945 prints in file order).
+  (ii) the final gather of 160-byte summary rows to rank 0 (plaac.java:755-945 prints in file order) - or, from four
+       ranks on, RangeExchange: an all-to-all after which every rank holds ONE contiguous range of the table (what a
+       multi-process host formats and writes into its part of the file), 1/N of a shard per link instead of a whole
+       shard on each of rank 0's links.
 Backend "nccl" is RCCL on ROCm (rows stay in HBM and travel over xGMI); "gloo" is used by the CPU tests.
 """
 import os
@@ -225,3 +228,83 @@ def gather_rows(rows_local, idx_local, nprot_total, device=None, offsets=None, c
         k = sizes[r]
         out[got_idx[r][:k]] = got_rows[r].reshape(nmax, ROW_BYTES)[:k]
     return out.reshape(-1).cpu().numpy()
+
+
+def range_bounds(nprot_total, world):
+    """first record of every rank's range of the table (world + 1 entries): rank d owns records [b[d], b[d+1])"""
+    return [d * nprot_total // world for d in range(world + 1)]
+
+
+class RangeExchange:
+    """Exchange step (ii) without a funnel (round 6; the verdict's "keep the 8-GPU day cheap"): the shards are dealt by
+    length (shard_plan), so a rank's rows are scattered over the whole table; gathered to rank 0 they cross seven of ITS
+    links, a whole shard each (1.25 M x 136 B = 170 MB per link and step at N = 8, priced at 2.2 - 3.4 ms against 2.6 ms
+    of scoring). Here every rank d ends with the rows of records [b[d], b[d+1]) in input order - the part of the table a
+    multi-process host would format (k_format_rows) and pwrite at its own offset - by ONE all-to-all of wire rows: a
+    shard's rows for range d are contiguous in the shard (the plans are ascending), so nothing is permuted before the send;
+    1/N of a shard crosses each link. plans: the index arrays of ALL ranks (shard_plan / shard_plan_torch, every rank
+    computes the same); offsets: the whole batch's (the receiver rebuilds prot_len from them).
+    reference: the loop being split is plaac.java:755 (one row per record, printed in file order :899-945)."""
+
+    def __init__(self, plans, offsets, rank, world, device=None):
+        import torch
+        self.rank, self.world = rank, world
+        dev = device if device is not None else (plans[0].device if hasattr(plans[0], "device") else "cpu")
+        plans = [torch.as_tensor(np.asarray(p.cpu() if hasattr(p, "cpu") else p, dtype=np.int64)) for p in plans]
+        off = torch.as_tensor(np.asarray(offsets.cpu() if hasattr(offsets, "cpu") else offsets).astype(np.int64))
+        n = off.numel() - 1
+        b = torch.tensor(range_bounds(n, world), dtype=torch.int64)
+        self.first, self.count = int(b[rank]), int(b[rank + 1] - b[rank])
+        cut = [torch.searchsorted(p, b) for p in plans]  # cut[s][d]: first row of shard s that belongs to range d
+        self.send_counts = [int(cut[rank][d + 1] - cut[rank][d]) for d in range(world)]
+        self.recv_counts = [int(cut[s][rank + 1] - cut[s][rank]) for s in range(world)]
+        gidx = torch.cat([plans[s][int(cut[s][rank]):int(cut[s][rank + 1])] for s in range(world)])
+        lens = off[1:] - off[:-1]
+        self.recv_lens = lens[gidx].to(dev)         # untrimmed lengths of the records whose rows arrive, in arrival order
+        self.recv_pos = (gidx - self.first).to(dev)  # their places in this rank's range
+        self.send_lens = lens[plans[rank]].to(dev)
+        self.device = dev
+        self._recv = None
+
+    def exchange(self, rows_u8, corelength, out):
+        """rows_u8: this rank's rows, uint8 [n_local * 160] in shard order; out: uint8 [count, 160] - the rows of this
+        rank's range in input order. On the current stream (RCCL) / through the host (gloo: plumbing tests)."""
+        import torch
+        import torch.distributed as dist
+        n_local = sum(self.send_counts)
+        wire = rows_to_wire_torch(rows_u8[:n_local * ROW_BYTES], self.send_lens)
+        nrecv = sum(self.recv_counts)
+        ins = [c * WIRE_ROW_BYTES for c in self.send_counts]
+        outs = [c * WIRE_ROW_BYTES for c in self.recv_counts]
+        if dist.get_backend() == "gloo" and wire.is_cuda:  # (gloo has no all-to-all for device tensors)
+            got = torch.empty(nrecv * WIRE_ROW_BYTES, dtype=torch.uint8)
+            dist.all_to_all_single(got, wire.cpu(), outs, ins)
+            got = got.to(wire.device)
+        else:
+            if self._recv is None or self._recv.device != wire.device:
+                self._recv = torch.empty(nrecv * WIRE_ROW_BYTES, dtype=torch.uint8, device=wire.device)
+            got = self._recv
+            dist.all_to_all_single(got, wire, outs, ins)
+        if nrecv:
+            out[self.recv_pos] = rows_from_wire_torch(got, self.recv_lens, corelength)
+        return out
+
+
+def gather_ranges(range_rows, nprot_total, dst=0):
+    """the ranges of a RangeExchange brought to one rank (checks, a single-process writer): uint8 [nprot_total, 160] on
+    dst, None elsewhere. Equal padded blocks (ranges differ by one row at most)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    b = range_bounds(nprot_total, world)
+    nmax = max(b[d + 1] - b[d] for d in range(world))
+    pad = torch.zeros(nmax, ROW_BYTES, dtype=torch.uint8, device=range_rows.device)
+    pad[:range_rows.shape[0]] = range_rows
+    if dist.get_backend() == "gloo" and pad.is_cuda:
+        pad = pad.cpu()
+    got = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, got, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([got[d][:b[d + 1] - b[d]] for d in range(world)]).to(range_rows.device)
+

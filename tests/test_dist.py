@@ -53,6 +53,22 @@ def _worker(rank, world, port, tmp):
     a_cs, a_os = pdist.extract_shard(ac, ao, aplan[rank])
     a_rows = oc.score_batch(P3, a_cs, a_os)
     out_a = pdist.gather_rows(a_rows, aplan[rank], len(ao) - 1, offsets=ao, corelength=25)
+    # exchange (ii) without the funnel (RangeExchange): an all-to-all after which rank d holds records [b[d], b[d+1]) of the
+    # table in input order; brought to rank 0 (gather_ranges) it is the same table
+    import torch
+    ranges = []
+    for rows_l, pl, of, c in ((rows_s, plan, offs, P2.corelength), (a_rows, aplan, ao, 25)):
+        rx = pdist.RangeExchange(pl, of, rank, world)
+        mine = torch.full((rx.count, pdist.ROW_BYTES), 0xFF, dtype=torch.uint8)
+        rx.exchange(torch.from_numpy(rows_l.view(np.uint8).reshape(-1).copy()), c, mine)
+        b = pdist.range_bounds(len(of) - 1, world)
+        assert (rx.first, rx.count) == (b[rank], b[rank + 1] - b[rank]) and sum(rx.send_counts) == len(pl[rank])
+        ranges.append(pdist.gather_ranges(mine, len(of) - 1))
+    if rank == 0:
+        assert ranges[0].numpy().tobytes() == oc.score_batch(P2, codes, offs).tobytes(), "range exchange differs"
+        assert ranges[1].numpy().tobytes() == oc.score_batch(P3, ac, ao).tobytes(), "range exchange of the adversarial set differs"
+    else:
+        assert ranges == [None, None]
     if rank == 0:
         want = oc.score_batch(P2, codes, offs)
         assert out.tobytes() == want.tobytes()
@@ -111,6 +127,15 @@ def test_two_rank_shard_histogram_and_gather(tmp_path):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").read_text() == "ok"
+
+
+def test_four_rank_range_exchange(tmp_path):
+    """the same worker over four ranks: the all-to-all of the range exchange with four ranges (a rank's rows for another
+    rank's range are a slice of its shard; shards of different sizes; ranges that differ by a row)"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
     assert (tmp_path / "ok").read_text() == "ok"
 
 
