@@ -336,6 +336,10 @@ def main():
     ap.add_argument("--no-weak-leg", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
     ap.add_argument("--e2e-nprot", type=int, default=0, help="sequences of the resident proteome written as FASTA "
                     "for the end-to-end leg (default: all of them, i.e. the 10 M sequences / 3.0 GB of cfg4)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rank0", "ranges"], help="N > 1, strong scaling: where the "
+                    "rows of a step end up. rank0: wire rows gathered to rank 0 (a whole shard on each of its links); ranges: an "
+                    "all-to-all after which every rank holds one contiguous range of the table (what a multi-process host "
+                    "formats and writes at its own offset); auto: ranges from four ranks on")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' + --one-device lets two ranks share one GPU for a plumbing check")
     ap.add_argument("--one-device", action="store_true", help="TEST ONLY: every rank uses cuda:0")
@@ -415,15 +419,19 @@ def main():
             self.plans = plans  # strong scaling, rank 0: the input indices of every rank's rows (else None)
             self.nmax = nmax    # rows of the largest shard (row buffers; equal blocks for dist.gather in weak mode)
             self.sizes = sizes  # strong scaling: records of every rank's shard (exact block sizes of the wire-row gather)
+            self.range_x = None  # strong scaling from four ranks on: the all-to-all that leaves every rank one range of the table
 
+    use_ranges = world > 1 and not args.weak and not args.nprot and (args.exchange == "ranges" or (args.exchange == "auto" and world >= 4))
     if strong:
         all_plans = pdist.shard_plan_torch(offsets_full, world)  # the C partitioner (plaac_shard_plan), every rank the same
         mine = all_plans[rank]
         c_s, o_s = pdist.extract_shard_torch(codes_full, offsets_full, mine)
         plans = all_plans if rank == 0 else None
         sizes = [int(p_.numel()) for p_ in all_plans]
+        range_x = pdist.RangeExchange(all_plans, offsets_full, rank, world, device=dev) if use_ranges else None
         del all_plans
         main_work = Work(c_s, o_s, plans, max(sizes), sizes)
+        main_work.range_x = range_x
         del mine
     else:
         main_work = Work(codes_full, offsets_full, None, nfull)
@@ -476,7 +484,10 @@ def main():
         # have): 160-byte rows in equal blocks
         wire_mode = world > 1 and W.sizes is not None
         gather_list = final = got = lens_of = None
-        if world > 1 and rank == 0:
+        range_x = W.range_x
+        if range_x is not None:  # every rank: the rows of its range of the table, per sweep point
+            final = [torch.zeros(range_x.count, RB, dtype=torch.uint8, device=dev) for _ in range(npoints)]
+        elif world > 1 and rank == 0:
             if wire_mode:
                 got = [None] + [torch.empty(W.sizes[r] * pdist.WIRE_ROW_BYTES, dtype=torch.uint8, device=dev) for r in range(1, world)]
                 lens_full = offsets_full[1:] - offsets_full[:-1]
@@ -498,6 +509,9 @@ def main():
             restored there"""
             if not wire_mode:
                 dist.gather(buf, gather_list, dst=0)
+                return
+            if range_x is not None:  # (ii'): all-to-all, 1/N of a shard per link; every rank rebuilds the rows of its range
+                range_x.exchange(buf, corelength, final[point])
                 return
             if rank != 0:
                 wire = pdist.rows_to_wire_torch(buf[:W.nprot * RB], lens_local)
@@ -578,6 +592,11 @@ def main():
             step()
             fence()
             last = (step_no[0] - 1) % nslots
+        if range_x is not None:  # the checks read ONE table: the ranges brought to rank 0 after the clock has stopped
+            torch.cuda.synchronize(dev)
+            final = [pdist.gather_ranges(f_, nfull) for f_ in final]
+            if rank != 0:
+                final = None
         return dt, {"rows": rows_pp[last], "final": final, "gather_list": gather_list, "sweep_rows": sweep_rows, "trk": trk,
                     "gather_ms": gms, "verified_step": "one more untimed step into buffers filled with 0xFF" if verify else None}
 
@@ -1115,7 +1134,11 @@ def main():
             "step_by_itself": by_itself,
             "predicted_strong_scaling": predicted,
             "gather_ms_per_step": None if bufs.get("gather_ms") is None else round(bufs["gather_ms"], 4),
-            "exchange": ("%s gather to rank 0: %s" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend,
+            "exchange": (("%s all-to-all of 136 B wire rows (include/plaac_native.h): every rank ends with one contiguous range of "
+                          "the table, rows rebuilt and in input order (1/N of a shard per link; the ranges are brought to rank 0 "
+                          "for the check after the clock has stopped)" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend))
+                         if use_ranges else
+                         "%s gather to rank 0: %s" % ("RCCL" if (args.backend or "nccl") == "nccl" else args.backend,
                          "136 B wire rows (include/plaac_native.h), point-to-point blocks of their exact sizes, rows rebuilt and "
                          "put in input order on rank 0" if strong else "160 B rows in equal blocks (weak scaling)"))
             if world > 1 else "none (1 GPU)",

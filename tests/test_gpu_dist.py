@@ -139,25 +139,28 @@ def test_node_resident_batch_two_pass_and_sweep_equal_independent_oracle_runs():
     assert np.any(np.diff(plan[0]) > 1) and sorted(np.concatenate(plan).tolist()) == list(range(nprot))
 
 
-@pytest.mark.parametrize("launcher", ["plain", "torchrun", "plain-sweep"])
+@pytest.mark.parametrize("launcher", ["plain", "plain-sweep", "ranges-torchrun", "ranges-sweep"])
 def test_bench_two_ranks_strong_scaling_line(tmp_path, launcher):
     """bench.py at N = 2 (its default at N > 1: ONE proteome cut by plaac_amd.dist.shard_plan over the ranks, 136-byte wire
     rows sent to rank 0, rebuilt and put back into input order there, the gathered table of a step made AFTER the timed
     region - into poisoned buffers - checked against the oracle): RCCL with two devices, gloo with both ranks on the box's
     one device. `plain`: `python bench.py --gpus 2` with no launcher and no WORLD_SIZE - the form the driver uses at N = 1
     must work at N > 1 (the parent starts its ranks as fresh children before it touches torch or HIP);
-    `torchrun`: under the launcher; `plain-sweep`: the nine-point sweep, every point's gathered table against the oracle."""
+    `plain-sweep`: the nine-point sweep, every point's gathered table against the oracle;
+    `ranges-torchrun` (under the launcher) / `ranges-sweep`: the exchange bench.py takes from four ranks on (--exchange ranges:
+    an all-to-all after which every rank holds one contiguous range of the table), forced at two ranks."""
     import json
     import subprocess
     import torch
     two = torch.cuda.device_count() >= 2
     bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "2", "--steps", "3", "--warmup", "1", "--no-e2e"]
     bench += [] if two else ["--one-device", "--backend", "gloo"]
-    if launcher == "torchrun":
+    if launcher.endswith("torchrun"):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(_free_port())] + bench
+               "--master-port", str(_free_port())] + bench + (["--exchange", "ranges"] if launcher.startswith("ranges") else [])
     else:
-        cmd = [sys.executable] + bench + (["--sweep"] if launcher == "plain-sweep" else [])
+        cmd = [sys.executable] + bench + (["--sweep"] if launcher.endswith("sweep") else []) + (
+            ["--exchange", "ranges"] if launcher.startswith("ranges") else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
@@ -168,7 +171,8 @@ def test_bench_two_ranks_strong_scaling_line(tmp_path, launcher):
     assert line["cpu_baseline"]["gpu_rows_match_oracle"] is True
     assert line["cpu_baseline"]["checked_table"].startswith("gathered rows of all ranks")
     assert line["config"]["wire_row_bytes"] == 136 and line["config"]["verified_step"]
-    if launcher != "plain-sweep":
+    assert ("all-to-all" in line["config"]["exchange"]) == launcher.startswith("ranges")
+    if not launcher.endswith("sweep"):
         assert line["weak"]["scaling"] == "weak" and line["weak"]["value"] > 0
 
 

@@ -1585,7 +1585,7 @@ def test_node_text_api_deals_batches_over_contexts_and_returns_the_table_in_file
     assert_rows_equal(r_node, r_ctx, "rows beside the node's per-residue table")
 
 
-def test_value_tolerance_mode_moves_only_the_five_floats_at_the_papa_centre(native, oracle):
+def test_value_tolerance_mode_moves_only_the_five_floats_at_the_papa_centre(native, oracle, monkeypatch):
     """Round 6: plaac_ctx_set_value_tolerance (off by default). The north star's bar for floats is 1e-6; with the switch on,
     the five floats reported at the PAPA centre come from first-level sums that slide over six neighbouring positions instead
     of 41 fixed-order taps each. TOLERANCE: |got - want| <= 1e-9 * max(1, |want|) for papa_combo, papa_prop, papa_fi, papa_llr,
@@ -1593,7 +1593,8 @@ def test_value_tolerance_mode_moves_only_the_five_floats_at_the_papa_centre(nati
     decision included, bit-identical to the oracle. Switched off again, the rows are bit-identical as before."""
     from plaac_amd import synth
     P = native.make_params()
-    codes, offs = synth.make_batch(4, nprot=300000, seed=41, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
+    monkeypatch.setenv("PLAAC_KB_LANE_MIN_GROUPS", "1")  # (the lane form, which a batch takes from 262,144 records on, at 60,000)
+    codes, offs = synth.make_batch(4, nprot=60000, seed=41, fg=np.array(P.fg), bg=np.array(P.bg), stop_fraction=0.1)
     want = oracle.score_batch(oracle.build_params(), codes, offs, nthreads=16)
     loose = ("papa_combo", "papa_prop", "papa_fi", "papa_llr", "papa_llr2")
     with native.Context(P) as ctx:

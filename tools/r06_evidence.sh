@@ -36,5 +36,7 @@ PY
   ;;
 ranks)
   # plumbing only: six ranks share one device over gloo (the GPU box allows six processes on its card; eight would be killed)
-  python3 bench.py --gpus 6 --backend gloo --one-device --nprot 200000 --steps 5 --warmup 1 --no-e2e --no-predict --no-tracks-leg --no-host-leg --no-clock-probe > $O/bench_6rank_one_device.json 2> $O/bench_6rank.err; echo "6 ranks rc=$?"; tail -c 600 $O/bench_6rank_one_device.json ;;
+  python3 bench.py --gpus 6 --backend gloo --one-device --nprot 200000 --steps 5 --warmup 1 --no-e2e --no-predict --no-tracks-leg --no-host-leg --no-clock-probe > $O/bench_6rank_one_device.json 2> $O/bench_6rank.err; echo "6 ranks rc=$?"; tail -c 600 $O/bench_6rank_one_device.json
+  # ... and ONE proteome cut over the six ranks (strong scaling; from four ranks on the rows end in ranges, by an all-to-all)
+  python3 bench.py --gpus 6 --backend gloo --one-device --config 2 --steps 5 --warmup 1 --no-e2e > $O/bench_6rank_one_device_strong_ranges.json 2> $O/bench_6rank_strong.err; echo "6 ranks strong rc=$?"; tail -c 900 $O/bench_6rank_one_device_strong_ranges.json ;;
 esac
