@@ -379,6 +379,11 @@ def main():
     from plaac_amd import native, synth
 
     rank, local_rank, world = pdist.init_process_group(args.backend)
+    t_start = time.perf_counter()
+
+    def mark(what):  # one short line per phase on stderr (rank 0): where a long multi-rank run is
+        if rank == 0 and (world > 1 or os.environ.get("PLAAC_BENCH_PROGRESS")):
+            print("bench.py [%6.1f s] %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
     if args.one_device:
         local_rank = 0
     if world != args.gpus:
@@ -399,6 +404,7 @@ def main():
     # rank builds the whole proteome and keeps its share); otherwise the seed differs per rank.
     seed_rank = 0 if strong else rank
     pieces, offs, base = [], [torch.zeros(1, dtype=torch.int64, device=dev)], 0
+    mark("ranks joined; generating the proteome")
     for ci, start in enumerate(range(0, nfull, SYNTH_CHUNK)):
         c_, o_ = synth.make_batch_torch(args.config, min(SYNTH_CHUNK, nfull - start), np.array(P.fg), np.array(P.bg),
                                         dev, seed=synth.SEED0 + args.config + 1000 * seed_rank + 100000 * ci,
@@ -422,6 +428,7 @@ def main():
             self.range_x = None  # strong scaling from four ranks on: the all-to-all that leaves every rank one range of the table
 
     use_ranges = world > 1 and not args.weak and not args.nprot and (args.exchange == "ranges" or (args.exchange == "auto" and world >= 4))
+    mark("proteome in HBM: %d sequences" % nfull)
     if strong:
         all_plans = pdist.shard_plan_torch(offsets_full, world)  # the C partitioner (plaac_shard_plan), every rank the same
         mine = all_plans[rank]
@@ -448,7 +455,8 @@ def main():
     # them, and RCCL orders the row gather after them
     streams = [torch.cuda.Stream(dev) for _ in range(nctx)]
     comm = torch.cuda.Stream(dev) if world > 1 else None
-    cnt = torch.zeros(22, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(22, dtype=torch.int64, device=dev)       # the job's counts (summed over the ranks): the two-pass parameters
+    cnt_probe = torch.zeros(22, dtype=torch.int64, device=dev)  # the timed background pass over THIS rank's batch writes here
 
     def background_counts(W, ctx, stream):
         """pass 1 of the reference (plaac.java:377-384): histogram of the input, summed over the ranks"""
@@ -600,7 +608,9 @@ def main():
         return dt, {"rows": rows_pp[last], "final": final, "gather_list": gather_list, "sweep_rows": sweep_rows, "trk": trk,
                     "gather_ms": gms, "verified_step": "one more untimed step into buffers filled with 0xFF" if verify else None}
 
+    mark("shards cut; timed region")
     dt, bufs = run_region(main_work, args.steps, args.warmup, args.tracks, verify=True)
+    mark("timed region done: %.3f s for %d steps; checked step made" % (dt, args.steps))
     nprot, total = main_work.nprot, main_work.total
     if world > 1:
         tot = torch.tensor([total, nprot], dtype=torch.int64, device=dev)
@@ -619,7 +629,9 @@ def main():
     if strong and not args.no_weak_leg and not args.tracks and not args.sweep:
         keep_final = bufs["final"]
         bufs["gather_list"] = bufs["rows"] = None
+        mark("weak-scaling leg")
         wdt, wb = run_region(Work(codes_full, offsets_full, None, nfull), args.steps, 1, False)
+        mark("weak-scaling leg done")
         del wb
         weak = {"value": round(total_full * world * args.steps / wdt, 1), "unit": "residues/s",
                 "ms_per_step": round(wdt / args.steps * 1e3, 4), "scaling": "weak",
@@ -649,14 +661,14 @@ def main():
         st = streams[0]
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         with torch.cuda.stream(st):
-            ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt.data_ptr(), stream=st.cuda_stream)
+            ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt_probe.data_ptr(), stream=st.cuda_stream)
             ev[0].record(st)
             for _ in range(3):
-                ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt.data_ptr(), stream=st.cuda_stream)
+                ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt_probe.data_ptr(), stream=st.cuda_stream)
             ev[1].record(st)
         st.synchronize()
         hist_ms = ev[0].elapsed_time(ev[1]) / 3
-        hist_sha = hashlib.sha256(cnt.cpu().numpy().tobytes()).hexdigest()[:16]
+        hist_sha = hashlib.sha256(cnt_probe.cpu().numpy().tobytes()).hexdigest()[:16]
     # the same step with every call ordered behind the whole previous one (plaac_ctx_set_overlap off): untimed extra steps
     by_itself = None
     if overlap and world == 1 and not args.tracks and not args.sweep:
@@ -765,7 +777,7 @@ def main():
         except native.PlaacError as e:
             clock = {"error": str(e)}
     if args.calibrate:
-        ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt.data_ptr(), stream=streams[0].cuda_stream)
+        ctxs[0].histogram_device(main_work.codes.data_ptr(), main_work.offsets.data_ptr(), nprot, cnt_probe.data_ptr(), stream=streams[0].cuda_stream)
         ctxs[0].calibration_reads(main_work.codes.data_ptr(), total, stream=streams[0].cuda_stream)
         torch.cuda.synchronize(dev)
     if rank != 0:
@@ -909,6 +921,7 @@ def main():
 
     # ---- rank 0: CPU baseline = the oracle (a port, not the Java reference: no JVM on this box), and the parity check of
     # this run's rows: slices spread over the WHOLE batch (strong scaling: over the gathered, re-ordered table)
+    mark("oracle check / cpu baseline")
     cpu, rc, oracle_keep = None, 0, []
     if not args.no_cpu_baseline:
         from oracle import oracle_ctypes as oc
