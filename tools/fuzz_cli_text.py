@@ -59,6 +59,8 @@ bad = 0
 with tempfile.TemporaryDirectory() as tmp:
     fa, o1, o2 = os.path.join(tmp, "f.fa"), os.path.join(tmp, "a.tsv"), os.path.join(tmp, "b.tsv")
     for it in range(iters):
+        if it and it % 50 == 0:  # (a run on the GPU box must not stay silent for minutes)
+            print("... %d iterations, %d mismatches so far" % (it, bad), flush=True)
         open(fa, "wb").write(fasta())
         args = ["-i", fa]
         if rng.random() < 0.3:
