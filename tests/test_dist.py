@@ -223,3 +223,31 @@ def test_torch_shard_plan_and_extract_equal_the_numpy_ones():
             c, o = pdist.extract_shard_torch(t_codes, t_off, idx)
             c_np, o_np = pdist.extract_shard(codes, offs, plan[rank])
             assert np.array_equal(c.numpy(), c_np) and np.array_equal(o.numpy().astype(np.uint64), o_np)
+
+
+def test_range_exchange_splits_are_consistent_for_any_world_and_tiny_batches():
+    """RangeExchange without a process group: for every rank the rows it sends to d are what d expects from it, every record
+    arrives exactly once at the place its index names - also when there are fewer records than ranks, or none"""
+    import torch
+    from plaac_amd import dist as pdist
+    rng = np.random.default_rng(12)
+    for n, world in ((0, 2), (1, 4), (3, 4), (5, 8), (64, 3), (1000, 8), (301, 6)):
+        lens = rng.integers(0, 50, n)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens)
+        plans = pdist.shard_plan(offs, world) if n else [np.zeros(0, dtype=np.int64) for _ in range(world)]
+        xs = [pdist.RangeExchange(plans, offs, r, world) for r in range(world)]
+        b = pdist.range_bounds(n, world)
+        assert b[0] == 0 and b[-1] == n and all(b[d] <= b[d + 1] for d in range(world))
+        seen = np.zeros(n, dtype=np.int64)
+        for d, x in enumerate(xs):
+            assert (x.first, x.count) == (b[d], b[d + 1] - b[d])
+            assert x.recv_counts == [xs[s].send_counts[d] for s in range(world)]
+            assert sum(x.send_counts) == len(plans[d]) and sum(x.recv_counts) == x.count
+            pos = x.recv_pos.numpy()
+            assert sorted(pos.tolist()) == list(range(x.count))  # every place of the range exactly once
+            seen[pos + x.first] += 1
+            # the arriving records' lengths are those of the records at these places
+            assert np.array_equal(x.recv_lens.numpy(), lens[pos + x.first])
+        assert np.all(seen == 1)
+
