@@ -330,7 +330,7 @@ class Context:
     def close(self):
         if self._h:
             self._L.plaac_ctx_destroy(self._h)
-            self._h = C.c_void_p()
+            self._h = None  # (not C.c_void_p(): at interpreter shutdown the module's globals may be gone already)
 
     __del__ = close
 
@@ -591,7 +591,7 @@ class Node:
         self._batches = []
         if self._h:
             self._L.plaac_node_destroy(self._h)
-            self._h = C.c_void_p()
+            self._h = None
 
     __del__ = close
 
@@ -768,7 +768,7 @@ class NodeBatch:
     def close(self):
         if getattr(self, "_h", None):
             self._L.plaac_node_batch_free(self._h)
-            self._h = C.c_void_p()
+            self._h = None
 
     __del__ = close
 
@@ -896,7 +896,7 @@ class Batch:
     def close(self):
         if self._h:
             self.ctx._L.plaac_batch_free(self._h)
-            self._h = C.c_void_p()
+            self._h = None
 
     __del__ = close
 
