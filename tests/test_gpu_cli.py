@@ -173,11 +173,14 @@ def test_streamed_pipeline_is_independent_of_batching_and_contexts(native, tmp_p
     args = ("-i", fa, "-a", 0.5, "-c", 40)
     base = run_env({"PLAAC_DEVICES": "0"}, *args)  # one context, one batch
     assert base.count(b"\n") > 1500
-    for env in ({"PLAAC_BATCH_RECORDS": 37}, {"PLAAC_BATCH_BYTES": 20000, "PLAAC_DEVICES": "0,0,0"},
-                {"PLAAC_BATCH_RECORDS": 100, "PLAAC_KEEP_BYTES": 1}, {"PLAAC_BATCH_RECORDS": 1, "PLAAC_DEVICES": "0,0"},
-                {"PLAAC_BATCH_RECORDS": 100, "PLAAC_KEEP_BYTES": 100000, "PLAAC_CTX_PER_DEVICE": 3},
-                {"PLAAC_FAST_EXIT": 1, "PLAAC_BATCH_RECORDS": 500}, {"PLAAC_TEARDOWN": 1, "PLAAC_BATCH_RECORDS": 300}):
-        assert run_env(env, *args) == base, env
+    envs = ({"PLAAC_BATCH_RECORDS": 37}, {"PLAAC_BATCH_BYTES": 20000, "PLAAC_DEVICES": "0,0,0"},
+            {"PLAAC_BATCH_RECORDS": 100, "PLAAC_KEEP_BYTES": 1}, {"PLAAC_BATCH_RECORDS": 1, "PLAAC_DEVICES": "0,0"},
+            {"PLAAC_BATCH_RECORDS": 100, "PLAAC_KEEP_BYTES": 100000, "PLAAC_CTX_PER_DEVICE": 3},
+            {"PLAAC_FAST_EXIT": 1, "PLAAC_BATCH_RECORDS": 500}, {"PLAAC_TEARDOWN": 1, "PLAAC_BATCH_RECORDS": 300})
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as pool:  # (four processes on the card at a time: a run is mostly HIP start-up)
+        for env, out in zip(envs, pool.map(lambda e: run_env(e, *args), envs)):
+            assert out == base, env
     # track mode streams too (8 MiB batches by default): every record, then a list
     tbase = run_env({"PLAAC_DEVICES": "0"}, "-i", fa, "-p", "all", "-s")
     assert run_env({"PLAAC_BATCH_RECORDS": 64, "PLAAC_DEVICES": "0,0"}, "-i", fa, "-p", "all", "-s") == tbase
@@ -369,8 +372,12 @@ def test_per_residue_table_from_the_device_is_the_hosts(native, tmp_path):
     lst.write_text("rec00007 some description\tShown as seven\nrec00003 some description\nnot-there\nrec00100 some description\tA hundred\n")
     for args in (["-i", fa, "-p", "all"], ["-i", fa, "-p", lst], ["-i", quirks, "-p", "all", "-s"], ["-i", fa, "-p", "all", "-a", "0.5"]):
         outs = []
-        for env in ({"PLAAC_DEVICE_FORMAT": "0"}, {}, {"PLAAC_BATCH_BYTES": "20000"}, {"PLAAC_DEVICES": "0,0", "PLAAC_BATCH_RECORDS": "50"}):
-            r = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300, env=dict(os.environ, **env))
+        envs = ({"PLAAC_DEVICE_FORMAT": "0"}, {}, {"PLAAC_BATCH_BYTES": "20000"}, {"PLAAC_DEVICES": "0,0", "PLAAC_BATCH_RECORDS": "50"})
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=4) as pool:  # (four processes on the card at a time: a run is mostly HIP start-up)
+            rs = list(pool.map(lambda env: subprocess.run([BIN] + [str(a) for a in args], capture_output=True, timeout=300,
+                                                          env=dict(os.environ, **env)), envs))
+        for r in rs:
             assert r.returncode == 0, r.stderr.decode(errors="replace")
             outs.append(r.stdout)
         assert all(o == outs[0] for o in outs[1:]), args
