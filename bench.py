@@ -380,6 +380,9 @@ def main():
 
     rank, local_rank, world = pdist.init_process_group(args.backend)
     t_start = time.perf_counter()
+    if os.environ.get("PLAAC_BENCH_STACKS"):  # diagnostic: every rank's Python stack on stderr after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PLAAC_BENCH_STACKS"]), exit=False)
 
     def mark(what):  # one short line per phase on stderr (rank 0): where a long multi-rank run is
         if rank == 0 and (world > 1 or os.environ.get("PLAAC_BENCH_PROGRESS")):
