@@ -524,13 +524,18 @@ def main():
             if range_x is not None:  # (ii'): all-to-all, 1/N of a shard per link; every rank rebuilds the rows of its range
                 range_x.exchange(buf, corelength, final[point])
                 return
+            host_staged = dist.get_backend() == "gloo"  # (plumbing runs: gloo moves device tensors at a crawl, 27 s per 680 MB)
             if rank != 0:
                 wire = pdist.rows_to_wire_torch(buf[:W.nprot * RB], lens_local)
-                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, wire, 0)]):
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, wire.cpu() if host_staged else wire, 0)]):
                     req.wait()
                 return
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, got[r], r) for r in range(1, world)]):
+            into = [None] + [torch.empty(got[r].numel(), dtype=torch.uint8) if host_staged else got[r] for r in range(1, world)]
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, into[r], r) for r in range(1, world)]):
                 req.wait()
+            if host_staged:
+                for r in range(1, world):
+                    got[r].copy_(into[r])
             fin = final[point]
             fin[W.plans[0]] = buf.view(-1, RB)[:W.nprot]
             for r in range(1, world):
